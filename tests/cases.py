@@ -1,0 +1,212 @@
+"""
+cases.py - seeded problem definitions shared by tools/gen_golden.py (which feeds them to
+the REFERENCE in the build container) and by the tests (which feed them to the oracle and
+to the HIP engine).  Pure data + closures; imports nothing but NumPy.
+
+Synthetic-input recipe follows SURVEY.md section 8(d).
+"""
+
+import numpy as np
+
+
+def gue(rng, n):
+    g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h = (g + g.conj().T) / 2
+    return h / np.linalg.norm(h, 2)
+
+
+def annihilation(n):
+    return np.diag(np.sqrt(np.arange(1, n)), k=1).astype(np.complex128)
+
+
+def column_states(matrix):
+    """(n x S) matrix -> (S x n x 1) stack of column vectors."""
+    return np.stack([matrix[:, [i]] for i in range(matrix.shape[1])]).astype(np.complex128)
+
+
+def random_unitary(rng, n):
+    q, r = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+class Case(object):
+    """
+    Fields: name, n, S, K, Nc, N, T, complex_controls, magnus, cost_eval_step,
+    h0 (n x n), g_re [K x n x n], g_im [K x n x n] or None, time_mod (None or omega: H0 is
+    multiplied by (1 + 0.3 cos(omega t)) to make the generator explicitly time dependent),
+    initial_states (S x n x 1), cost_specs [(class name, kwargs)], controls (B x Nc x K).
+    """
+
+    def __init__(self, **kw):
+        self.time_mod = None
+        self.g_im = None
+        self.magnus = "M2"
+        self.cost_eval_step = 1
+        self.complex_controls = False
+        self.__dict__.update(kw)
+
+    def hamiltonian(self):
+        h0, g_re, g_im, omega = self.h0, self.g_re, self.g_im, self.time_mod
+        complex_controls = self.complex_controls
+
+        def h(controls, time):
+            base = h0 if omega is None else h0 * (1 + 0.3 * np.cos(omega * time))
+            if controls is None:
+                return base
+            out = base
+            for k in range(len(g_re)):
+                if complex_controls:
+                    out = out + controls[k].real * g_re[k] + controls[k].imag * g_im[k]
+                else:
+                    out = out + controls[k] * g_re[k]
+            return out
+        return h
+
+
+def _controls(seed0, count, nc, k, complex_controls, sigma=0.1):
+    out = []
+    for b in range(count):
+        rng = np.random.default_rng(seed0 + b)
+        u = sigma * rng.standard_normal((nc, k))
+        if complex_controls:
+            u = u + 1j * sigma * rng.standard_normal((nc, k))
+        out.append(u)
+    return np.stack(out)
+
+
+def case_iswap(magnus="M2"):
+    """tests/test_core.py:447-469 of the reference: known answer, no controls."""
+    sx = np.array(((0, 1), (1, 0)), dtype=np.complex128)
+    sy = np.array(((0, -1j), (1j, 0)), dtype=np.complex128)
+    h0 = 0.5 * (np.kron(sx, sx) + np.kron(sy, sy))
+    return Case(name="iswap_" + magnus, n=4, S=4, K=0, Nc=0, N=1000, T=np.pi / 2,
+                h0=h0, g_re=[], initial_states=column_states(np.eye(4)),
+                cost_specs=[], controls=None, magnus=magnus)
+
+
+def case_random(name, n, N, seeds, h_seed, S=1, K=2, Nc=None, dt=0.05, magnus="M2",
+                sigma=0.1, full_unitary=False):
+    """GUE-like H0 and G_k of unit 2-norm, real controls N(0, sigma^2)."""
+    rng = np.random.default_rng(h_seed)
+    h0 = gue(rng, n)
+    g = [gue(rng, n) for _ in range(K)]
+    Nc = N if Nc is None else Nc
+    if full_unitary:
+        init = column_states(np.eye(n)[:, :S])
+        targ = column_states(random_unitary(rng, n)[:, :S])
+    else:
+        init = column_states(np.eye(n)[:, :S])
+        targ = column_states(np.roll(np.eye(n), 1, axis=0)[:, :S])
+    return Case(name=name, n=n, S=S, K=K, Nc=Nc, N=N, T=dt * (N - 1), h0=h0, g_re=g,
+                initial_states=init, magnus=magnus,
+                cost_specs=[("TargetStateInfidelity", dict(target_states=targ))],
+                controls=_controls(1000, seeds, Nc, K, False, sigma))
+
+
+def case_c2_transmon():
+    """BASELINE config 2: dim=8 transmon, 500 steps, 1 seed (physical variant)."""
+    n, N = 8, 501
+    a = annihilation(n)
+    ad = a.conj().T
+    omega, alpha = 2 * np.pi * 0.05, 2 * np.pi * (-0.2)
+    h0 = omega * ad @ a + 0.5 * alpha * ad @ ad @ a @ a
+    g = [a + ad, 1j * (a - ad)]
+    init = column_states(np.eye(n)[:, :1])
+    targ = column_states(np.eye(n)[:, 1:2])
+    return Case(name="c2_transmon", n=n, S=1, K=2, Nc=N, N=N, T=0.05 * (N - 1), h0=h0, g_re=g,
+                initial_states=init,
+                cost_specs=[("TargetStateInfidelity", dict(target_states=targ))],
+                controls=_controls(1000, 1, N, 2, False, 0.1))
+
+
+def case_small_complex(magnus="M2"):
+    """
+    Everything the headline config does not exercise: complex controls of the
+    u a + conj(u) a^dagger form (reference tests/test_core.py:529-531), control_eval_count
+    != system_eval_count, S = 2, explicit time dependence, cost_eval_step = 2, all three
+    state costs at once.
+    """
+    n, N, Nc = 4, 23, 7
+    rng = np.random.default_rng(4242)
+    a = annihilation(n)
+    ad = a.conj().T
+    h0 = gue(rng, n) * 1.5
+    init = column_states(random_unitary(rng, n)[:, :2])
+    targ = column_states(random_unitary(rng, n)[:, :2])
+    forb = np.stack([column_states(random_unitary(rng, n)[:, :2]),
+                     column_states(random_unitary(rng, n)[:, 1:3])])
+    specs = [
+        ("TargetStateInfidelity", dict(target_states=targ, cost_multiplier=0.7)),
+        ("TargetStateInfidelityTime", dict(system_eval_count=N, target_states=targ,
+                                           neglect_relative_pahse=True, cost_eval_step=2,
+                                           cost_multiplier=1.3)),
+        ("ForbidStates", dict(forbidden_states=forb, system_eval_count=N, cost_eval_step=2,
+                              cost_multiplier=0.9)),
+    ]
+    return Case(name="small_complex_" + magnus, n=n, S=2, K=1, Nc=Nc, N=N, T=2.2,
+                h0=h0, g_re=[a + ad], g_im=[1j * (a - ad)], complex_controls=True,
+                time_mod=1.7, initial_states=init, cost_specs=specs, cost_eval_step=2,
+                magnus=magnus, controls=_controls(77, 2, Nc, 1, True, 0.4))
+
+
+def case_scaled():
+    """dt = 1 => ||dt H||_1 >= theta_13 on most steps: exercises s > 0 (squarings)."""
+    c = case_random("scaled_n8", n=8, N=13, seeds=2, h_seed=909, S=2, K=2, dt=1.0,
+                    sigma=1.5, full_unitary=True)
+    c.h0 = c.h0 * 6.0
+    return c
+
+
+def case_nc_ne_n():
+    """control_eval_count != system_eval_count with real controls (test_core.py:511-514)."""
+    return case_random("nc10_n101", n=6, N=101, seeds=2, h_seed=515, S=1, K=2, Nc=10,
+                       dt=0.04, sigma=0.5)
+
+
+def case_control_costs(complex_controls):
+    """Control-only costs riding on a tiny evolution."""
+    c = case_random("ctrlcosts_" + ("c" if complex_controls else "r"), n=3, N=17, seeds=2,
+                    h_seed=31, S=1, K=2, dt=0.1, sigma=0.4)
+    nc, k = c.Nc, c.K
+    if complex_controls:
+        rng = np.random.default_rng(5)
+        c.complex_controls = True
+        c.g_im = [gue(rng, 3) for _ in range(k)]
+        c.controls = _controls(300, 2, nc, k, True, 0.4)
+    norms = np.array([0.9, 1.1])
+    c.cost_specs = c.cost_specs + [
+        ("ControlNorm", dict(control_count=k, control_eval_count=nc, cost_multiplier=0.5,
+                             max_control_norms=norms, control_weights=np.array([1.0, 0.3]))),
+        ("ControlVariation", dict(control_count=k, control_eval_count=nc, cost_multiplier=0.8,
+                                  max_control_norms=norms, order=1)),
+        ("ControlVariation", dict(control_count=k, control_eval_count=nc, cost_multiplier=0.6,
+                                  order=2)),
+        ("ControlArea", dict(control_count=k, control_eval_count=nc, cost_multiplier=0.4,
+                             max_control_norms=norms)),
+        ("ControlBandwidthMax", dict(control_count=k, control_eval_count=nc,
+                                     evolution_time=c.T, max_bandwidths=np.array([1.0, 2.0]),
+                                     cost_multiplier=0.25)),
+    ]
+    return c
+
+
+def all_cases():
+    cases = [case_iswap(m) for m in ("M2", "M4", "M6")]
+    cases.append(case_c2_transmon())
+    cases.append(case_random("c2_random", n=8, N=501, seeds=1, h_seed=2002))
+    cases.append(case_random("c3_subset", n=32, N=1001, seeds=4, h_seed=2003))
+    cases.append(case_random("c3_fullU_short", n=32, N=33, seeds=2, h_seed=2003, S=32,
+                             full_unitary=True))
+    cases.extend(case_small_complex(m) for m in ("M2", "M4", "M6"))
+    cases.append(case_scaled())
+    cases.append(case_nc_ne_n())
+    cases.append(case_control_costs(False))
+    cases.append(case_control_costs(True))
+    return cases
+
+
+def case_by_name(name):
+    for c in all_cases():
+        if c.name == name:
+            return c
+    raise KeyError(name)

@@ -1,0 +1,1 @@
+"""qutip stand-in (only imported by the reference's plotting module)."""
