@@ -1,0 +1,173 @@
+/*
+ * qocx.h - C ABI of the MI355X GRAPE propagation engine (libqocx.so).
+ *
+ * The reference (SchusterLab/qoc) is pure Python and has no FFI; the "interface" this
+ * library replaces is the Python call pair
+ *
+ *     error        = _evaluate_schroedinger_discrete(controls, pstate, reporter)
+ *                                   qoc/core/schroedingerdiscrete.py:356-438
+ *     error, grads = ans_jacobian(_evaluate_schroedinger_discrete, 0)(controls, pstate, reporter)
+ *                                   qoc/core/schroedingerdiscrete.py:318-319
+ *                                   qoc/standard/utils/autogradutil.py:10-31
+ *
+ * i.e. "controls in -> total cost, d cost / d controls and final states out", batched here
+ * over B independent control arrays (seeds).  Each entry point below cites the reference
+ * code whose work it performs.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add at those call sites.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; qocx_last_error() gives the text;
+ *   - the caller owns all host buffers (C-contiguous; complex = interleaved re,im float64);
+ *   - the library owns all device memory inside the opaque context;
+ *   - calls are blocking unless named *_async; one context per (host thread, device);
+ *   - no global mutable state besides the per-thread error string.
+ */
+#ifndef QOCX_H
+#define QOCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qocx_ctx qocx_ctx;
+
+#define QOCX_OK 0
+#define QOCX_ERR_ARG -1       /* invalid argument / unsupported size        */
+#define QOCX_ERR_HIP -2       /* HIP runtime error                          */
+#define QOCX_ERR_STATE -3     /* call sequence error (no problem set, ...)  */
+#define QOCX_ERR_SINGULAR -4  /* Pade denominator numerically singular (numpy.linalg.LinAlgError
+                                 in the reference: expm.py:246)             */
+#define QOCX_ERR_CAPACITY -5  /* squaring sub-step capacity exceeded        */
+#define QOCX_ERR_RCCL -6      /* RCCL error / librccl not loadable          */
+
+/* qoc.models.MagnusPolicy (qoc/models/magnuspolicy.py:8-26) */
+#define QOCX_MAGNUS_M2 2
+#define QOCX_MAGNUS_M4 4
+#define QOCX_MAGNUS_M6 6
+
+/* State-cost kinds evaluated on the device (qoc/standard/costs/). */
+#define QOCX_COST_TARGET_COHERENT 0   /* TargetStateInfidelity[Time], neglect_relative_pahse=False:
+                                         scale * (1 - |sum_s <t_s|psi_s>|^2 / S^2)
+                                         targetstateinfidelity.py:52-56                            */
+#define QOCX_COST_TARGET_INCOHERENT 1 /* ... neglect_relative_pahse=True:
+                                         scale * (1 - sum_s |<t_s|psi_s>|^2 / S)   :58-61          */
+#define QOCX_COST_FORBID 2            /* ForbidStates: scale * sum_s (1/F_s) sum_f |<f_sf|psi_s>|^2
+                                         forbidstates.py:64-81 (scale = multiplier / (E * S))      */
+
+typedef struct qocx_cost_desc {
+    int32_t kind;          /* QOCX_COST_*                                                         */
+    int32_t step_cost;     /* 1: evaluated at system steps j*cost_eval_step, j>=1, before evolving
+                              from that step (schroedingerdiscrete.py:412-416); 0: final states
+                              only (:429-432)                                                      */
+    double scale;          /* cost_multiplier (and 1/cost_eval_count etc.) folded in               */
+    const double* vectors; /* TARGET_*: [S][n] complex target states (NOT conjugated)
+                              FORBID  : [sum_s F_s][n] complex forbidden states, state-major       */
+    const int32_t* counts; /* FORBID: [S] F_s ; TARGET_*: ignored (may be NULL)                    */
+} qocx_cost_desc;
+
+/*
+ * Static data of one Schroedinger problem; mirrors the fields of
+ * GrapeSchroedingerDiscreteState / ProgramState (qoc/models/programstate.py:33-61,
+ * qoc/models/schroedingermodels.py:178-206) that the evolve loop reads.
+ *
+ * The Hamiltonian callable of the reference (schroedingerdiscrete.py:43-46, :485) is passed
+ * in structured form   H(u, t) = h0(t) + sum_k u_k g[k](t),  u real (a complex control is two
+ * real ones), sampled by the host at the quadrature times of the Magnus
+ * policy: nt = 1 (time independent) or nt = (system_eval_count-1) * nodes.
+ */
+typedef struct qocx_schroedinger_problem {
+    int32_t hilbert_size;        /* n, 1..32                                                       */
+    int32_t state_count;         /* S >= 1                                                          */
+    int32_t control_count;       /* K real controls, >= 0                                           */
+    int32_t control_eval_count;  /* Nc (>= 2 when K > 0)                                            */
+    int32_t system_eval_count;   /* N >= 2; N-1 propagator steps                                    */
+    int32_t cost_eval_step;      /* >= 1                                                            */
+    int32_t magnus_policy;       /* QOCX_MAGNUS_M2 (M4/M6: not implemented in the device engine)    */
+    int32_t nt;                  /* number of time samples of h0/g: 1 or (N-1)                      */
+    double evolution_time;       /* T; dt = T/(N-1), control_eval_times = linspace(0,T,Nc)          */
+    const double* h0;            /* [nt][n][n] complex                                              */
+    const double* g;             /* [nt][K][n][n] complex                                           */
+    const double* initial_states;/* [S][n] complex                                                  */
+    int32_t cost_count;
+    const qocx_cost_desc* costs; /* [cost_count]                                                    */
+} qocx_schroedinger_problem;
+
+const char* qocx_last_error(void);
+int qocx_version(void);
+
+/* Device discovery / context. device < 0: use LOCAL_RANK (or 0). */
+int qocx_device_count(int* count);
+int qocx_create(int device, qocx_ctx** out);
+int qocx_destroy(qocx_ctx* ctx);
+int qocx_synchronize(qocx_ctx* ctx);
+
+/* Upload a problem (replaces any previous one). Performs what the construction of
+ * GrapeSchroedingerDiscreteState does for the evolve loop: dt, control_eval_times,
+ * step-cost selection (programstate.py:41-61). */
+int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem* problem);
+
+/*
+ * One batched evaluation == B calls of _evaluate_schroedinger_discrete (+ its reverse-mode
+ * gradient when want_grad != 0), schroedingerdiscrete.py:318-324, :356-438.
+ *   controls      [B][Nc][K] float64 (ignored when K == 0)
+ *   cost_out      [B]
+ *   grad_out      [B][Nc][K] float64   (d cost / d controls; NULL allowed when !want_grad)
+ *   final_out     [B][S][n] complex    (reporter.final_states, :435-436; NULL allowed)
+ * Host buffers in, host buffers out (H2D/D2H inside the call).
+ */
+int qocx_eval_schroedinger(qocx_ctx* ctx, int32_t batch, const double* controls,
+                           int32_t want_grad, double* cost_out, double* grad_out,
+                           double* final_out);
+
+/* Same evaluation split so that inputs can be made resident first (bench.py times this). */
+int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls);
+int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad);
+int qocx_download_results(qocx_ctx* ctx, double* cost_out, double* grad_out, double* final_out);
+
+/* Optional: all system-step states of the last evaluation, [B][N][S][n] complex
+ * (what save_intermediate_states persists, schroedingerdiscrete.py:395-402). */
+int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep); /* before the evaluation */
+int qocx_download_step_states(qocx_ctx* ctx, double* states_out);
+
+/* Per-kernel timing, measured with HIP events on the context's stream.
+ * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`
+ * (0 pade_factor, 1 sweep, 2 krylov_grad, 3 scatter) the launch count and total ms
+ * since the last reset. */
+int qocx_set_timing(qocx_ctx* ctx, int32_t enable);
+int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms);
+int qocx_reset_timing(qocx_ctx* ctx);
+
+/* Seeds-per-chunk used by the pipelined evaluation (0 = auto). */
+int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk);
+
+/*
+ * Multi-GPU: one process per GPU; the seed axis is sharded by the caller, the summed
+ * cost/gradient is one RCCL all-reduce (no reference counterpart: the reference is single
+ * process).  unique_id is ncclUniqueId bytes (128) produced by rank 0.
+ */
+int qocx_comm_unique_id(uint8_t* id128);
+int qocx_comm_init(qocx_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world);
+int qocx_comm_allreduce_sum(qocx_ctx* ctx, double* buf_host, int64_t count);
+int qocx_comm_allreduce_max(qocx_ctx* ctx, double* buf_host, int64_t count);
+int qocx_comm_barrier(qocx_ctx* ctx);
+int qocx_comm_destroy(qocx_ctx* ctx);
+
+/*
+ * Debug / unit-test entry points (used by tests/, not by the host package).
+ *   qocx_debug_pade_factor: K1 on explicit generator matrices a [count][n][n] complex:
+ *     q_out, lu_out [count][n][n] complex (row-major, lu = L\U of the row-permuted P),
+ *     perm_out [count][n], dinv_out [count][n] complex (1/U_kk), s_out [count].
+ *   qocx_debug_selftest: wave-level primitives (DPP reductions, MFMA layout); returns the
+ *     number of failed checks in *failures.
+ */
+int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double* a,
+                           double* q_out, double* lu_out, int32_t* perm_out,
+                           double* dinv_out, int32_t* s_out);
+int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QOCX_H */

@@ -1,0 +1,872 @@
+// qocx_api.hip - host side of the C ABI declared in include/qocx.h: context, device memory,
+// problem upload (what GrapeSchroedingerDiscreteState prepares for the evolve loop,
+// qoc/models/programstate.py:33-61), the batched evaluation driver and the RCCL shim.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/qocx.h"
+#include "qocx_device.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(QOCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t count = 0;
+    int ensure(size_t n) {
+        if (n <= count && p != nullptr) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+        if (n == 0) return 0;
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e != hipSuccess) {
+            g_error = std::string("hipMalloc(") + std::to_string(n * sizeof(T)) +
+                      " bytes): " + hipGetErrorString(e);
+            return QOCX_ERR_HIP;
+        }
+        count = n;
+        return 0;
+    }
+    int upload(const std::vector<T>& v, hipStream_t st) {
+        int rc = ensure(v.size());
+        if (rc) return rc;
+        if (v.empty()) return 0;
+        hipError_t e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(QOCX_ERR_HIP, hipGetErrorString(e));
+        e = hipStreamSynchronize(st);  // v may be a temporary
+        if (e != hipSuccess) return fail(QOCX_ERR_HIP, hipGetErrorString(e));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+};
+
+const double THETA13 = 5.371920351148152;
+
+int pade_scale_count(double norm1) {
+    int s = 0;
+    double th = THETA13;
+    while (norm1 > th && s < 1000) {
+        th *= 2.0;
+        ++s;
+    }
+    return s;
+}
+
+double one_norm(const double* m, int n) {  // complex row-major
+    double best = 0;
+    for (int c = 0; c < n; ++c) {
+        double s = 0;
+        for (int r = 0; r < n; ++r) s += hypot(m[2 * ((size_t)r * n + c)], m[2 * ((size_t)r * n + c) + 1]);
+        best = std::max(best, s);
+    }
+    return best;
+}
+
+struct TimingRec {
+    int which;
+    hipEvent_t a, b;
+};
+
+// RCCL entry points, resolved lazily so that single-GPU use never loads librccl.
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct ncclUniqueIdBytes {
+    char internal[128];
+};
+
+struct qocx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // ---- problem ----
+    bool has_problem = false;
+    int n = 0, nb = 0, np = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nt = 1;
+    double T = 0, dt = 0;
+    int has_step_costs = 0, cost_count = 0;
+    double h0_norm_max = 0;
+    std::vector<double> g_norm_max;
+    DevBuf<double2> h0_cimg, g_cimg, h0_rimg, g_rimg, h0_timg, g_timg, psi0, cost_vectors;
+    DevBuf<qocx::StepInterp> interp;
+    DevBuf<qocx::DevCost> costs;
+    DevBuf<int> cost_counts, row_ptr, col_step;
+    DevBuf<double> weight;
+    // ---- evaluation state ----
+    int B = 0;
+    int sbound = 0;
+    size_t slot_cap = 0;
+    int chunk_user = 0;
+    int keep_step_states = 0;
+    bool have_results = false, have_grads = false, have_step_states = false;
+    DevBuf<double> controls, cost_out, grads, gstep;
+    DevBuf<double2> final_out, step_states;
+    DevBuf<double2> q_img, lu_img, dinv, states, xs;
+    DevBuf<int> perm, s_arr, offs, status;
+    // ---- timing ----
+    int timing = 0;
+    std::vector<TimingRec> pending;
+    int64_t t_launch[4] = {0, 0, 0, 0};
+    double t_ms[4] = {0, 0, 0, 0};
+    // ---- comm ----
+    Rccl rccl;
+    void* comm = nullptr;
+    DevBuf<double> comm_buf;
+};
+
+namespace {
+
+int geo_cpl(int np) { return np * np / 64; }
+
+void c_image(const double* m, int n, int nb, double2* out) {
+    for (int ti = 0; ti < nb; ++ti)
+        for (int tj = 0; tj < nb; ++tj)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, c = lane & 15;
+                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                    double2 e = make_double2(0, 0);
+                    if (row < n && col < n) {
+                        e.x = m[2 * ((size_t)row * n + col)];
+                        e.y = m[2 * ((size_t)row * n + col) + 1];
+                    }
+                    out[((ti * nb + tj) * 4 + r) * 64 + lane] = e;
+                }
+}
+
+void r_image(const double* m, int n, int np, bool transpose, double2* out) {
+    const int cpl = geo_cpl(np);
+    for (int cc = 0; cc < cpl; ++cc)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane % np, h = lane / np;
+            int row = i, col = h * cpl + cc;
+            if (transpose) std::swap(row, col);
+            double2 e = make_double2(0, 0);
+            if (row < n && col < n) {
+                e.x = m[2 * ((size_t)row * n + col)];
+                e.y = m[2 * ((size_t)row * n + col) + 1];
+            }
+            out[cc * 64 + lane] = e;
+        }
+}
+
+void from_r_image(const double2* img, int n, int np, double* out) {  // -> row-major n x n complex
+    const int cpl = geo_cpl(np);
+    for (int cc = 0; cc < cpl; ++cc)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane % np, h = lane / np;
+            const int row = i, col = h * cpl + cc;
+            if (row < n && col < n) {
+                out[2 * ((size_t)row * n + col)] = img[cc * 64 + lane].x;
+                out[2 * ((size_t)row * n + col) + 1] = img[cc * 64 + lane].y;
+            }
+        }
+}
+
+void time_begin(qocx_ctx* ctx, int which) {
+    if (!ctx->timing) return;
+    TimingRec r;
+    r.which = which;
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, ctx->stream);
+    ctx->pending.push_back(r);
+}
+
+void time_end(qocx_ctx* ctx) {
+    if (!ctx->timing) return;
+    (void)hipEventRecord(ctx->pending.back().b, ctx->stream);
+}
+
+void time_collect(qocx_ctx* ctx) {
+    for (auto& r : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->t_ms[r.which] += ms;
+            ctx->t_launch[r.which] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->pending.clear();
+}
+
+int load_rccl(qocx_ctx* ctx) {
+    if (ctx->rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(QOCX_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+    Rccl& r = ctx->rccl;
+    r.lib = lib;
+    *(void**)(&r.GetUniqueId) = dlsym(lib, "ncclGetUniqueId");
+    *(void**)(&r.AllReduce) = dlsym(lib, "ncclAllReduce");
+    *(void**)(&r.CommDestroy) = dlsym(lib, "ncclCommDestroy");
+    *(void**)(&r.GetErrorString) = dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !dlsym(lib, "ncclCommInitRank") || !r.AllReduce || !r.CommDestroy)
+        return fail(QOCX_ERR_RCCL, "librccl lacks the expected nccl* symbols");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qocx_last_error(void) { return g_error.c_str(); }
+
+int qocx_version(void) { return 100; }
+
+int qocx_device_count(int* count) {
+    if (!count) return fail(QOCX_ERR_ARG, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+int qocx_create(int device, qocx_ctx** out) {
+    if (!out) return fail(QOCX_ERR_ARG, "out is NULL");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(QOCX_ERR_HIP, "no HIP device visible");
+    if (device < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) : 0;
+        device %= count;
+    }
+    if (device >= count) return fail(QOCX_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    qocx_ctx* ctx = new qocx_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreate(&ctx->stream);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(QOCX_ERR_HIP, hipGetErrorString(e));
+    }
+    if (ctx->status.ensure(1)) {
+        delete ctx;
+        return QOCX_ERR_HIP;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int qocx_destroy(qocx_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    time_collect(ctx);
+    if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+    DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
+                             &ctx->g_timg, &ctx->psi0, &ctx->cost_vectors, &ctx->final_out,
+                             &ctx->step_states, &ctx->q_img, &ctx->lu_img, &ctx->dinv,
+                             &ctx->states, &ctx->xs};
+    for (auto* b : b2) b->release();
+    DevBuf<double>* b1[] = {&ctx->weight, &ctx->controls, &ctx->cost_out, &ctx->grads, &ctx->gstep,
+                            &ctx->comm_buf};
+    for (auto* b : b1) b->release();
+    DevBuf<int>* bi[] = {&ctx->cost_counts, &ctx->row_ptr, &ctx->col_step, &ctx->perm, &ctx->s_arr,
+                         &ctx->offs, &ctx->status};
+    for (auto* b : bi) b->release();
+    ctx->interp.release();
+    ctx->costs.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int qocx_synchronize(qocx_ctx* ctx) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem* p) {
+    if (!ctx || !p) return fail(QOCX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
+    const int N = p->system_eval_count, nc = p->control_eval_count;
+    if (n < 1 || n > 32)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..32 for the wavefront engine");
+    if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "state_count must be in 1..64");
+    if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
+    if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
+    if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");
+    if (p->cost_eval_step < 1) return fail(QOCX_ERR_ARG, "cost_eval_step must be >= 1");
+    if (p->magnus_policy != QOCX_MAGNUS_M2)
+        return fail(QOCX_ERR_ARG, "only MagnusPolicy.M2 is implemented in the device engine");
+    const int nsteps = N - 1;
+    if (p->nt != 1 && p->nt != nsteps) return fail(QOCX_ERR_ARG, "nt must be 1 or N-1");
+    if (!p->h0 || !p->initial_states || (K > 0 && !p->g))
+        return fail(QOCX_ERR_ARG, "h0 / g / initial_states missing");
+    if (p->cost_count < 0 || (p->cost_count > 0 && !p->costs))
+        return fail(QOCX_ERR_ARG, "costs missing");
+
+    const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np, nt = p->nt;
+    ctx->has_problem = false;
+    ctx->n = n; ctx->nb = nb; ctx->np = np; ctx->S = S; ctx->K = K; ctx->nc = nc; ctx->N = N;
+    ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt;
+    ctx->T = p->evolution_time;
+    ctx->dt = p->evolution_time / (N - 1);  // programstate.py:44
+
+    // Hamiltonian images + norms for the squaring bound
+    std::vector<double2> img((size_t)nt * mat);
+    ctx->h0_norm_max = 0;
+    for (int t = 0; t < nt; ++t) {
+        const double* m = p->h0 + (size_t)t * n * n * 2;
+        ctx->h0_norm_max = std::max(ctx->h0_norm_max, one_norm(m, n));
+        c_image(m, n, nb, img.data() + (size_t)t * mat);
+    }
+    if (ctx->h0_cimg.upload(img, ctx->stream)) return QOCX_ERR_HIP;
+    for (int t = 0; t < nt; ++t) r_image(p->h0 + (size_t)t * n * n * 2, n, np, false, img.data() + (size_t)t * mat);
+    if (ctx->h0_rimg.upload(img, ctx->stream)) return QOCX_ERR_HIP;
+    for (int t = 0; t < nt; ++t) r_image(p->h0 + (size_t)t * n * n * 2, n, np, true, img.data() + (size_t)t * mat);
+    if (ctx->h0_timg.upload(img, ctx->stream)) return QOCX_ERR_HIP;
+    ctx->g_norm_max.assign(K, 0.0);
+    std::vector<double2> gimg((size_t)nt * K * mat);
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int t = 0; t < nt; ++t)
+            for (int k = 0; k < K; ++k) {
+                const double* m = p->g + ((size_t)t * K + k) * n * n * 2;
+                double2* dst = gimg.data() + ((size_t)t * K + k) * mat;
+                if (pass == 0) {
+                    ctx->g_norm_max[k] = std::max(ctx->g_norm_max[k], one_norm(m, n));
+                    c_image(m, n, nb, dst);
+                } else {
+                    r_image(m, n, np, pass == 2, dst);
+                }
+            }
+        DevBuf<double2>& dst = pass == 0 ? ctx->g_cimg : (pass == 1 ? ctx->g_rimg : ctx->g_timg);
+        if (dst.upload(gimg, ctx->stream)) return QOCX_ERR_HIP;
+    }
+
+    // initial states, padded
+    std::vector<double2> psi((size_t)S * np, make_double2(0, 0));
+    for (int s = 0; s < S; ++s)
+        for (int i = 0; i < n; ++i)
+            psi[(size_t)s * np + i] = make_double2(p->initial_states[2 * ((size_t)s * n + i)],
+                                                   p->initial_states[2 * ((size_t)s * n + i) + 1]);
+    if (ctx->psi0.upload(psi, ctx->stream)) return QOCX_ERR_HIP;
+
+    // interpolation table at the M2 quadrature time t_j + dt/2 (mathmethods.py:54-65, :90)
+    std::vector<qocx::StepInterp> interp(nsteps);
+    std::vector<std::vector<std::pair<int, double>>> rows(K > 0 ? nc : 0);
+    if (K > 0) {
+        std::vector<double> xs(nc);
+        const double stepx = p->evolution_time / (nc - 1);  // numpy.linspace
+        for (int i = 0; i < nc; ++i) xs[i] = i * stepx;
+        xs[nc - 1] = p->evolution_time;
+        for (int j = 0; j < nsteps; ++j) {
+            const double time = j * ctx->dt;
+            const double x = time + ctx->dt * 0.5;
+            int i1, i2;
+            if (x <= xs[0]) {
+                i1 = 0; i2 = 1;
+            } else if (x >= xs[nc - 1]) {
+                i1 = nc - 2; i2 = nc - 1;
+            } else {
+                int idx = 0;
+                while (!(x <= xs[idx])) ++idx;
+                i1 = idx - 1; i2 = idx;
+            }
+            interp[j].i1 = i1; interp[j].i2 = i2;
+            interp[j].dx = xs[i2] - xs[i1];
+            interp[j].off = x - xs[i1];
+            const double theta = interp[j].off / interp[j].dx;
+            rows[i1].push_back(std::make_pair(j, 1.0 - theta));
+            rows[i2].push_back(std::make_pair(j, theta));
+        }
+    } else {
+        for (int j = 0; j < nsteps; ++j) interp[j] = qocx::StepInterp{0, 0, 1.0, 0.0};
+    }
+    if (ctx->interp.upload(interp, ctx->stream)) return QOCX_ERR_HIP;
+    std::vector<int> row_ptr(1, 0), col_step;
+    std::vector<double> weight;
+    for (auto& r : rows) {
+        for (auto& e : r) {
+            col_step.push_back(e.first);
+            weight.push_back(e.second);
+        }
+        row_ptr.push_back((int)col_step.size());
+    }
+    if (ctx->row_ptr.upload(row_ptr, ctx->stream)) return QOCX_ERR_HIP;
+    if (ctx->col_step.upload(col_step, ctx->stream)) return QOCX_ERR_HIP;
+    if (ctx->weight.upload(weight, ctx->stream)) return QOCX_ERR_HIP;
+
+    // costs
+    std::vector<qocx::DevCost> dcosts;
+    std::vector<double2> pool;
+    std::vector<int> counts;
+    ctx->has_step_costs = 0;
+    for (int ci = 0; ci < p->cost_count; ++ci) {
+        const qocx_cost_desc& c = p->costs[ci];
+        qocx::DevCost d;
+        d.kind = c.kind;
+        d.step_cost = c.step_cost ? 1 : 0;
+        d.scale = c.scale;
+        d.vec_offset = (int)(pool.size() / np);
+        d.cnt_offset = (int)counts.size();
+        if (!c.vectors) return fail(QOCX_ERR_ARG, "cost vectors missing");
+        int nvec = S;
+        if (c.kind == QOCX_COST_FORBID) {
+            if (!c.counts) return fail(QOCX_ERR_ARG, "forbid counts missing");
+            nvec = 0;
+            for (int s = 0; s < S; ++s) {
+                if (c.counts[s] < 1) return fail(QOCX_ERR_ARG, "forbid count < 1");
+                counts.push_back(c.counts[s]);
+                nvec += c.counts[s];
+            }
+        } else if (c.kind != QOCX_COST_TARGET_COHERENT && c.kind != QOCX_COST_TARGET_INCOHERENT) {
+            return fail(QOCX_ERR_ARG, "unknown cost kind");
+        }
+        for (int v = 0; v < nvec; ++v)
+            for (int i = 0; i < np; ++i) {
+                double2 e = make_double2(0, 0);
+                if (i < n) {
+                    e.x = c.vectors[2 * ((size_t)v * n + i)];
+                    e.y = c.vectors[2 * ((size_t)v * n + i) + 1];
+                }
+                pool.push_back(e);
+            }
+        if (d.step_cost) ctx->has_step_costs = 1;
+        dcosts.push_back(d);
+    }
+    ctx->cost_count = (int)dcosts.size();
+    if (ctx->costs.upload(dcosts, ctx->stream)) return QOCX_ERR_HIP;
+    if (ctx->cost_vectors.upload(pool, ctx->stream)) return QOCX_ERR_HIP;
+    if (ctx->cost_counts.upload(counts, ctx->stream)) return QOCX_ERR_HIP;
+    if (qocx::sweep_lds_bytes(nb, S) > 160 * 1024)
+        return fail(QOCX_ERR_ARG, "state_count too large for the sweep kernel's LDS");
+    ctx->has_problem = true;
+    ctx->have_results = false;
+    ctx->B = 0;
+    return 0;
+}
+
+int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (!ctx->has_problem) return fail(QOCX_ERR_STATE, "no problem set");
+    if (batch < 1) return fail(QOCX_ERR_ARG, "batch must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t per = (size_t)ctx->nc * ctx->K;
+    double bound = ctx->h0_norm_max;
+    if (ctx->K > 0) {
+        if (!controls) return fail(QOCX_ERR_ARG, "controls is NULL");
+        std::vector<double> umax(ctx->K, 0.0);
+        for (size_t e = 0; e < (size_t)batch * per; ++e) {
+            const double a = fabs(controls[e]);
+            const int k = (int)(e % ctx->K);
+            if (!(a <= umax[k])) umax[k] = a;  // also catches NaN
+        }
+        for (int k = 0; k < ctx->K; ++k) bound += umax[k] * ctx->g_norm_max[k];
+        if (ctx->controls.ensure((size_t)batch * per)) return QOCX_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(ctx->controls.p, controls, (size_t)batch * per * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    bound *= fabs(ctx->dt);
+    if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or Hamiltonian");
+    ctx->sbound = pade_scale_count(bound);
+    if (ctx->sbound > 10)
+        return fail(QOCX_ERR_CAPACITY,
+                    "||dt H||_1 bound needs more than 2^10 squaring sub-steps per step; reduce dt");
+    ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
+    ctx->B = batch;
+    ctx->have_results = false;
+    return 0;
+}
+
+int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    ctx->chunk_user = seeds_per_chunk < 0 ? 0 : seeds_per_chunk;
+    return 0;
+}
+
+int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    ctx->keep_step_states = keep ? 1 : 0;
+    return 0;
+}
+
+int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (!ctx->has_problem || ctx->B < 1) return fail(QOCX_ERR_STATE, "no problem / controls");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int B = ctx->B, np = ctx->np, mat = np * np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
+    want_grad = (want_grad && K > 0) ? 1 : 0;
+
+    // chunk size from the memory budget
+    const size_t per_seed = (size_t)nsteps * ((size_t)mat * 32 + (size_t)np * 20 + 4) +
+                            ctx->slot_cap * S * np * 32 + (size_t)(nsteps + 1) * 4 +
+                            (size_t)nsteps * std::max(K, 1) * 8;
+    int chunk = ctx->chunk_user;
+    if (chunk <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t have = ctx->q_img.count * 16 + ctx->lu_img.count * 16 + ctx->states.count * 16 +
+                      ctx->xs.count * 16;
+        size_t budget = (size_t)((double)(free_b + have) * 0.6);
+        chunk = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, budget / per_seed));
+    }
+    chunk = std::min(chunk, B);
+    const size_t cm = (size_t)chunk * nsteps;
+    if (ctx->q_img.ensure(cm * mat) || ctx->lu_img.ensure(cm * mat) || ctx->dinv.ensure(cm * np) ||
+        ctx->perm.ensure(cm * np) || ctx->s_arr.ensure(cm) ||
+        ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
+        ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
+        ctx->offs.ensure((size_t)chunk * (nsteps + 1)) ||
+        ctx->gstep.ensure(cm * std::max(K, 1)) || ctx->cost_out.ensure(B) ||
+        ctx->grads.ensure((size_t)B * ctx->nc * std::max(K, 1)) ||
+        ctx->final_out.ensure((size_t)B * S * np))
+        return QOCX_ERR_HIP;
+    if (ctx->keep_step_states)
+        if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
+
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = std::min(chunk, B - b0);
+        qocx::FactorArgs fa;
+        fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
+        fa.interp = ctx->interp.p;
+        fa.h0_cimg = ctx->h0_cimg.p;
+        fa.g_cimg = ctx->g_cimg.p;
+        fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+        fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p; fa.dinv = ctx->dinv.p;
+        fa.perm = ctx->perm.p; fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
+        time_begin(ctx, 0);
+        qocx::launch_factor(ctx->nb, fa, nsteps, bc, ctx->stream);
+        time_end(ctx);
+
+        qocx::SweepArgs sa;
+        sa.q_img = ctx->q_img.p; sa.lu_img = ctx->lu_img.p; sa.dinv = ctx->dinv.p;
+        sa.perm = ctx->perm.p; sa.s_arr = ctx->s_arr.p; sa.psi0 = ctx->psi0.p;
+        sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
+        sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
+        sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
+        sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
+        sa.states = ctx->states.p; sa.xs = ctx->xs.p; sa.offs = ctx->offs.p;
+        sa.cost_out = ctx->cost_out.p + b0;
+        sa.final_out = ctx->final_out.p + (size_t)b0 * S * np;
+        sa.step_states = ctx->keep_step_states
+                             ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np
+                             : nullptr;
+        sa.status = ctx->status.p;
+        time_begin(ctx, 1);
+        qocx::launch_sweep(ctx->nb, sa, bc, ctx->stream);
+        time_end(ctx);
+
+        if (want_grad) {
+            qocx::KrylovArgs ka;
+            ka.controls = fa.controls; ka.interp = ctx->interp.p;
+            ka.h0_rimg = ctx->h0_rimg.p; ka.h0_timg = ctx->h0_timg.p;
+            ka.g_rimg = ctx->g_rimg.p; ka.g_timg = ctx->g_timg.p;
+            ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
+            ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p; ka.offs = ctx->offs.p;
+            ka.states = ctx->states.p; ka.xs = ctx->xs.p; ka.slot_cap = ctx->slot_cap;
+            ka.gstep = ctx->gstep.p;
+            time_begin(ctx, 2);
+            qocx::launch_krylov(ctx->nb, ka, nsteps, bc, ctx->stream);
+            time_end(ctx);
+
+            qocx::ScatterArgs sc;
+            sc.gstep = ctx->gstep.p; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
+            sc.weight = ctx->weight.p;
+            sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
+            sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
+            time_begin(ctx, 3);
+            qocx::launch_scatter(sc, ctx->stream);
+            time_end(ctx);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    int status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    time_collect(ctx);
+    if (status & 2) return fail(QOCX_ERR_ARG, "non-finite generator norm");
+    if (status & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");
+    if (status & 4) return fail(QOCX_ERR_CAPACITY, "squaring sub-step capacity exceeded");
+    ctx->have_results = true;
+    ctx->have_grads = want_grad != 0;
+    ctx->have_step_states = ctx->keep_step_states != 0;
+    return 0;
+}
+
+int qocx_download_results(qocx_ctx* ctx, double* cost_out, double* grad_out, double* final_out) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (!ctx->have_results) return fail(QOCX_ERR_STATE, "no evaluation results");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int B = ctx->B, np = ctx->np, S = ctx->S, n = ctx->n;
+    if (cost_out)
+        HIP_TRY(hipMemcpyAsync(cost_out, ctx->cost_out.p, (size_t)B * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    if (grad_out) {
+        if (!ctx->have_grads) return fail(QOCX_ERR_STATE, "gradients were not computed");
+        HIP_TRY(hipMemcpyAsync(grad_out, ctx->grads.p, (size_t)B * ctx->nc * ctx->K * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<double2> fin;
+    if (final_out) {
+        fin.resize((size_t)B * S * np);
+        HIP_TRY(hipMemcpyAsync(fin.data(), ctx->final_out.p, fin.size() * sizeof(double2),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (final_out)
+        for (size_t v = 0; v < (size_t)B * S; ++v)
+            for (int i = 0; i < n; ++i) {
+                final_out[2 * (v * n + i)] = fin[v * np + i].x;
+                final_out[2 * (v * n + i) + 1] = fin[v * np + i].y;
+            }
+    return 0;
+}
+
+int qocx_download_step_states(qocx_ctx* ctx, double* states_out) {
+    if (!ctx || !states_out) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->have_results || !ctx->have_step_states)
+        return fail(QOCX_ERR_STATE, "step states were not kept (qocx_set_keep_step_states)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nvec = (size_t)ctx->B * (ctx->nsteps + 1) * ctx->S;
+    std::vector<double2> tmp(nvec * ctx->np);
+    HIP_TRY(hipMemcpy(tmp.data(), ctx->step_states.p, tmp.size() * sizeof(double2),
+                      hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < nvec; ++v)
+        for (int i = 0; i < ctx->n; ++i) {
+            states_out[2 * (v * ctx->n + i)] = tmp[v * ctx->np + i].x;
+            states_out[2 * (v * ctx->n + i) + 1] = tmp[v * ctx->np + i].y;
+        }
+    return 0;
+}
+
+int qocx_eval_schroedinger(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
+                           double* cost_out, double* grad_out, double* final_out) {
+    int rc = qocx_upload_controls(ctx, batch, controls);
+    if (rc) return rc;
+    rc = qocx_eval_resident(ctx, want_grad);
+    if (rc) return rc;
+    return qocx_download_results(ctx, cost_out, (want_grad && ctx->K > 0) ? grad_out : nullptr,
+                                 final_out);
+}
+
+int qocx_set_timing(qocx_ctx* ctx, int32_t enable) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    ctx->timing = enable ? 1 : 0;
+    return 0;
+}
+
+int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms) {
+    if (!ctx || which < 0 || which > 3) return fail(QOCX_ERR_ARG, "bad argument");
+    if (launches) *launches = ctx->t_launch[which];
+    if (total_ms) *total_ms = ctx->t_ms[which];
+    return 0;
+}
+
+int qocx_reset_timing(qocx_ctx* ctx) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    for (int i = 0; i < 4; ++i) {
+        ctx->t_launch[i] = 0;
+        ctx->t_ms[i] = 0;
+    }
+    return 0;
+}
+
+// ---- RCCL --------------------------------------------------------------------------------
+
+int qocx_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(QOCX_ERR_ARG, "id128 is NULL");
+    qocx_ctx tmp;
+    int rc = load_rccl(&tmp);
+    if (rc) return rc;
+    int e = tmp.rccl.GetUniqueId((void*)id128);
+    if (e != 0) return fail(QOCX_ERR_RCCL, "ncclGetUniqueId failed");
+    return 0;
+}
+
+int qocx_comm_init(qocx_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world) {
+    if (!ctx || !id128) return fail(QOCX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = load_rccl(ctx);
+    if (rc) return rc;
+    // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId id (by value), int rank)
+    typedef int (*init_fn)(void**, int, ncclUniqueIdBytes, int);
+    init_fn f = (init_fn)dlsym(ctx->rccl.lib, "ncclCommInitRank");
+    ncclUniqueIdBytes uid;
+    memcpy(uid.internal, id128, 128);
+    int e = f(&ctx->comm, world, uid, rank);
+    if (e != 0)
+        return fail(QOCX_ERR_RCCL, std::string("ncclCommInitRank: ") +
+                                       (ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(e) : "?"));
+    return 0;
+}
+
+static int comm_allreduce(qocx_ctx* ctx, double* buf, int64_t count, int op) {
+    if (!ctx || !buf || count < 1) return fail(QOCX_ERR_ARG, "bad argument");
+    if (!ctx->comm) return fail(QOCX_ERR_STATE, "communicator not initialised");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm_buf.ensure((size_t)count)) return QOCX_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(ctx->comm_buf.p, buf, count * sizeof(double), hipMemcpyHostToDevice,
+                           ctx->stream));
+    // ncclFloat64 = 8 ; ncclSum = 0, ncclMax = 2
+    int e = ctx->rccl.AllReduce(ctx->comm_buf.p, ctx->comm_buf.p, (size_t)count, 8, op, ctx->comm,
+                                ctx->stream);
+    if (e != 0)
+        return fail(QOCX_ERR_RCCL, std::string("ncclAllReduce: ") +
+                                       (ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(e) : "?"));
+    HIP_TRY(hipMemcpyAsync(buf, ctx->comm_buf.p, count * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int qocx_comm_allreduce_sum(qocx_ctx* ctx, double* buf_host, int64_t count) {
+    return comm_allreduce(ctx, buf_host, count, 0);
+}
+
+int qocx_comm_allreduce_max(qocx_ctx* ctx, double* buf_host, int64_t count) {
+    return comm_allreduce(ctx, buf_host, count, 2);
+}
+
+int qocx_comm_barrier(qocx_ctx* ctx) {
+    double one = 1.0;
+    return comm_allreduce(ctx, &one, 1, 0);
+}
+
+int qocx_comm_destroy(qocx_ctx* ctx) {
+    if (!ctx) return 0;
+    if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    return 0;
+}
+
+// ---- debug -------------------------------------------------------------------------------
+
+int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double* a, double* q_out,
+                           double* lu_out, int32_t* perm_out, double* dinv_out, int32_t* s_out) {
+    if (!ctx || !a || count < 1) return fail(QOCX_ERR_ARG, "bad argument");
+    if (n < 1 || n > 32) return fail(QOCX_ERR_ARG, "n must be in 1..32");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np;
+    DevBuf<double2> a_d, q_d, lu_d, dinv_d;
+    DevBuf<int> perm_d, s_d;
+    int rc = a_d.ensure((size_t)count * n * n) | q_d.ensure((size_t)count * mat) |
+             lu_d.ensure((size_t)count * mat) | dinv_d.ensure((size_t)count * np) |
+             perm_d.ensure((size_t)count * np) | s_d.ensure(count);
+    if (rc) return QOCX_ERR_HIP;
+    HIP_TRY(hipMemcpy(a_d.p, a, (size_t)count * n * n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
+    qocx::FactorArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.dinv = dinv_d.p; fa.perm = perm_d.p;
+    fa.s_arr = s_d.p; fa.status = ctx->status.p;
+    qocx::launch_factor_explicit(nb, a_d.p, n, fa, count, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double2> img((size_t)count * mat), dv((size_t)count * np);
+    std::vector<int> pm((size_t)count * np), sv(count);
+    HIP_TRY(hipMemcpy(img.data(), q_d.p, img.size() * 16, hipMemcpyDeviceToHost));
+    if (q_out)
+        for (int m = 0; m < count; ++m) from_r_image(img.data() + (size_t)m * mat, n, np, q_out + (size_t)m * n * n * 2);
+    HIP_TRY(hipMemcpy(img.data(), lu_d.p, img.size() * 16, hipMemcpyDeviceToHost));
+    if (lu_out)
+        for (int m = 0; m < count; ++m) from_r_image(img.data() + (size_t)m * mat, n, np, lu_out + (size_t)m * n * n * 2);
+    HIP_TRY(hipMemcpy(dv.data(), dinv_d.p, dv.size() * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pm.data(), perm_d.p, pm.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
+    for (int m = 0; m < count; ++m)
+        for (int i = 0; i < n; ++i) {
+            if (perm_out) perm_out[(size_t)m * n + i] = pm[(size_t)m * np + i];
+            if (dinv_out) {
+                dinv_out[2 * ((size_t)m * n + i)] = dv[(size_t)m * np + i].x;
+                dinv_out[2 * ((size_t)m * n + i) + 1] = dv[(size_t)m * np + i].y;
+            }
+        }
+    if (s_out) memcpy(s_out, sv.data(), count * sizeof(int));
+    a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); s_d.release();
+    int status = 0;
+    HIP_TRY(hipMemcpy(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (status & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");
+    return 0;
+}
+
+int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len) {
+    if (!ctx || !failures) return fail(QOCX_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<double> out;
+    if (out.ensure(512)) return QOCX_ERR_HIP;
+    qocx::launch_selftest(out.p, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double> h(512);
+    HIP_TRY(hipMemcpy(h.data(), out.p, 512 * sizeof(double), hipMemcpyDeviceToHost));
+    out.release();
+    int bad = 0;
+    std::string rep;
+    double vmax = 0, vsum = 0;
+    std::vector<double> v(64);
+    for (int l = 0; l < 64; ++l) {
+        v[l] = (double)((l * 37) % 64) + 0.25;
+        vmax = std::max(vmax, v[l]);
+        vsum += v[l];
+    }
+    for (int l = 0; l < 64; ++l) {
+        if (h[l] != vmax) { ++bad; rep += "wave_max lane " + std::to_string(l) + "\n"; }
+        if (fabs(h[64 + l] - vsum) > 1e-9) { ++bad; rep += "wave_sum lane " + std::to_string(l) + "\n"; }
+        if (h[384 + l] != v[5]) { ++bad; rep += "readlane lane " + std::to_string(l) + "\n"; }
+        const int mirror = (l & ~15) | (15 - (l & 15));
+        if (h[448 + l] != v[mirror]) { ++bad; rep += "row_mirror lane " + std::to_string(l) + "\n"; }
+        for (int r = 0; r < 4; ++r) {
+            // C[row][col], row = (lane>>4) + 4 r, col = lane & 15 ; A[i][k] = i + 16k, B[k][j] = 100k + j
+            const int row = (l >> 4) + 4 * r, col = l & 15;
+            double ref = 0;
+            for (int k = 0; k < 4; ++k) ref += (double)(row + 16 * k) * (double)(100 * k + col);
+            if (h[128 + l * 4 + r] != ref) {
+                ++bad;
+                if (rep.size() < 2000)
+                    rep += "mfma lane " + std::to_string(l) + " r " + std::to_string(r) + " got " +
+                           std::to_string(h[128 + l * 4 + r]) + " want " + std::to_string(ref) + "\n";
+            }
+        }
+    }
+    *failures = bad;
+    if (report && report_len > 0) {
+        strncpy(report, rep.c_str(), report_len - 1);
+        report[report_len - 1] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

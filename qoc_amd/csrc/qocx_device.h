@@ -1,0 +1,108 @@
+// qocx_device.h - argument blocks shared by the kernels (qocx_kernels.hip) and the host side of
+// the C ABI (qocx_api.hip). Plain structs of device pointers and sizes.
+#ifndef QOCX_DEVICE_H
+#define QOCX_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qocx {
+
+#define QOCX_DEV_COST_COHERENT 0
+#define QOCX_DEV_COST_INCOHERENT 1
+#define QOCX_DEV_COST_FORBID 2
+
+// Linear interpolation of the controls at the quadrature time of one propagator step
+// (qoc/core/mathmethods.py:33, :54-65): u = y[i1] + ((y[i2] - y[i1]) / dx) * off.
+struct StepInterp {
+    int i1, i2;
+    double dx, off;
+};
+
+struct DevCost {
+    int kind;
+    int step_cost;
+    double scale;
+    int vec_offset;  // first vector of this cost in the pooled cost_vectors, in units of vectors
+    int cnt_offset;  // FORBID: first entry in cost_counts
+};
+
+struct FactorArgs {
+    // inputs
+    const double* controls;    // [B][nc][K]
+    const StepInterp* interp;  // [nsteps]
+    const double2* h0_cimg;    // [nt] C-images
+    const double2* g_cimg;     // [nt][K] C-images
+    int K, nc, nsteps, nt;
+    double dt;
+    // outputs, indexed by (b * nsteps + step)
+    double2* q_img;
+    double2* lu_img;
+    double2* dinv;
+    int* perm;
+    int* s_arr;
+    int* status;
+};
+
+struct SweepArgs {
+    const double2* q_img;
+    const double2* lu_img;
+    const double2* dinv;
+    const int* perm;
+    const int* s_arr;
+    const double2* psi0;  // [S][NP]
+    int S, nsteps, cost_eval_step, want_grad, has_step_costs;
+    size_t slot_cap;      // sub-step slots per seed
+    // costs
+    int cost_count;
+    const DevCost* costs;
+    const double2* cost_vectors;  // pooled, padded to NP
+    const int* cost_counts;
+    // outputs
+    double2* states;       // [B][slot_cap][S][NP]  state before sub-step t
+    double2* xs;           // [B][slot_cap][S][NP]  x = P^-H lambda' of sub-step t
+    int* offs;             // [B][nsteps+1] first sub-step slot of each step
+    double* cost_out;      // [B]
+    double2* final_out;    // [B][S][NP]
+    double2* step_states;  // [B][nsteps+1][S][NP] or nullptr
+    int* status;
+};
+
+struct KrylovArgs {
+    const double* controls;
+    const StepInterp* interp;
+    const double2* h0_rimg;  // R-image of h0
+    const double2* h0_timg;  // R-image of h0^T
+    const double2* g_rimg;
+    const double2* g_timg;
+    int K, nc, nsteps, nt, S;
+    double dt;
+    const int* s_arr;
+    const int* offs;
+    const double2* states;
+    const double2* xs;
+    size_t slot_cap;
+    double* gstep;  // [B][nsteps][K]
+};
+
+struct ScatterArgs {
+    const double* gstep;
+    const int* row_ptr;   // [nc+1]
+    const int* col_step;  // [nnz]
+    const double* weight; // [nnz]
+    double* grads;        // [B][nc][K]
+    int B, nc, K, nsteps;
+};
+
+void launch_factor(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+void launch_factor_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
+                            hipStream_t st);
+void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
+int sweep_lds_bytes(int nb, int S);
+void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
+void launch_scatter(const ScatterArgs& a, hipStream_t st);
+void launch_selftest(double* out, hipStream_t st);
+
+}  // namespace qocx
+
+#endif

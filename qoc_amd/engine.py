@@ -1,0 +1,310 @@
+"""
+engine.py - thin ctypes binding of libqocx.so (include/qocx.h): NumPy in, NumPy out.
+
+This is the only way the package reaches the hot path, and there is no CPU fallback: if the
+HIP library is missing or no MI355X is visible, construction fails loudly.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "libqocx.so")
+
+COST_TARGET_COHERENT = 0
+COST_TARGET_INCOHERENT = 1
+COST_FORBID = 2
+
+MAGNUS_CODES = {"M2": 2, "M4": 4, "M6": 6}
+
+ERR_SINGULAR = -4
+
+KERNEL_NAMES = ("pade_factor", "sweep", "krylov_grad", "scatter")
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int_p = ctypes.POINTER(ctypes.c_int32)
+
+
+class QocxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libqocx error {}: {}".format(code, message))
+        self.code = code
+        self.message = message
+
+
+class _CostDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("step_cost", ctypes.c_int32),
+                ("scale", ctypes.c_double), ("vectors", _c_double_p), ("counts", _c_int_p)]
+
+
+class _SchroedingerProblem(ctypes.Structure):
+    _fields_ = [("hilbert_size", ctypes.c_int32), ("state_count", ctypes.c_int32),
+                ("control_count", ctypes.c_int32), ("control_eval_count", ctypes.c_int32),
+                ("system_eval_count", ctypes.c_int32), ("cost_eval_step", ctypes.c_int32),
+                ("magnus_policy", ctypes.c_int32), ("nt", ctypes.c_int32),
+                ("evolution_time", ctypes.c_double), ("h0", _c_double_p), ("g", _c_double_p),
+                ("initial_states", _c_double_p), ("cost_count", ctypes.c_int32),
+                ("costs", ctypes.POINTER(_CostDesc))]
+
+
+# name -> (restype, argtypes); every symbol declared in include/qocx.h
+_VP = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_U8P = ctypes.POINTER(ctypes.c_uint8)
+SIGNATURES = {
+    "qocx_last_error": (ctypes.c_char_p, []),
+    "qocx_version": (ctypes.c_int, []),
+    "qocx_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "qocx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_VP)]),
+    "qocx_destroy": (ctypes.c_int, [_VP]),
+    "qocx_synchronize": (ctypes.c_int, [_VP]),
+    "qocx_set_schroedinger_problem": (ctypes.c_int, [_VP, ctypes.POINTER(_SchroedingerProblem)]),
+    "qocx_eval_schroedinger": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
+                                              _c_double_p, _c_double_p]),
+    "qocx_upload_controls": (ctypes.c_int, [_VP, _I32, _c_double_p]),
+    "qocx_eval_resident": (ctypes.c_int, [_VP, _I32]),
+    "qocx_download_results": (ctypes.c_int, [_VP, _c_double_p, _c_double_p, _c_double_p]),
+    "qocx_set_keep_step_states": (ctypes.c_int, [_VP, _I32]),
+    "qocx_download_step_states": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_set_timing": (ctypes.c_int, [_VP, _I32]),
+    "qocx_get_timing": (ctypes.c_int, [_VP, _I32, ctypes.POINTER(_I64), _c_double_p]),
+    "qocx_reset_timing": (ctypes.c_int, [_VP]),
+    "qocx_set_chunk": (ctypes.c_int, [_VP, _I32]),
+    "qocx_comm_unique_id": (ctypes.c_int, [_U8P]),
+    "qocx_comm_init": (ctypes.c_int, [_VP, _U8P, _I32, _I32]),
+    "qocx_comm_allreduce_sum": (ctypes.c_int, [_VP, _c_double_p, _I64]),
+    "qocx_comm_allreduce_max": (ctypes.c_int, [_VP, _c_double_p, _I64]),
+    "qocx_comm_barrier": (ctypes.c_int, [_VP]),
+    "qocx_comm_destroy": (ctypes.c_int, [_VP]),
+    "qocx_debug_pade_factor": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p, _c_double_p,
+                                              _c_double_p, _c_int_p, _c_double_p, _c_int_p]),
+    "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libqocx.so and bind every declared symbol. Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIBRARY_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "qoc_amd: the HIP engine {} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback.".format(path))
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _dp(array):
+    return array.ctypes.data_as(_c_double_p)
+
+
+def _as_complex(array, shape=None):
+    out = np.ascontiguousarray(array, dtype=np.complex128)
+    if shape is not None:
+        out = out.reshape(shape)
+    return out
+
+
+class Engine(object):
+    """One context on one MI355X."""
+
+    def __init__(self, device=-1):
+        self._lib = load_library()
+        self._ctx = _VP()
+        self._check(self._lib.qocx_create(int(device), ctypes.byref(self._ctx)))
+        self._problem = None
+        self._keepalive = []
+        self.batch = 0
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def _check(self, code):
+        if code != 0:
+            msg = self._lib.qocx_last_error().decode("utf-8", "replace")
+            if code == ERR_SINGULAR:
+                raise np.linalg.LinAlgError(msg)
+            raise QocxError(code, msg)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value is not None:
+            self._lib.qocx_destroy(self._ctx)
+            self._ctx = _VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.qocx_synchronize(self._ctx))
+
+    # -- problem -------------------------------------------------------------------------------
+    def set_schroedinger_problem(self, hilbert_size, state_count, control_count,
+                                 control_eval_count, system_eval_count, evolution_time,
+                                 h0, g, initial_states, costs=(), cost_eval_step=1,
+                                 magnus_policy="M2"):
+        """
+        h0 :: (nt, n, n) complex, g :: (nt, K, n, n) complex, initial_states :: (S, n) complex,
+        costs :: iterable of dicts {kind, step_cost, scale, vectors, counts(optional)}.
+        """
+        n, S, K = int(hilbert_size), int(state_count), int(control_count)
+        h0 = _as_complex(h0)
+        if h0.ndim == 2:
+            h0 = h0[None]
+        nt = h0.shape[0]
+        h0 = _as_complex(h0, (nt, n, n))
+        g = _as_complex(g if K > 0 else np.zeros((nt, 0, n, n)), (nt, K, n, n))
+        psi = _as_complex(initial_states, (S, n))
+        keep = [h0, g, psi]
+        descs = (_CostDesc * max(1, len(costs)))()
+        for i, c in enumerate(costs):
+            vec = _as_complex(c["vectors"])
+            vec = vec.reshape(-1, n)
+            keep.append(vec)
+            descs[i].kind = int(c["kind"])
+            descs[i].step_cost = int(bool(c["step_cost"]))
+            descs[i].scale = float(c["scale"])
+            descs[i].vectors = _dp(vec)
+            if c.get("counts") is not None:
+                cnt = np.ascontiguousarray(c["counts"], dtype=np.int32)
+                keep.append(cnt)
+                descs[i].counts = cnt.ctypes.data_as(_c_int_p)
+        p = _SchroedingerProblem()
+        p.hilbert_size, p.state_count, p.control_count = n, S, K
+        p.control_eval_count, p.system_eval_count = int(control_eval_count), int(system_eval_count)
+        p.cost_eval_step = int(cost_eval_step)
+        p.magnus_policy = MAGNUS_CODES[magnus_policy]
+        p.nt = nt
+        p.evolution_time = float(evolution_time)
+        p.h0, p.g, p.initial_states = _dp(h0), _dp(g), _dp(psi)
+        p.cost_count = len(costs)
+        p.costs = descs
+        self._check(self._lib.qocx_set_schroedinger_problem(self._ctx, ctypes.byref(p)))
+        self._problem = dict(n=n, S=S, K=K, Nc=int(control_eval_count), N=int(system_eval_count))
+        self.batch = 0
+
+    # -- evaluation ----------------------------------------------------------------------------
+    def upload_controls(self, controls):
+        pr = self._problem
+        if pr["K"] > 0:
+            controls = np.ascontiguousarray(controls, dtype=np.float64)
+            controls = controls.reshape(-1, pr["Nc"], pr["K"])
+            batch = controls.shape[0]
+            self._check(self._lib.qocx_upload_controls(self._ctx, batch, _dp(controls)))
+        else:
+            batch = 1 if controls is None else int(controls)
+            self._check(self._lib.qocx_upload_controls(self._ctx, batch, None))
+        self.batch = batch
+
+    def eval_resident(self, want_grad=True):
+        self._check(self._lib.qocx_eval_resident(self._ctx, int(bool(want_grad))))
+
+    def download_results(self, want_grad=True, want_final=True):
+        pr, B = self._problem, self.batch
+        cost = np.empty(B, dtype=np.float64)
+        want_grad = want_grad and pr["K"] > 0
+        grads = np.empty((B, pr["Nc"], pr["K"]), dtype=np.float64) if want_grad else None
+        final = np.empty((B, pr["S"], pr["n"]), dtype=np.complex128) if want_final else None
+        self._check(self._lib.qocx_download_results(
+            self._ctx, _dp(cost), _dp(grads) if want_grad else None,
+            _dp(final) if want_final else None))
+        return cost, grads, final
+
+    def evaluate(self, controls, want_grad=True):
+        """(cost[B], grads[B,Nc,K] or None, final_states[B,S,n]) for controls[B,Nc,K]."""
+        self.upload_controls(controls)
+        self.eval_resident(want_grad)
+        return self.download_results(want_grad)
+
+    def set_keep_step_states(self, keep):
+        self._check(self._lib.qocx_set_keep_step_states(self._ctx, int(bool(keep))))
+
+    def download_step_states(self):
+        pr, B = self._problem, self.batch
+        out = np.empty((B, pr["N"], pr["S"], pr["n"]), dtype=np.complex128)
+        self._check(self._lib.qocx_download_step_states(self._ctx, _dp(out)))
+        return out
+
+    def set_chunk(self, seeds_per_chunk):
+        self._check(self._lib.qocx_set_chunk(self._ctx, int(seeds_per_chunk)))
+
+    # -- timing --------------------------------------------------------------------------------
+    def set_timing(self, enable):
+        self._check(self._lib.qocx_set_timing(self._ctx, int(bool(enable))))
+
+    def reset_timing(self):
+        self._check(self._lib.qocx_reset_timing(self._ctx))
+
+    def timing(self):
+        out = {}
+        for which, name in enumerate(KERNEL_NAMES):
+            launches, ms = _I64(0), ctypes.c_double(0)
+            self._check(self._lib.qocx_get_timing(self._ctx, which, ctypes.byref(launches),
+                                                  ctypes.byref(ms)))
+            out[name] = (launches.value, ms.value)
+        return out
+
+    # -- RCCL ----------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = (ctypes.c_uint8 * 128)()
+        code = lib.qocx_comm_unique_id(buf)
+        if code != 0:
+            raise QocxError(code, lib.qocx_last_error().decode("utf-8", "replace"))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.qocx_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def comm_allreduce_sum(self, array):
+        array = np.ascontiguousarray(array, dtype=np.float64)
+        self._check(self._lib.qocx_comm_allreduce_sum(self._ctx, _dp(array), array.size))
+        return array
+
+    def comm_allreduce_max(self, array):
+        array = np.ascontiguousarray(array, dtype=np.float64)
+        self._check(self._lib.qocx_comm_allreduce_max(self._ctx, _dp(array), array.size))
+        return array
+
+    def comm_barrier(self):
+        self._check(self._lib.qocx_comm_barrier(self._ctx))
+
+    def comm_destroy(self):
+        self._check(self._lib.qocx_comm_destroy(self._ctx))
+
+    # -- debug ---------------------------------------------------------------------------------
+    def debug_pade_factor(self, a):
+        a = _as_complex(a)
+        if a.ndim == 2:
+            a = a[None]
+        count, n = a.shape[0], a.shape[1]
+        q = np.empty((count, n, n), dtype=np.complex128)
+        lu = np.empty((count, n, n), dtype=np.complex128)
+        perm = np.empty((count, n), dtype=np.int32)
+        dinv = np.empty((count, n), dtype=np.complex128)
+        s = np.empty(count, dtype=np.int32)
+        self._check(self._lib.qocx_debug_pade_factor(
+            self._ctx, count, n, _dp(a), _dp(q), _dp(lu), perm.ctypes.data_as(_c_int_p),
+            _dp(dinv), s.ctypes.data_as(_c_int_p)))
+        return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s)
+
+    def selftest(self):
+        failures = ctypes.c_int32(0)
+        report = ctypes.create_string_buffer(4096)
+        self._check(self._lib.qocx_debug_selftest(self._ctx, ctypes.byref(failures), report, 4096))
+        return failures.value, report.value.decode("utf-8", "replace")

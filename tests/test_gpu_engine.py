@@ -1,0 +1,108 @@
+"""
+GPU parity tests (-m gpu): the HIP engine, through the C ABI, against the oracle's golden
+vectors (minted from the reference) and against the NumPy model of the device algorithm.
+Tolerances: states and cost 1e-10 relative, gradients 1e-8 relative.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import qoc_numpy as onp
+from tests import cases as cases_mod
+from tests import device_model as dm
+from tests.helpers import golden, oracle_costs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+M2_CASES = [c.name for c in cases_mod.all_cases() if c.magnus == "M2" and c.controls is not None]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from qoc_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_wave_primitives(engine):
+    failures, report = engine.selftest()
+    assert failures == 0, report
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 17, 32])
+def test_pade_factor_kernel(engine, n):
+    rng = np.random.default_rng(100 + n)
+    mats = []
+    for scale, skew in [(0.3, True), (2.0, True), (5.2, True), (5.5, True), (30.0, True),
+                        (1.0, False), (11.0, False), (300.0, False)]:
+        g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        a = -1j * (g + g.conj().T) / 2 if skew else g
+        mats.append(a * (scale / onp.one_norm(a)))
+    mats = np.stack(mats)
+    out = engine.debug_pade_factor(mats)
+    for m, a in enumerate(mats):
+        f = dm.pade_factor(a)
+        assert out["s"][m] == f["s"]
+        assert rel_err(out["q"][m], f["q"]) < 1e-12
+        assert np.array_equal(out["perm"][m], f["perm"])
+        assert rel_err(out["lu"][m], f["lu"]) < 1e-11
+        assert rel_err(out["dinv"][m], 1.0 / np.diag(f["lu"])) < 1e-11
+        # and the propagator itself against expm_pade (reference restatement)
+        u = dm.solve_lu(out["lu"][m], out["perm"][m], out["q"][m])
+        for _ in range(int(out["s"][m])):
+            u = u @ u
+        assert rel_err(u, onp.expm_pade(a)) < 1e-10
+
+
+@pytest.mark.parametrize("name", M2_CASES)
+def test_engine_matches_golden(engine, name):
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    host_specs = gh.setup_engine(engine, case)
+    cost, grads, final = engine.evaluate(gh.real_controls(case, case.controls), want_grad=True)
+    grads = gh.complex_grads(case, grads)
+    host_costs = [getattr(onp, k)(**kw) for k, kw in host_specs]
+    for b in range(len(case.controls)):
+        err = cost[b]
+        gb = grads[b].astype(np.complex128)
+        for c in host_costs:
+            err = err + c.cost(case.controls[b], None, case.N - 1)
+            gb = gb + c.controls_bar(case.controls[b], None, case.N - 1)
+        assert abs(err - g["error"][b]) <= 1e-10 * max(1.0, abs(g["error"][b])), (b, err)
+        assert rel_err(final[b][:, :, None], g["final_states"][b]) < 1e-10
+        assert rel_err(gb, g["grads_ad"][b]) < 1e-8
+        scale = np.max(np.abs(g["grads_ad"][b]))
+        assert np.max(np.abs(gb.flat[g["fd_index"][b]] - g["grads_fd"][b])) / scale < 1e-7
+
+
+def test_forward_only_and_iswap(engine):
+    case = cases_mod.case_iswap("M2")
+    from tests import gpu_helpers as gh
+    gh.setup_engine(engine, case)
+    engine.set_keep_step_states(True)
+    engine.upload_controls(1)
+    engine.eval_resident(False)
+    cost, _, final = engine.download_results(want_grad=False)
+    steps = engine.download_step_states()
+    engine.set_keep_step_states(False)
+    g = golden(case.name)
+    assert rel_err(final[0][:, :, None], g["final_states"][0]) < 1e-10
+    target = np.array(((1, 0, 0, 0), (0, 0, -1j, 0), (0, -1j, 0, 0), (0, 0, 0, 1)))
+    assert np.allclose(final[0].T, target)
+    assert np.allclose(steps[0, 0].T, np.eye(4))
+    assert rel_err(steps[0, -1], final[0]) == 0
+
+
+def test_chunked_equals_unchunked(engine):
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_by_name("nc10_n101")
+    gh.setup_engine(engine, case)
+    u = np.concatenate([case.controls, case.controls * 0.5, -case.controls])
+    ref = engine.evaluate(u, True)
+    engine.set_chunk(2)
+    out = engine.evaluate(u, True)
+    engine.set_chunk(0)
+    for a, b in zip(ref, out):
+        assert np.array_equal(a, b)
