@@ -1,0 +1,185 @@
+"""
+bench.py - propagator-steps/sec (fwd+grad) of the GRAPE hot path on MI355X.
+
+Workload (BASELINE.json configs[2]): dim=32 Schroedinger, 1000 propagator steps,
+256 random control seeds PER GPU (weak scaling), K=2 real controls, S=1 state,
+TargetStateInfidelity cost; synthetic GUE-like H0 and G_k of unit 2-norm, dt = 0.05,
+controls ~ N(0, 0.1^2), all seeded.
+
+One "step" = one evaluation (cost, d cost / d controls, final states) of every seed of every
+rank, controls resident in HBM when the clock starts. With --gpus N > 1 the driver launches
+one process per GPU (torchrun env); the seed axis is sharded and each step ends with the
+path's single RCCL all-reduce of [sum cost, sum gradient].
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DIM, N_EVAL, SEEDS_PER_GPU, K_CTRL, DT = 32, 1001, 256, 2, 0.05
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (spec; SURVEY.md 8d / BASELINE.md 3)
+
+
+def gue(rng, n):
+    g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h = (g + g.conj().T) / 2
+    return h / np.linalg.norm(h, 2)
+
+
+def make_problem():
+    rng = np.random.default_rng(2003)
+    h0 = gue(rng, DIM)
+    g = [gue(rng, DIM) for _ in range(K_CTRL)]
+    psi0 = np.eye(DIM, dtype=np.complex128)[:1]
+    target = np.eye(DIM, dtype=np.complex128)[1:2]
+    return h0, g, psi0, target
+
+
+def make_controls(first_seed, count):
+    out = np.empty((count, N_EVAL, K_CTRL))
+    for b in range(count):
+        out[b] = 0.1 * np.random.default_rng(1000 + first_seed + b).standard_normal((N_EVAL, K_CTRL))
+    return out
+
+
+# ---- CPU baseline: the oracle (NumPy restatement of the reference + hand adjoint) ----------
+
+def _cpu_worker(seed_ids):
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(1)
+    except Exception:  # pragma: no cover
+        limiter = None
+    from oracle import qoc_numpy as onp
+    h0, g, psi0, target = make_problem()
+    problem = onp.SchroedingerProblem(
+        DT * (N_EVAL - 1), lambda u, t: h0 + u[0] * g[0] + u[1] * g[1], psi0[:, :, None], N_EVAL,
+        control_eval_count=N_EVAL, costs=[onp.TargetStateInfidelity(target[:, :, None])],
+        control_count=K_CTRL)
+    t0 = time.perf_counter()
+    for sid in seed_ids:
+        onp.evaluate_with_grad(problem, make_controls(sid, 1)[0])
+    del limiter
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(seeds_per_worker=2):
+    """Oracle fwd+grad on a bounded sample: `cores` worker processes x seeds_per_worker seeds."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    jobs = [[w * seeds_per_worker + i for i in range(seeds_per_worker)] for w in range(cores)]
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    steps = cores * seeds_per_worker * (N_EVAL - 1)
+    return dict(value=steps / wall, unit="propagator-steps/s", cores=cores, kind="port",
+                sample="{} seeds x {} steps (oracle/qoc_numpy.py fwd+grad, {} processes, "
+                       "1 BLAS thread each, {:.1f}s wall incl. process start)".format(
+                           cores * seeds_per_worker, N_EVAL - 1, cores, wall))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seeds-per-gpu", type=int, default=SEEDS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from qoc_amd.engine import Engine, COST_TARGET_COHERENT
+    from qoc_amd import parallel
+
+    rank, world, local_rank = parallel.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node {}".format(args.gpus))
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    seeds = args.seeds_per_gpu
+
+    engine = Engine(local_rank)
+    comm = parallel.RcclComm(engine, rank, world) if world > 1 else parallel.SingleComm()
+    h0, g, psi0, target = make_problem()
+    engine.set_schroedinger_problem(
+        DIM, 1, K_CTRL, N_EVAL, N_EVAL, DT * (N_EVAL - 1), h0[None], np.stack(g)[None], psi0,
+        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+    controls = make_controls(rank * seeds, seeds)
+    engine.upload_controls(controls)  # resident in HBM before the clock starts
+
+    def one_step():
+        engine.eval_resident(True)
+        cost, grads, _ = engine.download_results(want_grad=True, want_final=False)
+        return parallel.summed_cost_and_gradient(cost, grads, comm)
+
+    for _ in range(args.warmup):
+        one_step()
+    engine.set_timing(True)
+    engine.reset_timing()
+    comm.barrier()
+    engine.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total_cost, total_grad = one_step()
+    engine.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
+    timing = engine.timing()
+    engine.set_timing(False)
+
+    units_per_step = world * seeds * (N_EVAL - 1)
+    value = units_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (pade_factor): algorithmic flops = Pade chain 6 n^3 +
+    # LU n^3/3 complex MACs per propagator step, 8 real flops each.
+    launches, total_ms = timing["pade_factor"]
+    k1_flops_per_unit = 8.0 * (6.0 + 1.0 / 3.0) * DIM ** 3
+    roofline = None
+    if launches > 0 and total_ms > 0:
+        avg_s = total_ms / launches * 1e-3
+        units_per_launch = seeds * (N_EVAL - 1) * args.steps / launches
+        achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
+        roofline = dict(bound="mfma", kernel="pade_factor_kernel<2>", achieved=achieved,
+                        peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                        avg_launch_ms=total_ms / launches)
+    kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}
+    path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
+    path_tflops = path_flops_per_unit * units_per_step * args.steps / elapsed / 1e12 / world
+
+    line = {
+        "metric": "propagator-steps/sec (fwd+grad), dim=32 Schroedinger, 1000 steps x 256 seeds",
+        "value": value, "unit": "propagator-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "configs[2]: dim=32 Schroedinger, 1000 propagator steps, "
+                               "{} seeds per GPU, K=2 real controls, S=1, M2".format(seeds),
+                   "seeds_per_gpu": seeds, "hilbert_size": DIM, "system_eval_count": N_EVAL,
+                   "parallelism": "seed-sharded x{}".format(world)},
+        "roofline": roofline,
+        "kernel_ms_per_launch": kernel_ms,
+        "path_algorithmic_tflops_per_gpu": path_tflops,
+        "check": {"sum_cost": total_cost, "grad_l2": float(np.linalg.norm(total_grad))},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    engine.close()
+
+
+if __name__ == "__main__":
+    main()
