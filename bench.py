@@ -73,7 +73,7 @@ def _cpu_worker(seed_ids):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(seeds_per_worker=2):
+def cpu_baseline(seeds_per_worker=4):
     """Oracle fwd+grad on a bounded sample: `cores` worker processes x seeds_per_worker seeds."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
