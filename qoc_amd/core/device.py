@@ -1,0 +1,149 @@
+"""
+device.py - the bridge between the reference-shaped host API and the HIP engine.
+
+`SchroedingerEvaluator` plays the role of `_evaluate_schroedinger_discrete` and of
+`ans_jacobian(_evaluate_schroedinger_discrete, 0)` (qoc/core/schroedingerdiscrete.py:318-319,
+:356-438): given controls it returns the total error, its gradient and the final states - for
+one control array or for a batch of independent seeds - by ONE call into libqocx.
+"""
+
+import numpy as np
+
+from qoc_amd.core import structure
+from qoc_amd.models.policies import InterpolationPolicy, MagnusPolicy
+
+_backend_factory = None
+
+
+def set_backend_factory(factory):
+    """Test hook: replace the engine constructor (tests inject the CPU oracle here)."""
+    global _backend_factory
+    _backend_factory = factory
+
+
+def make_backend(device=-1):
+    if _backend_factory is not None:
+        return _backend_factory()
+    from qoc_amd.engine import Engine  # raises loudly when libqocx.so / the GPU is missing
+    return Engine(device)
+
+
+class SchroedingerEvaluator(object):
+    def __init__(self, evolution_time, hamiltonian, initial_states, system_eval_count,
+                 control_count=0, control_eval_count=0, complex_controls=False, costs=(),
+                 cost_eval_step=1, interpolation_policy=InterpolationPolicy.LINEAR,
+                 magnus_policy=MagnusPolicy.M2, need_gradients=True, backend=None):
+        if interpolation_policy != InterpolationPolicy.LINEAR:
+            raise NotImplementedError("The interpolation policy {} is not yet supported for this "
+                                      "method.".format(interpolation_policy))
+        if not isinstance(magnus_policy, MagnusPolicy):
+            raise ValueError("Unrecognized magnus policy {}.".format(magnus_policy))
+        if magnus_policy != MagnusPolicy.M2:
+            raise NotImplementedError(
+                "{} is not implemented in the MI355X engine yet (only MagnusPolicy.M2); "
+                "there is no CPU fallback.".format(magnus_policy))
+        initial_states = np.asarray(initial_states)
+        self.state_count = initial_states.shape[0]
+        self.hilbert_size = initial_states.shape[1]
+        self.control_count = control_count
+        self.control_eval_count = control_eval_count
+        self.complex_controls = complex_controls
+        self.system_eval_count = system_eval_count
+        self.final_system_eval_step = system_eval_count - 1
+        self.costs = list(costs)
+        dt = evolution_time / (system_eval_count - 1)
+        times = [step * dt + dt * 0.5 for step in range(system_eval_count - 1)]
+        h0, g = structure.probe_hamiltonian(hamiltonian, self.hilbert_size, control_count,
+                                            complex_controls, times)
+        self.device_costs, self.host_costs, self.opaque_costs = [], [], []
+        descriptors = []
+        for cost in self.costs:
+            desc = cost.device_descriptor(self.state_count, self.hilbert_size) \
+                if hasattr(cost, "device_descriptor") else None
+            if desc is not None:
+                self.device_costs.append(cost)
+                descriptors.append(desc)
+            elif (getattr(cost, "uses_states", True) is False
+                  and not cost.requires_step_evaluation):
+                self.host_costs.append(cost)
+            else:
+                self.opaque_costs.append(cost)
+        if need_gradients:
+            for cost in self.opaque_costs:
+                raise NotImplementedError(
+                    "cost {} provides neither device_descriptor() nor a controls-only "
+                    "controls_bar(): the reference differentiates it with autograd, which this "
+                    "engine replaces by hand-derived adjoints (see qoc_amd.models.Cost)."
+                    "".format(cost))
+        self.backend = backend if backend is not None else make_backend()
+        self.kr = control_count * (2 if complex_controls else 1)
+        self.backend.set_schroedinger_problem(
+            self.hilbert_size, self.state_count, self.kr, control_eval_count, system_eval_count,
+            evolution_time, h0, g, initial_states.reshape(self.state_count, self.hilbert_size),
+            costs=descriptors, cost_eval_step=cost_eval_step, magnus_policy=magnus_policy.short)
+        self.cost_eval_step = cost_eval_step
+
+    def _host_terms(self, controls, want_grad):
+        value, grad = 0.0, None
+        for cost in self.host_costs:
+            value = value + cost.cost(controls, None, self.final_system_eval_step)
+            if want_grad:
+                bar = cost.controls_bar(controls, None, self.final_system_eval_step)
+                if bar is None:
+                    raise NotImplementedError("cost {} has no controls_bar()".format(cost))
+                grad = bar if grad is None else grad + bar
+        return value, grad
+
+    def evaluate_batch(self, controls_batch, want_grad=True, want_step_states=False):
+        """
+        controls_batch :: (B x Nc x K) (or None / an int B when control_count == 0).
+        Returns (errors[B], grads[B x Nc x K] or None, final_states[B x S x n x 1], step_states).
+        """
+        if self.control_count == 0:
+            batch = 1 if controls_batch is None else int(controls_batch)
+            want_grad = False
+            device_controls = batch
+        else:
+            controls_batch = np.asarray(controls_batch)
+            batch = controls_batch.shape[0]
+            device_controls = structure.to_real_controls(controls_batch, self.complex_controls)
+        need_steps = want_step_states or bool(self.opaque_costs)
+        if need_steps:
+            self.backend.set_keep_step_states(True)
+        self.backend.upload_controls(device_controls)
+        self.backend.eval_resident(want_grad)
+        cost, grads, final = self.backend.download_results(want_grad=want_grad)
+        step_states = None
+        if need_steps:
+            step_states = self.backend.download_step_states()[..., None]
+            self.backend.set_keep_step_states(False)
+        errors = np.array(cost, dtype=np.float64)
+        final = final[..., None]
+        if grads is not None:
+            grads = structure.from_real_gradients(grads, self.complex_controls)
+            if not self.complex_controls:
+                grads = np.array(grads, dtype=np.float64)
+        for b in range(batch):
+            controls = None if self.control_count == 0 else controls_batch[b]
+            value, host_grad = self._host_terms(controls, want_grad)
+            errors[b] += value
+            if host_grad is not None:
+                grads[b] = grads[b] + host_grad
+            for cost in self.opaque_costs:  # forward only: host evaluates the user's cost()
+                errors[b] += self._opaque_value(cost, controls, step_states[b])
+        return errors, grads, final, step_states
+
+    def _opaque_value(self, cost, controls, states_by_step):
+        if not cost.requires_step_evaluation:
+            return cost.cost(controls, states_by_step[-1], self.final_system_eval_step)
+        total = 0.0
+        for step in range(self.cost_eval_step, self.system_eval_count, self.cost_eval_step):
+            total = total + cost.cost(controls, states_by_step[step], step)
+        return total
+
+    def evaluate(self, controls, want_grad=True, want_step_states=False):
+        """Single control array, the reference's calling convention."""
+        batch = None if controls is None else np.asarray(controls)[None]
+        errors, grads, final, steps = self.evaluate_batch(batch, want_grad, want_step_states)
+        return (float(errors[0]), None if grads is None else grads[0], final[0],
+                None if steps is None else steps[0])

@@ -1,0 +1,93 @@
+"""
+structure.py - turn the user's Hamiltonian callable into the structured form the device needs.
+
+The reference calls `hamiltonian(controls, time)` (arbitrary autograd-traceable Python) inside
+its time loop (qoc/core/schroedingerdiscrete.py:483-486). A GPU kernel cannot call Python, so
+the host samples the callable once per problem at every quadrature time and extracts
+
+    H(u, t) = H0(t) + sum_k Re(u_k) G_k(t) + Im(u_k) G'_k(t)
+
+by probing u = 0, e_k, i e_k, then VERIFIES real-linearity at a random control value. Every
+Hamiltonian in the reference's examples and tests has this form (examples/0_transmon_pi.py:24-26,
+tests/test_core.py:529-531, :582). A callable that fails the check is rejected loudly - there is
+no CPU fallback.
+"""
+
+import numpy as np
+
+
+class NonLinearHamiltonianError(ValueError):
+    pass
+
+
+def probe_hamiltonian(hamiltonian, hilbert_size, control_count, complex_controls, times,
+                      rtol=1e-9):
+    """
+    Returns (h0, g): h0 :: (nt, n, n), g :: (nt, Kr, n, n) with Kr = K (real controls) or 2K
+    (complex: [Re_0, Im_0, Re_1, Im_1, ...]); nt == 1 when nothing depends on time.
+    """
+    n, k = hilbert_size, control_count
+    kr = k * (2 if complex_controls else 1)
+    dtype = np.complex128 if complex_controls else np.float64
+    rng = np.random.default_rng(12345)
+    h0 = np.empty((len(times), n, n), dtype=np.complex128)
+    g = np.empty((len(times), kr, n, n), dtype=np.complex128)
+    for ti, t in enumerate(times):
+        if k == 0:
+            h0[ti] = np.asarray(hamiltonian(None, t), dtype=np.complex128)
+            continue
+        zero = np.zeros(k, dtype=dtype)
+        base = np.asarray(hamiltonian(zero, t), dtype=np.complex128)
+        if base.shape != (n, n):
+            raise ValueError("hamiltonian returned shape {}, expected {}".format(base.shape, (n, n)))
+        h0[ti] = base
+        for j in range(k):
+            unit = zero.copy()
+            unit[j] = 1
+            slope = np.asarray(hamiltonian(unit, t), dtype=np.complex128) - base
+            if complex_controls:
+                g[ti, 2 * j] = slope
+                unit = zero.copy()
+                unit[j] = 1j
+                g[ti, 2 * j + 1] = np.asarray(hamiltonian(unit, t), dtype=np.complex128) - base
+            else:
+                g[ti, j] = slope
+        # real-linearity check at a random point
+        u = rng.standard_normal(k)
+        if complex_controls:
+            u = u + 1j * rng.standard_normal(k)
+        direct = np.asarray(hamiltonian(u.astype(dtype), t), dtype=np.complex128)
+        model = base.copy()
+        for j in range(k):
+            if complex_controls:
+                model = model + u[j].real * g[ti, 2 * j] + u[j].imag * g[ti, 2 * j + 1]
+            else:
+                model = model + u[j] * g[ti, j]
+        scale = max(1.0, float(np.max(np.abs(direct))))
+        if np.max(np.abs(direct - model)) > rtol * scale:
+            raise NonLinearHamiltonianError(
+                "hamiltonian(controls, time) is not real-linear in the controls at time {}: the "
+                "MI355X engine needs H = H0(t) + sum_k Re(u_k) G_k(t) + Im(u_k) G'_k(t) "
+                "(deviation {:.3e}). There is no CPU fallback.".format(
+                    t, float(np.max(np.abs(direct - model)))))
+    if len(times) > 1 and np.all(h0 == h0[0]) and np.all(g == g[0]):
+        h0, g = h0[:1], g[:1]
+    return h0, g
+
+
+def to_real_controls(controls, complex_controls):
+    """(..., K) controls -> (..., Kr) float64 in the device ordering."""
+    controls = np.asarray(controls)
+    if not complex_controls:
+        return np.ascontiguousarray(controls, dtype=np.float64)
+    out = np.empty(controls.shape[:-1] + (2 * controls.shape[-1],), dtype=np.float64)
+    out[..., 0::2] = controls.real
+    out[..., 1::2] = controls.imag
+    return out
+
+
+def from_real_gradients(grads, complex_controls):
+    """Inverse mapping for gradients: qoc's convention d/dRe + i d/dIm for complex controls."""
+    if not complex_controls:
+        return grads
+    return grads[..., 0::2] + 1j * grads[..., 1::2]

@@ -1,0 +1,126 @@
+"""
+oracle_backend.py - TEST INFRASTRUCTURE: an object with the Engine's method surface whose
+arithmetic is the CPU oracle. Injected through qoc_amd.core.device.set_backend_factory so that
+the host logic (entry points, structure extraction, control layouts, optimizers, bookkeeping)
+can be tested without a GPU. Never shipped, never selected by the product.
+"""
+
+import numpy as np
+
+from oracle import qoc_numpy as onp
+
+
+class _DescriptorCost(onp.OracleCost):
+    """Oracle-side evaluation of a device cost descriptor (include/qocx.h qocx_cost_desc)."""
+
+    def __init__(self, desc, state_count, n):
+        super().__init__(1.0)
+        self.kind = desc["kind"]
+        self.requires_step_evaluation = bool(desc["step_cost"])
+        self.scale = desc["scale"]
+        vec = np.asarray(desc["vectors"], dtype=np.complex128).reshape(-1, n)
+        self.S = state_count
+        if self.kind == 2:
+            counts = list(desc["counts"])
+            self.sets, base = [], 0
+            for c in counts:
+                self.sets.append(vec[base:base + c])
+                base += c
+        else:
+            self.targets = vec
+
+    def cost(self, controls, states, step):
+        psi = np.asarray(states)[:, :, 0]
+        if self.kind == 0:
+            tot = np.sum(np.sum(np.conj(self.targets) * psi, axis=1))
+            return self.scale * (1 - np.abs(tot) ** 2 / self.S ** 2)
+        if self.kind == 1:
+            ip = np.sum(np.conj(self.targets) * psi, axis=1)
+            return self.scale * (1 - np.sum(np.abs(ip) ** 2) / self.S)
+        total = 0
+        for s, fs in enumerate(self.sets):
+            ip = fs.conj() @ psi[s]
+            total += np.sum(np.abs(ip) ** 2) / len(fs)
+        return self.scale * total
+
+    def states_bar(self, controls, states, step):
+        psi = np.asarray(states)[:, :, 0]
+        out = np.zeros_like(psi)
+        if self.kind == 0:
+            tot = np.sum(np.sum(np.conj(self.targets) * psi, axis=1))
+            out = -(2 * self.scale / self.S ** 2) * tot * self.targets
+        elif self.kind == 1:
+            ip = np.sum(np.conj(self.targets) * psi, axis=1)
+            out = -(2 * self.scale / self.S) * ip[:, None] * self.targets
+        else:
+            for s, fs in enumerate(self.sets):
+                ip = fs.conj() @ psi[s]
+                out[s] = (2 * self.scale / len(fs)) * (ip[:, None] * fs).sum(axis=0)
+        return out[:, :, None]
+
+
+class OracleBackend(object):
+    def __init__(self):
+        self.keep = False
+        self.calls = 0
+
+    def set_schroedinger_problem(self, n, S, K, Nc, N, T, h0, g, psi0, costs=(),
+                                 cost_eval_step=1, magnus_policy="M2"):
+        h0 = np.asarray(h0, dtype=np.complex128).reshape(-1, n, n)
+        nt = h0.shape[0]
+        g = np.asarray(g, dtype=np.complex128).reshape(nt, K, n, n)
+        dt = T / (N - 1)
+
+        def hamiltonian(u, t):
+            j = 0 if nt == 1 else int(round((t - 0.5 * dt) / dt))
+            h = h0[j]
+            for k in range(K):
+                h = h + u[k] * g[j, k]
+            return h
+
+        ocosts = [_DescriptorCost(c, S, n) for c in costs]
+        self.problem = onp.SchroedingerProblem(
+            T, hamiltonian, np.asarray(psi0, dtype=np.complex128).reshape(S, n, 1), N,
+            control_eval_count=Nc, costs=ocosts, cost_eval_step=cost_eval_step,
+            magnus_policy=magnus_policy, complex_controls=False, control_count=K)
+        self.dims = (n, S, K, Nc, N)
+
+    def set_keep_step_states(self, keep):
+        self.keep = bool(keep)
+
+    def upload_controls(self, controls):
+        n, S, K, Nc, N = self.dims
+        if K == 0:
+            self.controls = [None] * (1 if controls is None else int(controls))
+        else:
+            self.controls = list(np.asarray(controls, dtype=np.float64).reshape(-1, Nc, K))
+        self.batch = len(self.controls)
+
+    def eval_resident(self, want_grad=True):
+        n, S, K, Nc, N = self.dims
+        self.calls += 1
+        self.cost, self.grads, self.final, self.steps = [], [], [], []
+        for u in self.controls:
+            if want_grad and K > 0:
+                err, gr, fin = onp.evaluate_with_grad(self.problem, u)
+                self.grads.append(gr)
+            else:
+                err, fin = onp.evaluate(self.problem, u)
+            if self.keep:
+                inter = []
+                onp.evaluate(self.problem, u, intermediate=inter)
+                self.steps.append(np.stack(inter)[:, :, :, 0])
+            self.cost.append(err)
+            self.final.append(np.asarray(fin)[:, :, 0])
+
+    def download_results(self, want_grad=True, want_final=True):
+        n, S, K, Nc, N = self.dims
+        grads = np.stack(self.grads) if (want_grad and K > 0 and self.grads) else None
+        return (np.array(self.cost, dtype=np.float64), grads,
+                np.stack(self.final) if want_final else None)
+
+    def download_step_states(self):
+        return np.stack(self.steps)
+
+    def close(self):
+        pass

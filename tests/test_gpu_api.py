@@ -1,0 +1,95 @@
+"""
+GPU tests (-m gpu) of the reference-shaped entry points on the real HIP engine: evolve against
+the reference fixtures, GRAPE iteration-by-iteration against the same host code driven by the
+oracle backend.
+"""
+
+import numpy as np
+import pytest
+
+import qoc_amd
+import qoc_amd.standard.costs as product_costs
+from qoc_amd.core import device
+from qoc_amd.standard import SGD, Adam
+from tests import cases as cases_mod
+from tests.helpers import golden, rel_err
+from tests.oracle_backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def product_cost_list(case):
+    return [getattr(product_costs, kind)(**kw) for kind, kw in case.cost_specs]
+
+
+@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases() if c.magnus == "M2"])
+def test_evolve_on_gpu(name):
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    controls = [None] if case.controls is None else list(case.controls)
+    for b, u in enumerate(controls):
+        result = qoc_amd.evolve_schroedinger_discrete(
+            case.T, case.hamiltonian(), case.initial_states, case.N, controls=u,
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case))
+        assert abs(result.error - g["error"][b]) < 1e-10 * max(1, abs(g["error"][b]))
+        assert rel_err(result.final_states, g["final_states"][b]) < 1e-10
+
+
+def run_grape(case, optimizer, iterations, **kw):
+    trace = []
+
+    class Recorder(object):
+        def __init__(self, inner):
+            self.inner = inner
+
+        def run(self, function, iteration_count, initial_params, jacobian, args=()):
+            def jac(params, *a):
+                grads, stop = jacobian(params, *a)
+                trace.append((a[1].error, grads.copy()))
+                return grads, stop
+            return self.inner.run(function, iteration_count, initial_params, jac, args=args)
+
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+        case.initial_states, case.N, complex_controls=case.complex_controls,
+        cost_eval_step=case.cost_eval_step, initial_controls=case.controls[0],
+        iteration_count=iterations, log_iteration_step=0, optimizer=Recorder(optimizer), **kw)
+    return result, trace
+
+
+@pytest.mark.parametrize("name,complex_norm", [("ctrlcosts_r", None), ("small_complex_M2", 3.0),
+                                              ("scaled_n8", None)])
+def test_grape_trajectory_matches_oracle_backend(name, complex_norm):
+    case = cases_mod.case_by_name(name)
+    norms = np.full(case.K, 5.0 if complex_norm is None else complex_norm)
+    gpu_result, gpu_trace = run_grape(case, Adam(learning_rate=2e-2), 6, max_control_norms=norms)
+    device.set_backend_factory(OracleBackend)
+    try:
+        cpu_result, cpu_trace = run_grape(case, Adam(learning_rate=2e-2), 6,
+                                          max_control_norms=norms)
+    finally:
+        device.set_backend_factory(None)
+    assert len(gpu_trace) == len(cpu_trace) == 6
+    for (ge, gg), (ce, cg) in zip(gpu_trace, cpu_trace):
+        assert abs(ge - ce) < 1e-9 * max(1, abs(ce))
+        assert rel_err(gg, cg) < 1e-7
+    assert gpu_result.best_iteration == cpu_result.best_iteration
+    assert rel_err(gpu_result.best_controls, cpu_result.best_controls) < 1e-7
+
+
+def test_transmon_pi_pulse_example():
+    """BASELINE configs[0] (examples/0_transmon_pi.py of the reference): 2-level pi pulse."""
+    from qoc_amd.standard import (TargetStateInfidelity, conjugate_transpose,
+                                  get_annihilation_operator, get_creation_operator)
+    hs = 2
+    a, ad = get_annihilation_operator(hs), get_creation_operator(hs)
+    h_sys = 2 * np.pi * 1e-2 * np.matmul(ad, a)
+    hamiltonian = lambda controls, time: (h_sys + controls[0] * a + np.conjugate(controls[0]) * ad)
+    initial = np.array([[[1], [0]]], dtype=np.complex128)
+    target = np.array([[[0], [1]]], dtype=np.complex128)
+    result = qoc_amd.grape_schroedinger_discrete(
+        1, 21, [TargetStateInfidelity(target)], 10.0, hamiltonian, initial, 21,
+        complex_controls=True, iteration_count=150, log_iteration_step=0,
+        optimizer=Adam(learning_rate=2e-2), max_control_norms=np.array([0.5]))
+    assert result.best_error < 1e-3
+    assert np.all(np.abs(result.best_controls) <= 0.5 + 1e-12)

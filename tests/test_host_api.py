@@ -1,0 +1,306 @@
+"""
+CPU tests of the host-side mirror of the reference interface: entry points, Cost / Optimizer
+plugins, control plumbing, Hamiltonian structure extraction. The GPU engine is replaced by the
+oracle through the test hook qoc_amd.core.device.set_backend_factory (tests/oracle_backend.py);
+the same entry points run on the real engine in tests/test_gpu_api.py.
+"""
+
+import numpy as np
+import pytest
+
+import qoc_amd
+from qoc_amd.core import common, device, structure
+from qoc_amd.models import (Cost, InterpolationPolicy, MagnusPolicy, OperationPolicy,
+                            PerformancePolicy, ProgramType)
+from qoc_amd.standard import (SIGMA_X, SIGMA_Y, Adam, LBFGSB, SGD, ControlNorm, ForbidStates,
+                              TargetStateInfidelity, TargetStateInfidelityTime,
+                              get_annihilation_operator, get_creation_operator)
+import qoc_amd.standard.costs as product_costs
+from oracle import qoc_numpy as onp
+from tests import cases as cases_mod
+from tests.helpers import golden, rel_err
+from tests.oracle_backend import OracleBackend
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    device.set_backend_factory(OracleBackend)
+    yield
+    device.set_backend_factory(None)
+
+
+def product_cost_list(case):
+    return [getattr(product_costs, kind)(**kw) for kind, kw in case.cost_specs]
+
+
+# ---- models / plugins ---------------------------------------------------------------------------
+
+def test_policy_strings():
+    assert str(MagnusPolicy.M2) == "magnus_m2" and repr(MagnusPolicy.M6) == "magnus_m6"
+    assert str(InterpolationPolicy.LINEAR) == "interpolation_linear"
+    assert str(ProgramType.EVOLVE) == "evolve" and str(ProgramType.GRAPE) == "grape"
+    assert str(OperationPolicy.GPU) == "operation_policy_gpu"
+    assert str(PerformancePolicy.MEMORY) == "performance_policy_memory"
+    assert MagnusPolicy.M4.value == 2
+
+
+def test_cost_base_class():
+    c = Cost(cost_multiplier=2.5)
+    assert c.cost_multiplier == 2.5 and str(c) == "parent_cost" and not c.requires_step_evaluation
+    with pytest.raises(NotImplementedError):
+        c.cost(None, None, 0)
+
+
+def test_state_cost_known_answers():
+    # reference tests/test_standard.py:70-90, :166-223 (stale third cases keyed by the flag)
+    state0, state1 = np.array([[1], [0]]), np.array([[0], [1]])
+    forbid1_0 = np.array([[1], [1]]) / np.sqrt(2)
+    forbid1_1 = np.array([[1j], [1j]]) / np.sqrt(2)
+    forbidden = np.array([[state0, state0], [forbid1_0, forbid1_1]])
+    fs = ForbidStates(forbidden, 11)
+    assert np.allclose(fs.cost(None, np.stack((state0, state1)), 0), 0.75 / 10)
+    t0 = np.array([[1], [0]])
+    assert np.allclose(TargetStateInfidelity(np.stack((t0,))).cost(None, np.stack((state1,)), None), 1)
+    assert np.allclose(TargetStateInfidelity(np.stack((state1,))).cost(None, np.stack((state1,)), None), 0)
+    s1 = np.array([[1j], [1]]) / np.sqrt(2)
+    tb = np.stack((np.array([[1j], [0]]), np.array([[1], [1]]) / np.sqrt(2)))
+    both = np.stack((state0, s1))
+    assert np.allclose(TargetStateInfidelity(tb, neglect_relative_pahse=True).cost(None, both, None), 0.25)
+    assert np.allclose(TargetStateInfidelityTime(11, tb, neglect_relative_pahse=True).cost(None, both, None), 0.025)
+    coherent = TargetStateInfidelity(tb).cost(None, both, None)
+    assert np.allclose(coherent, onp.TargetStateInfidelity(tb).cost(None, both, None))
+    assert np.allclose(TargetStateInfidelityTime(11, tb).cost(None, both, None), coherent / 10)
+
+
+@pytest.mark.parametrize("complex_controls", [False, True])
+def test_control_costs_value_and_gradient(complex_controls):
+    case = cases_mod.case_control_costs(complex_controls)
+    rng = np.random.default_rng(3)
+    for kind, kw in case.cost_specs[1:]:
+        mine = getattr(product_costs, kind)(**kw)
+        ref = getattr(onp, kind)(**kw)
+        u = case.controls[0]
+        assert np.allclose(mine.cost(u, None, 0), ref.cost(u, None, 0), rtol=1e-14, atol=0)
+        bar = mine.controls_bar(u, None, 0)
+        assert bar.dtype == u.dtype
+        assert rel_err(bar, ref.controls_bar(u, None, 0)) < 1e-13
+        # directional finite difference of the product's own cost()
+        d = rng.standard_normal(u.shape)
+        if complex_controls:
+            d = d + 1j * rng.standard_normal(u.shape)
+        h = 1e-6
+        fd = (mine.cost(u + h * d, None, 0) - mine.cost(u - h * d, None, 0)) / (2 * h)
+        assert abs(fd - np.sum(np.real(np.conj(bar) * d))) < 1e-8
+    with pytest.raises(NameError):
+        product_costs.ControlArea(2, 5).cost(np.ones((5, 2)), None, 0)
+
+
+def test_adam_known_answers():
+    # reference tests/test_standard.py:252-276
+    adam = Adam()
+    grads = np.array([[0, 1], [2, 3]])
+    params = np.array([[0, 1], [2, 3]], dtype=np.float64)
+    adam.run(None, 0, params, None, None)
+    p1 = adam.update(params, grads)   # (sic) argument order of the reference test
+    p2 = adam.update(np.array([[0, 0.999], [1.999, 2.999]]), grads)
+    assert np.allclose(p1, np.array([[0, 0.999], [1.999, 2.999]]))
+    assert np.allclose(p2, np.array([[0, 0.99900003], [1.99900001, 2.99900001]]))
+
+
+def test_adam_golden_trajectory_and_sgd():
+    g = golden("units")
+    adam = Adam(learning_rate=0.05, learning_rate_decay=7.0, clip_grads=0.6, scale_grads=1.5)
+    params = g["adam_traj"][0]
+    adam.run(None, 0, params, None, None)
+    for grads, expected in zip(g["adam_grads"], g["adam_traj"][1:]):
+        params = adam.update(grads, params)
+        assert np.array_equal(params, expected)
+    assert np.allclose(SGD(learning_rate=1).update(np.ones(5), np.ones(5)), np.zeros(5))
+    assert "adam, beta_1: 0.9" in str(Adam())
+
+
+def test_clip_strip_slap_and_defaults():
+    g = golden("units")
+    cr, cc = g["clip_in_real"].copy(), g["clip_in_complex"].copy()
+    common.clip_control_norms(cr, g["clip_norms"])
+    common.clip_control_norms(cc, g["clip_norms"])
+    assert np.array_equal(cr, g["clip_out_real"]) and np.array_equal(cc, g["clip_out_complex"])
+    flat = common.strip_controls(True, g["clip_in_complex"])
+    assert np.array_equal(flat, g["strip_complex"])
+    assert np.array_equal(common.slap_controls(True, flat, (6, 2)), g["slap_complex"])
+    # real controls: slap returns a view, so clipping aliases the optimizer's vector
+    params = np.array([3.0, -4.0, 0.1, 0.2])
+    view = common.slap_controls(False, params, (2, 2))
+    common.clip_control_norms(view, np.array([1.0, 1.0]))
+    assert np.array_equal(params, np.array([1.0, -1.0, 0.1, 0.2]))
+    controls, norms = common.initialize_controls(True, 2, 5, 1.0, None, None)
+    assert np.array_equal(norms, np.ones(2))
+    assert np.allclose(controls, (0.1 - 0.1j) / np.sqrt(2))
+    with pytest.raises(ValueError):
+        common.initialize_controls(True, 1, 3, 1.0, np.ones((3, 1)), None)
+    with pytest.raises(ValueError):
+        common.initialize_controls(False, 1, 3, 1.0, np.ones((3, 1)) * 1j, None)
+    with pytest.raises(ValueError):
+        common.initialize_controls(False, 1, 3, 1.0, np.ones((3, 1)) * 2, None)
+    cos = common.gen_controls_cos(False, 1, 40, 1.0, np.array([2.0]))
+    assert np.isclose(cos[0, 0], 1.0) and cos.shape == (40, 1)
+
+
+def test_constants():
+    a, ad = get_annihilation_operator(4), get_creation_operator(4)
+    assert np.allclose(a, ad.T) and np.isclose(a[2, 3], np.sqrt(3))
+    assert np.allclose(qoc_amd.standard.get_eij(1, 2, 3)[1, 2], 1)
+
+
+# ---- Hamiltonian structure ------------------------------------------------------------------------
+
+def test_probe_hamiltonian():
+    rng = np.random.default_rng(0)
+    h0, a = cases_mod.gue(rng, 4), cases_mod.annihilation(4)
+    ham = lambda u, t: h0 + u[0] * a + np.conjugate(u[0]) * a.conj().T
+    times = [0.1, 0.2, 0.3]
+    p0, g = structure.probe_hamiltonian(ham, 4, 1, True, times)
+    assert p0.shape == (1, 4, 4) and g.shape == (1, 2, 4, 4)
+    assert np.allclose(g[0, 0], a + a.conj().T) and np.allclose(g[0, 1], 1j * (a - a.conj().T))
+    ham_t = lambda u, t: h0 * np.cos(t) + u[0] * (a + a.conj().T)
+    p0, g = structure.probe_hamiltonian(ham_t, 4, 1, False, times)
+    assert p0.shape == (3, 4, 4) and np.allclose(p0[1], h0 * np.cos(0.2))
+    with pytest.raises(structure.NonLinearHamiltonianError):
+        structure.probe_hamiltonian(lambda u, t: h0 + u[0] ** 2 * a, 4, 1, False, times)
+    u = np.array([[1 + 2j, 3 - 1j]])
+    r = structure.to_real_controls(u, True)
+    assert np.array_equal(r, np.array([[1.0, 2.0, 3.0, -1.0]]))
+    assert np.array_equal(structure.from_real_gradients(r, True), u)
+
+
+# ---- entry points -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases() if c.magnus == "M2"])
+def test_evolve_matches_reference_fixtures(name):
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    controls = [None] if case.controls is None else list(case.controls[:2])
+    if name == "c3_subset":
+        controls = controls[:1]
+    for b, u in enumerate(controls):
+        result = qoc_amd.evolve_schroedinger_discrete(
+            case.T, case.hamiltonian(), case.initial_states, case.N, controls=u,
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case))
+        assert abs(result.error - g["error"][b]) < 1e-11 * max(1, abs(g["error"][b]))
+        assert result.final_states.shape == case.initial_states.shape
+        assert rel_err(result.final_states, g["final_states"][b]) < 1e-11
+
+
+def test_evolve_with_user_cost_and_errors():
+    case = cases_mod.case_by_name("nc10_n101")
+
+    class Population(Cost):
+        name = "population"
+        requires_step_evaluation = True
+
+        def cost(self, controls, states, step):
+            return float(np.abs(states[0, 0, 0]) ** 2) * 1e-3
+
+    r = qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
+                                             case.N, controls=case.controls[0],
+                                             costs=[Population()], cost_eval_step=10)
+    inter = []
+    onp.evaluate(onp.SchroedingerProblem(case.T, case.hamiltonian(), case.initial_states, case.N,
+                                         control_eval_count=case.Nc, control_count=case.K),
+                 case.controls[0], intermediate=inter)
+    expected = sum(abs(inter[s][0, 0, 0]) ** 2 * 1e-3 for s in range(10, case.N, 10))
+    assert abs(r.error - expected) < 1e-12
+    with pytest.raises(NotImplementedError):
+        qoc_amd.grape_schroedinger_discrete(case.K, case.Nc, [Population()], case.T,
+                                            case.hamiltonian(), case.initial_states, case.N,
+                                            iteration_count=1, log_iteration_step=0)
+    with pytest.raises(NotImplementedError):
+        qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
+                                             case.N, controls=case.controls[0],
+                                             magnus_policy=MagnusPolicy.M4)
+    with pytest.raises(NotImplementedError):
+        qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
+                                             case.N, controls=case.controls[0],
+                                             interpolation_policy="cubic")
+    with pytest.raises(ValueError):
+        qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
+                                             case.N, controls=case.controls[0], magnus_policy=7)
+
+
+def test_grape_clips_controls():
+    # reference tests/test_core.py:563-602
+    hm = 0.5 * (np.kron(SIGMA_X, SIGMA_X) + np.kron(SIGMA_Y, SIGMA_Y))
+    hamiltonian = lambda controls, t: controls[0] * hm
+    initial_states = np.array([[[0], [1], [0], [0]]])
+    forbidden_states = np.array([[[[0], [1], [0], [0]]]])
+    max_control_norms = np.repeat(1e-10, 1)
+    result = qoc_amd.grape_schroedinger_discrete(
+        1, 11, [ForbidStates(forbidden_states, 11)], 10, hamiltonian, initial_states, 11,
+        iteration_count=15, log_iteration_step=0, max_control_norms=max_control_norms)
+    assert np.less_equal(np.abs(result.best_controls[:, 0]), max_control_norms[0]).all()
+    assert result.best_final_states.shape == (1, 4, 1)
+
+
+def test_grape_optimizes_and_logs(capsys):
+    case = cases_mod.case_by_name("ctrlcosts_r")
+    costs = product_cost_list(case)
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, costs, case.T, case.hamiltonian(), case.initial_states, case.N,
+        initial_controls=case.controls[0], iteration_count=12, log_iteration_step=5,
+        optimizer=Adam(learning_rate=5e-2), max_control_norms=np.array([5.0, 5.0]))
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "iter   |   total error  |    grads_l2   "
+    assert out[1] == "=" * 41
+    rows = [line.split("|")[0].strip() for line in out[2:]]
+    assert rows == ["0", "5", "10", "11"]
+    first_error = float(out[2].split("|")[1])
+    assert result.best_error < first_error
+    assert result.best_iteration > 0 and result.best_controls.shape == (case.Nc, case.K)
+    # the first iteration's value/gradient are the golden ones
+    g = golden(case.name)
+    assert abs(first_error - g["error"][0]) < 1e-8
+
+
+def test_grape_complex_controls_min_error_and_lbfgsb():
+    case = cases_mod.case_small_complex("M2")
+    costs = product_cost_list(case)
+    seen = []
+
+    def conditions(controls):
+        seen.append(controls.copy())
+        controls[0, :] = 0
+        return controls
+
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, costs, case.T, case.hamiltonian(), case.initial_states, case.N,
+        complex_controls=True, cost_eval_step=case.cost_eval_step,
+        initial_controls=case.controls[0], impose_control_conditions=conditions,
+        iteration_count=4, log_iteration_step=0, optimizer=SGD(learning_rate=0.1),
+        max_control_norms=np.array([3.0]))
+    assert len(seen) == 4 and np.iscomplexobj(result.best_controls)
+    assert np.all(result.best_controls[0] == 0)
+    # min_error above the first error: terminate after one evaluation
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, costs, case.T, case.hamiltonian(), case.initial_states, case.N,
+        complex_controls=True, cost_eval_step=case.cost_eval_step,
+        initial_controls=case.controls[0], iteration_count=50, log_iteration_step=0,
+        min_error=10.0, max_control_norms=np.array([3.0]))
+    assert result.best_iteration == 0
+    real_case = cases_mod.case_by_name("ctrlcosts_r")
+    result = qoc_amd.grape_schroedinger_discrete(
+        real_case.K, real_case.Nc, product_cost_list(real_case), real_case.T,
+        real_case.hamiltonian(), real_case.initial_states, real_case.N,
+        initial_controls=real_case.controls[0], iteration_count=3, log_iteration_step=0,
+        optimizer=LBFGSB(), max_control_norms=np.array([5.0, 5.0]))
+    assert result.best_error < golden(real_case.name)["error"][0]
+
+
+def test_batch_evaluator_matches_single():
+    case = cases_mod.case_by_name("scaled_n8")
+    ev = device.SchroedingerEvaluator(case.T, case.hamiltonian(), case.initial_states, case.N,
+                                      control_count=case.K, control_eval_count=case.Nc,
+                                      costs=product_cost_list(case))
+    errors, grads, final, _ = ev.evaluate_batch(case.controls)
+    g = golden(case.name)
+    assert rel_err(errors, g["error"]) < 1e-11 and rel_err(grads, g["grads_ad"]) < 1e-9
+    assert rel_err(final, g["final_states"]) < 1e-11
