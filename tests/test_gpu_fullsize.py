@@ -1,0 +1,98 @@
+"""
+GPU tests (-m gpu) at BASELINE.json's full size (configs[2]: dim=32, 1000 steps, 256 seeds),
+where the oracle is too slow to run everything: size-independent properties of the domain
+(unitarity, time-reversal round trip, determinism, batch independence, gradient vs directional
+finite differences of the engine's own cost) plus the 4-seed subset pinned by the reference
+fixture. Also the single-rank RCCL path of the communicator.
+"""
+
+import numpy as np
+import pytest
+
+from tests.helpers import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DIM, N_EVAL, K = 32, 1001, 2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import bench
+    from qoc_amd.engine import Engine, COST_TARGET_COHERENT
+    h0, g, psi0, target = bench.make_problem()
+    engine = Engine(0)
+
+    def configure(sign=1.0, initial=psi0):
+        engine.set_schroedinger_problem(
+            DIM, 1, K, N_EVAL, N_EVAL, bench.DT * (N_EVAL - 1), sign * h0[None],
+            sign * np.stack(g)[None], initial,
+            costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+    configure()
+    controls = bench.make_controls(0, 256)
+    yield engine, configure, controls, psi0
+    engine.close()
+
+
+def test_full_batch_properties(setup):
+    engine, configure, controls, psi0 = setup
+    cost, grads, final = engine.evaluate(controls, True)
+    assert cost.shape == (256,) and grads.shape == (256, N_EVAL, K) and final.shape == (256, 1, DIM)
+    assert np.all(np.isfinite(grads))
+    assert np.all((cost >= 0) & (cost <= 1))
+    # unitarity of 1000 chained propagators
+    assert np.max(np.abs(np.linalg.norm(final[:, 0], axis=1) - 1)) < 1e-11
+    # cost recomputed on the host from the returned states
+    assert np.max(np.abs(cost - (1 - np.abs(final[:, 0, 1]) ** 2))) < 1e-12
+    # the reference-pinned subset (same seeds as tests/golden/c3_subset.npz)
+    g = golden("c3_subset")
+    assert np.max(np.abs(cost[:4] - g["error"])) < 1e-10
+    assert rel_err(final[:4, :, :, None], g["final_states"]) < 1e-10
+    for b in range(4):
+        assert rel_err(grads[b], g["grads_ad"][b]) < 1e-8
+    # determinism and independence of the batch composition
+    cost2, grads2, final2 = engine.evaluate(controls, True)
+    assert np.array_equal(cost, cost2) and np.array_equal(grads, grads2)
+    cost3, grads3, final3 = engine.evaluate(controls[100:103], True)
+    assert np.array_equal(cost3, cost[100:103]) and np.array_equal(grads3, grads[100:103])
+    assert np.array_equal(final3, final[100:103])
+
+
+def test_gradient_vs_directional_differences(setup):
+    engine, configure, controls, psi0 = setup
+    rng = np.random.default_rng(11)
+    u = controls[:8]
+    d = rng.standard_normal(u.shape)
+    _, grads, _ = engine.evaluate(u, True)
+    h = 1e-5
+    cp, _, _ = engine.evaluate(u + h * d, False)
+    cm, _, _ = engine.evaluate(u - h * d, False)
+    fd = (cp - cm) / (2 * h)
+    an = np.sum(grads * d, axis=(1, 2))
+    assert np.max(np.abs(fd - an) / np.maximum(np.abs(an), 1e-3)) < 1e-6
+
+
+def test_time_reversal_round_trip(setup):
+    engine, configure, controls, psi0 = setup
+    u = controls[:16]
+    _, _, final = engine.evaluate(u, False)
+    back = np.empty_like(final)
+    for b in range(4):  # H -> -H with time-reversed controls undoes the evolution
+        configure(sign=-1.0, initial=final[b])
+        _, _, out = engine.evaluate(u[b:b + 1, ::-1], False)
+        back[b] = out[0]
+    configure()
+    assert np.max(np.abs(back[:4] - psi0[None])) < 1e-10
+
+
+def test_rccl_single_rank(setup):
+    engine, configure, controls, psi0 = setup
+    from qoc_amd import parallel
+    comm = parallel.RcclComm(engine, rank=0, world=1)
+    x = np.arange(2003, dtype=np.float64) * 0.5
+    assert np.array_equal(comm.allreduce_sum(x.copy()), x)
+    assert np.array_equal(comm.allreduce_max(x.copy()), x)
+    comm.barrier()
+    total, grad = parallel.summed_cost_and_gradient(np.ones(3), np.ones((3, 5, 2)), comm)
+    assert total == 3.0 and np.array_equal(grad, 3 * np.ones((5, 2)))
+    engine.comm_destroy()
