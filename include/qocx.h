@@ -133,7 +133,7 @@ int qocx_download_step_states(qocx_ctx* ctx, double* states_out);
 
 /* Per-kernel timing, measured with HIP events on the context's stream.
  * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`
- * (0 pade_factor, 1 sweep, 2 krylov_grad, 3 scatter) the launch count and total ms
+ * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu) the launch count and total ms
  * since the last reset. */
 int qocx_set_timing(qocx_ctx* ctx, int32_t enable);
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms);

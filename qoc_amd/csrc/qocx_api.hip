@@ -134,12 +134,12 @@ struct qocx_ctx {
     DevBuf<double> controls, cost_out, grads, gstep;
     DevBuf<double2> final_out, step_states;
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
-    DevBuf<int> perm, s_arr, offs, status;
+    DevBuf<int> perm, iperm, s_arr, offs, status;
     // ---- timing ----
     int timing = 0;
     std::vector<TimingRec> pending;
-    int64_t t_launch[4] = {0, 0, 0, 0};
-    double t_ms[4] = {0, 0, 0, 0};
+    int64_t t_launch[5] = {0, 0, 0, 0, 0};
+    double t_ms[5] = {0, 0, 0, 0, 0};
     // ---- comm ----
     Rccl rccl;
     void* comm = nullptr;
@@ -147,8 +147,6 @@ struct qocx_ctx {
 };
 
 namespace {
-
-int geo_cpl(int np) { return np * np / 64; }
 
 void c_image(const double* m, int n, int nb, double2* out) {
     for (int ti = 0; ti < nb; ++ti)
@@ -166,32 +164,29 @@ void c_image(const double* m, int n, int nb, double2* out) {
                 }
 }
 
+// Column-major NP x NP image of a row-major n x n matrix (or of its transpose), zero padded.
 void r_image(const double* m, int n, int np, bool transpose, double2* out) {
-    const int cpl = geo_cpl(np);
-    for (int cc = 0; cc < cpl; ++cc)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane % np, h = lane / np;
-            int row = i, col = h * cpl + cc;
-            if (transpose) std::swap(row, col);
+    for (int col = 0; col < np; ++col)
+        for (int row = 0; row < np; ++row) {
+            int r = row, c = col;
+            if (transpose) std::swap(r, c);
             double2 e = make_double2(0, 0);
-            if (row < n && col < n) {
-                e.x = m[2 * ((size_t)row * n + col)];
-                e.y = m[2 * ((size_t)row * n + col) + 1];
+            if (r < n && c < n) {
+                e.x = m[2 * ((size_t)r * n + c)];
+                e.y = m[2 * ((size_t)r * n + c) + 1];
             }
-            out[cc * 64 + lane] = e;
+            out[(size_t)col * np + row] = e;
         }
 }
 
-void from_r_image(const double2* img, int n, int np, double* out) {  // -> row-major n x n complex
-    const int cpl = geo_cpl(np);
-    for (int cc = 0; cc < cpl; ++cc)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane % np, h = lane / np;
-            const int row = i, col = h * cpl + cc;
-            if (row < n && col < n) {
-                out[2 * ((size_t)row * n + col)] = img[cc * 64 + lane].x;
-                out[2 * ((size_t)row * n + col) + 1] = img[cc * 64 + lane].y;
-            }
+// column-major image -> row-major n x n complex; row_map (optional) gives the image row of each
+// output row (the LU factors are stored in original row order: row_map = perm)
+void from_image(const double2* img, int n, int np, const int* row_map, double* out) {
+    for (int row = 0; row < n; ++row)
+        for (int col = 0; col < n; ++col) {
+            const int src = row_map ? row_map[row] : row;
+            out[2 * ((size_t)row * n + col)] = img[(size_t)col * np + src].x;
+            out[2 * ((size_t)row * n + col) + 1] = img[(size_t)col * np + src].y;
         }
 }
 
@@ -298,7 +293,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     DevBuf<double>* b1[] = {&ctx->weight, &ctx->controls, &ctx->cost_out, &ctx->grads, &ctx->gstep,
                             &ctx->comm_buf};
     for (auto* b : b1) b->release();
-    DevBuf<int>* bi[] = {&ctx->cost_counts, &ctx->row_ptr, &ctx->col_step, &ctx->perm, &ctx->s_arr,
+    DevBuf<int>* bi[] = {&ctx->cost_counts, &ctx->row_ptr, &ctx->col_step, &ctx->perm, &ctx->iperm, &ctx->s_arr,
                          &ctx->offs, &ctx->status};
     for (auto* b : bi) b->release();
     ctx->interp.release();
@@ -545,7 +540,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     chunk = std::min(chunk, B);
     const size_t cm = (size_t)chunk * nsteps;
     if (ctx->q_img.ensure(cm * mat) || ctx->lu_img.ensure(cm * mat) || ctx->dinv.ensure(cm * np) ||
-        ctx->perm.ensure(cm * np) || ctx->s_arr.ensure(cm) ||
+        ctx->perm.ensure(cm * np) || ctx->iperm.ensure(cm * np) || ctx->s_arr.ensure(cm) ||
         ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
         ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
         ctx->offs.ensure((size_t)chunk * (nsteps + 1)) ||
@@ -565,15 +560,22 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.h0_cimg = ctx->h0_cimg.p;
         fa.g_cimg = ctx->g_cimg.p;
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
-        fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p; fa.dinv = ctx->dinv.p;
-        fa.perm = ctx->perm.p; fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
+        fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
+        fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         time_begin(ctx, 0);
-        qocx::launch_factor(ctx->nb, fa, nsteps, bc, ctx->stream);
+        qocx::launch_pq(ctx->nb, fa, nsteps, bc, ctx->stream);
+        time_end(ctx);
+        qocx::LuArgs la;
+        la.lu_img = ctx->lu_img.p; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
+        la.iperm = ctx->iperm.p; la.status = ctx->status.p;
+        time_begin(ctx, 4);
+        qocx::launch_lu(ctx->nb, la, (size_t)bc * nsteps, ctx->stream);
         time_end(ctx);
 
         qocx::SweepArgs sa;
         sa.q_img = ctx->q_img.p; sa.lu_img = ctx->lu_img.p; sa.dinv = ctx->dinv.p;
-        sa.perm = ctx->perm.p; sa.s_arr = ctx->s_arr.p; sa.psi0 = ctx->psi0.p;
+        sa.perm = ctx->perm.p; sa.iperm = ctx->iperm.p; sa.s_arr = ctx->s_arr.p;
+        sa.psi0 = ctx->psi0.p;
         sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
         sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
         sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
@@ -689,7 +691,7 @@ int qocx_set_timing(qocx_ctx* ctx, int32_t enable) {
 }
 
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms) {
-    if (!ctx || which < 0 || which > 3) return fail(QOCX_ERR_ARG, "bad argument");
+    if (!ctx || which < 0 || which > 4) return fail(QOCX_ERR_ARG, "bad argument");
     if (launches) *launches = ctx->t_launch[which];
     if (total_ms) *total_ms = ctx->t_ms[which];
     return 0;
@@ -697,7 +699,7 @@ int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* tot
 
 int qocx_reset_timing(qocx_ctx* ctx) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         ctx->t_launch[i] = 0;
         ctx->t_ms[i] = 0;
     }
@@ -781,30 +783,39 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     HIP_TRY(hipSetDevice(ctx->device));
     const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np;
     DevBuf<double2> a_d, q_d, lu_d, dinv_d;
-    DevBuf<int> perm_d, s_d;
+    DevBuf<int> perm_d, iperm_d, s_d;
     int rc = a_d.ensure((size_t)count * n * n) | q_d.ensure((size_t)count * mat) |
              lu_d.ensure((size_t)count * mat) | dinv_d.ensure((size_t)count * np) |
-             perm_d.ensure((size_t)count * np) | s_d.ensure(count);
+             perm_d.ensure((size_t)count * np) | iperm_d.ensure((size_t)count * np) |
+             s_d.ensure(count);
     if (rc) return QOCX_ERR_HIP;
     HIP_TRY(hipMemcpy(a_d.p, a, (size_t)count * n * n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
     qocx::FactorArgs fa;
     memset(&fa, 0, sizeof(fa));
-    fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.dinv = dinv_d.p; fa.perm = perm_d.p;
-    fa.s_arr = s_d.p; fa.status = ctx->status.p;
-    qocx::launch_factor_explicit(nb, a_d.p, n, fa, count, ctx->stream);
+    fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
+    qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
+    qocx::LuArgs la;
+    la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
+    la.status = ctx->status.p;
+    qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<double2> img((size_t)count * mat), dv((size_t)count * np);
     std::vector<int> pm((size_t)count * np), sv(count);
+    HIP_TRY(hipMemcpy(pm.data(), perm_d.p, pm.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(img.data(), q_d.p, img.size() * 16, hipMemcpyDeviceToHost));
     if (q_out)
-        for (int m = 0; m < count; ++m) from_r_image(img.data() + (size_t)m * mat, n, np, q_out + (size_t)m * n * n * 2);
+        for (int m = 0; m < count; ++m)
+            from_image(img.data() + (size_t)m * mat, n, np, nullptr, q_out + (size_t)m * n * n * 2);
     HIP_TRY(hipMemcpy(img.data(), lu_d.p, img.size() * 16, hipMemcpyDeviceToHost));
     if (lu_out)
-        for (int m = 0; m < count; ++m) from_r_image(img.data() + (size_t)m * mat, n, np, lu_out + (size_t)m * n * n * 2);
+        for (int m = 0; m < count; ++m) {
+            std::vector<int> rows(pm.begin() + (size_t)m * np, pm.begin() + (size_t)(m + 1) * np);
+            for (auto& r : rows) r = std::min(std::max(r, 0), np - 1);
+            from_image(img.data() + (size_t)m * mat, n, np, rows.data(), lu_out + (size_t)m * n * n * 2);
+        }
     HIP_TRY(hipMemcpy(dv.data(), dinv_d.p, dv.size() * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pm.data(), perm_d.p, pm.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
     for (int m = 0; m < count; ++m)
         for (int i = 0; i < n; ++i) {
@@ -815,7 +826,8 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
             }
         }
     if (s_out) memcpy(s_out, sv.data(), count * sizeof(int));
-    a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); s_d.release();
+    a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release();
+    iperm_d.release(); s_d.release();
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
     if (status & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");

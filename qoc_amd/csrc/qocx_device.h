@@ -35,12 +35,18 @@ struct FactorArgs {
     const double2* g_cimg;     // [nt][K] C-images
     int K, nc, nsteps, nt;
     double dt;
-    // outputs, indexed by (b * nsteps + step)
+    // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
-    double2* lu_img;
-    double2* dinv;
-    int* perm;
+    double2* lu_img;  // receives P; lu_kernel factors it in place
     int* s_arr;
+    int* status;
+};
+
+struct LuArgs {
+    double2* lu_img;  // in: P, out: L\\U of the row-permuted P (column-major)
+    double2* dinv;    // [NP] 1/U_kk
+    int* perm;        // [NP] perm[pos] = original row
+    int* iperm;       // [NP] iperm[row] = pos
     int* status;
 };
 
@@ -49,6 +55,7 @@ struct SweepArgs {
     const double2* lu_img;
     const double2* dinv;
     const int* perm;
+    const int* iperm;
     const int* s_arr;
     const double2* psi0;  // [S][NP]
     int S, nsteps, cost_eval_step, want_grad, has_step_costs;
@@ -71,8 +78,8 @@ struct SweepArgs {
 struct KrylovArgs {
     const double* controls;
     const StepInterp* interp;
-    const double2* h0_rimg;  // R-image of h0
-    const double2* h0_timg;  // R-image of h0^T
+    const double2* h0_rimg;  // column-major h0
+    const double2* h0_timg;  // column-major h0^T
     const double2* g_rimg;
     const double2* g_timg;
     int K, nc, nsteps, nt, S;
@@ -94,9 +101,10 @@ struct ScatterArgs {
     int B, nc, K, nsteps;
 };
 
-void launch_factor(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st);
-void launch_factor_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
-                            hipStream_t st);
+void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
+                        hipStream_t st);
+void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st);
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);

@@ -2,11 +2,13 @@
 //
 // One 64-lane wavefront owns one Hilbert-space tile (n <= 32, padded to NP = 16 or 32):
 //
-//   K1 pade_factor : generator a = -i dt H(u_mid) 2^-s  ->  Pade-13 numerator/denominator
-//                    Q = v+u, P = v-u  (6 complex GEMMs on v_mfma_f64_16x16x4_f64, A operand
-//                    staged in LDS, B operand / accumulators in registers)  ->  LU(P) with
-//                    partial pivoting.        reference: qoc/standard/functions/expm.py:153-159,
-//                    :210-246, qoc/core/schroedingerdiscrete.py:483-489, mathmethods.py:36-67,:90-93
+//   K1a pade_pq    : generator a = -i dt H(u_mid) 2^-s  ->  Pade-13 numerator/denominator
+//                    Q = v+u, P = v-u: 6 complex GEMMs on v_mfma_f64_16x16x4_f64 (A operand
+//                    staged in LDS, B operand / accumulators in registers).
+//                    reference: qoc/standard/functions/expm.py:153-159, :210-246,
+//                    qoc/core/schroedingerdiscrete.py:483-489, mathmethods.py:36-67, :90-93
+//   K1b lu         : LU(P) with partial pivoting (numpy.linalg.solve = LAPACK zgesv,
+//                    expm.py:246), in place, at several waves per SIMD to hide its latencies.
 //   K2 sweep       : psi_{j+1} = (P^-1 Q)^(2^s) psi_j (serial in j, one wave per seed), state
 //                    costs, then lambda_j = Q^H P^-H lambda_{j+1} backwards.
 //                    reference: schroedingerdiscrete.py:393-436, expm.py:246-250, costs/*.py
@@ -14,15 +16,17 @@
 //                    replaces autograd's tape: autogradutil.py:26-30); SURVEY.md Appendix A.
 //   K4 scatter     : transpose of the linear interpolation (mathmethods.py:33, :54-65).
 //
-// Register/LDS layouts
-//   C-layout  : MFMA accumulator layout. lane = 16*q + c; tile (ti,tj), reg r holds element
-//               (row 16 ti + 4 r + q, col 16 tj + c).  A C-layout tile IS the B operand of the
-//               next MFMA (k-step kk <-> row block kk>>2, reg kk&3), so GEMM chains need no
-//               shuffles; only the A operand goes through LDS.
-//   R-layout  : lane = h*NP + i holds row i, columns h*CPL .. h*CPL+CPL-1 (CPL = NP*NP/64).
-//               Used by LU, triangular solves and matvecs. Its HBM image stores element
-//               (row i, col h*CPL+cc) at complex index cc*64 + lane: every load/store
-//               instruction moves one contiguous KiB.
+// Register / memory layouts (H = 64/NP lane groups, CPL = NP/H columns per lane)
+//   C-layout : MFMA accumulator layout. lane = 16*q + c; tile (ti,tj), reg r holds element
+//              (row 16 ti + 4 r + q, col 16 tj + c).  A C-layout tile IS the B operand of the
+//              next MFMA (k-step kk <-> row block kk>>2, reg kk&3), so GEMM chains need no
+//              shuffles; only the A operand goes through LDS.
+//   R-layout : lane = h*NP + i holds row i and the interleaved columns cc*H + h, cc < CPL
+//              (balanced work for LU / triangular updates). Loading complex index cc*64 + lane
+//              of a COLUMN-MAJOR NP x NP matrix lands directly in R-layout, one contiguous KiB
+//              per instruction. Every matrix in HBM (Q, LU, H0, G_k) is such a column-major
+//              image.
+//   F-layout : lane l (any group) holds the full row l % NP (index c*NP + i of the image).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,6 +60,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return make_f64(lo, hi);
 }
 
+// lane must be wave-uniform
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -65,7 +70,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // DPP controls (gfx9): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
 // row_mirror = 0x140. Four symmetric exchanges leave every lane of a 16-lane row with the row
 // result; the four rows are then combined through SGPRs.
-#ifndef QOCX_SAFE_REDUCE
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_f64<0xB1>(v));
     v = fmax(v, dpp_f64<0x4E>(v));
@@ -84,23 +88,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
     return (r0 + r1) + (r2 + r3);
 }
-#else
-__device__ __forceinline__ double wave_max(double v) {
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m);
-    return v;
-}
-#endif
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// A block is exactly one wavefront: this is an ordering point for its LDS traffic.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// Every block is exactly ONE wavefront. The LDS executes a wave's DS instructions in issue
+// order, so a later ds_read of the same wave observes an earlier ds_write without a hardware
+// barrier; this only has to stop the compiler from reordering the accesses.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 1/x to full double precision: v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------
 // layouts
@@ -114,7 +124,6 @@ struct Geo {
     static constexpr int CPL = NP / H;        // columns per lane in R-layout
     static constexpr int MAT = NP * NP;       // complex elements per matrix image
     static constexpr int PLANE = NP * PITCH;  // f64 per LDS plane
-    static constexpr int TP = NP + 1;         // pitch (complex) of the LDS transpose buffer
 };
 
 template <int NB>
@@ -134,6 +143,17 @@ __device__ __forceinline__ void cmat_zero(CMat<NB>& m) {
         }
 }
 
+template <int NB>
+__device__ __forceinline__ void cmat_scale(CMat<NB>& m, double s) {
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {
+            m.re[ti][tj] *= s;
+            m.im[ti][tj] *= s;
+        }
+}
+
 // C-layout registers -> planar LDS slot (row-major, pitch PITCH). 16 consecutive lanes write 16
 // consecutive f64: conflict free.
 template <int NB>
@@ -150,6 +170,18 @@ __device__ __forceinline__ void cmat_to_lds(const CMat<NB>& m, double* lre, doub
                 lre[off] = m.re[ti][tj][r];
                 lim[off] = m.im[ti][tj][r];
             }
+}
+
+// planar LDS slot -> column-major HBM image, through R-layout registers.
+template <int NB>
+__device__ __forceinline__ void lds_to_image(const double* lre, const double* lim, double2* img) {
+    typedef Geo<NB> G;
+    const int lane = lane_id(), i = lane % G::NP, h = lane / G::NP;
+#pragma unroll
+    for (int cc = 0; cc < G::CPL; ++cc) {
+        const int off = i * G::PITCH + cc * G::H + h;
+        img[cc * 64 + lane] = make_double2(lre[off], lim[off]);
+    }
 }
 
 // acc += A * B. A from the planar LDS slot, B given per (k-step, column tile) by `bf`.
@@ -185,10 +217,6 @@ __device__ __forceinline__ void zgemm_acc(CMat<NB>& acc, const double* lre, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// generator assembly (K1 and K3 share it)
-// ------------------------------------------------------------------------------------------
-
 // u_k(t_mid): the reference's formula y1 + ((y2 - y1)/(x2 - x1)) * (x3 - x1), mathmethods.py:33.
 __device__ __forceinline__ double control_at(const double* ctl_b, const StepInterp& si, int K,
                                               int k) {
@@ -198,43 +226,33 @@ __device__ __forceinline__ double control_at(const double* ctl_b, const StepInte
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: Pade-13 numerator / denominator and LU
+// K1a: Pade-13 numerator / denominator
 // ------------------------------------------------------------------------------------------
 
-struct FactorOut {
-    double2* q_img;    // R-image of Q
-    double2* lu_img;   // R-image of the row-permuted L\U
-    double2* dinv;     // [NP] 1/U_kk
-    int* perm;         // [NP] perm[pos] = original row
-    int* s_out;        // squarings
-    int* status;       // device status word (bit 0: singular pivot, bit 1: bad norm)
+struct PqOut {
+    double2* q_img;   // column-major Q
+    double2* p_img;   // column-major P (LU'd in place by K1b)
+    int* s_out;       // squarings
+    int* status;      // bit 1: non-finite norm
 };
 
-// LDS carve of K1 (bytes): planar A slot | pivot row | multipliers
 template <int NB>
-struct FactorLds {
-    typedef Geo<NB> G;
-    static constexpr int SLOT_BYTES = 2 * G::PLANE * 8;
-    static constexpr int PROW_OFF = SLOT_BYTES;
-    static constexpr int MULT_OFF = PROW_OFF + G::NP * 16;
-    static constexpr int BYTES = MULT_OFF + G::NP * 16;
+struct PqLds {
+    static constexpr int BYTES = 2 * Geo<NB>::PLANE * 8;  // planar A-operand slot
 };
 
-// The body of K1 after the (unscaled) generator has been built by `gen(a)` into C-layout.
+// The body of K1a; `gen(a)` builds the unscaled generator in C-layout.
 template <int NB, class Gen>
-__device__ __forceinline__ void pade_factor_body(Gen gen, const FactorOut& out, char* smem) {
+__device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* smem) {
     typedef Geo<NB> G;
-    constexpr int NP = G::NP, CPL = G::CPL;
     double* lre = reinterpret_cast<double*>(smem);
     double* lim = lre + G::PLANE;
-    double2* prow = reinterpret_cast<double2*>(smem + FactorLds<NB>::PROW_OFF);
-    double2* mult = reinterpret_cast<double2*>(smem + FactorLds<NB>::MULT_OFF);
     const int lane = lane_id();
 
     // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
     CMat<NB> a;
     gen(a);
-    double colsum[NB];
+    double norm1 = 0;
 #pragma unroll
     for (int tj = 0; tj < NB; ++tj) {
         double s = 0;
@@ -245,11 +263,8 @@ __device__ __forceinline__ void pade_factor_body(Gen gen, const FactorOut& out, 
                 s += sqrt(a.re[ti][tj][r] * a.re[ti][tj][r] + a.im[ti][tj][r] * a.im[ti][tj][r]);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        colsum[tj] = s;
+        norm1 = (tj == 0) ? s : fmax(norm1, s);
     }
-    double norm1 = colsum[0];
-#pragma unroll
-    for (int tj = 1; tj < NB; ++tj) norm1 = fmax(norm1, colsum[tj]);
     norm1 = wave_max(norm1);
     int sq = 0;
     {
@@ -258,21 +273,13 @@ __device__ __forceinline__ void pade_factor_body(Gen gen, const FactorOut& out, 
             th *= 2.0;
             ++sq;
         }
-        if (!(norm1 <= th)) {  // inf / nan
+        if (!(norm1 <= th)) {  // inf / nan / absurd
             if (lane == 0) atomicOr(out.status, 2);
             sq = 0;
         }
     }
     const double scale = ldexp(1.0, -sq);
-    if (sq > 0) {
-#pragma unroll
-        for (int ti = 0; ti < NB; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < NB; ++tj) {
-                a.re[ti][tj] *= scale;
-                a.im[ti][tj] *= scale;
-            }
-    }
+    if (sq > 0) cmat_scale<NB>(a, scale);
     if (lane == 0) *out.s_out = sq;
 
     // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
@@ -336,15 +343,7 @@ __device__ __forceinline__ void pade_factor_body(Gen gen, const FactorOut& out, 
 
     // ---- u = a w2 + b1 a (expm.py:157) ; P = v - u ; Q = v + u (expm.py:246) ---------------
     gen(a);
-    if (sq > 0) {
-#pragma unroll
-        for (int ti = 0; ti < NB; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < NB; ++tj) {
-                a.re[ti][tj] *= scale;
-                a.im[ti][tj] *= scale;
-            }
-    }
+    if (sq > 0) cmat_scale<NB>(a, scale);
     cmat_to_lds<NB>(a, lre, lim);
     wave_sync();
     CMat<NB> u;
@@ -361,117 +360,41 @@ __device__ __forceinline__ void pade_factor_body(Gen gen, const FactorOut& out, 
     });
     wave_sync();
 
-    const int i = lane % NP, h = lane / NP;
-    // Q: C-layout -> LDS -> R-layout -> HBM image (one contiguous KiB per store instruction)
-    {
-        CMat<NB> t;
+    // C-layout -> LDS -> R-layout -> column-major images (one contiguous KiB per store)
+    CMat<NB> t;
 #pragma unroll
-        for (int ti = 0; ti < NB; ++ti)
+    for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < NB; ++tj) {
-                t.re[ti][tj] = v.re[ti][tj] + u.re[ti][tj];
-                t.im[ti][tj] = v.im[ti][tj] + u.im[ti][tj];
-            }
-        cmat_to_lds<NB>(t, lre, lim);
-        wave_sync();
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const int off = i * G::PITCH + h * CPL + cc;
-            out.q_img[cc * 64 + lane] = make_double2(lre[off], lim[off]);
+        for (int tj = 0; tj < NB; ++tj) {
+            t.re[ti][tj] = v.re[ti][tj] + u.re[ti][tj];
+            t.im[ti][tj] = v.im[ti][tj] + u.im[ti][tj];
         }
-        wave_sync();
+    cmat_to_lds<NB>(t, lre, lim);
+    wave_sync();
+    lds_to_image<NB>(lre, lim, out.q_img);
+    wave_sync();
 #pragma unroll
-        for (int ti = 0; ti < NB; ++ti)
+    for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < NB; ++tj) {
-                t.re[ti][tj] = v.re[ti][tj] - u.re[ti][tj];
-                t.im[ti][tj] = v.im[ti][tj] - u.im[ti][tj];
-            }
-        cmat_to_lds<NB>(t, lre, lim);
-        wave_sync();
-    }
-
-    // ---- LU with partial pivoting in R-layout (numpy.linalg.solve == LAPACK zgesv, expm.py:246)
-    // Rows are never moved: lane (h,i) keeps row i and remembers the step at which it became
-    // the pivot row; the image is written row-permuted at the end. Pivot choice = first
-    // maximum of |re|+|im| (LAPACK izamax).
-    double pre[CPL], pim[CPL];
-#pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-        const int off = i * G::PITCH + h * CPL + cc;
-        pre[cc] = lre[off];
-        pim[cc] = lim[off];
-    }
-    int mypos = -1;
-    double dinv_re = 0, dinv_im = 0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int hk = k / CPL, ck = k % CPL;
-        const bool mine = (h == hk) && (mypos < 0);
-        const double cand = mine ? (fabs(pre[ck]) + fabs(pim[ck])) : -1.0;
-        const double mx = wave_max(cand);
-        const unsigned long long ball = __ballot(cand == mx);
-        const int p = (__ffsll((long long)ball) - 1) % NP;
-        if (!(mx > 0.0) && lane == 0) atomicOr(out.status, 1);
-        if (i == p) {
-#pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) prow[h * CPL + cc] = make_double2(pre[cc], pim[cc]);
+        for (int tj = 0; tj < NB; ++tj) {
+            t.re[ti][tj] = v.re[ti][tj] - u.re[ti][tj];
+            t.im[ti][tj] = v.im[ti][tj] - u.im[ti][tj];
         }
-        wave_sync();
-        const double2 piv = prow[k];
-        const double den = piv.x * piv.x + piv.y * piv.y;
-        const double rden = 1.0 / den;
-        const double rre = piv.x * rden, rim = -piv.y * rden;
-        if (lane == k) {
-            dinv_re = rre;
-            dinv_im = rim;
-        }
-        if (h == hk) {
-            double mre = 0, mim = 0;
-            if (mypos < 0 && i != p) {
-                mre = pre[ck] * rre - pim[ck] * rim;
-                mim = pre[ck] * rim + pim[ck] * rre;
-                pre[ck] = mre;
-                pim[ck] = mim;
-            }
-            mult[i] = make_double2(mre, mim);
-        }
-        wave_sync();
-        const double2 m = mult[i];
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            if (h * CPL + cc > k) {
-                const double2 pv = prow[h * CPL + cc];
-                pre[cc] -= m.x * pv.x - m.y * pv.y;
-                pim[cc] -= m.x * pv.y + m.y * pv.x;
-            }
-        }
-        if (i == p) mypos = k;
-        wave_sync();
-    }
-    if (mypos < 0 || mypos >= NP) {  // only reachable with non-finite input
-        mypos = i;
-        atomicOr(out.status, 2);
-    }
-#pragma unroll
-    for (int cc = 0; cc < CPL; ++cc)
-        out.lu_img[cc * 64 + h * NP + mypos] = make_double2(pre[cc], pim[cc]);
-    if (h == 0) out.perm[mypos] = i;
-    if (lane < NP) out.dinv[lane] = make_double2(dinv_re, dinv_im);
+    cmat_to_lds<NB>(t, lre, lim);
+    wave_sync();
+    lds_to_image<NB>(lre, lim, out.p_img);
 }
 
 template <int NB>
-__global__ __launch_bounds__(64) void pade_factor_kernel(FactorArgs args) {
+__global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int step = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id();
     const size_t m = (size_t)b * args.nsteps + step;
-    FactorOut out;
+    PqOut out;
     out.q_img = args.q_img + m * G::MAT;
-    out.lu_img = args.lu_img + m * G::MAT;
-    out.dinv = args.dinv + m * G::NP;
-    out.perm = args.perm + m * G::NP;
+    out.p_img = args.lu_img + m * G::MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
     const StepInterp si = args.interp[step];
@@ -517,23 +440,22 @@ __global__ __launch_bounds__(64) void pade_factor_kernel(FactorArgs args) {
                 a.im[ti][tj] = -dt * hm.re[ti][tj];
             }
     };
-    pade_factor_body<NB>(gen, out, smem);
+    pade_pq_body<NB>(gen, out, smem);
 }
 
-// Debug / explicit-generator variant: a[count][n][n] row-major complex in HBM.
+// Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
+// the form a Magnus M4/M6 generator kernel would feed).
 template <int NB>
-__global__ __launch_bounds__(64) void pade_factor_explicit_kernel(const double2* a_in, int n,
-                                                                  FactorArgs args) {
+__global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_in, int n,
+                                                              FactorArgs args) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t m = blockIdx.x;
     const int lane = lane_id();
     const int q = lane >> 4, c = lane & 15;
-    FactorOut out;
+    PqOut out;
     out.q_img = args.q_img + m * G::MAT;
-    out.lu_img = args.lu_img + m * G::MAT;
-    out.dinv = args.dinv + m * G::NP;
-    out.perm = args.perm + m * G::NP;
+    out.p_img = args.lu_img + m * G::MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
     const double2* am = a_in + m * (size_t)n * n;
@@ -551,106 +473,178 @@ __global__ __launch_bounds__(64) void pade_factor_explicit_kernel(const double2*
                     a.im[ti][tj][r] = e.y;
                 }
     };
-    pade_factor_body<NB>(gen, out, smem);
+    pade_pq_body<NB>(gen, out, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b: LU with partial pivoting, in place on the column-major P image
+// ------------------------------------------------------------------------------------------
+// Rows are never moved: lane (h,i) keeps row i (columns cc*H+h) and remembers the step at which
+// it became the pivot row. The factors are stored in ORIGINAL row order (column k as soon as it
+// is final, which frees its registers); perm/iperm give the row order. Pivot choice = first
+// maximum of |re|+|im| (LAPACK izamax). Only the pivot row goes through LDS; the pivot element
+// comes from a dynamic v_readlane, the multipliers cross lane groups by ds_bpermute.
+// wave-wide max of a u32 (DPP folds into v_max_u32; rows combined on the scalar unit)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// value of lane group `g` (static) of a double, replicated to every lane group
+template <int NB, int g>
+__device__ __forceinline__ double from_group(double v, int i) {
+    if (Geo<NB>::H == 2) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return make_f64((int)a[g], (int)b[g]);
+    }
+    return __shfl(v, g * Geo<NB>::NP + i);
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
+    typedef Geo<NB> G;
+    constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
+    __shared__ __attribute__((aligned(16))) double2 prow[NP];
+    const size_t m = blockIdx.x;
+    const int lane = lane_id(), i = lane % NP, h = lane / NP;
+    double2* img = args.lu_img + m * G::MAT;
+    double pre[CPL], pim[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+        const double2 e = img[cc * 64 + lane];
+        pre[cc] = e.x;
+        pim[cc] = e.y;
+    }
+    int mypos = -1;
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int hk = k % H, ck = k / H;
+        // ---- pivot search: exact argmax of |re|+|im| over the unpivoted rows, as two u32
+        // reductions of the (monotonic) bit pattern; first maximum wins (LAPACK izamax).
+        const bool mine = (h == hk) && (mypos < 0);
+        const double mag = fabs(pre[ck]) + fabs(pim[ck]);
+        const unsigned long long bits =
+            mine ? ((unsigned long long)__double_as_longlong(mag) + 1ull) : 0ull;
+        const unsigned khi = (unsigned)(bits >> 32), klo = (unsigned)bits;
+        const unsigned mh = wave_max_u32(khi);
+        const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
+        const unsigned long long ball = __ballot(khi == mh && klo == ml);
+        const int lp = __ffsll((long long)ball) - 1;  // a lane of group hk, never -1
+        const int p = lp % NP;
+        singular = singular || (mh == 0u && ml <= 1u);
+        // ---- reciprocal pivot, multipliers
+        const double pr = readlane_f64(pre[ck], lp), pi = readlane_f64(pim[ck], lp);
+        const double rden = fast_rcp(pr * pr + pi * pi);
+        const double rre = pr * rden, rim = -pi * rden;
+        if (lane == k) args.dinv[m * NP + k] = make_double2(rre, rim);  // 1/U_kk
+        const bool elim = mine && (i != p);
+        const double mre_own = elim ? (pre[ck] * rre - pim[ck] * rim) : 0.0;
+        const double mim_own = elim ? (pre[ck] * rim + pim[ck] * rre) : 0.0;
+        // column k is final now (multipliers / U entries): store it, in ORIGINAL row order
+        if (h == hk)
+            img[k * NP + i] = make_double2(elim ? mre_own : pre[ck], elim ? mim_own : pim[ck]);
+        double mre = mre_own, mim = mim_own;
+        if (H > 1) {
+            if (hk == 0) { mre = from_group<NB, 0>(mre_own, i); mim = from_group<NB, 0>(mim_own, i); }
+            if (hk == 1) { mre = from_group<NB, 1>(mre_own, i); mim = from_group<NB, 1>(mim_own, i); }
+            if (hk == 2) { mre = from_group<NB, 2>(mre_own, i); mim = from_group<NB, 2>(mim_own, i); }
+            if (hk == 3) { mre = from_group<NB, 3>(mre_own, i); mim = from_group<NB, 3>(mim_own, i); }
+        }
+        // ---- pivot row through LDS (only the columns still active), rank-1 update
+        if (i == p) {
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc)
+                if (cc * H + (H - 1) > k)  // compile time: some lane group still needs it
+                    if (cc * H + h > k) prow[cc * H + h] = make_double2(pre[cc], pim[cc]);
+        }
+        mypos = (i == p) ? k : mypos;
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) {
+            if (cc * H + (H - 1) > k) {
+                const double2 pv = prow[cc * H + h];
+                const bool on = (cc * H + h > k);
+                const double ure = on ? mre : 0.0, uim = on ? mim : 0.0;
+                pre[cc] -= ure * pv.x - uim * pv.y;
+                pim[cc] -= ure * pv.y + uim * pv.x;
+            }
+        }
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled steps from interleaving
+    }
+    if (singular && lane == 0) atomicOr(args.status, 1);
+    if (mypos < 0 || mypos >= NP) {  // only reachable with non-finite input
+        mypos = i;
+        atomicOr(args.status, 2);
+    }
+    if (h == 0) {
+        args.perm[m * NP + mypos] = i;   // row of P that ended at position mypos
+        args.iperm[m * NP + i] = mypos;  // position of row i
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // K2: serial state sweep (forward), costs, adjoint sweep (backward)
 // ------------------------------------------------------------------------------------------
 
-// Triangular solves in R-layout, axpy form. z is replicated in every lane group h; in phase hk
-// only group hk (which holds columns hk*CPL..) updates, then its copy is broadcast.
-// LOWER: forward substitution (row k known before rows > k). UNIT: unit diagonal, otherwise the
-// lane's diagonal reciprocal d is applied. CONJ: use conj of the stored coefficients.
+// Triangular solves, axpy form, coefficient rows in F-layout (every lane group holds the full
+// row i = lane % NP, so all groups run the solve redundantly and z stays replicated).
+// LOWER: forward substitution. UNIT: unit diagonal, otherwise the lane's reciprocal diagonal
+// (dre, dim) is applied. CONJ: use conj of the stored coefficients.
 template <int NB, bool LOWER, bool UNIT, bool CONJ>
-__device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::CPL],
-                                          const double (&tim)[Geo<NB>::CPL], double& zre,
-                                          double& zim, double dre, double dim, int h, int i) {
-    typedef Geo<NB> G;
-    constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
+__device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
+                                          const double (&tim)[Geo<NB>::NP], double& zre,
+                                          double& zim, double dre, double dim, int i) {
+    constexpr int NP = Geo<NB>::NP;
     if (CONJ) dim = -dim;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-        const int hk = LOWER ? hh : (H - 1 - hh);
-#pragma unroll
-        for (int cs = 0; cs < CPL; ++cs) {
-            const int ck = LOWER ? cs : (CPL - 1 - cs);
-            const int k = hk * CPL + ck;
-            double vre = zre, vim = zim;
-            if (!UNIT) {
-                vre = zre * dre - zim * dim;
-                vim = zre * dim + zim * dre;
-            }
-            const double kre = readlane_f64(vre, hk * NP + k);
-            const double kim = readlane_f64(vim, hk * NP + k);
-            if (!UNIT) {
-                if (i == k) {
-                    zre = kre;
-                    zim = kim;
-                }
-            }
-            const double lre = tre[ck];
-            const double lim = CONJ ? -tim[ck] : tim[ck];
-            const bool upd = (h == hk) && (LOWER ? (i > k) : (i < k));
-            if (upd) {
-                zre -= lre * kre - lim * kim;
-                zim -= lre * kim + lim * kre;
+    for (int kk = 0; kk < NP; ++kk) {
+        const int k = LOWER ? kk : (NP - 1 - kk);
+        double vre = zre, vim = zim;
+        if (!UNIT) {
+            vre = zre * dre - zim * dim;
+            vim = zre * dim + zim * dre;
+        }
+        const double kre = readlane_f64(vre, k), kim = readlane_f64(vim, k);
+        if (!UNIT) {
+            if (i == k) {
+                zre = kre;
+                zim = kim;
             }
         }
-        if (H > 1) {
-            zre = __shfl(zre, hk * NP + i);
-            zim = __shfl(zim, hk * NP + i);
+        const double cre = tre[k], cim = CONJ ? -tim[k] : tim[k];
+        if (LOWER ? (i > k) : (i < k)) {
+            zre -= cre * kre - cim * kim;
+            zim -= cre * kim + cim * kre;
         }
     }
 }
 
-// y = M v (or conj(M) v) with M in R-layout registers, v in LDS; the result is replicated in all
-// lane groups. `part` is an LDS scratch of H*NP complex.
-template <int NB, bool CONJ>
-__device__ __forceinline__ void matvec(const double (&mre)[Geo<NB>::CPL],
-                                       const double (&mim)[Geo<NB>::CPL], const double2* v,
-                                       double2* part, int h, int i, double& yre, double& yim) {
-    typedef Geo<NB> G;
-    constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
-    double sre = 0, sim = 0;
-#pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-        const double2 x = v[h * CPL + cc];
-        const double mr = mre[cc], mi = CONJ ? -mim[cc] : mim[cc];
-        sre += mr * x.x - mi * x.y;
-        sim += mr * x.y + mi * x.x;
-    }
-    part[h * NP + i] = make_double2(sre, sim);
-    wave_sync();
-    yre = 0;
-    yim = 0;
-#pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-        const double2 p = part[hh * NP + i];
-        yre += p.x;
-        yim += p.y;
-    }
-    wave_sync();
-}
-
-// <t|psi> over the first NP lanes (lane group 0), result uniform.
+// <t|psi> over lane group 0, result wave-uniform.
 __device__ __forceinline__ void inner(const double2 t, const double2 p, bool active, double& re,
                                       double& im) {
-    // conj(t) * p
-    double pr = active ? (t.x * p.x + t.y * p.y) : 0.0;
+    double pr = active ? (t.x * p.x + t.y * p.y) : 0.0;  // conj(t) * p
     double pi = active ? (t.x * p.y - t.y * p.x) : 0.0;
     re = wave_sum(pr);
     im = wave_sum(pi);
 }
 
-// Evaluate the selected costs on the S states held in `vecs` (LDS, [S][NP]).
-// If lam != nullptr also adds dC/dRe + i dC/dIm into lam (LDS, [S][NP]).
+// Evaluate the selected costs on the S states in `vecs` (LDS, [S][NP]). If lam != nullptr also
+// adds dC/dRe + i dC/dIm into lam (LDS, [S][NP]). Formulas: qoc/standard/costs/
+// targetstateinfidelity.py:52-61, forbidstates.py:64-81; cotangents SURVEY.md Appendix A.
 template <int NB>
 __device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pass,
                                              bool final_pass, const double2* vecs, double2* lam,
                                              int h, int i) {
-    typedef Geo<NB> G;
-    constexpr int NP = G::NP;
+    constexpr int NP = Geo<NB>::NP;
     const int S = args.S;
     const bool act = (h == 0);
     double total = 0;
@@ -725,40 +719,77 @@ __device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pa
 template <int NB>
 struct SweepLds {
     typedef Geo<NB> G;
-    static constexpr int TR_OFF = 0;                                  // transpose buffer
-    static constexpr int TR_BYTES = G::NP * G::TP * 16;
-    static constexpr int PART_OFF = TR_OFF + TR_BYTES;                // H*NP complex
-    static constexpr int TMP_OFF = PART_OFF + 64 * 16;                // NP complex
-    static constexpr int VEC_OFF = TMP_OFF + G::NP * 16;              // [S][NP] states
-    static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }  // + [S][NP] lambda
+    static constexpr int BUF_BYTES = G::MAT * 16;              // one matrix image
+    static constexpr int Q_OFF = 0;                            // 2 x Q image (double buffer)
+    static constexpr int L_OFF = Q_OFF + 2 * BUF_BYTES;         // 2 x LU image
+    static constexpr int TMP_OFF = L_OFF + 2 * BUF_BYTES;       // NP complex scratch vector
+    static constexpr int VEC_OFF = TMP_OFF + G::NP * 16;        // [S][NP] states, [S][NP] lambda
+    static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
 
-// R-image rows (registers) -> transposed R-layout registers through LDS.
+// Per-step operands of the sweep, in registers: Q in R-layout (matvec), LU in F-layout (solves).
 template <int NB>
-__device__ __forceinline__ void transpose_r(double (&mre)[Geo<NB>::CPL], double (&mim)[Geo<NB>::CPL],
-                                            double2* tr, int h, int i) {
+struct StepRegs {
+    double qre[Geo<NB>::CPL], qim[Geo<NB>::CPL];
+    double lre[Geo<NB>::NP], lim[Geo<NB>::NP];
+};
+
+template <int NB>
+struct StepScalars {
+    double2 dv;               // this lane's 1/U_ii
+    int pm;                   // forward: perm[i] (row at position i); adjoint: iperm[i]
+    int nsub;                 // 2^s sub-steps
+    int permk[Geo<NB>::NP];   // adjoint only: the whole row order, wave-uniform (SGPRs)
+};
+
+// One 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `g` land at lds_base + 16*l.
+__device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// Stream one column-major image into LDS. TRANSPOSE: gather so that LDS holds the image of the
+// transposed matrix (position r*NP + c <- element (r, c)).
+template <int NB, bool TRANSPOSE>
+__device__ __forceinline__ void dma_image(const double2* img, double2* lds, int lane) {
     typedef Geo<NB> G;
-    constexpr int CPL = G::CPL, TP = G::TP;
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) tr[i * TP + h * CPL + cc] = make_double2(mre[cc], mim[cc]);
-    wave_sync();
-#pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-        const double2 e = tr[(h * CPL + cc) * TP + i];
-        mre[cc] = e.x;
-        mim[cc] = e.y;
+    for (int j = 0; j < G::MAT / 64; ++j) {
+        const int q = j * 64 + lane;
+        const int src = TRANSPOSE ? ((q % G::NP) * G::NP + q / G::NP) : q;
+        dma16(img + src, lds + j * 64);
     }
-    wave_sync();
+}
+
+// LDS images -> registers. The LU image is stored in original row order, so the row at position
+// i is row perm[i] (forward: per-lane index; adjoint, transposed image: per-column scalar).
+template <int NB, bool ADJOINT>
+__device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, StepRegs<NB>& r,
+                                            const StepScalars<NB>& sc, int lane, int i) {
+    typedef Geo<NB> G;
+#pragma unroll
+    for (int cc = 0; cc < G::CPL; ++cc) {
+        const double2 e = qb[cc * 64 + lane];
+        r.qre[cc] = e.x;
+        r.qim[cc] = e.y;
+    }
+#pragma unroll
+    for (int c = 0; c < G::NP; ++c) {
+        const double2 e = ADJOINT ? lb[sc.permk[c] * G::NP + i] : lb[c * G::NP + sc.pm];
+        r.lre[c] = e.x;
+        r.lim[c] = e.y;
+    }
 }
 
 template <int NB>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
     typedef SweepLds<NB> L;
-    constexpr int NP = G::NP, CPL = G::CPL;
+    constexpr int NP = G::NP, CPL = G::CPL, H = G::H, MAT = G::MAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2* tr = reinterpret_cast<double2*>(smem + L::TR_OFF);
-    double2* part = reinterpret_cast<double2*>(smem + L::PART_OFF);
+    double2* qbuf = reinterpret_cast<double2*>(smem + L::Q_OFF);
+    double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
     double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF);
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
     const int S = args.S;
@@ -771,6 +802,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     double2* xs_b = args.xs + (size_t)b * cap * S * NP;
     int* offs_b = args.offs + (size_t)b * (nsteps + 1);
     const bool g0 = (h == 0);
+    const size_t m0 = (size_t)b * nsteps;
 
     for (int s = 0; s < S; ++s)
         if (g0) {
@@ -783,7 +815,57 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     double cost = 0;
     int slot = 0;
     bool overflow = false;
-    for (int step = 0; step <= nsteps; ++step) {
+    StepRegs<NB> r;
+
+    auto load_scalars = [&](size_t m, bool adjoint) {
+        StepScalars<NB> sc;
+        sc.dv = args.dinv[m * NP + i];
+        const int pv = adjoint ? args.iperm[m * NP + i] : args.perm[m * NP + i];
+        sc.pm = min(max(pv, 0), NP - 1);
+        sc.nsub = 1 << min(max(args.s_arr[m], 0), 30);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            sc.permk[k] = adjoint ? min(max(args.perm[m * NP + k], 0), NP - 1) : 0;
+        return sc;
+    };
+
+    // one propagator step on all S states with the operands in `r`
+    auto forward_step = [&](const StepScalars<NB>& sc) {
+        for (int sub = 0; sub < sc.nsub; ++sub) {
+            if ((size_t)slot + 1 >= cap) {
+                overflow = true;
+                break;
+            }
+            for (int s = 0; s < S; ++s) {
+                // y = Q psi : partial sums over this lane group's columns, then combine
+                double yre = 0, yim = 0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 x = vecs[s * NP + cc * H + h];
+                    yre += r.qre[cc] * x.x - r.qim[cc] * x.y;
+                    yim += r.qre[cc] * x.y + r.qim[cc] * x.x;
+                }
+#pragma unroll
+                for (int d = NP; d < 64; d <<= 1) {
+                    yre += __shfl_xor(yre, d);
+                    yim += __shfl_xor(yim, d);
+                }
+                // z = Pi y ; L z' = z ; U psi' = z'
+                double zre = __shfl(yre, sc.pm), zim = __shfl(yim, sc.pm);
+                tri_solve<NB, true, true, false>(r.lre, r.lim, zre, zim, 0, 0, i);
+                tri_solve<NB, false, false, false>(r.lre, r.lim, zre, zim, sc.dv.x, sc.dv.y, i);
+                wave_sync();
+                if (g0) {
+                    const double2 p = make_double2(zre, zim);
+                    vecs[s * NP + i] = p;
+                    states_b[((size_t)(slot + 1) * S + s) * NP + i] = p;
+                }
+                wave_sync();
+            }
+            ++slot;
+        }
+    };
+    auto before_step = [&](int step) {
         if (step != 0 && (step % args.cost_eval_step) == 0)
             cost += eval_costs<NB>(args, true, false, vecs, nullptr, h, i);
         if (g0 && args.step_states != nullptr)
@@ -791,53 +873,37 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 args.step_states[(((size_t)b * (nsteps + 1) + step) * S + s) * NP + i] =
                     vecs[s * NP + i];
         if (lane == 0) offs_b[step] = slot;
-        if (step == nsteps) break;
-        const size_t m = (size_t)b * nsteps + step;
-        const int nsub = 1 << min(max(args.s_arr[m], 0), 30);
-        const double2* qi = args.q_img + m * G::MAT;
-        const double2* li = args.lu_img + m * G::MAT;
-        double qre[CPL], qim[CPL], lre[CPL], lim[CPL];
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const double2 e = qi[cc * 64 + lane];
-            qre[cc] = e.x;
-            qim[cc] = e.y;
-            const double2 f = li[cc * 64 + lane];
-            lre[cc] = f.x;
-            lim[cc] = f.y;
-        }
-        const double2 dv = args.dinv[m * NP + i];
-        const int pm = min(max(args.perm[m * NP + i], 0), NP - 1);
-        for (int sub = 0; sub < nsub; ++sub) {
-            if ((size_t)slot + 1 >= cap) {
-                overflow = true;
-                break;
-            }
-            for (int s = 0; s < S; ++s) {
-                double yre, yim;
-                matvec<NB, false>(qre, qim, vecs + s * NP, part, h, i, yre, yim);
-                if (g0) tmp[i] = make_double2(yre, yim);
-                wave_sync();
-                const double2 zp = tmp[pm];  // z = Pi y
-                wave_sync();
-                double zre = zp.x, zim = zp.y;
-                tri_solve<NB, true, true, false>(lre, lim, zre, zim, 0, 0, h, i);
-                tri_solve<NB, false, false, false>(lre, lim, zre, zim, dv.x, dv.y, h, i);
-                if (g0) {
-                    const double2 p = make_double2(zre, zim);
-                    vecs[s * NP + i] = p;
-                    states_b[((size_t)(slot + 1) * S + s) * NP + i] = p;
-                }
-            }
+    };
+
+    // ---- forward sweep: the next step's Q and LU stream into LDS (LDS-DMA, no registers)
+    // while the current step's dependent chains run --------------------------------------
+    {
+        dma_image<NB, false>(args.q_img + m0 * MAT, qbuf, lane);
+        dma_image<NB, false>(args.lu_img + m0 * MAT, lbuf, lane);
+        StepScalars<NB> cur = load_scalars(m0, false), nxt = cur;
+        for (int step = 0; step < nsteps; ++step) {
+            const int par = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            ++slot;
+            lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, r, cur, lane, i);
+            wave_sync();
+            if (step + 1 < nsteps) {
+                dma_image<NB, false>(args.q_img + (m0 + step + 1) * MAT, qbuf + (par ^ 1) * MAT, lane);
+                dma_image<NB, false>(args.lu_img + (m0 + step + 1) * MAT, lbuf + (par ^ 1) * MAT, lane);
+                nxt = load_scalars(m0 + step + 1, false);
+            }
+            before_step(step);
+            forward_step(cur);
+            if (overflow) break;
+            cur = nxt;
         }
-        if (overflow) break;
     }
     if (overflow) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) atomicOr(args.status, 4);
         return;
     }
+    before_step(nsteps);
     cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
     if (lane == 0) args.cost_out[b] = cost;
     if (g0)
@@ -850,42 +916,40 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     wave_sync();
     // cotangent seeds on the final states: non-step costs, and step costs if the final step is
     // a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
-    {
-        const bool final_is_step = (nsteps % args.cost_eval_step) == 0;
-        (void)eval_costs<NB>(args, final_is_step, true, vecs, lam, h, i);
-    }
-    for (int step = nsteps - 1; step >= 0; --step) {
-        const size_t m = (size_t)b * nsteps + step;
-        const int nsub = 1 << min(max(args.s_arr[m], 0), 30);
-        const double2* qi = args.q_img + m * G::MAT;
-        const double2* li = args.lu_img + m * G::MAT;
-        double qre[CPL], qim[CPL], lre[CPL], lim[CPL];
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const double2 e = qi[cc * 64 + lane];
-            qre[cc] = e.x;
-            qim[cc] = e.y;
-            const double2 f = li[cc * 64 + lane];
-            lre[cc] = f.x;
-            lim[cc] = f.y;
-        }
-        transpose_r<NB>(qre, qim, tr, h, i);
-        transpose_r<NB>(lre, lim, tr, h, i);
-        const double2 dv = args.dinv[m * NP + i];
-        const int pm = min(max(args.perm[m * NP + i], 0), NP - 1);
-        for (int sub = nsub - 1; sub >= 0; --sub) {
+    (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+
+    auto adjoint_step = [&](const StepScalars<NB>& sc, int step) {
+        for (int sub = sc.nsub - 1; sub >= 0; --sub) {
             --slot;
             for (int s = 0; s < S; ++s) {
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // U^H w = lambda (lower, conj, diagonal 1/conj(U_kk)); L^H v = w (upper, unit, conj)
-                tri_solve<NB, true, false, true>(lre, lim, zre, zim, dv.x, dv.y, h, i);
-                tri_solve<NB, false, true, true>(lre, lim, zre, zim, 0, 0, h, i);
-                if (g0) tmp[pm] = make_double2(zre, zim);  // x = Pi^T v
+                tri_solve<NB, true, false, true>(r.lre, r.lim, zre, zim, sc.dv.x, sc.dv.y, i);
+                tri_solve<NB, false, true, true>(r.lre, r.lim, zre, zim, 0, 0, i);
+                // x = Pi^T v : x_i = v[position of row i]
+                const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
                 wave_sync();
-                if (g0) xs_b[((size_t)slot * S + s) * NP + i] = tmp[i];
-                double yre, yim;
-                matvec<NB, true>(qre, qim, tmp, part, h, i, yre, yim);  // lambda = Q^H x
+                if (g0) {
+                    const double2 x = make_double2(xre, xim);
+                    tmp[i] = x;
+                    xs_b[((size_t)slot * S + s) * NP + i] = x;
+                }
+                wave_sync();
+                // lambda = Q^H x ; r.q holds rows of Q^T (lane (h,i): Q[cc*H+h][i])
+                double yre = 0, yim = 0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 x = tmp[cc * H + h];
+                    yre += r.qre[cc] * x.x + r.qim[cc] * x.y;
+                    yim += r.qre[cc] * x.y - r.qim[cc] * x.x;
+                }
+#pragma unroll
+                for (int d = NP; d < 64; d <<= 1) {
+                    yre += __shfl_xor(yre, d);
+                    yim += __shfl_xor(yim, d);
+                }
+                wave_sync();
                 if (g0) lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
             }
@@ -897,6 +961,27 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                     vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
             wave_sync();
             (void)eval_costs<NB>(args, true, false, vecs, lam, h, i);
+        }
+    };
+    {
+        // the DMA gathers transposed images, so the same LDS reads deliver Q^T and LU^T rows
+        const size_t ml = m0 + nsteps - 1;
+        dma_image<NB, true>(args.q_img + ml * MAT, qbuf, lane);
+        dma_image<NB, true>(args.lu_img + ml * MAT, lbuf, lane);
+        StepScalars<NB> cur = load_scalars(ml, true), nxt = cur;
+        for (int step = nsteps - 1, it = 0; step >= 0; --step, ++it) {
+            const int par = it & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, r, cur, lane, i);
+            wave_sync();
+            if (step - 1 >= 0) {
+                dma_image<NB, true>(args.q_img + (m0 + step - 1) * MAT, qbuf + (par ^ 1) * MAT, lane);
+                dma_image<NB, true>(args.lu_img + (m0 + step - 1) * MAT, lbuf + (par ^ 1) * MAT, lane);
+                nxt = load_scalars(m0 + step - 1, true);
+            }
+            adjoint_step(cur, step);
+            cur = nxt;
         }
     }
 }
@@ -1030,9 +1115,9 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
                     double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0;
 #pragma unroll
                     for (int cc = 0; cc < CPL; ++cc) {
-                        const double2 v0 = vv[h * CPL + cc];
-                        const double2 v1 = vv[NP + h * CPL + cc];
-                        const double2 v2 = vv[2 * NP + h * CPL + cc];
+                        const double2 v0 = vv[cc * H + h];
+                        const double2 v1 = vv[NP + cc * H + h];
+                        const double2 v2 = vv[2 * NP + cc * H + h];
                         s0r += are[cc] * v0.x - aim[cc] * v0.y;
                         s0i += are[cc] * v0.y + aim[cc] * v0.x;
                         s1r += are[cc] * v1.x - aim[cc] * v1.y;
@@ -1069,7 +1154,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
             for (int tt = 0; tt < 13; ++tt) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 r = rho_l[tt * NP + h * CPL + cc];
+                    const double2 r = rho_l[tt * NP + cc * H + h];
                     // tau * conj(rho)
                     abr[cc] += tvr[tt] * r.x + tvi[tt] * r.y;
                     abi[cc] += tvi[tt] * r.x - tvr[tt] * r.y;
@@ -1130,15 +1215,14 @@ __global__ __launch_bounds__(64) void selftest_kernel(double* out) {
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int NB>
-static void launch_factor_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(pade_factor_kernel<NB>, dim3(nsteps, batch), dim3(64),
-                       FactorLds<NB>::BYTES, st, a);
+static void launch_pq_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(pade_pq_kernel<NB>, dim3(nsteps, batch), dim3(64), PqLds<NB>::BYTES, st, a);
 }
 template <int NB>
-static void launch_factor_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
-                                     hipStream_t st) {
-    hipLaunchKernelGGL(pade_factor_explicit_kernel<NB>, dim3(count), dim3(64),
-                       FactorLds<NB>::BYTES, st, a_in, n, a);
+static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(pade_pq_explicit_kernel<NB>, dim3(count), dim3(64), PqLds<NB>::BYTES, st,
+                       a_in, n, a);
 }
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
@@ -1154,14 +1238,18 @@ static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStrea
                        KrylovLds<NB>::BYTES, st, a);
 }
 
-void launch_factor(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    if (nb == 1) launch_factor_t<1>(a, nsteps, batch, st);
-    else launch_factor_t<2>(a, nsteps, batch, st);
+void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
+    else launch_pq_t<2>(a, nsteps, batch, st);
 }
-void launch_factor_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
-                            hipStream_t st) {
-    if (nb == 1) launch_factor_explicit_t<1>(a_in, n, a, count, st);
-    else launch_factor_explicit_t<2>(a_in, n, a, count, st);
+void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
+                        hipStream_t st) {
+    if (nb == 1) launch_pq_explicit_t<1>(a_in, n, a, count, st);
+    else launch_pq_explicit_t<2>(a_in, n, a, count, st);
+}
+void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
+    if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
 }
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st) {
     if (nb == 1) launch_sweep_t<1>(a, batch, st);
