@@ -129,6 +129,9 @@ struct qocx_ctx {
     int sbound = 0;
     size_t slot_cap = 0;
     int chunk_user = 0;
+    int pipe_user = 0;
+    std::vector<hipStream_t> sweep_streams;
+    std::vector<hipEvent_t> ev_factored, ev_swept;
     int keep_step_states = 0;
     bool have_results = false, have_grads = false, have_step_states = false;
     DevBuf<double> controls, cost_out, grads, gstep;
@@ -190,19 +193,19 @@ void from_image(const double2* img, int n, int np, const int* row_map, double* o
         }
 }
 
-void time_begin(qocx_ctx* ctx, int which) {
+void time_begin(qocx_ctx* ctx, int which, hipStream_t st) {
     if (!ctx->timing) return;
     TimingRec r;
     r.which = which;
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
-    (void)hipEventRecord(r.a, ctx->stream);
+    (void)hipEventRecord(r.a, st);
     ctx->pending.push_back(r);
 }
 
-void time_end(qocx_ctx* ctx) {
+void time_end(qocx_ctx* ctx, hipStream_t st) {
     if (!ctx->timing) return;
-    (void)hipEventRecord(ctx->pending.back().b, ctx->stream);
+    (void)hipEventRecord(ctx->pending.back().b, st);
 }
 
 void time_collect(qocx_ctx* ctx) {
@@ -275,6 +278,23 @@ int qocx_create(int device, qocx_ctx** out) {
         delete ctx;
         return QOCX_ERR_HIP;
     }
+    // side streams of the latency-bound sweeps get the highest priority, so that their few
+    // waves are placed as soon as a SIMD frees up under the compute stream's big grids
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    for (int i = 0; i < 8; ++i) {
+        hipStream_t st;
+        hipEvent_t e1, e2;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
+            g_error = "cannot create the pipeline streams";
+            return QOCX_ERR_HIP;
+        }
+        ctx->sweep_streams.push_back(st);
+        ctx->ev_factored.push_back(e1);
+        ctx->ev_swept.push_back(e2);
+    }
     *out = ctx;
     return 0;
 }
@@ -298,6 +318,9 @@ int qocx_destroy(qocx_ctx* ctx) {
     for (auto* b : bi) b->release();
     ctx->interp.release();
     ctx->costs.release();
+    for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
+    for (auto e : ctx->ev_factored) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_swept) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -511,6 +534,12 @@ int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk) {
     return 0;
 }
 
+int qocx_set_pipeline(qocx_ctx* ctx, int32_t sub_chunks) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    ctx->pipe_user = sub_chunks < 0 ? 0 : sub_chunks;
+    return 0;
+}
+
 int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
     ctx->keep_step_states = keep ? 1 : 0;
@@ -552,66 +581,96 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
 
+    // Pipelined schedule. The serial sweep of a seed is latency bound (one wave, 2(N-1)
+    // dependent steps), so each memory chunk is cut into `pipe` sub-chunks: the compute stream
+    // runs pade_pq + lu of every sub-chunk back to back, each sub-chunk's sweep runs on its own
+    // side stream behind its lu, and krylov_grad + scatter of sub-chunk i follow on the compute
+    // stream once sweep i is done - the sweeps hide behind the other sub-chunks' kernels.
+    const int max_pipe = (int)ctx->sweep_streams.size();
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
-        qocx::FactorArgs fa;
-        fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
-        fa.interp = ctx->interp.p;
-        fa.h0_cimg = ctx->h0_cimg.p;
-        fa.g_cimg = ctx->g_cimg.p;
-        fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
-        fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
-        fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
-        time_begin(ctx, 0);
-        qocx::launch_pq(ctx->nb, fa, nsteps, bc, ctx->stream);
-        time_end(ctx);
-        qocx::LuArgs la;
-        la.lu_img = ctx->lu_img.p; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
-        la.iperm = ctx->iperm.p; la.status = ctx->status.p;
-        time_begin(ctx, 4);
-        qocx::launch_lu(ctx->nb, la, (size_t)bc * nsteps, ctx->stream);
-        time_end(ctx);
+        // default: 2 sub-chunks (measured best on MI355X: a running sweep wave blocks its SIMD for
+        // the 382-VGPR pade_pq waves, so more overlap costs more than it hides)
+        const int want_pipe = ctx->pipe_user > 0 ? ctx->pipe_user : (bc >= 64 ? 2 : 1);
+        const int pipe = std::max(1, std::min(std::min(max_pipe, want_pipe), bc));
+        std::vector<int> sub_lo(pipe + 1);
+        for (int i = 0; i <= pipe; ++i) sub_lo[i] = (int)((long long)bc * i / pipe);
+        for (int i = 0; i < pipe; ++i) {
+            const int lo = sub_lo[i], nb_ = sub_lo[i + 1] - sub_lo[i];  // seeds lo.. within chunk
+            const size_t mo = (size_t)lo * nsteps;
+            qocx::FactorArgs fa;
+            fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)(b0 + lo) * ctx->nc * K : nullptr;
+            fa.interp = ctx->interp.p;
+            fa.h0_cimg = ctx->h0_cimg.p;
+            fa.g_cimg = ctx->g_cimg.p;
+            fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+            fa.q_img = ctx->q_img.p + mo * mat; fa.lu_img = ctx->lu_img.p + mo * mat;
+            fa.s_arr = ctx->s_arr.p + mo; fa.status = ctx->status.p;
+            time_begin(ctx, 0, ctx->stream);
+            qocx::launch_pq(ctx->nb, fa, nsteps, nb_, ctx->stream);
+            time_end(ctx, ctx->stream);
+            qocx::LuArgs la;
+            la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p + mo * np; la.perm = ctx->perm.p + mo * np;
+            la.iperm = ctx->iperm.p + mo * np; la.status = ctx->status.p;
+            time_begin(ctx, 4, ctx->stream);
+            qocx::launch_lu(ctx->nb, la, (size_t)nb_ * nsteps, ctx->stream);
+            time_end(ctx, ctx->stream);
+            HIP_TRY(hipEventRecord(ctx->ev_factored[i], ctx->stream));
 
-        qocx::SweepArgs sa;
-        sa.q_img = ctx->q_img.p; sa.lu_img = ctx->lu_img.p; sa.dinv = ctx->dinv.p;
-        sa.perm = ctx->perm.p; sa.iperm = ctx->iperm.p; sa.s_arr = ctx->s_arr.p;
-        sa.psi0 = ctx->psi0.p;
-        sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
-        sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
-        sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
-        sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
-        sa.states = ctx->states.p; sa.xs = ctx->xs.p; sa.offs = ctx->offs.p;
-        sa.cost_out = ctx->cost_out.p + b0;
-        sa.final_out = ctx->final_out.p + (size_t)b0 * S * np;
-        sa.step_states = ctx->keep_step_states
-                             ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np
-                             : nullptr;
-        sa.status = ctx->status.p;
-        time_begin(ctx, 1);
-        qocx::launch_sweep(ctx->nb, sa, bc, ctx->stream);
-        time_end(ctx);
-
-        if (want_grad) {
+            hipStream_t ss = (pipe == 1) ? ctx->stream : ctx->sweep_streams[i];
+            if (pipe > 1) HIP_TRY(hipStreamWaitEvent(ss, ctx->ev_factored[i], 0));
+            qocx::SweepArgs sa;
+            sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;
+            sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
+            sa.psi0 = ctx->psi0.p;
+            sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
+            sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
+            sa.diag = 0;
+            sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
+            sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
+            sa.states = ctx->states.p + (size_t)lo * ctx->slot_cap * S * np;
+            sa.xs = ctx->xs.p + (want_grad ? (size_t)lo * ctx->slot_cap * S * np : 0);
+            sa.offs = ctx->offs.p + (size_t)lo * (nsteps + 1);
+            sa.cost_out = ctx->cost_out.p + b0 + lo;
+            sa.final_out = ctx->final_out.p + (size_t)(b0 + lo) * S * np;
+            sa.step_states = ctx->keep_step_states
+                                 ? ctx->step_states.p + (size_t)(b0 + lo) * (nsteps + 1) * S * np
+                                 : nullptr;
+            sa.status = ctx->status.p;
+            time_begin(ctx, 1, ss);
+            qocx::launch_sweep(ctx->nb, sa, nb_, ss);
+            time_end(ctx, ss);
+            if (pipe > 1) HIP_TRY(hipEventRecord(ctx->ev_swept[i], ss));
+        }
+        for (int i = 0; i < pipe; ++i) {
+            const int lo = sub_lo[i], nb_ = sub_lo[i + 1] - sub_lo[i];
+            const size_t mo = (size_t)lo * nsteps;
+            if (pipe > 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_swept[i], 0));
+            if (!want_grad) continue;
             qocx::KrylovArgs ka;
-            ka.controls = fa.controls; ka.interp = ctx->interp.p;
+            ka.controls = ctx->controls.p + (size_t)(b0 + lo) * ctx->nc * K;
+            ka.interp = ctx->interp.p;
             ka.h0_rimg = ctx->h0_rimg.p; ka.h0_timg = ctx->h0_timg.p;
             ka.g_rimg = ctx->g_rimg.p; ka.g_timg = ctx->g_timg.p;
             ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
-            ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p; ka.offs = ctx->offs.p;
-            ka.states = ctx->states.p; ka.xs = ctx->xs.p; ka.slot_cap = ctx->slot_cap;
-            ka.gstep = ctx->gstep.p;
-            time_begin(ctx, 2);
-            qocx::launch_krylov(ctx->nb, ka, nsteps, bc, ctx->stream);
-            time_end(ctx);
+            ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p + mo;
+            ka.offs = ctx->offs.p + (size_t)lo * (nsteps + 1);
+            ka.states = ctx->states.p + (size_t)lo * ctx->slot_cap * S * np;
+            ka.xs = ctx->xs.p + (size_t)lo * ctx->slot_cap * S * np;
+            ka.slot_cap = ctx->slot_cap;
+            ka.gstep = ctx->gstep.p + mo * K;
+            time_begin(ctx, 2, ctx->stream);
+            qocx::launch_krylov(ctx->nb, ka, nsteps, nb_, ctx->stream);
+            time_end(ctx, ctx->stream);
 
             qocx::ScatterArgs sc;
-            sc.gstep = ctx->gstep.p; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
+            sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
             sc.weight = ctx->weight.p;
-            sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
-            sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
-            time_begin(ctx, 3);
+            sc.grads = ctx->grads.p + (size_t)(b0 + lo) * ctx->nc * K;
+            sc.B = nb_; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
+            time_begin(ctx, 3, ctx->stream);
             qocx::launch_scatter(sc, ctx->stream);
-            time_end(ctx);
+            time_end(ctx, ctx->stream);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -817,6 +876,19 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
         }
     HIP_TRY(hipMemcpy(dv.data(), dinv_d.p, dv.size() * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
+    if (lu_out)  // the device stores U' = D^-1 U above the diagonal: undo the row scaling
+        for (int m = 0; m < count; ++m)
+            for (int r = 0; r < n; ++r) {
+                const double2 d = dv[(size_t)m * np + r];
+                const double den = d.x * d.x + d.y * d.y;
+                const double ur = d.x / den, ui = -d.y / den;  // U_rr = 1 / dinv_r
+                for (int c = r + 1; c < n; ++c) {
+                    double* e = lu_out + 2 * (((size_t)m * n + r) * n + c);
+                    const double xr = e[0], xi = e[1];
+                    e[0] = xr * ur - xi * ui;
+                    e[1] = xr * ui + xi * ur;
+                }
+            }
     for (int m = 0; m < count; ++m)
         for (int i = 0; i < n; ++i) {
             if (perm_out) perm_out[(size_t)m * n + i] = pm[(size_t)m * np + i];

@@ -59,6 +59,7 @@ struct SweepArgs {
     const int* s_arr;
     const double2* psi0;  // [S][NP]
     int S, nsteps, cost_eval_step, want_grad, has_step_costs;
+    int diag;             // timing-only ablation bits (QOCX_SWEEP_DIAG); 0 in production
     size_t slot_cap;      // sub-step slots per seed
     // costs
     int cost_count;

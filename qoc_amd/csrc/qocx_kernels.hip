@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "qocx_device.h"
 
 namespace qocx {
@@ -524,6 +526,7 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
     }
     int mypos = -1;
     bool singular = false;
+    double my_dre = 0, my_dim = 0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int hk = k % H, ck = k / H;
@@ -548,9 +551,21 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
         const bool elim = mine && (i != p);
         const double mre_own = elim ? (pre[ck] * rre - pim[ck] * rim) : 0.0;
         const double mim_own = elim ? (pre[ck] * rim + pim[ck] * rre) : 0.0;
-        // column k is final now (multipliers / U entries): store it, in ORIGINAL row order
-        if (h == hk)
-            img[k * NP + i] = make_double2(elim ? mre_own : pre[ck], elim ? mim_own : pim[ck]);
+        // this lane's reciprocal pivot, fixed from the step at which its row becomes the pivot
+        // row (the empty asm keeps the compiler from deferring 32 selects to the end)
+        my_dre = (i == p) ? rre : my_dre;
+        my_dim = (i == p) ? rim : my_dim;
+        asm volatile("" : "+v"(my_dre), "+v"(my_dim));
+        // column k is final now: store it, in ORIGINAL row order. Unpivoted rows: multiplier
+        // L_ik; the new pivot row: U_kk; rows pivoted earlier: U'_ik = U_ik / U_ii, so that
+        // both triangular solves of the sweep have a unit diagonal.
+        if (h == hk) {
+            const bool done = (mypos >= 0);
+            const double sre = pre[ck] * my_dre - pim[ck] * my_dim;
+            const double sim = pre[ck] * my_dim + pim[ck] * my_dre;
+            img[k * NP + i] = make_double2(elim ? mre_own : (done ? sre : pre[ck]),
+                                           elim ? mim_own : (done ? sim : pim[ck]));
+        }
         double mre = mre_own, mim = mim_own;
         if (H > 1) {
             if (hk == 0) { mre = from_group<NB, 0>(mre_own, i); mim = from_group<NB, 0>(mim_own, i); }
@@ -566,6 +581,7 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
                     if (cc * H + h > k) prow[cc * H + h] = make_double2(pre[cc], pim[cc]);
         }
         mypos = (i == p) ? k : mypos;
+        asm volatile("" : "+v"(mypos));
         wave_sync();
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
@@ -595,37 +611,82 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
 // K2: serial state sweep (forward), costs, adjoint sweep (backward)
 // ------------------------------------------------------------------------------------------
 
-// Triangular solves, axpy form, coefficient rows in F-layout (every lane group holds the full
-// row i = lane % NP, so all groups run the solve redundantly and z stays replicated).
-// LOWER: forward substitution. UNIT: unit diagonal, otherwise the lane's reciprocal diagonal
-// (dre, dim) is applied. CONJ: use conj of the stored coefficients.
-template <int NB, bool LOWER, bool UNIT, bool CONJ>
+// Unit-diagonal triangular solves, axpy form, coefficient rows in F-layout (every lane group
+// holds the full row i = lane % NP, so all groups run the solve redundantly and z stays
+// replicated). Per column k: z_k is broadcast with v_readlane and the rows below (LOWER) or
+// above it take one complex FMA; the row predicate is a compile-time EXEC mask, so the update is
+// exactly four v_fma_f64. CONJ: use conj of the stored coefficients.
+template <int NB, bool LOWER>
+__device__ __forceinline__ constexpr unsigned long long row_mask(int k) {
+    constexpr int NP = Geo<NB>::NP;
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int i = l % NP;
+        if (LOWER ? (i > k) : (i < k)) m |= (1ull << l);
+    }
+    return m;
+}
+
+// z -= c * zk (or conj(c) * zk) on the lanes of a compile-time EXEC mask (two 32-bit literals:
+// no SGPRs are tied up); all 64 lanes are active on entry and on exit.
+template <bool CONJ, unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_cfma(double& zre, double& zim, double cre, double cim,
+                                            double kre, double kim) {
+    if (CONJ) {
+        asm volatile(
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
+            "v_fma_f64 %[zr], -%[ci], %[ki], %[zr]\n\t"
+            "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
+            "v_fma_f64 %[zi], %[ci], %[kr], %[zi]\n\t"
+            "s_mov_b64 exec, -1"
+            : [zr] "+v"(zre), [zi] "+v"(zim)
+            : [cr] "v"(cre), [ci] "v"(cim), [kr] "s"(kre), [ki] "s"(kim), [lo] "i"(LO), [hi] "i"(HI)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
+            "v_fma_f64 %[zr], %[ci], %[ki], %[zr]\n\t"
+            "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
+            "v_fma_f64 %[zi], -%[ci], %[kr], %[zi]\n\t"
+            "s_mov_b64 exec, -1"
+            : [zr] "+v"(zre), [zi] "+v"(zim)
+            : [cr] "v"(cre), [ci] "v"(cim), [kr] "s"(kre), [ki] "s"(kim), [lo] "i"(LO), [hi] "i"(HI)
+            : "memory");
+    }
+}
+
+template <int NB, bool LOWER, bool CONJ, int KK, class Hook>
+__device__ __forceinline__ void tri_step(const double (&tre)[Geo<NB>::NP],
+                                         const double (&tim)[Geo<NB>::NP], double& zre,
+                                         double& zim, Hook& hook) {
+    constexpr int NP = Geo<NB>::NP;
+    constexpr int k = LOWER ? KK : (NP - 1 - KK);
+    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
+    const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
+    hook(KK);  // independent work issued into the bubble of the dependent chain
+    masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
+        zre, zim, tre[k], tim[k], kre, kim);
+}
+
+template <int NB, bool LOWER, bool CONJ, class Hook, int... KK>
+__device__ __forceinline__ void tri_solve_seq(const double (&tre)[Geo<NB>::NP],
+                                              const double (&tim)[Geo<NB>::NP], double& zre,
+                                              double& zim, Hook& hook,
+                                              std::integer_sequence<int, KK...>) {
+    (tri_step<NB, LOWER, CONJ, KK>(tre, tim, zre, zim, hook), ...);
+}
+
+// hook(kk), kk = 0 .. NP-2, is called once per column between the broadcast and the update.
+template <int NB, bool LOWER, bool CONJ, class Hook>
 __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                           const double (&tim)[Geo<NB>::NP], double& zre,
-                                          double& zim, double dre, double dim, int i) {
-    constexpr int NP = Geo<NB>::NP;
-    if (CONJ) dim = -dim;
-#pragma unroll
-    for (int kk = 0; kk < NP; ++kk) {
-        const int k = LOWER ? kk : (NP - 1 - kk);
-        double vre = zre, vim = zim;
-        if (!UNIT) {
-            vre = zre * dre - zim * dim;
-            vim = zre * dim + zim * dre;
-        }
-        const double kre = readlane_f64(vre, k), kim = readlane_f64(vim, k);
-        if (!UNIT) {
-            if (i == k) {
-                zre = kre;
-                zim = kim;
-            }
-        }
-        const double cre = tre[k], cim = CONJ ? -tim[k] : tim[k];
-        if (LOWER ? (i > k) : (i < k)) {
-            zre -= cre * kre - cim * kim;
-            zim -= cre * kim + cim * kre;
-        }
-    }
+                                          double& zim, Hook& hook) {
+    tri_solve_seq<NB, LOWER, CONJ>(tre, tim, zre, zim, hook,
+                                   std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
 // <t|psi> over lane group 0, result wave-uniform.
@@ -722,7 +783,9 @@ struct SweepLds {
     static constexpr int BUF_BYTES = G::MAT * 16;              // one matrix image
     static constexpr int Q_OFF = 0;                            // 2 x Q image (double buffer)
     static constexpr int L_OFF = Q_OFF + 2 * BUF_BYTES;         // 2 x LU image
-    static constexpr int TMP_OFF = L_OFF + 2 * BUF_BYTES;       // NP complex scratch vector
+    static constexpr int D_OFF = L_OFF + 2 * BUF_BYTES;         // 2 x 64 complex: 1/U_kk
+    static constexpr int P_OFF = D_OFF + 2 * 64 * 16;           // 2 x 64 int: perm | iperm
+    static constexpr int TMP_OFF = P_OFF + 2 * 64 * 4;          // NP complex scratch vector
     static constexpr int VEC_OFF = TMP_OFF + G::NP * 16;        // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
@@ -734,12 +797,9 @@ struct StepRegs {
     double lre[Geo<NB>::NP], lim[Geo<NB>::NP];
 };
 
-template <int NB>
 struct StepScalars {
-    double2 dv;               // this lane's 1/U_ii
-    int pm;                   // forward: perm[i] (row at position i); adjoint: iperm[i]
-    int nsub;                 // 2^s sub-steps
-    int permk[Geo<NB>::NP];   // adjoint only: the whole row order, wave-uniform (SGPRs)
+    double2 dv;  // this lane's 1/U_ii (position i)
+    int pm;      // forward: perm[i] (row at position i); adjoint: iperm[i] (position of row i)
 };
 
 // One 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `g` land at lds_base + 16*l.
@@ -749,24 +809,28 @@ __device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
         (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-// Stream one column-major image into LDS. TRANSPOSE: gather so that LDS holds the image of the
-// transposed matrix (position r*NP + c <- element (r, c)).
+// One KiB piece j of a column-major image into LDS. TRANSPOSE: gather so that LDS holds the image
+// of the transposed matrix (position r*NP + c <- element (r, c)).
 template <int NB, bool TRANSPOSE>
-__device__ __forceinline__ void dma_image(const double2* img, double2* lds, int lane) {
+__device__ __forceinline__ void dma_piece(const double2* img, double2* lds, int j, int lane) {
     typedef Geo<NB> G;
-#pragma unroll
-    for (int j = 0; j < G::MAT / 64; ++j) {
-        const int q = j * 64 + lane;
-        const int src = TRANSPOSE ? ((q % G::NP) * G::NP + q / G::NP) : q;
-        dma16(img + src, lds + j * 64);
-    }
+    const int q = j * 64 + lane;
+    const int src = TRANSPOSE ? ((q % G::NP) * G::NP + q / G::NP) : q;
+    dma16(img + src, lds + j * 64);
+}
+
+__device__ __forceinline__ void dma4(const int* g, int* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 
 // LDS images -> registers. The LU image is stored in original row order, so the row at position
-// i is row perm[i] (forward: per-lane index; adjoint, transposed image: per-column scalar).
+// k is row perm[k]: the forward F-layout gathers row perm[i] per lane; the adjoint (transposed
+// image) reads column perm[k] for every k, with perm[k] fetched as an LDS broadcast.
 template <int NB, bool ADJOINT>
-__device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, StepRegs<NB>& r,
-                                            const StepScalars<NB>& sc, int lane, int i) {
+__device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, const int* pb,
+                                            StepRegs<NB>& r, int pm, int lane, int i) {
     typedef Geo<NB> G;
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
@@ -776,7 +840,10 @@ __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb
     }
 #pragma unroll
     for (int c = 0; c < G::NP; ++c) {
-        const double2 e = ADJOINT ? lb[sc.permk[c] * G::NP + i] : lb[c * G::NP + sc.pm];
+        int src;
+        if (ADJOINT) src = min(max(pb[c], 0), G::NP - 1) * G::NP + i;
+        else src = c * G::NP + pm;
+        const double2 e = lb[src];
         r.lre[c] = e.x;
         r.lim[c] = e.y;
     }
@@ -790,6 +857,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* qbuf = reinterpret_cast<double2*>(smem + L::Q_OFF);
     double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
+    double2* dbuf = reinterpret_cast<double2*>(smem + L::D_OFF);
+    int* pbuf = reinterpret_cast<int*>(smem + L::P_OFF);
     double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF);
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
     const int S = args.S;
@@ -817,21 +886,56 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     bool overflow = false;
     StepRegs<NB> r;
 
-    auto load_scalars = [&](size_t m, bool adjoint) {
-        StepScalars<NB> sc;
-        sc.dv = args.dinv[m * NP + i];
-        const int pv = adjoint ? args.iperm[m * NP + i] : args.perm[m * NP + i];
-        sc.pm = min(max(pv, 0), NP - 1);
-        sc.nsub = 1 << min(max(args.s_arr[m], 0), 30);
+    // Everything a step needs arrives by LDS-DMA one step ahead: Q and LU images (the adjoint
+    // gathers the transposed images), 1/U_kk, perm | iperm: 2*MAT/64 + 2 pieces. They are issued
+    // one per column of the current step's triangular solves, into the bubbles of the
+    // dependent readlane -> fma chain (an in-order wave cannot fill them otherwise).
+    constexpr int IMG_PIECES = MAT / 64, PIECES = 2 * IMG_PIECES + 2;
+    auto dma_one = [&](size_t m, int par, bool adjoint, int piece) {
+        if (piece < IMG_PIECES) {
+            if (adjoint) dma_piece<NB, true>(args.q_img + m * MAT, qbuf + par * MAT, piece, lane);
+            else dma_piece<NB, false>(args.q_img + m * MAT, qbuf + par * MAT, piece, lane);
+        } else if (piece < 2 * IMG_PIECES) {
+            if (adjoint) dma_piece<NB, true>(args.lu_img + m * MAT, lbuf + par * MAT, piece - IMG_PIECES, lane);
+            else dma_piece<NB, false>(args.lu_img + m * MAT, lbuf + par * MAT, piece - IMG_PIECES, lane);
+        } else if (piece == 2 * IMG_PIECES) {
+            dma16(args.dinv + m * NP + i, dbuf + par * 64);
+        } else if (piece == 2 * IMG_PIECES + 1) {
+            dma4((lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP, pbuf + par * 64);
+        }
+    };
+    auto issue_dma = [&](size_t m, int par, bool adjoint) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-            sc.permk[k] = adjoint ? min(max(args.perm[m * NP + k], 0), NP - 1) : 0;
+        for (int piece = 0; piece < PIECES; ++piece) dma_one(m, par, adjoint, piece);
+    };
+    // prefetch state of the step being computed: which step to fetch, and whether it is still due
+    size_t pf_m = 0;
+    int pf_par = 0;
+    bool pf_adjoint = false, pf_due = false;
+    auto hook_a = [&](int kk) {  // first solve of a step: pieces 0 .. NP-2
+        if (pf_due) dma_one(pf_m, pf_par, pf_adjoint, kk);
+    };
+    auto hook_b = [&](int kk) {  // second solve: the remaining pieces
+        if (pf_due && (NP - 1 + kk) < PIECES) dma_one(pf_m, pf_par, pf_adjoint, NP - 1 + kk);
+    };
+    auto finish_prefetch = [&]() {  // pieces that did not fit into the two solves (NP = 16)
+        if (pf_due) {
+#pragma unroll
+            for (int piece = 2 * (NP - 1); piece < PIECES; ++piece)
+                dma_one(pf_m, pf_par, pf_adjoint, piece);
+        }
+        pf_due = false;
+    };
+    auto scalars = [&](int par, bool adjoint) {
+        StepScalars sc;
+        sc.dv = dbuf[par * 64 + i];
+        sc.pm = min(max(pbuf[par * 64 + (adjoint ? 32 : 0) + i], 0), NP - 1);
         return sc;
     };
 
     // one propagator step on all S states with the operands in `r`
-    auto forward_step = [&](const StepScalars<NB>& sc) {
-        for (int sub = 0; sub < sc.nsub; ++sub) {
+    auto forward_step = [&](const StepScalars& sc, int nsub) {
+        for (int sub = 0; sub < nsub; ++sub) {
             if ((size_t)slot + 1 >= cap) {
                 overflow = true;
                 break;
@@ -842,18 +946,24 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     const double2 x = vecs[s * NP + cc * H + h];
-                    yre += r.qre[cc] * x.x - r.qim[cc] * x.y;
-                    yim += r.qre[cc] * x.y + r.qim[cc] * x.x;
+                    yre = fma(r.qre[cc], x.x, yre);
+                    yre = fma(-r.qim[cc], x.y, yre);
+                    yim = fma(r.qre[cc], x.y, yim);
+                    yim = fma(r.qim[cc], x.x, yim);
                 }
 #pragma unroll
                 for (int d = NP; d < 64; d <<= 1) {
                     yre += __shfl_xor(yre, d);
                     yim += __shfl_xor(yim, d);
                 }
-                // z = Pi y ; L z' = z ; U psi' = z'
+                // z = Pi y ; L z' = z ; z'' = D^-1 z' ; U' psi' = z''  (both solves unit-diagonal)
                 double zre = __shfl(yre, sc.pm), zim = __shfl(yim, sc.pm);
-                tri_solve<NB, true, true, false>(r.lre, r.lim, zre, zim, 0, 0, i);
-                tri_solve<NB, false, false, false>(r.lre, r.lim, zre, zim, sc.dv.x, sc.dv.y, i);
+                tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
+                const double t = zre * sc.dv.x - zim * sc.dv.y;
+                zim = zre * sc.dv.y + zim * sc.dv.x;
+                zre = t;
+                tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
+                finish_prefetch();
                 wave_sync();
                 if (g0) {
                     const double2 p = make_double2(zre, zim);
@@ -875,27 +985,30 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         if (lane == 0) offs_b[step] = slot;
     };
 
-    // ---- forward sweep: the next step's Q and LU stream into LDS (LDS-DMA, no registers)
-    // while the current step's dependent chains run --------------------------------------
+    // ---- forward sweep: the next step's operands stream into LDS while the current step's
+    // dependent chains run -------------------------------------------------------------------
     {
-        dma_image<NB, false>(args.q_img + m0 * MAT, qbuf, lane);
-        dma_image<NB, false>(args.lu_img + m0 * MAT, lbuf, lane);
-        StepScalars<NB> cur = load_scalars(m0, false), nxt = cur;
+        issue_dma(m0, 0, false);
+        int nsub_next = 1 << min(max(args.s_arr[m0], 0), 30);
         for (int step = 0; step < nsteps; ++step) {
             const int par = step & 1;
+            const int nsub = nsub_next;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, r, cur, lane, i);
+            const StepScalars sc = scalars(par, false);
+            lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
+                                   lane, i);
             wave_sync();
-            if (step + 1 < nsteps) {
-                dma_image<NB, false>(args.q_img + (m0 + step + 1) * MAT, qbuf + (par ^ 1) * MAT, lane);
-                dma_image<NB, false>(args.lu_img + (m0 + step + 1) * MAT, lbuf + (par ^ 1) * MAT, lane);
-                nxt = load_scalars(m0 + step + 1, false);
+            pf_due = (step + 1 < nsteps);
+            if (pf_due) {
+                pf_m = m0 + step + 1;
+                pf_par = par ^ 1;
+                pf_adjoint = false;
+                nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             }
             before_step(step);
-            forward_step(cur);
+            forward_step(sc, nsub);
             if (overflow) break;
-            cur = nxt;
         }
     }
     if (overflow) {
@@ -918,15 +1031,19 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     // a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
     (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
 
-    auto adjoint_step = [&](const StepScalars<NB>& sc, int step) {
-        for (int sub = sc.nsub - 1; sub >= 0; --sub) {
+    auto adjoint_step = [&](const StepScalars& sc, int nsub, int step) {
+        for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
             for (int s = 0; s < S; ++s) {
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
-                // U^H w = lambda (lower, conj, diagonal 1/conj(U_kk)); L^H v = w (upper, unit, conj)
-                tri_solve<NB, true, false, true>(r.lre, r.lim, zre, zim, sc.dv.x, sc.dv.y, i);
-                tri_solve<NB, false, true, true>(r.lre, r.lim, zre, zim, 0, 0, i);
+                // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
+                tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
+                const double t = zre * sc.dv.x + zim * sc.dv.y;
+                zim = zim * sc.dv.x - zre * sc.dv.y;
+                zre = t;
+                tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
+                finish_prefetch();
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
                 wave_sync();
@@ -941,8 +1058,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     const double2 x = tmp[cc * H + h];
-                    yre += r.qre[cc] * x.x + r.qim[cc] * x.y;
-                    yim += r.qre[cc] * x.y - r.qim[cc] * x.x;
+                    yre = fma(r.qre[cc], x.x, yre);
+                    yre = fma(r.qim[cc], x.y, yre);
+                    yim = fma(r.qre[cc], x.y, yim);
+                    yim = fma(-r.qim[cc], x.x, yim);
                 }
 #pragma unroll
                 for (int d = NP; d < 64; d <<= 1) {
@@ -964,24 +1083,26 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         }
     };
     {
-        // the DMA gathers transposed images, so the same LDS reads deliver Q^T and LU^T rows
         const size_t ml = m0 + nsteps - 1;
-        dma_image<NB, true>(args.q_img + ml * MAT, qbuf, lane);
-        dma_image<NB, true>(args.lu_img + ml * MAT, lbuf, lane);
-        StepScalars<NB> cur = load_scalars(ml, true), nxt = cur;
+        issue_dma(ml, 0, true);
+        int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
         for (int step = nsteps - 1, it = 0; step >= 0; --step, ++it) {
             const int par = it & 1;
+            const int nsub = nsub_next;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, r, cur, lane, i);
+            const StepScalars sc = scalars(par, true);
+            lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
+                                  lane, i);
             wave_sync();
-            if (step - 1 >= 0) {
-                dma_image<NB, true>(args.q_img + (m0 + step - 1) * MAT, qbuf + (par ^ 1) * MAT, lane);
-                dma_image<NB, true>(args.lu_img + (m0 + step - 1) * MAT, lbuf + (par ^ 1) * MAT, lane);
-                nxt = load_scalars(m0 + step - 1, true);
+            pf_due = (step - 1 >= 0);
+            if (pf_due) {
+                pf_m = m0 + step - 1;
+                pf_par = par ^ 1;
+                pf_adjoint = true;
+                nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             }
-            adjoint_step(cur, step);
-            cur = nxt;
+            adjoint_step(sc, nsub, step);
         }
     }
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     "qocx_get_timing": (ctypes.c_int, [_VP, _I32, ctypes.POINTER(_I64), _c_double_p]),
     "qocx_reset_timing": (ctypes.c_int, [_VP]),
     "qocx_set_chunk": (ctypes.c_int, [_VP, _I32]),
+    "qocx_set_pipeline": (ctypes.c_int, [_VP, _I32]),
     "qocx_comm_unique_id": (ctypes.c_int, [_U8P]),
     "qocx_comm_init": (ctypes.c_int, [_VP, _U8P, _I32, _I32]),
     "qocx_comm_allreduce_sum": (ctypes.c_int, [_VP, _c_double_p, _I64]),
@@ -240,6 +241,9 @@ class Engine(object):
 
     def set_chunk(self, seeds_per_chunk):
         self._check(self._lib.qocx_set_chunk(self._ctx, int(seeds_per_chunk)))
+
+    def set_pipeline(self, sub_chunks):
+        self._check(self._lib.qocx_set_pipeline(self._ctx, int(sub_chunks)))
 
     # -- timing --------------------------------------------------------------------------------
     def set_timing(self, enable):

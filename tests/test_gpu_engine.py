@@ -106,3 +106,10 @@ def test_chunked_equals_unchunked(engine):
     engine.set_chunk(0)
     for a, b in zip(ref, out):
         assert np.array_equal(a, b)
+    # pipelined sub-chunks (sweep overlapped on side streams) vs one stream
+    for pipe in (1, 3, 6):
+        engine.set_pipeline(pipe)
+        out = engine.evaluate(u, True)
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b)
+    engine.set_pipeline(0)
