@@ -52,6 +52,23 @@ def make_controls(first_seed, count):
     return out
 
 
+def pmc_traffic_bytes(kernel, units_per_launch):
+    """
+    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/r01_v3_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, gfx950
+    correction applied), rescaled to this run's units per launch. PMC counters cannot be
+    collected from inside the timed run; None if the summary is absent.
+    """
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f)["kernels"][kernel]
+        measured_units = 128 * (N_EVAL - 1)
+        return entry["hbm_bytes_per_dispatch_corrected"] * units_per_launch / measured_units
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 # ---- CPU baseline: the oracle (NumPy restatement of the reference + hand adjoint) ----------
 
 def _cpu_worker(seed_ids):
@@ -153,7 +170,8 @@ def main():
         achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
         roofline = dict(bound="mfma", kernel="pade_pq_kernel<2>", achieved=achieved,
                         peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS,
+                        traffic=pmc_traffic_bytes("qocx::pade_pq_kernel<2>", units_per_launch),
                         avg_launch_ms=total_ms / launches)
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}
     path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
