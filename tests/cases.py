@@ -210,3 +210,77 @@ def case_by_name(name):
         if c.name == name:
             return c
     raise KeyError(name)
+
+
+# ---- Lindblad cases ---------------------------------------------------------------------------
+
+class LindbladCase(Case):
+    """Adds: dissipators (L,), operators (L x n x n), initial_densities (S x n x n)."""
+
+    def lindblad_data(self):
+        gam, ops = self.dissipators, self.operators
+        if gam is None:
+            return None
+        return lambda time: (gam, ops)
+
+
+def random_density(rng, n):
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    rho = a @ a.conj().T
+    return rho / np.trace(rho)
+
+
+def lindblad_case(name, n, N, S, K, seeds, h_seed, Nc=None, T=None, complex_controls=False,
+                  sigma=0.4, cost_eval_step=1, with_forbid=False, ops="ladder"):
+    rng = np.random.default_rng(h_seed)
+    a = annihilation(n)
+    ad = a.conj().T
+    h0 = gue(rng, n) * 1.2
+    if complex_controls:
+        g_re, g_im = [a + ad], [1j * (a - ad)]
+        K = 1
+    else:
+        g_re, g_im = [gue(rng, n) for _ in range(K)], None
+    Nc = N if Nc is None else Nc
+    T = 0.05 * (N - 1) if T is None else T
+    if ops == "ladder":
+        operators = np.stack([a / np.sqrt(max(n - 1, 1)), ad @ a / max(n - 1, 1)])
+        dissipators = np.array([0.05, 0.02])
+    else:
+        operators = np.stack([gue(rng, n) + 0.3j * gue(rng, n)])
+        dissipators = np.array([0.3])
+    init = np.stack([random_density(rng, n) for _ in range(S)])
+    targ = np.stack([random_density(rng, n) for _ in range(S)])
+    specs = [("TargetDensityInfidelity", dict(target_densities=targ, cost_multiplier=0.8))]
+    if with_forbid:
+        forb = np.stack([np.stack([random_density(rng, n) for _ in range(2)]) for _ in range(S)])
+        specs.append(("ForbidDensities", dict(forbidden_densities=forb, system_eval_count=N,
+                                              cost_eval_step=cost_eval_step, cost_multiplier=1.5)))
+        specs.append(("TargetDensityInfidelityTime", dict(system_eval_count=N, target_densities=targ,
+                                                          cost_eval_step=cost_eval_step,
+                                                          cost_multiplier=0.6)))
+    c = LindbladCase(name=name, n=n, S=S, K=K, Nc=Nc, N=N, T=T, h0=h0, g_re=g_re, g_im=g_im,
+                     complex_controls=complex_controls, initial_states=None,
+                     cost_specs=specs, cost_eval_step=cost_eval_step,
+                     controls=_controls(500, seeds, Nc, K, complex_controls, sigma))
+    c.initial_densities = init
+    c.dissipators = dissipators
+    c.operators = operators
+    return c
+
+
+def lindblad_cases():
+    return [
+        lindblad_case("lindblad_n4", n=4, N=11, S=2, K=2, seeds=2, h_seed=71, with_forbid=True,
+                      cost_eval_step=2),
+        lindblad_case("lindblad_n4_complex", n=4, N=9, S=1, K=1, seeds=2, h_seed=72, Nc=5, T=0.9,
+                      complex_controls=True, ops="random"),
+        lindblad_case("lindblad_c4_short", n=16, N=6, S=1, K=2, seeds=2, h_seed=2004, sigma=0.1),
+    ]
+
+
+def lindblad_case_by_name(name):
+    for c in lindblad_cases():
+        if c.name == name:
+            return c
+    raise KeyError(name)
