@@ -56,6 +56,12 @@ typedef struct qocx_ctx qocx_ctx;
 #define QOCX_COST_FORBID 2            /* ForbidStates: scale * sum_s (1/F_s) sum_f |<f_sf|psi_s>|^2
                                          forbidstates.py:64-81 (scale = multiplier / (E * S))      */
 
+#define QOCX_COST_TARGET_DENSITY 3    /* TargetDensityInfidelity[Time]:
+                                         scale * (1 - sum_s |tr(T_s^H rho_s)| / (S n))
+                                         targetdensityinfidelity.py:41-69; vectors = [S][n][n]      */
+#define QOCX_COST_FORBID_DENSITY 4    /* ForbidDensities: scale * sum_s (1/F_s) sum_f |tr(F_sf^H rho_s)/n|^2
+                                         forbiddensities.py:53-85; vectors = [sum_s F_s][n][n]       */
+
 typedef struct qocx_cost_desc {
     int32_t kind;          /* QOCX_COST_*                                                         */
     int32_t step_cost;     /* 1: evaluated at system steps j*cost_eval_step, j>=1, before evolving
@@ -94,6 +100,30 @@ typedef struct qocx_schroedinger_problem {
     const qocx_cost_desc* costs; /* [cost_count]                                                    */
 } qocx_schroedinger_problem;
 
+/*
+ * Static data of one Lindblad problem; mirrors the fields of GrapeLindbladDiscreteState
+ * (qoc/models/lindbladmodels.py:125-203) that _evaluate_lindblad_discrete reads
+ * (qoc/core/lindbladdiscrete.py:357-441). hamiltonian(u, t) = h0 + sum_k u_k g[k] and
+ * lindblad_data(t) = (dissipators, operators) must not depend on time explicitly.
+ */
+typedef struct qocx_lindblad_problem {
+    int32_t hilbert_size;         /* n, 1..16                                                      */
+    int32_t density_count;        /* S >= 1                                                        */
+    int32_t control_count;        /* K real controls, 0..8                                         */
+    int32_t control_eval_count;   /* Nc                                                            */
+    int32_t system_eval_count;    /* N >= 2                                                        */
+    int32_t cost_eval_step;
+    int32_t operator_count;       /* L >= 0 Lindblad operators                                     */
+    double evolution_time;
+    const double* h0;             /* [n][n] complex                                                */
+    const double* g;              /* [K][n][n] complex                                             */
+    const double* dissipators;    /* [L] float64 (gamma_i)                                         */
+    const double* operators;      /* [L][n][n] complex                                             */
+    const double* initial_densities; /* [S][n][n] complex                                          */
+    int32_t cost_count;
+    const qocx_cost_desc* costs;  /* kinds QOCX_COST_TARGET_DENSITY / QOCX_COST_FORBID_DENSITY     */
+} qocx_lindblad_problem;
+
 const char* qocx_last_error(void);
 int qocx_version(void);
 
@@ -131,9 +161,21 @@ int qocx_download_results(qocx_ctx* ctx, double* cost_out, double* grad_out, dou
 int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep); /* before the evaluation */
 int qocx_download_step_states(qocx_ctx* ctx, double* states_out);
 
+/*
+ * Lindblad path: B calls of _evaluate_lindblad_discrete (+ gradient), lindbladdiscrete.py:321-322,
+ * :357-441. The device integrates the same master equation with a fixed-step DOP853 scheme
+ * and its exact discrete adjoint (parity tolerances there).
+ *   controls [B][Nc][K]; cost_out [B]; grad_out [B][Nc][K]; final_out [B][S][n][n] complex.
+ * qocx_download_step_densities: [B][N][S][n][n] complex after qocx_set_keep_step_states(ctx, 1).
+ */
+int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* problem);
+int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
+                       double* cost_out, double* grad_out, double* final_out);
+int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out);
+
 /* Per-kernel timing, measured with HIP events on the context's stream.
  * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`
- * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu) the launch count and total ms
+ * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu, 5 lindblad) the launch count and total ms
  * since the last reset. */
 int qocx_set_timing(qocx_ctx* ctx, int32_t enable);
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms);

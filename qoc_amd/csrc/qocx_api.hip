@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/qocx.h"
@@ -138,11 +139,36 @@ struct qocx_ctx {
     DevBuf<double2> final_out, step_states;
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
     DevBuf<int> perm, iperm, s_arr, offs, status;
+    // ---- Lindblad problem / evaluation state ----
+    struct Lindblad {
+        bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
+        int n = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nops = 0;
+        double T = 0, dt = 0, h0_norm = 0, diss_norm = 0;
+        std::vector<double> g_norm;
+        int has_step_costs = 0, cost_count = 0;
+        DevBuf<double2> a0l, a0r, a0ld, a0rd, gp, gpd, gpt, ops, rho0, cost_matrices;
+        DevBuf<double> gammas;
+        DevBuf<qocx::DevCost> costs;
+        DevBuf<int> cost_counts;
+        // sub-interval tables, by sub-division count
+        struct Grid {
+            int nsub = 0;
+            DevBuf<qocx::SubStep> substeps;
+            DevBuf<int> row_ptr, col;
+            DevBuf<double> weight;
+        };
+        std::map<int, Grid> grids;
+        // per evaluation
+        int B = 0;
+        std::vector<int> order;  // device position -> seed
+        DevBuf<double> gsub, cost_out, grads, controls;
+        DevBuf<double2> checkpoints, final_out, step_densities;
+    } lb;
     // ---- timing ----
     int timing = 0;
     std::vector<TimingRec> pending;
-    int64_t t_launch[5] = {0, 0, 0, 0, 0};
-    double t_ms[5] = {0, 0, 0, 0, 0};
+    int64_t t_launch[6] = {0, 0, 0, 0, 0, 0};
+    double t_ms[6] = {0, 0, 0, 0, 0, 0};
     // ---- comm ----
     Rccl rccl;
     void* comm = nullptr;
@@ -318,6 +344,23 @@ int qocx_destroy(qocx_ctx* ctx) {
     for (auto* b : bi) b->release();
     ctx->interp.release();
     ctx->costs.release();
+    {
+        auto& lb = ctx->lb;
+        DevBuf<double2>* l2[] = {&lb.a0l, &lb.a0r, &lb.a0ld, &lb.a0rd, &lb.gp, &lb.gpd, &lb.gpt,
+                                 &lb.ops, &lb.rho0, &lb.cost_matrices, &lb.checkpoints,
+                                 &lb.final_out, &lb.step_densities};
+        for (auto* b : l2) b->release();
+        DevBuf<double>* l1[] = {&lb.gammas, &lb.gsub, &lb.cost_out, &lb.grads, &lb.controls};
+        for (auto* b : l1) b->release();
+        lb.costs.release();
+        lb.cost_counts.release();
+        for (auto& kv : lb.grids) {
+            kv.second.substeps.release();
+            kv.second.row_ptr.release();
+            kv.second.col.release();
+            kv.second.weight.release();
+        }
+    }
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
     for (auto e : ctx->ev_factored) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_swept) (void)hipEventDestroy(e);
@@ -750,7 +793,7 @@ int qocx_set_timing(qocx_ctx* ctx, int32_t enable) {
 }
 
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms) {
-    if (!ctx || which < 0 || which > 4) return fail(QOCX_ERR_ARG, "bad argument");
+    if (!ctx || which < 0 || which > 5) return fail(QOCX_ERR_ARG, "bad argument");
     if (launches) *launches = ctx->t_launch[which];
     if (total_ms) *total_ms = ctx->t_ms[which];
     return 0;
@@ -758,10 +801,438 @@ int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* tot
 
 int qocx_reset_timing(qocx_ctx* ctx) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         ctx->t_launch[i] = 0;
         ctx->t_ms[i] = 0;
     }
+    return 0;
+}
+
+// ---- Lindblad ----------------------------------------------------------------------------
+
+namespace {
+
+typedef std::vector<double> cmat;  // row-major n x n complex, interleaved
+
+cmat cm_zero(int n) { return cmat((size_t)2 * n * n, 0.0); }
+
+cmat cm_from(const double* p, int n) { return cmat(p, p + (size_t)2 * n * n); }
+
+cmat cm_adjoint(const cmat& a, int n) {
+    cmat o = cm_zero(n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            o[2 * ((size_t)c * n + r)] = a[2 * ((size_t)r * n + c)];
+            o[2 * ((size_t)c * n + r) + 1] = -a[2 * ((size_t)r * n + c) + 1];
+        }
+    return o;
+}
+
+cmat cm_transpose(const cmat& a, int n) {
+    cmat o = cm_zero(n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            o[2 * ((size_t)c * n + r)] = a[2 * ((size_t)r * n + c)];
+            o[2 * ((size_t)c * n + r) + 1] = a[2 * ((size_t)r * n + c) + 1];
+        }
+    return o;
+}
+
+cmat cm_mul(const cmat& a, const cmat& b, int n) {
+    cmat o = cm_zero(n);
+    for (int r = 0; r < n; ++r)
+        for (int k = 0; k < n; ++k) {
+            const double ar = a[2 * ((size_t)r * n + k)], ai = a[2 * ((size_t)r * n + k) + 1];
+            for (int c = 0; c < n; ++c) {
+                const double br = b[2 * ((size_t)k * n + c)], bi = b[2 * ((size_t)k * n + c) + 1];
+                o[2 * ((size_t)r * n + c)] += ar * br - ai * bi;
+                o[2 * ((size_t)r * n + c) + 1] += ar * bi + ai * br;
+            }
+        }
+    return o;
+}
+
+// o = alpha * a (alpha complex)
+cmat cm_scale(const cmat& a, double sr, double si) {
+    cmat o(a.size());
+    for (size_t e = 0; e < a.size(); e += 2) {
+        o[e] = sr * a[e] - si * a[e + 1];
+        o[e + 1] = sr * a[e + 1] + si * a[e];
+    }
+    return o;
+}
+
+void cm_axpy(cmat& y, double alpha, const cmat& x) {
+    for (size_t e = 0; e < y.size(); ++e) y[e] += alpha * x[e];
+}
+
+// C-layout dump (NB = 1): reg r of lane l <-> element (row 4r + (l >> 4), col l & 15), index r*64+l
+void c_dump(const cmat& m, int n, double2* out) {
+    for (int r = 0; r < 4; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = 4 * r + (lane >> 4), col = lane & 15;
+            double2 e = make_double2(0, 0);
+            if (row < n && col < n) {
+                e.x = m[2 * ((size_t)row * n + col)];
+                e.y = m[2 * ((size_t)row * n + col) + 1];
+            }
+            out[r * 64 + lane] = e;
+        }
+}
+
+void from_c_dump(const double2* d, int n, double* out) {
+    for (int r = 0; r < 4; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = 4 * r + (lane >> 4), col = lane & 15;
+            if (row < n && col < n) {
+                out[2 * ((size_t)row * n + col)] = d[r * 64 + lane].x;
+                out[2 * ((size_t)row * n + col) + 1] = d[r * 64 + lane].y;
+            }
+        }
+}
+
+double cm_norm_inf(const cmat& m, int n) {
+    double best = 0;
+    for (int r = 0; r < n; ++r) {
+        double s = 0;
+        for (int c = 0; c < n; ++c) s += hypot(m[2 * ((size_t)r * n + c)], m[2 * ((size_t)r * n + c) + 1]);
+        best = std::max(best, s);
+    }
+    return best;
+}
+
+int upload_dumps(DevBuf<double2>& dst, const std::vector<cmat>& mats, int n, hipStream_t st) {
+    std::vector<double2> img(mats.size() * 256);
+    for (size_t i = 0; i < mats.size(); ++i) c_dump(mats[i], n, img.data() + i * 256);
+    return dst.upload(img, st);
+}
+
+}  // namespace
+
+int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
+    if (!ctx || !p) return fail(QOCX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = p->hilbert_size, S = p->density_count, K = p->control_count;
+    const int N = p->system_eval_count, nc = p->control_eval_count, L = p->operator_count;
+    if (n < 1 || n > 16)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..16 for the Lindblad engine");
+    if (S < 1 || S > 8) return fail(QOCX_ERR_ARG, "density_count must be in 1..8");
+    if (K < 0 || K > QOCX_LINDBLAD_MAX_K) return fail(QOCX_ERR_ARG, "control_count must be in 0..8");
+    if (L < 0 || L > 4) return fail(QOCX_ERR_ARG, "operator_count must be in 0..4");
+    if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
+    if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");
+    if (p->cost_eval_step < 1) return fail(QOCX_ERR_ARG, "cost_eval_step must be >= 1");
+    if (!p->initial_densities || (K > 0 && !p->g) || (L > 0 && (!p->operators || !p->dissipators)))
+        return fail(QOCX_ERR_ARG, "missing problem arrays");
+    if (qocx::lindblad_lds_size(S, L) > 160 * 1024)
+        return fail(QOCX_ERR_ARG, "too many densities / operators for the kernel's LDS");
+    auto& lb = ctx->lb;
+    lb.has_problem = false;
+    lb.n = n; lb.S = S; lb.K = K; lb.nc = nc; lb.N = N; lb.nsteps = N - 1; lb.ces = p->cost_eval_step;
+    lb.nops = L; lb.T = p->evolution_time; lb.dt = p->evolution_time / (N - 1);
+
+    const cmat h0 = p->h0 ? cm_from(p->h0, n) : cm_zero(n);
+    cmat decay = cm_zero(n);  // sum gamma_i L_i^H L_i
+    std::vector<cmat> ops;
+    std::vector<double> gammas(L);
+    lb.diss_norm = 0;
+    for (int i = 0; i < L; ++i) {
+        ops.push_back(cm_from(p->operators + (size_t)i * n * n * 2, n));
+        gammas[i] = p->dissipators[i];
+        cm_axpy(decay, gammas[i], cm_mul(cm_adjoint(ops[i], n), ops[i], n));
+        lb.diss_norm += fabs(gammas[i]) * one_norm(ops[i].data(), n) * cm_norm_inf(ops[i], n);
+    }
+    // A0L = -i H0 - decay/2 ; A0R = +i H0 - decay/2   (mathmethods.py:188, :200-203)
+    cmat a0l = cm_scale(h0, 0.0, -1.0), a0r = cm_scale(h0, 0.0, 1.0);
+    cm_axpy(a0l, -0.5, decay);
+    cm_axpy(a0r, -0.5, decay);
+    lb.h0_norm = one_norm(h0.data(), n);
+    std::vector<cmat> gp, gpd, gpt;
+    lb.g_norm.assign(K, 0.0);
+    for (int k = 0; k < K; ++k) {
+        const cmat gk = cm_from(p->g + (size_t)k * n * n * 2, n);
+        lb.g_norm[k] = one_norm(gk.data(), n);
+        gp.push_back(cm_scale(gk, 0.0, -1.0));  // Gp = -i G
+        gpd.push_back(cm_adjoint(gp.back(), n));
+        gpt.push_back(cm_transpose(gp.back(), n));
+    }
+    if (upload_dumps(lb.a0l, {a0l}, n, ctx->stream) || upload_dumps(lb.a0r, {a0r}, n, ctx->stream) ||
+        upload_dumps(lb.a0ld, {cm_adjoint(a0l, n)}, n, ctx->stream) ||
+        upload_dumps(lb.a0rd, {cm_adjoint(a0r, n)}, n, ctx->stream) ||
+        upload_dumps(lb.gp, gp, n, ctx->stream) || upload_dumps(lb.gpd, gpd, n, ctx->stream) ||
+        upload_dumps(lb.gpt, gpt, n, ctx->stream) || upload_dumps(lb.ops, ops, n, ctx->stream) ||
+        lb.gammas.upload(gammas, ctx->stream))
+        return QOCX_ERR_HIP;
+    std::vector<cmat> rho0;
+    for (int s = 0; s < S; ++s) rho0.push_back(cm_from(p->initial_densities + (size_t)s * n * n * 2, n));
+    if (upload_dumps(lb.rho0, rho0, n, ctx->stream)) return QOCX_ERR_HIP;
+
+    std::vector<qocx::DevCost> dcosts;
+    std::vector<cmat> pool;
+    std::vector<int> counts;
+    lb.has_step_costs = 0;
+    for (int ci = 0; ci < p->cost_count; ++ci) {
+        const qocx_cost_desc& c = p->costs[ci];
+        qocx::DevCost d;
+        d.step_cost = c.step_cost ? 1 : 0;
+        d.scale = c.scale;
+        d.vec_offset = (int)pool.size();
+        d.cnt_offset = (int)counts.size();
+        if (!c.vectors) return fail(QOCX_ERR_ARG, "cost matrices missing");
+        int nmat = S;
+        if (c.kind == QOCX_COST_TARGET_DENSITY) {
+            d.kind = QOCX_DEV_COST_TARGET_DENSITY;
+        } else if (c.kind == QOCX_COST_FORBID_DENSITY) {
+            d.kind = QOCX_DEV_COST_FORBID_DENSITY;
+            if (!c.counts) return fail(QOCX_ERR_ARG, "forbid counts missing");
+            nmat = 0;
+            for (int s = 0; s < S; ++s) {
+                if (c.counts[s] < 1) return fail(QOCX_ERR_ARG, "forbid count < 1");
+                counts.push_back(c.counts[s]);
+                nmat += c.counts[s];
+            }
+        } else {
+            return fail(QOCX_ERR_ARG, "cost kind not valid for the Lindblad path");
+        }
+        for (int m = 0; m < nmat; ++m) pool.push_back(cm_from(c.vectors + (size_t)m * n * n * 2, n));
+        if (d.step_cost) lb.has_step_costs = 1;
+        dcosts.push_back(d);
+    }
+    lb.cost_count = (int)dcosts.size();
+    if (lb.costs.upload(dcosts, ctx->stream) || upload_dumps(lb.cost_matrices, pool, n, ctx->stream) ||
+        lb.cost_counts.upload(counts, ctx->stream))
+        return QOCX_ERR_HIP;
+    for (auto& kv : lb.grids) {
+        kv.second.substeps.release();
+        kv.second.row_ptr.release();
+        kv.second.col.release();
+        kv.second.weight.release();
+    }
+    lb.grids.clear();
+    lb.has_problem = true;
+    lb.have_results = false;
+    return 0;
+}
+
+namespace {
+
+// Sub-interval table of one sub-division count: uniform pieces per system step, cut at control
+// knots, with the interpolation weights of both ends and the CSR of their transpose.
+int build_lindblad_grid(qocx_ctx* ctx, int ksub, qocx_ctx::Lindblad::Grid& gr) {
+    auto& lb = ctx->lb;
+    const int K = lb.K, nc = lb.nc, nsteps = lb.nsteps;
+    std::vector<double> knots(K > 0 ? nc : 0);
+    for (int i = 0; i < (int)knots.size(); ++i) knots[i] = i * (lb.T / (nc - 1));
+    if (!knots.empty()) knots.back() = lb.T;
+    std::vector<qocx::SubStep> subs;
+    for (int step = 0; step < nsteps; ++step) {
+        const double t0 = step * lb.dt, t1 = (step + 1) * lb.dt;
+        std::vector<double> pts;
+        for (int q = 0; q < ksub; ++q) pts.push_back(t0 + (t1 - t0) * q / ksub);
+        pts.push_back(t1);
+        for (double kn : knots)
+            if (kn > t0 + 1e-12 * lb.dt && kn < t1 - 1e-12 * lb.dt) pts.push_back(kn);
+        std::sort(pts.begin(), pts.end());
+        pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+        for (size_t i = 0; i + 1 < pts.size(); ++i) {
+            qocx::SubStep ss;
+            ss.h = pts[i + 1] - pts[i];
+            // both ends interpolate on the knot interval that contains the sub-interval
+            int m1 = 0, m2 = 0;
+            if (!knots.empty()) {
+                const double mid = 0.5 * (pts[i] + pts[i + 1]);
+                if (mid <= knots[0]) { m1 = 0; m2 = 1; }
+                else if (mid >= knots[nc - 1]) { m1 = nc - 2; m2 = nc - 1; }
+                else {
+                    int idx = 0;
+                    while (!(mid <= knots[idx])) ++idx;
+                    m1 = idx - 1; m2 = idx;
+                }
+            }
+            auto end_weights = [&](double x, double& w1, double& w2) {
+                if (knots.empty()) { w1 = 1; w2 = 0; return; }
+                const double theta = (x - knots[m1]) / (knots[m2] - knots[m1]);
+                w1 = 1.0 - theta; w2 = theta;
+            };
+            ss.ia1 = ss.ib1 = m1; ss.ia2 = ss.ib2 = m2;
+            end_weights(pts[i], ss.wa1, ss.wa2);
+            end_weights(pts[i + 1], ss.wb1, ss.wb2);
+            ss.step = step;
+            ss.first_of_step = (i == 0) ? 1 : 0;
+            subs.push_back(ss);
+        }
+    }
+    const int nsub = (int)subs.size();
+    std::vector<std::vector<std::pair<int, double>>> rows(K > 0 ? nc : 0);
+    if (K > 0)
+        for (int q = 0; q < nsub; ++q) {
+            rows[subs[q].ia1].push_back({2 * q, subs[q].wa1});
+            rows[subs[q].ia2].push_back({2 * q, subs[q].wa2});
+            rows[subs[q].ib1].push_back({2 * q + 1, subs[q].wb1});
+            rows[subs[q].ib2].push_back({2 * q + 1, subs[q].wb2});
+        }
+    std::vector<int> row_ptr(1, 0), col;
+    std::vector<double> weight;
+    for (auto& r : rows) {
+        for (auto& e : r) { col.push_back(e.first); weight.push_back(e.second); }
+        row_ptr.push_back((int)col.size());
+    }
+    if (gr.substeps.upload(subs, ctx->stream) || gr.row_ptr.upload(row_ptr, ctx->stream) ||
+        gr.col.upload(col, ctx->stream) || gr.weight.upload(weight, ctx->stream))
+        return QOCX_ERR_HIP;
+    gr.nsub = nsub;
+    return 0;
+}
+
+}  // namespace
+
+int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
+                       double* cost_out, double* grad_out, double* final_out) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    auto& lb = ctx->lb;
+    if (!lb.has_problem) return fail(QOCX_ERR_STATE, "no Lindblad problem set");
+    if (batch < 1) return fail(QOCX_ERR_ARG, "batch must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = lb.n, S = lb.S, K = lb.K, nc = lb.nc, nsteps = lb.nsteps, B = batch;
+    want_grad = (want_grad && K > 0) ? 1 : 0;
+    if (K > 0 && !controls) return fail(QOCX_ERR_ARG, "controls is NULL");
+
+    // Each seed picks its own sub-division count from ITS controls (|| Liouvillian || * length
+    // <= 0.4 per sub-interval), so a seed's result never depends on its batch neighbours. Seeds
+    // with equal counts are evaluated together: `order` lists the seeds group by group.
+    std::vector<int> ksub_of(B);
+    for (int b = 0; b < B; ++b) {
+        double bound = lb.h0_norm;
+        for (int k = 0; k < K; ++k) {
+            double um = 0;
+            for (int i = 0; i < nc; ++i) {
+                const double a = fabs(controls[((size_t)b * nc + i) * K + k]);
+                if (!(a <= um)) um = a;
+            }
+            bound += um * lb.g_norm[k];
+        }
+        bound = 2 * bound + 2 * lb.diss_norm;
+        if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or operators");
+        const double pieces = ceil(bound * fabs(lb.dt) / 0.4);
+        if (pieces * nsteps > (double)(1 << 24))
+            return fail(QOCX_ERR_CAPACITY, "too many sub-intervals");
+        ksub_of[b] = std::max(1, (int)pieces);
+    }
+    std::map<int, std::vector<int>> groups;
+    for (int b = 0; b < B; ++b) groups[ksub_of[b]].push_back(b);
+    if (lb.grids.size() > 64) {  // bounded cache of sub-interval tables
+        for (auto& kv : lb.grids) {
+            kv.second.substeps.release(); kv.second.row_ptr.release();
+            kv.second.col.release(); kv.second.weight.release();
+        }
+        lb.grids.clear();
+    }
+    size_t ckpt_total = 0, gsub_total = 0;
+    lb.order.clear();
+    for (auto& kv : groups) {
+        auto it = lb.grids.find(kv.first);
+        if (it == lb.grids.end()) {
+            int rc = build_lindblad_grid(ctx, kv.first, lb.grids[kv.first]);
+            if (rc) return rc;
+            it = lb.grids.find(kv.first);
+        }
+        ckpt_total += kv.second.size() * (size_t)it->second.nsub * S * 256;
+        gsub_total += kv.second.size() * (size_t)it->second.nsub * 2 * std::max(K, 1);
+        for (int b : kv.second) lb.order.push_back(b);
+    }
+    const size_t csz = (size_t)nc * K;
+    if (lb.controls.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.cost_out.ensure(B) ||
+        lb.grads.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.gsub.ensure(gsub_total) ||
+        lb.checkpoints.ensure(ckpt_total) || lb.final_out.ensure((size_t)B * S * 256))
+        return QOCX_ERR_HIP;
+    if (ctx->keep_step_states)
+        if (lb.step_densities.ensure((size_t)B * (nsteps + 1) * S * 256)) return QOCX_ERR_HIP;
+    std::vector<double> gathered;
+    if (K > 0) {
+        gathered.resize((size_t)B * csz);
+        for (int pos = 0; pos < B; ++pos)
+            memcpy(gathered.data() + (size_t)pos * csz, controls + (size_t)lb.order[pos] * csz,
+                   csz * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(lb.controls.p, gathered.data(), gathered.size() * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    }
+    size_t pos0 = 0, ckpt_off = 0, gsub_off = 0;
+    for (auto& kv : groups) {
+        const auto& gr = lb.grids[kv.first];
+        const int Bg = (int)kv.second.size(), nsub = gr.nsub;
+        qocx::LindbladArgs la;
+        la.controls = lb.controls.p + pos0 * csz; la.substeps = gr.substeps.p;
+        la.a0l_cimg = lb.a0l.p; la.a0r_cimg = lb.a0r.p; la.a0ld_cimg = lb.a0ld.p; la.a0rd_cimg = lb.a0rd.p;
+        la.gp_cimg = lb.gp.p; la.gpd_cimg = lb.gpd.p; la.gpt_cimg = lb.gpt.p; la.op_cimg = lb.ops.p;
+        la.gammas = lb.gammas.p; la.rho0_cimg = lb.rho0.p;
+        la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
+        la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
+        la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;
+        la.cost_counts = lb.cost_counts.p;
+        la.checkpoints = lb.checkpoints.p + ckpt_off; la.gsub = lb.gsub.p + gsub_off;
+        la.cost_out = lb.cost_out.p + pos0;
+        la.final_out = lb.final_out.p + pos0 * S * 256;
+        la.step_densities = ctx->keep_step_states
+                                ? lb.step_densities.p + pos0 * (nsteps + 1) * S * 256 : nullptr;
+        time_begin(ctx, 5, ctx->stream);
+        qocx::launch_lindblad(la, Bg, ctx->stream);
+        time_end(ctx, ctx->stream);
+        if (want_grad) {
+            qocx::ScatterArgs sc;
+            sc.gstep = la.gsub; sc.row_ptr = gr.row_ptr.p; sc.col_step = gr.col.p;
+            sc.weight = gr.weight.p; sc.grads = lb.grads.p + pos0 * csz;
+            sc.B = Bg; sc.nc = nc; sc.K = K; sc.nsteps = 2 * nsub;
+            time_begin(ctx, 3, ctx->stream);
+            qocx::launch_scatter(sc, ctx->stream);
+            time_end(ctx, ctx->stream);
+        }
+        pos0 += Bg;
+        ckpt_off += (size_t)Bg * nsub * S * 256;
+        gsub_off += (size_t)Bg * nsub * 2 * std::max(K, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<double2> fin(final_out ? (size_t)B * S * 256 : 0);
+    std::vector<double> cst(B), grd(want_grad && grad_out ? (size_t)B * csz : 0);
+    HIP_TRY(hipMemcpyAsync(cst.data(), lb.cost_out.p, (size_t)B * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    if (!grd.empty())
+        HIP_TRY(hipMemcpyAsync(grd.data(), lb.grads.p, grd.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    if (final_out)
+        HIP_TRY(hipMemcpyAsync(fin.data(), lb.final_out.p, fin.size() * sizeof(double2),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    time_collect(ctx);
+    for (int pos = 0; pos < B; ++pos) {
+        const int b = lb.order[pos];
+        if (cost_out) cost_out[b] = cst[pos];
+        if (!grd.empty())
+            memcpy(grad_out + (size_t)b * csz, grd.data() + (size_t)pos * csz, csz * sizeof(double));
+        if (final_out)
+            for (int s = 0; s < S; ++s)
+                from_c_dump(fin.data() + ((size_t)pos * S + s) * 256, n,
+                            final_out + ((size_t)b * S + s) * n * n * 2);
+    }
+    lb.B = B;
+    lb.have_results = true;
+    lb.have_steps = ctx->keep_step_states != 0;
+    return 0;
+}
+
+int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out) {
+    if (!ctx || !densities_out) return fail(QOCX_ERR_ARG, "NULL argument");
+    auto& lb = ctx->lb;
+    if (!lb.have_results || !lb.have_steps)
+        return fail(QOCX_ERR_STATE, "step densities were not kept (qocx_set_keep_step_states)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t per_seed = (size_t)(lb.nsteps + 1) * lb.S;
+    std::vector<double2> tmp((size_t)lb.B * per_seed * 256);
+    HIP_TRY(hipMemcpy(tmp.data(), lb.step_densities.p, tmp.size() * sizeof(double2),
+                      hipMemcpyDeviceToHost));
+    for (int pos = 0; pos < lb.B; ++pos)
+        for (size_t v = 0; v < per_seed; ++v)
+            from_c_dump(tmp.data() + ((size_t)pos * per_seed + v) * 256, lb.n,
+                        densities_out + ((size_t)lb.order[pos] * per_seed + v) * lb.n * lb.n * 2);
     return 0;
 }
 

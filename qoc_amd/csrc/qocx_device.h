@@ -11,6 +11,9 @@ namespace qocx {
 #define QOCX_DEV_COST_COHERENT 0
 #define QOCX_DEV_COST_INCOHERENT 1
 #define QOCX_DEV_COST_FORBID 2
+#define QOCX_DEV_COST_TARGET_DENSITY 3
+#define QOCX_DEV_COST_FORBID_DENSITY 4
+#define QOCX_LINDBLAD_MAX_K 8
 
 // Linear interpolation of the controls at the quadrature time of one propagator step
 // (qoc/core/mathmethods.py:33, :54-65): u = y[i1] + ((y[i2] - y[i1]) / dx) * off.
@@ -101,6 +104,44 @@ struct ScatterArgs {
     double* grads;        // [B][nc][K]
     int B, nc, K, nsteps;
 };
+
+// One sub-interval of the fixed-step Lindblad integrator: [t_a, t_b] inside system step `step`,
+// never straddling a control knot; u(t_a), u(t_b) by linear interpolation on the control grid.
+struct SubStep {
+    double h;
+    int ia1, ia2, ib1, ib2;
+    double wa1, wa2, wb1, wb2;
+    int step;
+    int first_of_step;
+};
+
+struct LindbladArgs {
+    const double* controls;    // [B][nc][K]
+    const SubStep* substeps;   // [nsub]
+    const double2* a0l_cimg;   // C-dumps (256 complex): A0L, A0R and their conjugate transposes
+    const double2* a0r_cimg;
+    const double2* a0ld_cimg;
+    const double2* a0rd_cimg;
+    const double2* gp_cimg;    // [K] Gp_k = -i G_k
+    const double2* gpd_cimg;   // [K] Gp_k^H
+    const double2* gpt_cimg;   // [K] Gp_k^T
+    const double2* op_cimg;    // [nops] L_i
+    const double* gammas;      // [nops]
+    const double2* rho0_cimg;  // [S]
+    int n, S, K, nc, nops, nsub, nsteps, cost_eval_step, want_grad, has_step_costs;
+    int cost_count;
+    const DevCost* costs;
+    const double2* cost_matrices;  // pooled C-dumps
+    const int* cost_counts;
+    double2* checkpoints;      // [B][nsub][S] C-dumps: densities at the start of each sub-interval
+    double* gsub;              // [B][nsub][2][K] control cotangents at t_a / t_b
+    double* cost_out;          // [B]
+    double2* final_out;        // [B][S] C-dumps
+    double2* step_densities;   // [B][nsteps+1][S] C-dumps or nullptr
+};
+
+void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
+int lindblad_lds_size(int S, int nops);
 
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,

@@ -1,0 +1,512 @@
+// qocx_lindblad.hip - hand-written CDNA4 (gfx950) kernel of the Lindblad GRAPE path.
+//
+// Reference: _evaluate_lindblad_discrete (qoc/core/lindbladdiscrete.py:357-441) integrates
+//     d rho/dt = -i[H, rho] + sum_i gamma_i (L_i rho L_i^H - 1/2 {L_i^H L_i, rho})
+// (get_lindbladian, qoc/core/mathmethods.py:169-206) with an adaptive RK5(4) restarted at every
+// system step, and autograd differentiates through that integrator. The device integrates the
+// SAME matrix-form equation, rewritten as
+//     d rho/dt = A_L rho + rho A_R + sum_i gamma_i L_i rho L_i^H,
+//     A_L = -i H(u(t)) - 1/2 sum_i gamma_i L_i^H L_i,   A_R = +i H(u(t)) - 1/2 sum_i gamma_i L_i^H L_i,
+// with the FIXED-step 12-stage Dormand-Prince 8(5,3) scheme on host-chosen sub-intervals that
+// never straddle a control knot (so u(t) is linear inside each), and applies the exact discrete
+// adjoint of that scheme, recomputing each sub-interval from a checkpoint (tests/lindblad_model.py
+// is the NumPy model of exactly this). All products are n x n (n <= 16: ONE MFMA tile):
+// every right-hand side is 2 + 2L complex 16^3 GEMMs on v_mfma_f64_16x16x4_f64.
+//
+// One wavefront per seed; the S densities of a seed advance together, sub-interval by
+// sub-interval (the recursion in time is serial).
+#include "dop853_tableau.h"
+#include "qocx_wave.h"
+
+namespace qocx {
+
+namespace {
+
+constexpr int LNB = 1;                 // n <= 16
+typedef Geo<LNB> LG;
+typedef CMat<LNB> Mat;                 // 16 x 16 complex in C-layout: 16 VGPRs
+constexpr int LNP = LG::NP;            // 16
+constexpr int LPLANE = LG::PLANE;      // doubles per LDS plane
+constexpr int SLOT_BYTES = 2 * LPLANE * 8;  // planar left-operand slot
+constexpr int DUMP_BYTES = 256 * 16;        // C-layout dump of one matrix (lane-linear)
+constexpr int STAGES = QOCX_RK_STAGES;
+
+// the Butcher tableau in constant memory (runtime-indexed by the rolled stage loops)
+struct TableauInit {
+    double a[STAGES * STAGES], b[STAGES], c[STAGES];
+    constexpr TableauInit() : a(), b(), c() {
+        for (int i = 0; i < STAGES; ++i) {
+            b[i] = QOCX_RK_B[i];
+            c[i] = QOCX_RK_C[i];
+            for (int j = 0; j < STAGES; ++j) a[i * STAGES + j] = QOCX_RK_A[i][j];
+        }
+    }
+};
+constexpr TableauInit TABLEAU{};
+__device__ __constant__ const TableauInit TABLEAU_DEV = TABLEAU;
+#define RK_A_DEV TABLEAU_DEV.a
+#define RK_B_DEV TABLEAU_DEV.b
+#define RK_C_DEV TABLEAU_DEV.c
+
+struct Slot {
+    double* re;
+    double* im;
+};
+
+__device__ __forceinline__ Slot slot_at(char* base) {
+    Slot s;
+    s.re = reinterpret_cast<double*>(base);
+    s.im = s.re + LPLANE;
+    return s;
+}
+
+// C-layout dump: reg r of lane l <-> complex index r*64 + l (conflict free, coalesced)
+__device__ __forceinline__ void dump_store(const Mat& m, double2* d) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r * 64 + lane] = make_double2(m.re[0][0][r], m.im[0][0][r]);
+}
+__device__ __forceinline__ void dump_load(Mat& m, const double2* d) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double2 e = d[r * 64 + lane];
+        m.re[0][0][r] = e.x;
+        m.im[0][0][r] = e.y;
+    }
+}
+
+// C-layout registers of M^H from the planar image of M
+__device__ __forceinline__ void load_adjoint(Mat& m, const Slot& s) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int off = c * LG::PITCH + 4 * r + q;  // element (row 4r+q, col c) of M^H = conj M[c][4r+q]
+        m.re[0][0][r] = s.re[off];
+        m.im[0][0][r] = -s.im[off];
+    }
+}
+
+__device__ __forceinline__ void mat_zero(Mat& m) { cmat_zero<LNB>(m); }
+__device__ __forceinline__ void mat_axpy(Mat& y, double a, const Mat& x) {
+    y.re[0][0] += a * x.re[0][0];
+    y.im[0][0] += a * x.im[0][0];
+}
+
+// acc += Left * right, Left = the planar slot (or its conjugate transpose), right in registers
+template <bool LEFT_ADJ>
+__device__ __forceinline__ void gemm(Mat& acc, const Slot& left, const Mat& right) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int off = LEFT_ADJ ? ((4 * kk + q) * LG::PITCH + c) : (c * LG::PITCH + 4 * kk + q);
+        const double are = left.re[off];
+        const double aim = LEFT_ADJ ? -left.im[off] : left.im[off];
+        const double bre = right.re[0][0][kk], bim = right.im[0][0][kk];
+        acc.re[0][0] = mfma_f64(are, bre, acc.re[0][0]);
+        acc.re[0][0] = mfma_f64(-aim, bim, acc.re[0][0]);
+        acc.im[0][0] = mfma_f64(are, bim, acc.im[0][0]);
+        acc.im[0][0] = mfma_f64(aim, bre, acc.im[0][0]);
+    }
+}
+
+struct Operands {     // LDS addresses of one direction (forward or adjoint) of the RHS
+    Slot gen_left;    // A_L (forward) or A_L^H (adjoint), rebuilt per stage
+    Slot y_left;      // the argument, as a left operand
+    Slot tmp;         // gamma_i L_i Y
+    char* op_left;    // [L] planar slots: L_i (forward) / L_i^H (adjoint)
+    double2* op_right;  // [L] dumps:     L_i^H (forward) / L_i (adjoint)
+};
+
+// out = Gen y + y GenRight + sum_i gamma_i Op_i y OpRight_i
+__device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen_right,
+                                          const Operands& o, int nops, const double* gammas) {
+    cmat_to_lds<LNB>(y, o.y_left.re, o.y_left.im);
+    wave_sync();
+    mat_zero(out);
+    gemm<false>(out, o.gen_left, y);
+    gemm<false>(out, o.y_left, gen_right);
+    for (int i = 0; i < nops; ++i) {
+        Mat t, opr;
+        mat_zero(t);
+        gemm<false>(t, slot_at(o.op_left + (size_t)i * SLOT_BYTES), y);
+        const double gm = gammas[i];
+        t.re[0][0] *= gm;
+        t.im[0][0] *= gm;
+        wave_sync();
+        cmat_to_lds<LNB>(t, o.tmp.re, o.tmp.im);
+        wave_sync();
+        dump_load(opr, o.op_right + (size_t)i * 256);
+        gemm<false>(out, o.tmp, opr);
+    }
+    wave_sync();
+}
+
+// <X, Y> = sum conj(X) Y over the whole matrix, wave-uniform
+__device__ __forceinline__ void frob_inner(const Mat& x, const Mat& y, double& re, double& im) {
+    double pr = 0, pi = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pr += x.re[0][0][r] * y.re[0][0][r] + x.im[0][0][r] * y.im[0][0][r];
+        pi += x.re[0][0][r] * y.im[0][0][r] - x.im[0][0][r] * y.re[0][0][r];
+    }
+    re = wave_sum(pr);
+    im = wave_sum(pi);
+}
+
+// Density costs on the S densities in `dens` (LDS dumps); optionally adds the cotangents into
+// `lam`. qoc/standard/costs/targetdensityinfidelity.py:41-69, forbiddensities.py:53-85.
+__device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step_pass,
+                                                bool final_pass, const double2* dens,
+                                                double2* lam) {
+    const int S = a.S, n = a.n;
+    double total = 0;
+    for (int ci = 0; ci < a.cost_count; ++ci) {
+        const DevCost c = a.costs[ci];
+        const bool on = c.step_cost ? step_pass : final_pass;
+        if (!on) continue;
+        const double2* pool = a.cost_matrices + (size_t)c.vec_offset * 256;
+        if (c.kind == QOCX_DEV_COST_TARGET_DENSITY) {
+            double fid = 0;
+            for (int s = 0; s < S; ++s) {
+                Mat t, rho;
+                dump_load(t, pool + (size_t)s * 256);
+                dump_load(rho, dens + (size_t)s * 256);
+                double zr, zi;
+                frob_inner(t, rho, zr, zi);  // tr(T^H rho)
+                const double mag = sqrt(zr * zr + zi * zi);
+                fid += mag;
+                if (lam != nullptr && mag > 0) {
+                    const double f = -c.scale / ((double)S * n * mag);
+                    Mat l;
+                    dump_load(l, lam + (size_t)s * 256);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        l.re[0][0][r] += f * (zr * t.re[0][0][r] - zi * t.im[0][0][r]);
+                        l.im[0][0][r] += f * (zr * t.im[0][0][r] + zi * t.re[0][0][r]);
+                    }
+                    dump_store(l, lam + (size_t)s * 256);
+                }
+            }
+            total += c.scale * (1.0 - fid / ((double)S * n));
+        } else {  // QOCX_DEV_COST_FORBID_DENSITY
+            int base = 0;
+            double acc = 0;
+            for (int s = 0; s < S; ++s) {
+                const int fs = a.cost_counts[c.cnt_offset + s];
+                Mat rho, l;
+                dump_load(rho, dens + (size_t)s * 256);
+                if (lam != nullptr) dump_load(l, lam + (size_t)s * 256);
+                for (int f = 0; f < fs; ++f) {
+                    Mat t;
+                    dump_load(t, pool + (size_t)(base + f) * 256);
+                    double zr, zi;
+                    frob_inner(t, rho, zr, zi);
+                    zr /= n;
+                    zi /= n;
+                    acc += (zr * zr + zi * zi) / fs;
+                    if (lam != nullptr) {
+                        const double g = 2.0 * c.scale / ((double)fs * n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            l.re[0][0][r] += g * (zr * t.re[0][0][r] - zi * t.im[0][0][r]);
+                            l.im[0][0][r] += g * (zr * t.im[0][0][r] + zi * t.re[0][0][r]);
+                        }
+                    }
+                }
+                if (lam != nullptr) dump_store(l, lam + (size_t)s * 256);
+                base += fs;
+            }
+            total += c.scale * acc;
+        }
+    }
+    wave_sync();
+    return total;
+}
+
+}  // namespace
+
+// LDS carve (bytes): 3 planar work slots | per operator: planar L, planar L^H, dump L, dump L^H |
+// S density dumps | S lambda dumps | STAGES stage-derivative dumps
+__host__ __device__ inline int lindblad_lds_bytes(int S, int nops) {
+    return 3 * SLOT_BYTES + nops * (2 * SLOT_BYTES + 2 * DUMP_BYTES) + 2 * S * DUMP_BYTES +
+           STAGES * DUMP_BYTES;
+}
+
+namespace {
+
+// Everything one wave needs; the stage loops are template recursions over the (compile-time)
+// Butcher tableau so that the stage derivatives stay in registers.
+struct Wave {
+    const LindbladArgs& a;
+    Slot slot_gen, slot_y, slot_tmp;
+    Operands fwd, adj;
+    double2* kdump;  // STAGES dumps: stage derivatives k_j, then (adjoint) Ybar_j
+    const double* ctl_b;
+
+    // Generators of one stage. The reference applies -i[H, rho] with the SAME H on both sides
+    // (mathmethods.py:188), so the left and right factors are kept separate (they are adjoints
+    // of each other only for Hermitian H):
+    //   forward : left = A_L = A0L + sum u_k Gp_k ,  right = A_R = A0R - sum u_k Gp_k , Gp = -i G
+    //   adjoint : left = A_L^H,  right = A_R^H  (images of the conjugate transposes)
+    __device__ __forceinline__ void build_generator(const SubStep& ss, double c, bool adjoint,
+                                                    Mat& left, Mat& right) const {
+        dump_load(left, adjoint ? a.a0ld_cimg : a.a0l_cimg);
+        dump_load(right, adjoint ? a.a0rd_cimg : a.a0r_cimg);
+        const int K = a.K;
+        for (int k = 0; k < K; ++k) {
+            const double ua = ss.wa1 * ctl_b[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl_b[(size_t)ss.ia2 * K + k];
+            const double ub = ss.wb1 * ctl_b[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl_b[(size_t)ss.ib2 * K + k];
+            const double u = (1.0 - c) * ua + c * ub;  // u(t) is linear inside a sub-interval
+            Mat g;
+            dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * 256);
+            mat_axpy(left, u, g);
+            mat_axpy(right, -u, g);
+        }
+    }
+
+    // ---- forward stages -------------------------------------------------------------------
+    // The stage derivatives k_j live in slot j of `kdump` (LDS). Plain runtime loops over the
+    // tableau (in constant memory): the body is GEMM bound, and rolled loops keep the register
+    // allocation small.
+    __device__ __forceinline__ void stage_value(Mat& y, const Mat& y0, int i, double h) const {
+        y = y0;
+        for (int j = 0; j < i; ++j) {
+            const double aij = RK_A_DEV[i * STAGES + j];
+            if (aij != 0.0) {
+                Mat k;
+                dump_load(k, kdump + (size_t)j * 256);
+                mat_axpy(y, h * aij, k);
+            }
+        }
+    }
+    // all stage derivatives of the sub-interval starting at y0 -> kdump; optionally advance y0
+    __device__ __forceinline__ void substep(const SubStep& ss, Mat& y0, bool advance) const {
+        for (int i = 0; i < STAGES; ++i) {
+            Mat y, k, gl, gr;
+            stage_value(y, y0, i, ss.h);
+            build_generator(ss, RK_C_DEV[i], false, gl, gr);
+            wave_sync();
+            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
+            wave_sync();
+            rhs_apply(k, y, gr, fwd, a.nops, a.gammas);
+            dump_store(k, kdump + (size_t)i * 256);
+            wave_sync();
+        }
+        if (advance)
+            for (int i = 0; i < STAGES; ++i) {
+                const double bi = RK_B_DEV[i];
+                if (bi != 0.0) {
+                    Mat k;
+                    dump_load(k, kdump + (size_t)i * 256);
+                    mat_axpy(y0, ss.h * bi, k);
+                }
+            }
+    }
+
+    // ---- adjoint stages -------------------------------------------------------------------
+    // Going down in i, slot i of kdump is turned from k_i into Ybar_i once Y_i has been rebuilt
+    // (Y_i needs only k_j, j < i; kbar_i needs only Ybar_j, j > i).
+    __device__ __forceinline__ void adjoint_substep(const SubStep& ss, const Mat& y0,
+                                                    const Mat& lambda, Mat& lambda_new,
+                                                    double (&ga)[QOCX_LINDBLAD_MAX_K],
+                                                    double (&gb)[QOCX_LINDBLAD_MAX_K]) const {
+        for (int i = STAGES - 1; i >= 0; --i) {
+            // kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j)
+            Mat kb;
+            mat_zero(kb);
+            const double bi = RK_B_DEV[i], ci = RK_C_DEV[i];
+            if (bi != 0.0) mat_axpy(kb, ss.h * bi, lambda);
+            for (int j = i + 1; j < STAGES; ++j) {
+                const double aji = RK_A_DEV[j * STAGES + i];
+                if (aji != 0.0) {
+                    Mat yb;
+                    dump_load(yb, kdump + (size_t)j * 256);
+                    mat_axpy(kb, ss.h * aji, yb);
+                }
+            }
+            Mat gl, gr, ybar;
+            build_generator(ss, ci, true, gl, gr);
+            wave_sync();
+            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);  // A_L^H is the left operand now
+            wave_sync();
+            rhs_apply(ybar, kb, gr, adj, a.nops, a.gammas);
+            mat_axpy(lambda_new, 1.0, ybar);
+            // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
+            // Z = Y kbar^H - kbar^H Y  (slot_y still holds kbar as a planar image)
+            Mat y, kbd, z, z2;
+            stage_value(y, y0, i, ss.h);  // the stage value Y_i again
+            wave_sync();
+            dump_store(ybar, kdump + (size_t)i * 256);  // k_i is no longer needed
+            load_adjoint(kbd, slot_y);
+            mat_zero(z2);
+            gemm<true>(z2, slot_y, y);  // kbar^H Y
+            wave_sync();
+            cmat_to_lds<LNB>(y, slot_tmp.re, slot_tmp.im);
+            wave_sync();
+            mat_zero(z);
+            gemm<false>(z, slot_tmp, kbd);  // Y kbar^H
+            mat_axpy(z, -1.0, z2);
+            const int K = a.K;
+            for (int k = 0; k < K; ++k) {
+                Mat gt;
+                dump_load(gt, a.gpt_cimg + (size_t)k * 256);  // C-image of Gp_k^T
+                double pr = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                const double g = wave_sum(pr);
+#pragma unroll
+                for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                    if (kk == k) {
+                        ga[kk] += (1.0 - ci) * g;
+                        gb[kk] += ci * g;
+                    }
+            }
+            wave_sync();
+        }
+    }
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int S = a.S, K = a.K, nops = a.nops, nsub = a.nsub;
+    const int b = blockIdx.x;
+    char* p = smem;
+    const Slot slot_gen = slot_at(p); p += SLOT_BYTES;
+    const Slot slot_y = slot_at(p); p += SLOT_BYTES;
+    const Slot slot_tmp = slot_at(p); p += SLOT_BYTES;
+    char* op_planar = p; p += (size_t)nops * SLOT_BYTES;     // L_i
+    char* opd_planar = p; p += (size_t)nops * SLOT_BYTES;    // L_i^H
+    double2* op_dump = reinterpret_cast<double2*>(p); p += (size_t)nops * DUMP_BYTES;   // L_i
+    double2* opd_dump = reinterpret_cast<double2*>(p); p += (size_t)nops * DUMP_BYTES;  // L_i^H
+    double2* dens = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
+    double2* lam = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
+    double2* kdump = reinterpret_cast<double2*>(p);
+
+    // static operators into LDS in the four forms the two RHS directions need
+    for (int i = 0; i < nops; ++i) {
+        Mat op, opd;
+        dump_load(op, a.op_cimg + (size_t)i * 256);
+        cmat_to_lds<LNB>(op, slot_at(op_planar + (size_t)i * SLOT_BYTES).re,
+                         slot_at(op_planar + (size_t)i * SLOT_BYTES).im);
+        dump_store(op, op_dump + (size_t)i * 256);
+        wave_sync();
+        load_adjoint(opd, slot_at(op_planar + (size_t)i * SLOT_BYTES));
+        cmat_to_lds<LNB>(opd, slot_at(opd_planar + (size_t)i * SLOT_BYTES).re,
+                         slot_at(opd_planar + (size_t)i * SLOT_BYTES).im);
+        dump_store(opd, opd_dump + (size_t)i * 256);
+    }
+    for (int s = 0; s < S; ++s) {
+        Mat rho;
+        dump_load(rho, a.rho0_cimg + (size_t)s * 256);
+        dump_store(rho, dens + (size_t)s * 256);
+    }
+    wave_sync();
+
+    Operands fwd, adj;
+    fwd.gen_left = slot_gen; fwd.y_left = slot_y; fwd.tmp = slot_tmp;
+    fwd.op_left = op_planar; fwd.op_right = opd_dump;
+    adj = fwd;
+    adj.op_left = opd_planar; adj.op_right = op_dump;
+    const Wave w{a, slot_gen, slot_y, slot_tmp, fwd, adj, kdump,
+                 a.controls + (size_t)b * a.nc * K};
+    double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * 256;
+
+    // ---- forward ------------------------------------------------------------------------
+    double cost = 0;
+    for (int q = 0; q < nsub; ++q) {
+        const SubStep ss = a.substeps[q];
+        if (ss.first_of_step) {
+            if (ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
+                cost += density_costs(a, true, false, dens, nullptr);
+            if (a.step_densities != nullptr)
+                for (int s = 0; s < S; ++s) {
+                    Mat rho;
+                    dump_load(rho, dens + (size_t)s * 256);
+                    dump_store(rho, a.step_densities +
+                                        (((size_t)b * (a.nsteps + 1) + ss.step) * S + s) * 256);
+                }
+        }
+        for (int s = 0; s < S; ++s) {
+            Mat y0;
+            dump_load(y0, dens + (size_t)s * 256);
+            dump_store(y0, ckpt_b + ((size_t)q * S + s) * 256);
+            w.substep(ss, y0, true);
+            wave_sync();
+            dump_store(y0, dens + (size_t)s * 256);
+            wave_sync();
+        }
+    }
+    if ((a.nsteps % a.cost_eval_step) == 0) cost += density_costs(a, true, false, dens, nullptr);
+    cost += density_costs(a, false, true, dens, nullptr);
+    if (lane == 0) a.cost_out[b] = cost;
+    for (int s = 0; s < S; ++s) {
+        Mat rho;
+        dump_load(rho, dens + (size_t)s * 256);
+        dump_store(rho, a.final_out + ((size_t)b * S + s) * 256);
+        if (a.step_densities != nullptr)
+            dump_store(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * 256);
+    }
+    if (!a.want_grad) return;
+
+    // ---- discrete adjoint ----------------------------------------------------------------
+    {
+        Mat zero;
+        mat_zero(zero);
+        for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * 256);
+    }
+    wave_sync();
+    (void)density_costs(a, (a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+
+    for (int q = nsub - 1; q >= 0; --q) {
+        const SubStep ss = a.substeps[q];
+        double ga[QOCX_LINDBLAD_MAX_K], gb[QOCX_LINDBLAD_MAX_K];
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
+            ga[k] = 0;
+            gb[k] = 0;
+        }
+        for (int s = 0; s < S; ++s) {
+            Mat y0;
+            dump_load(y0, ckpt_b + ((size_t)q * S + s) * 256);
+            w.substep(ss, y0, false);  // recompute the stage derivatives -> kdump
+            Mat lambda, lambda_new;
+            dump_load(lambda, lam + (size_t)s * 256);
+            lambda_new = lambda;
+            w.adjoint_substep(ss, y0, lambda, lambda_new, ga, gb);
+            dump_store(lambda_new, lam + (size_t)s * 256);
+            wave_sync();
+        }
+        if (lane == 0)
+            for (int k = 0; k < K; ++k) {
+                a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + k] = ga[k];
+                a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + k] = gb[k];
+            }
+        // step costs are evaluated on the densities at the START of their system step
+        if (ss.first_of_step && ss.step != 0 && (ss.step % a.cost_eval_step) == 0 &&
+            a.has_step_costs) {
+            for (int s = 0; s < S; ++s) {
+                Mat rho;
+                dump_load(rho, ckpt_b + ((size_t)q * S + s) * 256);
+                dump_store(rho, dens + (size_t)s * 256);
+            }
+            wave_sync();
+            (void)density_costs(a, true, false, dens, lam);
+        }
+    }
+}
+
+void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
+    const int bytes = lindblad_lds_bytes(a.S, a.nops);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL(lindblad_kernel, dim3(batch), dim3(64), bytes, st, a);
+}
+
+int lindblad_lds_size(int S, int nops) { return lindblad_lds_bytes(S, nops); }
+
+}  // namespace qocx

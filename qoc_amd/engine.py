@@ -16,12 +16,14 @@ LIBRARY_PATH = os.path.join(_HERE, "libqocx.so")
 COST_TARGET_COHERENT = 0
 COST_TARGET_INCOHERENT = 1
 COST_FORBID = 2
+COST_TARGET_DENSITY = 3
+COST_FORBID_DENSITY = 4
 
 MAGNUS_CODES = {"M2": 2, "M4": 4, "M6": 6}
 
 ERR_SINGULAR = -4
 
-KERNEL_NAMES = ("pade_pq", "sweep", "krylov_grad", "scatter", "lu")
+KERNEL_NAMES = ("pade_pq", "sweep", "krylov_grad", "scatter", "lu", "lindblad")
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int32)
@@ -49,6 +51,16 @@ class _SchroedingerProblem(ctypes.Structure):
                 ("costs", ctypes.POINTER(_CostDesc))]
 
 
+class _LindbladProblem(ctypes.Structure):
+    _fields_ = [("hilbert_size", ctypes.c_int32), ("density_count", ctypes.c_int32),
+                ("control_count", ctypes.c_int32), ("control_eval_count", ctypes.c_int32),
+                ("system_eval_count", ctypes.c_int32), ("cost_eval_step", ctypes.c_int32),
+                ("operator_count", ctypes.c_int32), ("evolution_time", ctypes.c_double),
+                ("h0", _c_double_p), ("g", _c_double_p), ("dissipators", _c_double_p),
+                ("operators", _c_double_p), ("initial_densities", _c_double_p),
+                ("cost_count", ctypes.c_int32), ("costs", ctypes.POINTER(_CostDesc))]
+
+
 # name -> (restype, argtypes); every symbol declared in include/qocx.h
 _VP = ctypes.c_void_p
 _I32 = ctypes.c_int32
@@ -69,6 +81,10 @@ SIGNATURES = {
     "qocx_download_results": (ctypes.c_int, [_VP, _c_double_p, _c_double_p, _c_double_p]),
     "qocx_set_keep_step_states": (ctypes.c_int, [_VP, _I32]),
     "qocx_download_step_states": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_set_lindblad_problem": (ctypes.c_int, [_VP, ctypes.POINTER(_LindbladProblem)]),
+    "qocx_eval_lindblad": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
+                                          _c_double_p, _c_double_p]),
+    "qocx_download_step_densities": (ctypes.c_int, [_VP, _c_double_p]),
     "qocx_set_timing": (ctypes.c_int, [_VP, _I32]),
     "qocx_get_timing": (ctypes.c_int, [_VP, _I32, ctypes.POINTER(_I64), _c_double_p]),
     "qocx_reset_timing": (ctypes.c_int, [_VP]),
@@ -237,6 +253,79 @@ class Engine(object):
         pr, B = self._problem, self.batch
         out = np.empty((B, pr["N"], pr["S"], pr["n"]), dtype=np.complex128)
         self._check(self._lib.qocx_download_step_states(self._ctx, _dp(out)))
+        return out
+
+    # -- Lindblad -------------------------------------------------------------------------------
+    def set_lindblad_problem(self, hilbert_size, density_count, control_count,
+                             control_eval_count, system_eval_count, evolution_time,
+                             h0, g, dissipators, operators, initial_densities, costs=(),
+                             cost_eval_step=1):
+        """
+        h0 :: (n, n), g :: (K, n, n), dissipators :: (L,), operators :: (L, n, n),
+        initial_densities :: (S, n, n); costs :: dicts {kind (3|4), step_cost, scale,
+        vectors (matrices), counts(optional)}.
+        """
+        n, S, K = int(hilbert_size), int(density_count), int(control_count)
+        h0 = _as_complex(h0, (n, n))
+        g = _as_complex(g if K > 0 else np.zeros((0, n, n)), (K, n, n))
+        L = 0 if operators is None else len(operators)
+        ops = _as_complex(operators if L > 0 else np.zeros((0, n, n)), (L, n, n))
+        gam = np.ascontiguousarray(dissipators if L > 0 else np.zeros(0), dtype=np.float64)
+        gam = gam.reshape(L)
+        rho = _as_complex(initial_densities, (S, n, n))
+        keep = [h0, g, ops, gam, rho]
+        descs = (_CostDesc * max(1, len(costs)))()
+        for i, c in enumerate(costs):
+            mats = _as_complex(c["vectors"]).reshape(-1, n, n)
+            keep.append(mats)
+            descs[i].kind = int(c["kind"])
+            descs[i].step_cost = int(bool(c["step_cost"]))
+            descs[i].scale = float(c["scale"])
+            descs[i].vectors = _dp(mats)
+            if c.get("counts") is not None:
+                cnt = np.ascontiguousarray(c["counts"], dtype=np.int32)
+                keep.append(cnt)
+                descs[i].counts = cnt.ctypes.data_as(_c_int_p)
+        p = _LindbladProblem()
+        p.hilbert_size, p.density_count, p.control_count = n, S, K
+        p.control_eval_count, p.system_eval_count = int(control_eval_count), int(system_eval_count)
+        p.cost_eval_step = int(cost_eval_step)
+        p.operator_count = L
+        p.evolution_time = float(evolution_time)
+        p.h0, p.g, p.initial_densities = _dp(h0), _dp(g), _dp(rho)
+        p.dissipators, p.operators = _dp(gam), _dp(ops)
+        p.cost_count = len(costs)
+        p.costs = descs
+        self._check(self._lib.qocx_set_lindblad_problem(self._ctx, ctypes.byref(p)))
+        self._lindblad = dict(n=n, S=S, K=K, Nc=int(control_eval_count),
+                              N=int(system_eval_count))
+        self._lindblad_batch = 0
+
+    def evaluate_lindblad(self, controls, want_grad=True, want_final=True):
+        """(cost[B], grads[B,Nc,K] or None, final_densities[B,S,n,n]) for controls[B,Nc,K]."""
+        pr = self._lindblad
+        if pr["K"] > 0:
+            controls = np.ascontiguousarray(controls, dtype=np.float64)
+            controls = controls.reshape(-1, pr["Nc"], pr["K"])
+            B = controls.shape[0]
+        else:
+            B = 1 if controls is None else int(controls)
+            controls = None
+        cost = np.empty(B, dtype=np.float64)
+        want_grad = bool(want_grad) and pr["K"] > 0
+        grads = np.empty((B, pr["Nc"], pr["K"]), dtype=np.float64) if want_grad else None
+        final = (np.empty((B, pr["S"], pr["n"], pr["n"]), dtype=np.complex128)
+                 if want_final else None)
+        self._check(self._lib.qocx_eval_lindblad(
+            self._ctx, B, _dp(controls) if controls is not None else None, int(want_grad),
+            _dp(cost), _dp(grads) if want_grad else None, _dp(final) if want_final else None))
+        self._lindblad_batch = B
+        return cost, grads, final
+
+    def download_step_densities(self):
+        pr, B = self._lindblad, self._lindblad_batch
+        out = np.empty((B, pr["N"], pr["S"], pr["n"], pr["n"]), dtype=np.complex128)
+        self._check(self._lib.qocx_download_step_densities(self._ctx, _dp(out)))
         return out
 
     def set_chunk(self, seeds_per_chunk):

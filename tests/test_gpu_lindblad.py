@@ -1,0 +1,164 @@
+"""
+GPU parity tests (-m gpu) of the Lindblad engine, through the C ABI, against
+
+* the golden vectors minted from the reference forward (adaptive RKDP5, atol 1e-12) and the
+  frozen-mesh AD gradients, and
+* the NumPy model of the device algorithm (tests/lindblad_model.py), which runs the same
+  fixed-step DOP853 + discrete adjoint, to near round-off.
+
+Tolerances: the reference integrator reproduces itself to ~1e-10 only
+(tests/test_lindblad_oracle.py header), so golden densities are held to 1e-8 / cost 1e-9 and
+gradients to 1e-6 relative; against the device model 1e-11 / 1e-9.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import qoc_lindblad_numpy as ol
+from tests import cases as cases_mod
+from tests import lindblad_model as lm
+from tests.helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+NAMES = [c.name for c in cases_mod.lindblad_cases()]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from qoc_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def real_form(case, array):
+    array = np.asarray(array)
+    if not case.complex_controls:
+        return np.asarray(array, dtype=np.float64)
+    return np.stack([array[..., 0].real, array[..., 0].imag], axis=-1)
+
+
+def model_system(case):
+    from tests import gpu_helpers as gh
+    return lm.StructuredLindblad(case.h0, gh.lindblad_generators(case), case.dissipators,
+                                 case.operators)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_lindblad_engine_matches_golden_and_model(engine, name):
+    from tests import gpu_helpers as gh
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    gh.setup_lindblad_engine(engine, case)
+    controls = real_form(case, np.stack(case.controls))
+    cost, grads, final = engine.evaluate_lindblad(controls)
+    costs = [getattr(ol, k)(**kw) for k, kw in case.cost_specs]
+    system = model_system(case)
+    for b in range(controls.shape[0]):
+        assert abs(cost[b] - g["error"][b]) < 1e-9
+        assert np.max(np.abs(final[b] - g["final_densities"][b])) < 1e-8
+        ref = real_form(case, g["grads_ad"][b])
+        assert np.max(np.abs(grads[b] - ref)) / np.max(np.abs(ref)) < 1e-6
+        m_err, m_grads, m_final = lm.evaluate_with_grad(
+            system, controls[b], case.initial_densities, case.T, case.N, costs,
+            case.cost_eval_step)
+        assert abs(cost[b] - m_err) < 1e-12
+        assert np.max(np.abs(final[b] - m_final)) < 1e-12
+        assert np.max(np.abs(grads[b] - m_grads)) / np.max(np.abs(m_grads)) < 1e-10
+        assert abs(np.trace(final[b, 0]) - 1) < 1e-10
+
+
+def test_lindblad_forward_only_and_step_densities(engine):
+    from tests import gpu_helpers as gh
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+    gh.setup_lindblad_engine(engine, case)
+    controls = real_form(case, np.stack(case.controls))
+    cost, grads, final = engine.evaluate_lindblad(controls)
+    engine.set_keep_step_states(True)
+    try:
+        cost2, none, final2 = engine.evaluate_lindblad(controls, want_grad=False)
+        steps = engine.download_step_densities()
+    finally:
+        engine.set_keep_step_states(False)
+    assert none is None
+    assert np.array_equal(cost, cost2) and np.array_equal(final, final2)
+    assert steps.shape == (controls.shape[0], case.N, 2, case.n, case.n)
+    assert np.array_equal(steps[:, -1], final)
+    assert np.max(np.abs(steps[:, 0] - case.initial_densities[None])) == 0
+    # intermediate densities against the reference integrator, step by step
+    problem = ol.LindbladProblem(case.T, case.initial_densities, 2,
+                                 hamiltonian=case.hamiltonian(),
+                                 lindblad_data=case.lindblad_data(), control_eval_count=case.Nc,
+                                 control_count=case.K)
+    traces = np.trace(steps, axis1=-2, axis2=-1)
+    assert np.max(np.abs(traces - 1)) < 1e-10
+    herm = steps - np.conj(np.swapaxes(steps, -1, -2))
+    assert np.max(np.abs(herm)) < 1e-12
+    del problem
+
+
+def test_lindblad_known_answers(engine):
+    """iSWAP under H = (XX+YY)/2 for pi/2 and T1 decay (reference tests/test_core.py:82-148)."""
+    sx = np.array(((0, 1), (1, 0)))
+    sy = np.array(((0, -1j), (1j, 0)))
+    hs = 0.5 * (np.kron(sx, sx) + np.kron(sy, sy))
+    iswap = np.array(((1, 0, 0, 0), (0, 0, -1j, 0), (0, -1j, 0, 0), (0, 0, 0, 1)))
+    init = cases_mod.column_states(np.eye(4))
+    targ = cases_mod.column_states(iswap)
+    rho0 = np.matmul(init, np.conj(np.swapaxes(init, -1, -2)))
+    rho1 = np.matmul(targ, np.conj(np.swapaxes(targ, -1, -2)))
+    engine.set_lindblad_problem(4, 4, 0, 0, 2, np.pi / 2, hs, None, None, None, rho0)
+    _, _, final = engine.evaluate_lindblad(None, want_grad=False)
+    assert np.max(np.abs(final[0] - rho1)) < 1e-10
+    gamma, a0, b0 = 2.0, 0.3, 0.4
+    c0 = 1 - a0
+    rho = np.stack((np.array(((a0, b0), (b0, c0)), dtype=np.complex128),))
+    sp = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    expected = np.array(((1 - c0 * np.exp(-gamma), b0 * np.exp(-gamma / 2)),
+                         (b0 * np.exp(-gamma / 2), c0 * np.exp(-gamma))))
+    engine.set_lindblad_problem(2, 1, 0, 0, 2, 1.0, np.zeros((2, 2)), None, np.array((gamma,)),
+                                np.stack((sp,)), rho)
+    _, _, final = engine.evaluate_lindblad(None, want_grad=False)
+    assert np.max(np.abs(final[0, 0] - expected)) < 1e-10
+
+
+def test_lindblad_gradient_vs_finite_differences(engine):
+    from tests import gpu_helpers as gh
+    case = cases_mod.lindblad_case_by_name("lindblad_c4_short")
+    gh.setup_lindblad_engine(engine, case)
+    u = real_form(case, case.controls[0])
+    _, grads, _ = engine.evaluate_lindblad(u[None])
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal(u.shape)
+    h = 1e-4
+    cost, _, _ = engine.evaluate_lindblad(np.stack([u + h * d, u - h * d]), want_grad=False)
+    fd = (cost[0] - cost[1]) / (2 * h)
+    assert abs(fd - np.sum(grads[0] * d)) < 1e-8 * max(1.0, abs(fd) / 1e-3)
+
+
+def test_lindblad_batch_independent_of_neighbours(engine):
+    from tests import gpu_helpers as gh
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+    gh.setup_lindblad_engine(engine, case)
+    u = real_form(case, np.stack(case.controls))
+    big = np.concatenate([u] * 40)
+    cost, grads, final = engine.evaluate_lindblad(big)
+    c1, g1, f1 = engine.evaluate_lindblad(u)
+    assert np.array_equal(cost.reshape(40, -1), np.broadcast_to(c1, (40,) + c1.shape))
+    assert np.array_equal(grads[:2], g1) and np.array_equal(grads[-2:], g1)
+    assert np.array_equal(final[-2:], f1)
+    # seeds with larger controls take more sub-intervals; mixing them in a batch changes nothing
+    mixed = np.concatenate([u, 4.0 * u, u[:1] * 0.0, 9.0 * u[1:]])
+    cm, gm, fm = engine.evaluate_lindblad(mixed)
+    for b in range(mixed.shape[0]):
+        cb, gb, fb = engine.evaluate_lindblad(mixed[b:b + 1])
+        assert cm[b] == cb[0] and np.array_equal(gm[b], gb[0]) and np.array_equal(fm[b], fb[0])
+    assert np.array_equal(cm[:2], c1)
+
+
+def test_lindblad_rejects_unsupported(engine):
+    from qoc_amd.engine import QocxError
+    with pytest.raises(QocxError):
+        engine.set_lindblad_problem(17, 1, 0, 0, 2, 1.0, np.zeros((17, 17)), None, None, None,
+                                    np.eye(17)[None] / 17)
