@@ -6,6 +6,8 @@ SchusterLab/qoc (host: NumPy; device: hand-written gfx950 HIP through a ctypes C
     from qoc_amd.standard import TargetStateInfidelity, Adam
 """
 
-from .core import evolve_schroedinger_discrete, grape_schroedinger_discrete
+from .core import (evolve_lindblad_discrete, evolve_schroedinger_discrete,
+                   grape_lindblad_discrete, grape_schroedinger_discrete)
 
-__all__ = ["evolve_schroedinger_discrete", "grape_schroedinger_discrete"]
+__all__ = ["evolve_lindblad_discrete", "evolve_schroedinger_discrete",
+           "grape_lindblad_discrete", "grape_schroedinger_discrete"]

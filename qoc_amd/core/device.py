@@ -147,3 +147,116 @@ class SchroedingerEvaluator(object):
         errors, grads, final, steps = self.evaluate_batch(batch, want_grad, want_step_states)
         return (float(errors[0]), None if grads is None else grads[0], final[0],
                 None if steps is None else steps[0])
+
+
+class LindbladEvaluator(object):
+    """
+    Plays the role of `_evaluate_lindblad_discrete` and of its `ans_jacobian`
+    (qoc/core/lindbladdiscrete.py:321-322, :357-441) through qocx_eval_lindblad.
+    """
+
+    MAX_HILBERT_SIZE = 16
+
+    def __init__(self, evolution_time, initial_densities, system_eval_count, hamiltonian=None,
+                 lindblad_data=None, control_count=0, control_eval_count=0,
+                 complex_controls=False, costs=(), cost_eval_step=1,
+                 interpolation_policy=InterpolationPolicy.LINEAR, need_gradients=True,
+                 backend=None):
+        if interpolation_policy != InterpolationPolicy.LINEAR:
+            raise NotImplementedError("This operation does not yet support the interpolation "
+                                      "policy {}.".format(interpolation_policy))
+        initial_densities = np.asarray(initial_densities)
+        self.density_count = initial_densities.shape[0]
+        self.hilbert_size = initial_densities.shape[1]
+        if self.hilbert_size > self.MAX_HILBERT_SIZE:
+            raise NotImplementedError(
+                "the MI355X Lindblad engine handles hilbert_size <= {} (got {}); there is no "
+                "CPU fallback.".format(self.MAX_HILBERT_SIZE, self.hilbert_size))
+        self.control_count = control_count
+        self.control_eval_count = control_eval_count
+        self.complex_controls = complex_controls
+        self.system_eval_count = system_eval_count
+        self.final_system_eval_step = system_eval_count - 1
+        self.cost_eval_step = cost_eval_step
+        self.costs = list(costs)
+        h0, g, dissipators, operators = structure.probe_static_lindblad_system(
+            hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
+            evolution_time)
+        self.device_costs, self.host_costs, self.opaque_costs = [], [], []
+        descriptors = []
+        for cost in self.costs:
+            desc = cost.device_descriptor(self.density_count, self.hilbert_size) \
+                if hasattr(cost, "device_descriptor") else None
+            if desc is not None:
+                self.device_costs.append(cost)
+                descriptors.append(desc)
+            elif (getattr(cost, "uses_states", True) is False
+                  and not cost.requires_step_evaluation):
+                self.host_costs.append(cost)
+            else:
+                self.opaque_costs.append(cost)
+        if need_gradients and self.opaque_costs:
+            raise NotImplementedError(
+                "cost {} provides neither device_descriptor() nor a controls-only "
+                "controls_bar(): the reference differentiates it with autograd, which this "
+                "engine replaces by hand-derived adjoints (see qoc_amd.models.Cost)."
+                "".format(self.opaque_costs[0]))
+        self.backend = backend if backend is not None else make_backend()
+        self.kr = control_count * (2 if complex_controls else 1)
+        self.backend.set_lindblad_problem(
+            self.hilbert_size, self.density_count, self.kr, control_eval_count,
+            system_eval_count, evolution_time, h0, g, dissipators, operators, initial_densities,
+            costs=descriptors, cost_eval_step=cost_eval_step)
+
+    def evaluate_batch(self, controls_batch, want_grad=True, want_step_densities=False):
+        """
+        controls_batch :: (B x Nc x K) (or None / an int B when control_count == 0).
+        Returns (errors[B], grads or None, final_densities[B x S x n x n], step_densities).
+        """
+        if self.control_count == 0:
+            batch = 1 if controls_batch is None else int(controls_batch)
+            want_grad = False
+            device_controls = batch
+        else:
+            controls_batch = np.asarray(controls_batch)
+            batch = controls_batch.shape[0]
+            device_controls = structure.to_real_controls(controls_batch, self.complex_controls)
+        need_steps = want_step_densities or bool(self.opaque_costs)
+        if need_steps:
+            self.backend.set_keep_step_states(True)
+        try:
+            cost, grads, final = self.backend.evaluate_lindblad(device_controls,
+                                                                want_grad=want_grad)
+            step_densities = self.backend.download_step_densities() if need_steps else None
+        finally:
+            if need_steps:
+                self.backend.set_keep_step_states(False)
+        errors = np.array(cost, dtype=np.float64)
+        if grads is not None:
+            grads = structure.from_real_gradients(grads, self.complex_controls)
+            if not self.complex_controls:
+                grads = np.array(grads, dtype=np.float64)
+        for b in range(batch):
+            controls = None if self.control_count == 0 else controls_batch[b]
+            for cost_ in self.host_costs:
+                errors[b] += cost_.cost(controls, None, self.final_system_eval_step)
+                if want_grad:
+                    bar = cost_.controls_bar(controls, None, self.final_system_eval_step)
+                    if bar is None:
+                        raise NotImplementedError("cost {} has no controls_bar()".format(cost_))
+                    grads[b] = grads[b] + bar
+            for cost_ in self.opaque_costs:  # forward only: host evaluates the user's cost()
+                if not cost_.requires_step_evaluation:
+                    errors[b] += cost_.cost(controls, step_densities[b][-1],
+                                            self.final_system_eval_step)
+                else:
+                    for step in range(self.cost_eval_step, self.system_eval_count,
+                                      self.cost_eval_step):
+                        errors[b] += cost_.cost(controls, step_densities[b][step], step)
+        return errors, grads, final, step_densities
+
+    def evaluate(self, controls, want_grad=True, want_step_densities=False):
+        batch = None if controls is None else np.asarray(controls)[None]
+        errors, grads, final, steps = self.evaluate_batch(batch, want_grad, want_step_densities)
+        return (float(errors[0]), None if grads is None else grads[0], final[0],
+                None if steps is None else steps[0])

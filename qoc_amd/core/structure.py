@@ -75,6 +75,56 @@ def probe_hamiltonian(hamiltonian, hilbert_size, control_count, complex_controls
     return h0, g
 
 
+class TimeDependentSystemError(NotImplementedError):
+    pass
+
+
+def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, control_count,
+                                 complex_controls, evolution_time, probe_count=7):
+    """
+    Structure of the Lindblad path's inputs (qoc/core/lindbladdiscrete.py:444-493):
+    hamiltonian(controls, time) and lindblad_data(time) -> (dissipators, operators).
+    Returns (h0 (n, n), g (Kr, n, n), dissipators (L,) or None, operators (L, n, n) or None).
+    The engine integrates time-independent H0, G_k, gamma_i, L_i; explicit time dependence
+    (sampled at `probe_count` times across the evolution) is rejected loudly.
+    """
+    n = hilbert_size
+    times = [evolution_time * q / (probe_count - 1) for q in range(probe_count)]
+    if hamiltonian is None:
+        h0 = np.zeros((1, n, n), dtype=np.complex128)
+        kr = control_count * (2 if complex_controls else 1)
+        g = np.zeros((1, kr, n, n), dtype=np.complex128)
+    else:
+        h0, g = probe_hamiltonian(hamiltonian, n, control_count, complex_controls, times)
+    if h0.shape[0] != 1:
+        raise TimeDependentSystemError(
+            "hamiltonian(controls, time) depends on time explicitly: the MI355X Lindblad engine "
+            "integrates H = H0 + sum_k u_k(t) G_k with constant H0, G_k. There is no CPU "
+            "fallback.")
+    dissipators, operators = None, None
+    if lindblad_data is not None:
+        first = lindblad_data(times[0])
+        if first[0] is not None and first[1] is not None:
+            dissipators = np.asarray(first[0], dtype=np.float64)
+            operators = np.asarray(first[1], dtype=np.complex128)
+            if operators.shape != (dissipators.shape[0], n, n):
+                raise ValueError("lindblad_data returned operators of shape {}, expected {}"
+                                 "".format(operators.shape, (dissipators.shape[0], n, n)))
+            if np.any(np.iscomplex(np.asarray(first[0]))):
+                raise ValueError("lindblad_data returned complex dissipators")
+        for t in times[1:]:
+            d, o = lindblad_data(t)
+            same = ((d is None) == (dissipators is None)) and (
+                dissipators is None
+                or (np.array_equal(np.asarray(d, dtype=np.float64), dissipators)
+                    and np.array_equal(np.asarray(o, dtype=np.complex128), operators)))
+            if not same:
+                raise TimeDependentSystemError(
+                    "lindblad_data(time) depends on time: the MI355X Lindblad engine needs "
+                    "constant dissipators and operators. There is no CPU fallback.")
+    return h0[0], g[0], dissipators, operators
+
+
 def to_real_controls(controls, complex_controls):
     """(..., K) controls -> (..., Kr) float64 in the device ordering."""
     controls = np.asarray(controls)

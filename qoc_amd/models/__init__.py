@@ -2,6 +2,8 @@
 
 from .cost import Cost
 from .dummy import Dummy
+from .lindbladmodels import (EvolveLindbladDiscreteState, EvolveLindbladResult,
+                             GrapeLindbladDiscreteState, GrapeLindbladResult)
 from .policies import (InterpolationPolicy, MagnusPolicy, OperationPolicy, PerformancePolicy,
                        ProgramType)
 from .programstate import GrapeState, ProgramState
@@ -11,6 +13,8 @@ from .schroedingermodels import (EvolveSchroedingerDiscreteState, EvolveSchroedi
 __all__ = [
     "Cost", "Dummy", "InterpolationPolicy", "MagnusPolicy", "OperationPolicy",
     "PerformancePolicy", "ProgramType", "ProgramState", "GrapeState",
+    "EvolveLindbladDiscreteState", "EvolveLindbladResult", "GrapeLindbladDiscreteState",
+    "GrapeLindbladResult",
     "EvolveSchroedingerDiscreteState", "EvolveSchroedingerResult",
     "GrapeSchroedingerDiscreteState", "GrapeSchroedingerResult",
 ]

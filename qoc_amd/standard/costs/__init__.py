@@ -1,9 +1,11 @@
-"""costs - the Cost plugins of the Schroedinger path (same names as qoc.standard.costs)."""
+"""costs - the Cost plugins of the hot paths (same names as qoc.standard.costs)."""
 
 from .controlcosts import ControlArea, ControlBandwidthMax, ControlNorm, ControlVariation
+from .densitycosts import ForbidDensities, TargetDensityInfidelity, TargetDensityInfidelityTime
 from .statecosts import ForbidStates, TargetStateInfidelity, TargetStateInfidelityTime
 
 __all__ = [
     "ControlArea", "ControlBandwidthMax", "ControlNorm", "ControlVariation",
-    "ForbidStates", "TargetStateInfidelity", "TargetStateInfidelityTime",
+    "ForbidDensities", "ForbidStates", "TargetDensityInfidelity", "TargetDensityInfidelityTime",
+    "TargetStateInfidelity", "TargetStateInfidelityTime",
 ]

@@ -89,7 +89,7 @@ class StructuredLindblad(object):
 
 
 def evaluate_with_grad(system, controls, initial_densities, evolution_time, system_eval_count,
-                       costs, cost_eval_step=1, want_grad=True):
+                       costs, cost_eval_step=1, want_grad=True, stop_step=None):
     """
     controls :: (Nc x K) real. costs :: oracle cost objects (cost / states_bar on
     (S x n x n) densities). Returns (error, grads (Nc x K), final_densities).
@@ -129,6 +129,8 @@ def evaluate_with_grad(system, controls, initial_densities, evolution_time, syst
                 hits.setdefault(step, []).append(c)
         if step == n_steps:
             break
+        if stop_step is not None and step == stop_step:  # densities at a system step (tests)
+            return error, None, rho
         for ta, tb in grid[step]:
             checkpoints.append((step, ta, tb, rho))
             rho = run_substep(rho, ta, tb)

@@ -59,6 +59,47 @@ class _DescriptorCost(onp.OracleCost):
         return out[:, :, None]
 
 
+class _DensityDescriptorCost(object):
+    """Oracle-side evaluation of a density cost descriptor (qocx.h kinds 3 and 4)."""
+
+    def __init__(self, desc, density_count, n):
+        self.kind = desc["kind"]
+        self.requires_step_evaluation = bool(desc["step_cost"])
+        self.scale = desc["scale"]
+        mats = np.asarray(desc["vectors"], dtype=np.complex128).reshape(-1, n, n)
+        self.S, self.n = density_count, n
+        if self.kind == 4:
+            self.sets, base = [], 0
+            for c in desc["counts"]:
+                self.sets.append(mats[base:base + c])
+                base += c
+        else:
+            self.targets = mats
+
+    def cost(self, controls, densities, step):
+        if self.kind == 3:
+            ip = np.einsum("sij,sij->s", self.targets.conj(), densities)
+            return self.scale * (1 - np.sum(np.abs(ip)) / (self.S * self.n))
+        total = 0
+        for s, fs in enumerate(self.sets):
+            ip = np.einsum("fij,ij->f", fs.conj(), densities[s]) / self.n
+            total += np.sum(np.abs(ip) ** 2) / len(fs)
+        return self.scale * total
+
+    def states_bar(self, controls, densities, step):
+        out = np.zeros_like(np.asarray(densities, dtype=np.complex128))
+        if self.kind == 3:
+            ip = np.einsum("sij,sij->s", self.targets.conj(), densities)
+            for s in range(self.S):
+                if abs(ip[s]) > 0:
+                    out[s] = -(self.scale / (self.S * self.n)) * (ip[s] / abs(ip[s])) * self.targets[s]
+        else:
+            for s, fs in enumerate(self.sets):
+                ip = np.einsum("fij,ij->f", fs.conj(), densities[s]) / self.n
+                out[s] = (2 * self.scale / (len(fs) * self.n)) * np.einsum("f,fij->ij", ip, fs)
+        return out
+
+
 class OracleBackend(object):
     def __init__(self):
         self.keep = False
@@ -121,6 +162,47 @@ class OracleBackend(object):
 
     def download_step_states(self):
         return np.stack(self.steps)
+
+    # -- Lindblad: the NumPy model of the device algorithm (tests/lindblad_model.py) -----------
+    def set_lindblad_problem(self, n, S, K, Nc, N, T, h0, g, dissipators, operators,
+                             initial_densities, costs=(), cost_eval_step=1):
+        from tests import lindblad_model as lm
+        g = np.asarray(g if K > 0 else np.zeros((0, n, n)), dtype=np.complex128).reshape(K, n, n)
+        self.lb_system = lm.StructuredLindblad(np.asarray(h0).reshape(n, n), list(g),
+                                               dissipators, operators)
+        self.lb_costs = [_DensityDescriptorCost(c, S, n) for c in costs]
+        self.lb = dict(n=n, S=S, K=K, Nc=Nc, N=N, T=T, ces=cost_eval_step,
+                       rho0=np.asarray(initial_densities, dtype=np.complex128).reshape(S, n, n))
+
+    def evaluate_lindblad(self, controls, want_grad=True, want_final=True):
+        from tests import lindblad_model as lm
+        p = self.lb
+        if p["K"] == 0:
+            batch = [np.zeros((2, 0))] * (1 if controls is None else int(controls))
+        else:
+            batch = list(np.asarray(controls, dtype=np.float64).reshape(-1, p["Nc"], p["K"]))
+        want_grad = want_grad and p["K"] > 0
+        cost, grads, final, self.lb_steps = [], [], [], []
+        self.calls += 1
+        for u in batch:
+            err, gr, fin = lm.evaluate_with_grad(self.lb_system, u, p["rho0"], p["T"], p["N"],
+                                                 self.lb_costs, p["ces"], want_grad=want_grad)
+            cost.append(err)
+            grads.append(gr)
+            final.append(fin)
+            if self.keep:
+                steps = [p["rho0"]]
+                for step in range(1, p["N"]):
+                    _, _, rho = lm.evaluate_with_grad(
+                        self.lb_system, u, p["rho0"], p["T"], p["N"], [], 1, want_grad=False,
+                        stop_step=step)
+                    steps.append(rho)
+                self.lb_steps.append(np.stack(steps))
+        return (np.array(cost, dtype=np.float64), np.stack(grads) if want_grad else None,
+                np.stack(final))
+
+    def download_step_densities(self):
+        return np.stack(self.lb_steps)
 
     def close(self):
         pass

@@ -1,0 +1,84 @@
+"""
+GPU tests (-m gpu) of the reference-shaped Lindblad entry points on the real HIP engine: evolve
+against the reference fixtures, GRAPE iteration-by-iteration against the same host code driven
+by the NumPy model of the device algorithm.
+"""
+
+import numpy as np
+import pytest
+
+import qoc_amd
+from qoc_amd.core import device
+from qoc_amd.standard import Adam
+from tests import cases as cases_mod
+from tests.helpers import golden
+from tests.oracle_backend import OracleBackend
+from tests.test_lindblad_host_api import product_cost_list, run_grape
+
+pytestmark = pytest.mark.gpu
+
+NAMES = [c.name for c in cases_mod.lindblad_cases()]
+
+
+@pytest.fixture(autouse=True)
+def real_engine():
+    device.set_backend_factory(None)
+    yield
+    device.set_backend_factory(None)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_evolve_lindblad_on_gpu(name):
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    for b, u in enumerate(case.controls):
+        result = qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=u,
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case),
+            hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
+        assert abs(result.error - g["error"][b]) < 1e-9
+        assert np.max(np.abs(result.final_densities - g["final_densities"][b])) < 1e-8
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_grape_lindblad_trajectory_matches_model_backend(name):
+    case = cases_mod.lindblad_case_by_name(name)
+    norms = np.full(case.K, 5.0)
+    gpu_result, gpu_trace = run_grape(case, Adam(learning_rate=2e-2), 5, log_iteration_step=0,
+                                      max_control_norms=norms)
+    device.set_backend_factory(OracleBackend)
+    try:
+        cpu_result, cpu_trace = run_grape(case, Adam(learning_rate=2e-2), 5,
+                                          log_iteration_step=0, max_control_norms=norms)
+    finally:
+        device.set_backend_factory(None)
+    assert len(gpu_trace) == len(cpu_trace) == 5
+    for (ge, gg), (ce, cg) in zip(gpu_trace, cpu_trace):
+        assert abs(ge - ce) < 1e-10
+        assert np.max(np.abs(gg - cg)) / np.max(np.abs(cg)) < 1e-8
+    assert gpu_result.best_iteration == cpu_result.best_iteration
+    assert np.max(np.abs(gpu_result.best_controls - cpu_result.best_controls)) < 1e-8
+    assert np.max(np.abs(gpu_result.best_final_densities
+                         - cpu_result.best_final_densities)) < 1e-9
+
+
+def test_user_density_cost_forward_on_gpu():
+    from qoc_amd.models import Cost
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+
+    class Purity(Cost):
+        name = "purity"
+        requires_step_evaluation = True
+
+        def cost(self, controls, densities, step):
+            return float(np.real(np.trace(densities[0] @ densities[0]))) * 1e-2
+
+    args = dict(controls=case.controls[0], cost_eval_step=5, costs=[Purity()],
+                hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
+    gpu = qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N, **args)
+    device.set_backend_factory(OracleBackend)
+    try:
+        cpu = qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N, **args)
+    finally:
+        device.set_backend_factory(None)
+    assert abs(gpu.error - cpu.error) < 1e-12

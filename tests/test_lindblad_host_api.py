@@ -1,0 +1,271 @@
+"""
+CPU tests of the host-side mirror of the reference's Lindblad interface
+(evolve_lindblad_discrete / grape_lindblad_discrete, density Cost plugins, program states).
+The GPU engine is replaced through qoc_amd.core.device.set_backend_factory by the NumPy model
+of the device algorithm (tests/oracle_backend.py -> tests/lindblad_model.py); the same entry
+points run on the real engine in tests/test_gpu_lindblad_api.py.
+"""
+
+import numpy as np
+import pytest
+
+import qoc_amd
+import qoc_amd.standard.costs as product_costs
+from oracle import qoc_lindblad_numpy as ol
+from qoc_amd.core import device, structure
+from qoc_amd.models import (Cost, EvolveLindbladResult, GrapeLindbladResult)
+from qoc_amd.standard import (Adam, SGD, ForbidDensities, TargetDensityInfidelity,
+                              TargetDensityInfidelityTime, get_annihilation_operator,
+                              get_creation_operator)
+from tests import cases as cases_mod
+from tests.helpers import golden
+from tests.oracle_backend import OracleBackend
+from tests.test_lindblad_oracle import density_cost_known_answers
+
+NAMES = [c.name for c in cases_mod.lindblad_cases()]
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    device.set_backend_factory(OracleBackend)
+    yield
+    device.set_backend_factory(None)
+
+
+def product_cost_list(case):
+    return [getattr(product_costs, kind)(**kw) for kind, kw in case.cost_specs]
+
+
+def test_density_costs_known_answers_and_names():
+    density_cost_known_answers(product_costs)
+    t = np.stack((np.eye(2) / 2,))
+    assert str(TargetDensityInfidelity(t)) == "target_density_infidelity"
+    assert str(TargetDensityInfidelityTime(5, t)) == "target_density_infidelity_time"
+    f = ForbidDensities(np.stack((np.stack((np.eye(2) / 2,)),)), 5, cost_multiplier=2.)
+    assert str(f) == "forbid_densities" and f.requires_step_evaluation
+    assert f.cost_multiplier == 2. and f.cost_normalization_constant == 4
+    assert f.hilbert_size == 2 and list(f.forbidden_densities_count) == [1]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_product_density_costs_match_oracle(name):
+    case = cases_mod.lindblad_case_by_name(name)
+    rng = np.random.default_rng(5)
+    dens = np.stack([cases_mod.random_density(rng, case.n)
+                     for _ in range(case.initial_densities.shape[0])])
+    for (kind, kw), cost in zip(case.cost_specs, product_cost_list(case)):
+        ref = getattr(ol, kind)(**kw)
+        assert abs(cost.cost(None, dens, 3) - ref.cost(None, dens, 3)) < 1e-15
+        assert cost.requires_step_evaluation == ref.requires_step_evaluation
+        desc = cost.device_descriptor(dens.shape[0], case.n)
+        assert desc["kind"] in (3, 4) and desc["step_cost"] == int(ref.requires_step_evaluation)
+        with pytest.raises(ValueError):
+            cost.device_descriptor(dens.shape[0] + 1, case.n)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_evolve_matches_reference_fixtures(name):
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    for b, u in enumerate(case.controls):
+        result = qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=u,
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case),
+            hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
+        assert isinstance(result, EvolveLindbladResult)
+        assert abs(result.error - g["error"][b]) < 1e-9
+        assert result.final_densities.shape == case.initial_densities.shape
+        assert np.max(np.abs(result.final_densities - g["final_densities"][b])) < 1e-8
+
+
+def test_evolve_known_answers():
+    # reference tests/test_core.py:82-148: hamiltonian only, lindblad_data only
+    from qoc_amd.standard import SIGMA_X, SIGMA_Y
+    hs = 0.5 * (np.kron(SIGMA_X, SIGMA_X) + np.kron(SIGMA_Y, SIGMA_Y))
+    iswap = np.array(((1, 0, 0, 0), (0, 0, -1j, 0), (0, -1j, 0, 0), (0, 0, 0, 1)))
+    init = cases_mod.column_states(np.eye(4))
+    targ = cases_mod.column_states(iswap)
+    rho0 = np.matmul(init, np.conj(np.swapaxes(init, -1, -2)))
+    rho1 = np.matmul(targ, np.conj(np.swapaxes(targ, -1, -2)))
+    r = qoc_amd.evolve_lindblad_discrete(np.pi / 2, rho0, 2,
+                                         hamiltonian=lambda controls, time: hs)
+    assert r.error == 0 and np.allclose(r.final_densities, rho1)
+    gamma, a0, b0 = 2.0, 0.3, 0.4
+    c0 = 1 - a0
+    rho = np.stack((np.array(((a0, b0), (b0, c0)), dtype=np.complex128),))
+    sp = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    expected = np.array(((1 - c0 * np.exp(-gamma), b0 * np.exp(-gamma / 2)),
+                         (b0 * np.exp(-gamma / 2), c0 * np.exp(-gamma))))
+    r = qoc_amd.evolve_lindblad_discrete(
+        1.0, rho, 2, lindblad_data=lambda time: (np.array((gamma,)), np.stack((sp,))))
+    assert np.allclose(r.final_densities[0], expected)
+
+
+def test_structure_rejects_time_dependence_and_size():
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+    h = case.hamiltonian()
+    with pytest.raises(structure.TimeDependentSystemError):
+        qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=case.controls[0],
+            hamiltonian=lambda u, t: h(u, t) * (1 + 0.1 * t))
+    gam, ops = case.dissipators, case.operators
+    with pytest.raises(structure.TimeDependentSystemError):
+        qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=case.controls[0],
+            hamiltonian=h, lindblad_data=lambda t: (gam * (1 + t), ops))
+    with pytest.raises(structure.NonLinearHamiltonianError):
+        qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=case.controls[0],
+            hamiltonian=lambda u, t: case.h0 + u[0] ** 2 * case.g_re[0])
+    with pytest.raises(NotImplementedError):
+        qoc_amd.evolve_lindblad_discrete(1.0, np.eye(17)[None] / 17, 2,
+                                         hamiltonian=lambda u, t: np.eye(17))
+    with pytest.raises(NotImplementedError):
+        qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N,
+                                         controls=case.controls[0], hamiltonian=h,
+                                         interpolation_policy="cubic")
+
+
+def test_user_cost_forward_only():
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+
+    class Purity(Cost):
+        name = "purity"
+        requires_step_evaluation = True
+
+        def cost(self, controls, densities, step):
+            return float(np.real(np.trace(densities[0] @ densities[0]))) * 1e-2
+
+    r = qoc_amd.evolve_lindblad_discrete(
+        case.T, case.initial_densities, case.N, controls=case.controls[0], cost_eval_step=5,
+        costs=[Purity()], hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
+    problem = ol.LindbladProblem(case.T, case.initial_densities, 6,
+                                 hamiltonian=case.hamiltonian(),
+                                 lindblad_data=case.lindblad_data(), control_eval_count=case.Nc,
+                                 control_count=case.K)
+    problem.evolution_time = case.T / 2  # densities at system step 5 of 10
+    xs = np.linspace(0, case.T, case.Nc)
+    half = ol.LindbladProblem(case.T / 2, case.initial_densities, 2,
+                              hamiltonian=lambda u, t: case.hamiltonian()(u, t),
+                              lindblad_data=case.lindblad_data(), control_eval_count=6,
+                              control_count=case.K)
+    # controls on the first half: knots 0..5 of the 11 (Nc == N here), same piecewise line
+    _, mid = ol.evaluate(half, case.controls[0][:6])
+    _, end = ol.evaluate(ol.LindbladProblem(
+        case.T, case.initial_densities, case.N, hamiltonian=case.hamiltonian(),
+        lindblad_data=case.lindblad_data(), control_eval_count=case.Nc, control_count=case.K),
+        case.controls[0])
+    expected = 1e-2 * (np.real(np.trace(mid[0] @ mid[0])) + np.real(np.trace(end[0] @ end[0])))
+    assert abs(r.error - expected) < 1e-9
+    del problem, xs
+    with pytest.raises(NotImplementedError):
+        qoc_amd.grape_lindblad_discrete(case.K, case.Nc, [Purity()], case.T,
+                                        case.initial_densities, case.N,
+                                        hamiltonian=case.hamiltonian(), iteration_count=1,
+                                        log_iteration_step=0)
+
+
+def run_grape(case, optimizer, iterations, **kw):
+    trace = []
+
+    class Recorder(object):
+        def __init__(self, inner):
+            self.inner = inner
+
+        def run(self, function, iteration_count, initial_params, jacobian, args=()):
+            def jac(params, *a):
+                grads, stop = jacobian(params, *a)
+                trace.append((a[1].error, grads.copy()))
+                return grads, stop
+            return self.inner.run(function, iteration_count, initial_params, jac, args=args)
+
+    result = qoc_amd.grape_lindblad_discrete(
+        case.K, case.Nc, product_cost_list(case), case.T, case.initial_densities, case.N,
+        complex_controls=case.complex_controls, cost_eval_step=case.cost_eval_step,
+        hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data(),
+        initial_controls=case.controls[0], iteration_count=iterations,
+        optimizer=Recorder(optimizer), **kw)
+    return result, trace
+
+
+@pytest.mark.parametrize("name", NAMES[:2])
+def test_grape_first_gradient_is_the_fixture_and_error_decreases(name, capsys):
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    result, trace = run_grape(case, Adam(learning_rate=2e-2), 5, log_iteration_step=2,
+                              max_control_norms=np.full(case.K, 5.0))
+    assert isinstance(result, GrapeLindbladResult)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "iter   |   total error  |    grads_l2   " and out[1] == "=" * 41
+    assert [line.split("|")[0].strip() for line in out[2:]] == ["0", "2", "4"]
+    err0, grads0 = trace[0]
+    assert abs(err0 - g["error"][0]) < 1e-9
+    ref = g["grads_ad"][0]
+    if case.complex_controls:
+        ref = np.concatenate([ref.real.ravel(), ref.imag.ravel()])  # strip_controls layout
+        assert grads0.shape == ref.shape
+    else:
+        ref = ref.ravel()
+    assert np.max(np.abs(grads0.ravel() - ref)) / np.max(np.abs(ref)) < 1e-6
+    assert result.best_error < err0 and result.best_iteration > 0
+    assert result.best_controls.shape == (case.Nc, case.K)
+    assert np.iscomplexobj(result.best_controls) == case.complex_controls
+    assert result.best_final_densities.shape == case.initial_densities.shape
+
+
+def test_grape_conditions_min_error_and_clipping():
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+
+    def conditions(controls):
+        controls[0, :] = 0
+        controls[-1, :] = 0
+        return controls
+
+    result, trace = run_grape(case, SGD(learning_rate=200.0), 3, log_iteration_step=0,
+                              impose_control_conditions=conditions,
+                              max_control_norms=np.full(case.K, 1.5))
+    assert np.all(result.best_controls[0] == 0) and np.all(result.best_controls[-1] == 0)
+    assert np.max(np.abs(result.best_controls)) <= 1.5
+    result, trace = run_grape(case, Adam(), 50, log_iteration_step=0, min_error=10.0)
+    assert len(trace) == 1 and result.best_iteration == 0
+
+
+def test_batch_evaluator_matches_single():
+    case = cases_mod.lindblad_case_by_name("lindblad_n4_complex")
+    ev = device.LindbladEvaluator(
+        case.T, case.initial_densities, case.N, hamiltonian=case.hamiltonian(),
+        lindblad_data=case.lindblad_data(), control_count=case.K, control_eval_count=case.Nc,
+        complex_controls=True, costs=product_cost_list(case), cost_eval_step=case.cost_eval_step)
+    errs, grads, final, _ = ev.evaluate_batch(np.stack(case.controls))
+    g = golden(case.name)
+    for b, u in enumerate(case.controls):
+        e1, g1, f1, _ = ev.evaluate(u)
+        assert e1 == errs[b] and np.array_equal(g1, grads[b]) and np.array_equal(f1, final[b])
+        assert np.iscomplexobj(g1)
+        assert np.max(np.abs(g1 - g["grads_ad"][b])) / np.max(np.abs(g["grads_ad"][b])) < 1e-6
+
+
+def test_lindblad_transmon_example_shape():
+    # the reference's Lindblad GRAPE usage (tests/test_core.py:312-365): a driven, decaying qubit
+    n = 3
+    a, ad = get_annihilation_operator(n), get_creation_operator(n)
+    h0 = 0.3 * (ad @ a) + (-0.2 / 2) * (ad @ ad @ a @ a)
+    hamiltonian = lambda controls, time: h0 + controls[0] * (a + ad)
+    lindblad_data = lambda time: (np.array([0.02]), np.stack([a]))
+    rho0 = np.zeros((1, n, n), dtype=np.complex128)
+    rho0[0, 0, 0] = 1
+    target = np.zeros((1, n, n), dtype=np.complex128)
+    target[0, 1, 1] = 1
+    n_eval = 21
+    costs = [TargetDensityInfidelity(target),
+             ForbidDensities(np.stack((np.stack((np.diag([0, 0, 1.]).astype(complex),)),)),
+                             n_eval, cost_multiplier=0.3)]
+    result = qoc_amd.grape_lindblad_discrete(
+        1, n_eval, costs, 4.0, rho0, n_eval, hamiltonian=hamiltonian,
+        lindblad_data=lindblad_data, iteration_count=25, log_iteration_step=0,
+        optimizer=Adam(learning_rate=5e-2), max_control_norms=np.array([1.5]))
+    first = qoc_amd.evolve_lindblad_discrete(
+        4.0, rho0, n_eval, controls=np.zeros((n_eval, 1)), costs=costs,
+        hamiltonian=hamiltonian, lindblad_data=lindblad_data)
+    assert result.best_error < 0.95 * first.error  # fidelity is |tr|/(S n) <= 1/3 here
+    assert abs(np.trace(result.best_final_densities[0]) - 1) < 1e-9
