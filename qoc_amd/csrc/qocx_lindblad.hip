@@ -87,6 +87,17 @@ __device__ __forceinline__ void load_adjoint(Mat& m, const Slot& s) {
     }
 }
 
+// C-layout registers of M from the planar image of M
+__device__ __forceinline__ void load_plain(Mat& m, const Slot& s) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int off = (4 * r + q) * LG::PITCH + c;
+        m.re[0][0][r] = s.re[off];
+        m.im[0][0][r] = s.im[off];
+    }
+}
+
 __device__ __forceinline__ void mat_zero(Mat& m) { cmat_zero<LNB>(m); }
 __device__ __forceinline__ void mat_axpy(Mat& y, double a, const Mat& x) {
     y.re[0][0] += a * x.re[0][0];
@@ -114,11 +125,11 @@ struct Operands {     // LDS addresses of one direction (forward or adjoint) of 
     Slot gen_left;    // A_L (forward) or A_L^H (adjoint), rebuilt per stage
     Slot y_left;      // the argument, as a left operand
     Slot tmp;         // gamma_i L_i Y
-    char* op_left;    // [L] planar slots: L_i (forward) / L_i^H (adjoint)
-    double2* op_right;  // [L] dumps:     L_i^H (forward) / L_i (adjoint)
+    char* op_planar;  // [L] planar slots of L_i; both directions read L_i and L_i^H from them
 };
 
-// out = Gen y + y GenRight + sum_i gamma_i Op_i y OpRight_i
+// out = Gen y + y GenRight + sum_i gamma_i Op_i y Op_i^H   (ADJ: Op_i^H y Op_i)
+template <bool ADJ>
 __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen_right,
                                           const Operands& o, int nops, const double* gammas) {
     cmat_to_lds<LNB>(y, o.y_left.re, o.y_left.im);
@@ -129,14 +140,16 @@ __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen
     for (int i = 0; i < nops; ++i) {
         Mat t, opr;
         mat_zero(t);
-        gemm<false>(t, slot_at(o.op_left + (size_t)i * SLOT_BYTES), y);
+        const Slot op = slot_at(o.op_planar + (size_t)i * SLOT_BYTES);
+        gemm<ADJ>(t, op, y);
         const double gm = gammas[i];
         t.re[0][0] *= gm;
         t.im[0][0] *= gm;
         wave_sync();
         cmat_to_lds<LNB>(t, o.tmp.re, o.tmp.im);
         wave_sync();
-        dump_load(opr, o.op_right + (size_t)i * 256);
+        if (ADJ) load_plain(opr, op);
+        else load_adjoint(opr, op);
         gemm<false>(out, o.tmp, opr);
     }
     wave_sync();
@@ -226,11 +239,10 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
 
 }  // namespace
 
-// LDS carve (bytes): 3 planar work slots | per operator: planar L, planar L^H, dump L, dump L^H |
-// S density dumps | S lambda dumps | STAGES stage-derivative dumps
+// LDS carve (bytes): 3 planar work slots | per operator: planar L | S density dumps |
+// S lambda dumps | STAGES stage-derivative dumps.  80 KB at S = 1, L = 2: two seeds per CU.
 __host__ __device__ inline int lindblad_lds_bytes(int S, int nops) {
-    return 3 * SLOT_BYTES + nops * (2 * SLOT_BYTES + 2 * DUMP_BYTES) + 2 * S * DUMP_BYTES +
-           STAGES * DUMP_BYTES;
+    return 3 * SLOT_BYTES + nops * SLOT_BYTES + 2 * S * DUMP_BYTES + STAGES * DUMP_BYTES;
 }
 
 namespace {
@@ -289,7 +301,7 @@ struct Wave {
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
             wave_sync();
-            rhs_apply(k, y, gr, fwd, a.nops, a.gammas);
+            rhs_apply<false>(k, y, gr, fwd, a.nops, a.gammas);
             dump_store(k, kdump + (size_t)i * 256);
             wave_sync();
         }
@@ -330,7 +342,7 @@ struct Wave {
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);  // A_L^H is the left operand now
             wave_sync();
-            rhs_apply(ybar, kb, gr, adj, a.nops, a.gammas);
+            rhs_apply<true>(ybar, kb, gr, adj, a.nops, a.gammas);
             mat_axpy(lambda_new, 1.0, ybar);
             // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
             // Z = Y kbar^H - kbar^H Y  (slot_y still holds kbar as a planar image)
@@ -380,25 +392,17 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     const Slot slot_y = slot_at(p); p += SLOT_BYTES;
     const Slot slot_tmp = slot_at(p); p += SLOT_BYTES;
     char* op_planar = p; p += (size_t)nops * SLOT_BYTES;     // L_i
-    char* opd_planar = p; p += (size_t)nops * SLOT_BYTES;    // L_i^H
-    double2* op_dump = reinterpret_cast<double2*>(p); p += (size_t)nops * DUMP_BYTES;   // L_i
-    double2* opd_dump = reinterpret_cast<double2*>(p); p += (size_t)nops * DUMP_BYTES;  // L_i^H
     double2* dens = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
     double2* lam = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
     double2* kdump = reinterpret_cast<double2*>(p);
 
-    // static operators into LDS in the four forms the two RHS directions need
+    // static operators into LDS (planar: left operand directly, right operand by a
+    // transposing read)
     for (int i = 0; i < nops; ++i) {
-        Mat op, opd;
+        Mat op;
         dump_load(op, a.op_cimg + (size_t)i * 256);
         cmat_to_lds<LNB>(op, slot_at(op_planar + (size_t)i * SLOT_BYTES).re,
                          slot_at(op_planar + (size_t)i * SLOT_BYTES).im);
-        dump_store(op, op_dump + (size_t)i * 256);
-        wave_sync();
-        load_adjoint(opd, slot_at(op_planar + (size_t)i * SLOT_BYTES));
-        cmat_to_lds<LNB>(opd, slot_at(opd_planar + (size_t)i * SLOT_BYTES).re,
-                         slot_at(opd_planar + (size_t)i * SLOT_BYTES).im);
-        dump_store(opd, opd_dump + (size_t)i * 256);
     }
     for (int s = 0; s < S; ++s) {
         Mat rho;
@@ -409,9 +413,8 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
 
     Operands fwd, adj;
     fwd.gen_left = slot_gen; fwd.y_left = slot_y; fwd.tmp = slot_tmp;
-    fwd.op_left = op_planar; fwd.op_right = opd_dump;
+    fwd.op_planar = op_planar;
     adj = fwd;
-    adj.op_left = opd_planar; adj.op_right = op_dump;
     const Wave w{a, slot_gen, slot_y, slot_tmp, fwd, adj, kdump,
                  a.controls + (size_t)b * a.nc * K};
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * 256;
