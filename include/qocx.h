@@ -90,8 +90,9 @@ typedef struct qocx_schroedinger_problem {
     int32_t control_eval_count;  /* Nc (>= 2 when K > 0)                                            */
     int32_t system_eval_count;   /* N >= 2; N-1 propagator steps                                    */
     int32_t cost_eval_step;      /* >= 1                                                            */
-    int32_t magnus_policy;       /* QOCX_MAGNUS_M2 (M4/M6: not implemented in the device engine)    */
-    int32_t nt;                  /* number of time samples of h0/g: 1 or (N-1)                      */
+    int32_t magnus_policy;       /* QOCX_MAGNUS_M2 / _M4 / _M6 (mathmethods.py:72-164)               */
+    int32_t nt;                  /* time samples of h0/g: 1 or (N-1)*nodes, nodes = 1/2/3 for M2/4/6,
+                                    ordered [step][node], t = step*dt + c_node*dt                   */
     double evolution_time;       /* T; dt = T/(N-1), control_eval_times = linspace(0,T,Nc)          */
     const double* h0;            /* [nt][n][n] complex                                              */
     const double* g;             /* [nt][K][n][n] complex                                           */

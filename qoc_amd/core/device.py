@@ -38,10 +38,6 @@ class SchroedingerEvaluator(object):
                                       "method.".format(interpolation_policy))
         if not isinstance(magnus_policy, MagnusPolicy):
             raise ValueError("Unrecognized magnus policy {}.".format(magnus_policy))
-        if magnus_policy != MagnusPolicy.M2:
-            raise NotImplementedError(
-                "{} is not implemented in the MI355X engine yet (only MagnusPolicy.M2); "
-                "there is no CPU fallback.".format(magnus_policy))
         initial_states = np.asarray(initial_states)
         self.state_count = initial_states.shape[0]
         self.hilbert_size = initial_states.shape[1]
@@ -52,7 +48,8 @@ class SchroedingerEvaluator(object):
         self.final_system_eval_step = system_eval_count - 1
         self.costs = list(costs)
         dt = evolution_time / (system_eval_count - 1)
-        times = [step * dt + dt * 0.5 for step in range(system_eval_count - 1)]
+        times = [step * dt + dt * c for step in range(system_eval_count - 1)
+                 for c in magnus_policy.nodes]
         h0, g = structure.probe_hamiltonian(hamiltonian, self.hilbert_size, control_count,
                                             complex_controls, times)
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []

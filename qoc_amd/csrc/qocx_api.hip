@@ -140,6 +140,9 @@ struct qocx_ctx {
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
     DevBuf<int> perm, iperm, s_arr, offs, status;
     // ---- Lindblad problem / evaluation state ----
+    // ---- Magnus M4/M6 ----
+    int nodes = 1;
+    DevBuf<double2> m_rm, mbar_rm, magnus_scratch;
     struct Lindblad {
         bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
         int n = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nops = 0;
@@ -331,6 +334,9 @@ int qocx_destroy(qocx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     time_collect(ctx);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+    ctx->m_rm.release();
+    ctx->mbar_rm.release();
+    ctx->magnus_scratch.release();
     DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
                              &ctx->g_timg, &ctx->psi0, &ctx->cost_vectors, &ctx->final_out,
                              &ctx->step_states, &ctx->q_img, &ctx->lu_img, &ctx->dinv,
@@ -388,10 +394,13 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
     if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");
     if (p->cost_eval_step < 1) return fail(QOCX_ERR_ARG, "cost_eval_step must be >= 1");
-    if (p->magnus_policy != QOCX_MAGNUS_M2)
-        return fail(QOCX_ERR_ARG, "only MagnusPolicy.M2 is implemented in the device engine");
+    if (p->magnus_policy != QOCX_MAGNUS_M2 && p->magnus_policy != QOCX_MAGNUS_M4 &&
+        p->magnus_policy != QOCX_MAGNUS_M6)
+        return fail(QOCX_ERR_ARG, "unknown magnus_policy");
     const int nsteps = N - 1;
-    if (p->nt != 1 && p->nt != nsteps) return fail(QOCX_ERR_ARG, "nt must be 1 or N-1");
+    const int nodes = p->magnus_policy / 2;  // quadrature nodes per step: 1, 2, 3
+    if (p->nt != 1 && p->nt != nsteps * nodes)
+        return fail(QOCX_ERR_ARG, "nt must be 1 or (N-1) * (quadrature nodes of the policy)");
     if (!p->h0 || !p->initial_states || (K > 0 && !p->g))
         return fail(QOCX_ERR_ARG, "h0 / g / initial_states missing");
     if (p->cost_count < 0 || (p->cost_count > 0 && !p->costs))
@@ -400,7 +409,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np, nt = p->nt;
     ctx->has_problem = false;
     ctx->n = n; ctx->nb = nb; ctx->np = np; ctx->S = S; ctx->K = K; ctx->nc = nc; ctx->N = N;
-    ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt;
+    ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt; ctx->nodes = nodes;
     ctx->T = p->evolution_time;
     ctx->dt = p->evolution_time / (N - 1);  // programstate.py:44
 
@@ -443,36 +452,43 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
                                                    p->initial_states[2 * ((size_t)s * n + i) + 1]);
     if (ctx->psi0.upload(psi, ctx->stream)) return QOCX_ERR_HIP;
 
-    // interpolation table at the M2 quadrature time t_j + dt/2 (mathmethods.py:54-65, :90)
-    std::vector<qocx::StepInterp> interp(nsteps);
+    // interpolation table at the quadrature times t_j + c_q dt of the Magnus policy
+    // (mathmethods.py:54-65; nodes :72, :96-97, :125-127)
+    static const double node_c[3][3] = {
+        {0.5, 0, 0},
+        {0.5 - std::sqrt(3.0) / 6, 0.5 + std::sqrt(3.0) / 6, 0},
+        {0.5 - std::sqrt(15.0) / 10, 0.5, 0.5 + std::sqrt(15.0) / 10}};
+    std::vector<qocx::StepInterp> interp((size_t)nsteps * nodes);
     std::vector<std::vector<std::pair<int, double>>> rows(K > 0 ? nc : 0);
     if (K > 0) {
         std::vector<double> xs(nc);
         const double stepx = p->evolution_time / (nc - 1);  // numpy.linspace
         for (int i = 0; i < nc; ++i) xs[i] = i * stepx;
         xs[nc - 1] = p->evolution_time;
-        for (int j = 0; j < nsteps; ++j) {
-            const double time = j * ctx->dt;
-            const double x = time + ctx->dt * 0.5;
-            int i1, i2;
-            if (x <= xs[0]) {
-                i1 = 0; i2 = 1;
-            } else if (x >= xs[nc - 1]) {
-                i1 = nc - 2; i2 = nc - 1;
-            } else {
-                int idx = 0;
-                while (!(x <= xs[idx])) ++idx;
-                i1 = idx - 1; i2 = idx;
+        for (int j = 0; j < nsteps; ++j)
+            for (int q = 0; q < nodes; ++q) {
+                const double time = j * ctx->dt;
+                const double x = time + ctx->dt * node_c[nodes - 1][q];
+                int i1, i2;
+                if (x <= xs[0]) {
+                    i1 = 0; i2 = 1;
+                } else if (x >= xs[nc - 1]) {
+                    i1 = nc - 2; i2 = nc - 1;
+                } else {
+                    int idx = 0;
+                    while (!(x <= xs[idx])) ++idx;
+                    i1 = idx - 1; i2 = idx;
+                }
+                qocx::StepInterp& e = interp[(size_t)j * nodes + q];
+                e.i1 = i1; e.i2 = i2;
+                e.dx = xs[i2] - xs[i1];
+                e.off = x - xs[i1];
+                const double theta = e.off / e.dx;
+                rows[i1].push_back(std::make_pair(j * nodes + q, 1.0 - theta));
+                rows[i2].push_back(std::make_pair(j * nodes + q, theta));
             }
-            interp[j].i1 = i1; interp[j].i2 = i2;
-            interp[j].dx = xs[i2] - xs[i1];
-            interp[j].off = x - xs[i1];
-            const double theta = interp[j].off / interp[j].dx;
-            rows[i1].push_back(std::make_pair(j, 1.0 - theta));
-            rows[i2].push_back(std::make_pair(j, theta));
-        }
     } else {
-        for (int j = 0; j < nsteps; ++j) interp[j] = qocx::StepInterp{0, 0, 1.0, 0.0};
+        for (auto& e : interp) e = qocx::StepInterp{0, 0, 1.0, 0.0};
     }
     if (ctx->interp.upload(interp, ctx->stream)) return QOCX_ERR_HIP;
     std::vector<int> row_ptr(1, 0), col_step;
@@ -560,6 +576,15 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     bound *= fabs(ctx->dt);
+    if (ctx->nodes == 2) {
+        // ||dt/2 (a1+a2) + sqrt(3)/12 dt^2 [a2,a1]||
+        bound = bound + (std::sqrt(3.0) / 12) * 2 * bound * bound;
+    } else if (ctx->nodes == 3) {
+        const double b1 = bound, b2 = (std::sqrt(15.0) / 3) * 2 * bound, b3 = (10.0 / 3) * 4 * bound;
+        const double c12 = 2 * b1 * b2, x = 20 * b1 + b3 + c12, w = 2 * b3 + c12;
+        const double y = b2 + (1.0 / 60) * 2 * b1 * w;
+        bound = b1 + 0.5 * b3 + (1.0 / 240) * 2 * x * y;
+    }
     if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or Hamiltonian");
     ctx->sbound = pade_scale_count(bound);
     if (ctx->sbound > 10)
@@ -599,7 +624,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // chunk size from the memory budget
     const size_t per_seed = (size_t)nsteps * ((size_t)mat * 32 + (size_t)np * 20 + 4) +
                             ctx->slot_cap * S * np * 32 + (size_t)(nsteps + 1) * 4 +
-                            (size_t)nsteps * std::max(K, 1) * 8;
+                            (size_t)nsteps * ctx->nodes * std::max(K, 1) * 8 +
+                            (ctx->nodes > 1 ? (size_t)nsteps * mat * 32 : 0);
+    const int nodes = ctx->nodes;
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -616,12 +643,17 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
         ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
         ctx->offs.ensure((size_t)chunk * (nsteps + 1)) ||
-        ctx->gstep.ensure(cm * std::max(K, 1)) || ctx->cost_out.ensure(B) ||
+        ctx->gstep.ensure(cm * nodes * std::max(K, 1)) || ctx->cost_out.ensure(B) ||
         ctx->grads.ensure((size_t)B * ctx->nc * std::max(K, 1)) ||
         ctx->final_out.ensure((size_t)B * S * np))
         return QOCX_ERR_HIP;
     if (ctx->keep_step_states)
         if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
+    const int magnus_blocks = (int)std::min<size_t>(cm, 1024);
+    if (nodes > 1)
+        if (ctx->m_rm.ensure(cm * mat) || ctx->mbar_rm.ensure(want_grad ? cm * mat : 1) ||
+            ctx->magnus_scratch.ensure(qocx::magnus_scratch_elems(ctx->nb, magnus_blocks)))
+            return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
 
     // Pipelined schedule. The serial sweep of a seed is latency bound (one wave, 2(N-1)
@@ -649,8 +681,23 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
             fa.q_img = ctx->q_img.p + mo * mat; fa.lu_img = ctx->lu_img.p + mo * mat;
             fa.s_arr = ctx->s_arr.p + mo; fa.status = ctx->status.p;
+            qocx::MagnusArgs ma;
+            if (nodes > 1) {
+                ma.controls = fa.controls; ma.interp = ctx->interp.p;
+                ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
+                ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
+                ma.dt = ctx->dt;
+                ma.m_rm = ctx->m_rm.p + mo * mat; ma.mbar_rm = nullptr; ma.gstep = nullptr;
+                ma.scratch = ctx->magnus_scratch.p; ma.total = (size_t)nb_ * nsteps;
+            }
             time_begin(ctx, 0, ctx->stream);
-            qocx::launch_pq(ctx->nb, fa, nsteps, nb_, ctx->stream);
+            if (nodes > 1) {
+                qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks),
+                                        ctx->stream);
+                qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, nb_ * nsteps, ctx->stream);
+            } else {
+                qocx::launch_pq(ctx->nb, fa, nsteps, nb_, ctx->stream);
+            }
             time_end(ctx, ctx->stream);
             qocx::LuArgs la;
             la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p + mo * np; la.perm = ctx->perm.p + mo * np;
@@ -701,16 +748,29 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             ka.states = ctx->states.p + (size_t)lo * ctx->slot_cap * S * np;
             ka.xs = ctx->xs.p + (size_t)lo * ctx->slot_cap * S * np;
             ka.slot_cap = ctx->slot_cap;
-            ka.gstep = ctx->gstep.p + mo * K;
+            ka.gstep = ctx->gstep.p + mo * nodes * K;
+            ka.m_rm = nodes > 1 ? ctx->m_rm.p + mo * mat : nullptr;
+            ka.mbar_rm = nodes > 1 ? ctx->mbar_rm.p + mo * mat : nullptr;
             time_begin(ctx, 2, ctx->stream);
             qocx::launch_krylov(ctx->nb, ka, nsteps, nb_, ctx->stream);
+            if (nodes > 1) {
+                qocx::MagnusArgs ma;
+                ma.controls = ka.controls; ma.interp = ctx->interp.p;
+                ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
+                ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
+                ma.dt = ctx->dt;
+                ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
+                ma.scratch = ctx->magnus_scratch.p; ma.total = (size_t)nb_ * nsteps;
+                qocx::launch_magnus_vjp(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks),
+                                        ctx->stream);
+            }
             time_end(ctx, ctx->stream);
 
             qocx::ScatterArgs sc;
             sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
             sc.weight = ctx->weight.p;
             sc.grads = ctx->grads.p + (size_t)(b0 + lo) * ctx->nc * K;
-            sc.B = nb_; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
+            sc.B = nb_; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * nodes;
             time_begin(ctx, 3, ctx->stream);
             qocx::launch_scatter(sc, ctx->stream);
             time_end(ctx, ctx->stream);

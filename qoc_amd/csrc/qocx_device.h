@@ -94,6 +94,25 @@ struct KrylovArgs {
     const double2* xs;
     size_t slot_cap;
     double* gstep;  // [B][nsteps][K]
+    // Magnus M4/M6: the generator is read from m_rm (row-major padded NP x NP, unscaled) and the
+    // cotangent of M is written to mbar_rm instead of the contraction with G_k. nullptr for M2.
+    const double2* m_rm;
+    double2* mbar_rm;
+};
+
+// Magnus M4 / M6 generator kernels (qocx_magnus.hip)
+struct MagnusArgs {
+    const double* controls;    // [B][nc][K]
+    const StepInterp* interp;  // [nsteps * nodes]
+    const double2* h0_cimg;    // [nt] C-images, nt = 1 or nsteps * nodes
+    const double2* g_cimg;     // [nt][K]
+    int K, nc, nsteps, nt, nodes;
+    double dt;
+    double2* m_rm;             // fwd out: [B][nsteps] row-major padded generators
+    const double2* mbar_rm;    // vjp in : cotangents of the generators
+    double* gstep;             // vjp out: [B][nsteps * nodes][K]
+    double2* scratch;          // [blocks][11] lane-linear matrix dumps
+    size_t total;              // B * nsteps
 };
 
 struct ScatterArgs {
@@ -151,6 +170,9 @@ void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);
+void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
+void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
+size_t magnus_scratch_elems(int nb, int blocks);
 void launch_selftest(double* out, hipStream_t st);
 
 }  // namespace qocx

@@ -954,7 +954,21 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
 
     // a (rows) and a^H (rows) of the scaled generator
     double are[CPL], aim[CPL], hre[CPL], him[CPL];
-    {
+    const bool explicit_gen = args.m_rm != nullptr;
+    if (explicit_gen) {
+        // Magnus M4/M6: a = 2^-s M with M from magnus_fwd_kernel (row-major, padded)
+        const double2* mm = args.m_rm + m * G::MAT;
+        const double sc = ldexp(1.0, -sq);
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) {
+            const double2 e = mm[(size_t)i * NP + cc * H + h];
+            are[cc] = sc * e.x;
+            aim[cc] = sc * e.y;
+            const double2 f = mm[(size_t)(cc * H + h) * NP + i];
+            hre[cc] = sc * f.x;
+            him[cc] = -sc * f.y;
+        }
+    } else {
         double xr[CPL], xi[CPL], tr_[CPL], ti_[CPL];
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
@@ -1089,6 +1103,14 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
         }
     }
 
+    if (explicit_gen) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
+        double2* mb = args.mbar_rm + m * G::MAT;
+        const double sc = ldexp(1.0, -sq);
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc)
+            mb[(size_t)i * NP + cc * H + h] = make_double2(sc * abr[cc], sc * abi[cc]);
+        return;
+    }
     // g_k = Re <abar, E_k>, E_k = d a / d u_k = -i dts G_k  (H-bar = i dt M-bar, Appendix A)
     for (int k = 0; k < K; ++k) {
         double acc = 0;

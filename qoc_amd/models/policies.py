@@ -33,6 +33,13 @@ class MagnusPolicy(_NamedEnum):
     def short(self):
         return {1: "M2", 2: "M4", 3: "M6"}[self.value]
 
+    @property
+    def nodes(self):
+        """Quadrature nodes c_q (t = time + c_q dt), qoc/core/mathmethods.py:70, :96-97, :125-127."""
+        return {1: (0.5,),
+                2: (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
+                3: (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}[self.value]
+
 
 class InterpolationPolicy(_NamedEnum):
     """How time-discrete controls are evaluated between their grid points."""

@@ -190,8 +190,19 @@ def case_control_costs(complex_controls):
     return c
 
 
+def case_magnus_big(magnus):
+    """M4 / M6 on a two-tile problem (n = 20): real controls, Nc != N, large steps so that the
+    commutator terms matter, explicit time dependence, two states, squarings on some steps."""
+    c = case_random("magnus_n20_" + magnus, n=20, N=9, seeds=2, h_seed=606, S=2, K=2, Nc=5,
+                    dt=0.45, magnus=magnus, sigma=1.2, full_unitary=True)
+    c.h0 = c.h0 * 4.0
+    c.time_mod = 2.3
+    return c
+
+
 def all_cases():
     cases = [case_iswap(m) for m in ("M2", "M4", "M6")]
+    cases.extend(case_magnus_big(m) for m in ("M4", "M6"))
     cases.append(case_c2_transmon())
     cases.append(case_random("c2_random", n=8, N=501, seeds=1, h_seed=2002))
     cases.append(case_random("c3_subset", n=32, N=1001, seeds=4, h_seed=2003))

@@ -6,7 +6,7 @@ from qoc_amd import engine as eng
 
 
 def sample_hamiltonian(case):
-    """h0[nt][n][n], g[nt][Kr][n][n] at the M2 quadrature times (Kr real controls)."""
+    """h0[nt][n][n], g[nt][Kr][n][n] at the quadrature times of case.magnus (Kr real controls)."""
     nsteps = case.N - 1
     dt = case.T / (case.N - 1)
     g_list = []
@@ -18,7 +18,9 @@ def sample_hamiltonian(case):
         h0 = np.asarray(case.h0, dtype=np.complex128)[None]
         g = np.asarray(g_list, dtype=np.complex128).reshape(1, len(g_list), case.n, case.n)
     else:
-        times = [j * dt + dt * 0.5 for j in range(nsteps)]
+        nodes = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
+                 "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}[case.magnus]
+        times = [j * dt + dt * c for j in range(nsteps) for c in nodes]
         h0 = np.stack([case.h0 * (1 + 0.3 * np.cos(case.time_mod * t)) for t in times])
         g = np.stack([np.asarray(g_list, dtype=np.complex128) for _ in times])
     return h0, g

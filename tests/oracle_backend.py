@@ -111,9 +111,12 @@ class OracleBackend(object):
         nt = h0.shape[0]
         g = np.asarray(g, dtype=np.complex128).reshape(nt, K, n, n)
         dt = T / (N - 1)
+        nodes = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
+                 "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}[magnus_policy]
+        sample_times = np.array([step * dt + dt * c for step in range(N - 1) for c in nodes])
 
         def hamiltonian(u, t):
-            j = 0 if nt == 1 else int(round((t - 0.5 * dt) / dt))
+            j = 0 if nt == 1 else int(np.argmin(np.abs(sample_times - t)))
             h = h0[j]
             for k in range(K):
                 h = h + u[k] * g[j, k]

@@ -10,6 +10,7 @@ import pytest
 import qoc_amd
 import qoc_amd.standard.costs as product_costs
 from qoc_amd.core import device
+from qoc_amd.models import MagnusPolicy
 from qoc_amd.standard import SGD, Adam
 from tests import cases as cases_mod
 from tests.helpers import golden, rel_err
@@ -22,7 +23,7 @@ def product_cost_list(case):
     return [getattr(product_costs, kind)(**kw) for kind, kw in case.cost_specs]
 
 
-@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases() if c.magnus == "M2"])
+@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases()])
 def test_evolve_on_gpu(name):
     case = cases_mod.case_by_name(name)
     g = golden(name)
@@ -30,7 +31,8 @@ def test_evolve_on_gpu(name):
     for b, u in enumerate(controls):
         result = qoc_amd.evolve_schroedinger_discrete(
             case.T, case.hamiltonian(), case.initial_states, case.N, controls=u,
-            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case))
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case),
+            magnus_policy=getattr(MagnusPolicy, case.magnus))
         assert abs(result.error - g["error"][b]) < 1e-10 * max(1, abs(g["error"][b]))
         assert rel_err(result.final_states, g["final_states"][b]) < 1e-10
 
@@ -53,12 +55,14 @@ def run_grape(case, optimizer, iterations, **kw):
         case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
         case.initial_states, case.N, complex_controls=case.complex_controls,
         cost_eval_step=case.cost_eval_step, initial_controls=case.controls[0],
-        iteration_count=iterations, log_iteration_step=0, optimizer=Recorder(optimizer), **kw)
+        iteration_count=iterations, log_iteration_step=0, optimizer=Recorder(optimizer),
+        magnus_policy=getattr(MagnusPolicy, case.magnus), **kw)
     return result, trace
 
 
 @pytest.mark.parametrize("name,complex_norm", [("ctrlcosts_r", None), ("small_complex_M2", 3.0),
-                                              ("scaled_n8", None)])
+                                              ("scaled_n8", None), ("small_complex_M6", 3.0),
+                                              ("magnus_n20_M4", None)])
 def test_grape_trajectory_matches_oracle_backend(name, complex_norm):
     case = cases_mod.case_by_name(name)
     norms = np.full(case.K, 5.0 if complex_norm is None else complex_norm)

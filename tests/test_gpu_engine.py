@@ -14,7 +14,7 @@ from tests.helpers import golden, oracle_costs, rel_err
 
 pytestmark = pytest.mark.gpu
 
-M2_CASES = [c.name for c in cases_mod.all_cases() if c.magnus == "M2" and c.controls is not None]
+GRAD_CASES = [c.name for c in cases_mod.all_cases() if c.controls is not None]
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +55,7 @@ def test_pade_factor_kernel(engine, n):
         assert rel_err(u, onp.expm_pade(a)) < 1e-10
 
 
-@pytest.mark.parametrize("name", M2_CASES)
+@pytest.mark.parametrize("name", GRAD_CASES)
 def test_engine_matches_golden(engine, name):
     from tests import gpu_helpers as gh
     case = cases_mod.case_by_name(name)
@@ -77,8 +77,9 @@ def test_engine_matches_golden(engine, name):
         assert np.max(np.abs(gb.flat[g["fd_index"][b]] - g["grads_fd"][b])) / scale < 1e-7
 
 
-def test_forward_only_and_iswap(engine):
-    case = cases_mod.case_iswap("M2")
+@pytest.mark.parametrize("magnus", ["M2", "M4", "M6"])
+def test_forward_only_and_iswap(engine, magnus):
+    case = cases_mod.case_iswap(magnus)
     from tests import gpu_helpers as gh
     gh.setup_engine(engine, case)
     engine.set_keep_step_states(True)

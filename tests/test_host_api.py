@@ -175,7 +175,7 @@ def test_probe_hamiltonian():
 
 # ---- entry points -----------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases() if c.magnus == "M2"])
+@pytest.mark.parametrize("name", [c.name for c in cases_mod.all_cases()])
 def test_evolve_matches_reference_fixtures(name):
     case = cases_mod.case_by_name(name)
     g = golden(name)
@@ -185,7 +185,8 @@ def test_evolve_matches_reference_fixtures(name):
     for b, u in enumerate(controls):
         result = qoc_amd.evolve_schroedinger_discrete(
             case.T, case.hamiltonian(), case.initial_states, case.N, controls=u,
-            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case))
+            cost_eval_step=case.cost_eval_step, costs=product_cost_list(case),
+            magnus_policy=getattr(MagnusPolicy, case.magnus))
         assert abs(result.error - g["error"][b]) < 1e-11 * max(1, abs(g["error"][b]))
         assert result.final_states.shape == case.initial_states.shape
         assert rel_err(result.final_states, g["final_states"][b]) < 1e-11
@@ -214,10 +215,6 @@ def test_evolve_with_user_cost_and_errors():
         qoc_amd.grape_schroedinger_discrete(case.K, case.Nc, [Population()], case.T,
                                             case.hamiltonian(), case.initial_states, case.N,
                                             iteration_count=1, log_iteration_step=0)
-    with pytest.raises(NotImplementedError):
-        qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
-                                             case.N, controls=case.controls[0],
-                                             magnus_policy=MagnusPolicy.M4)
     with pytest.raises(NotImplementedError):
         qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
                                              case.N, controls=case.controls[0],
