@@ -142,7 +142,7 @@ struct qocx_ctx {
     // ---- Lindblad problem / evaluation state ----
     // ---- Magnus M4/M6 ----
     int nodes = 1;
-    DevBuf<double2> m_rm, mbar_rm, magnus_scratch;
+    DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
     struct Lindblad {
         bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
         int n = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nops = 0;
@@ -311,16 +311,17 @@ int qocx_create(int device, qocx_ctx** out) {
     // waves are placed as soon as a SIMD frees up under the compute stream's big grids
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 32; ++i) {
         hipStream_t st;
         hipEvent_t e1, e2;
-        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        if ((i == 0 &&
+             hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) != hipSuccess) ||
             hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
             g_error = "cannot create the pipeline streams";
             return QOCX_ERR_HIP;
         }
-        ctx->sweep_streams.push_back(st);
+        if (i == 0) ctx->sweep_streams.push_back(st);
         ctx->ev_factored.push_back(e1);
         ctx->ev_swept.push_back(e2);
     }
@@ -335,6 +336,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     time_collect(ctx);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     ctx->m_rm.release();
+    ctx->lam_buf.release();
     ctx->mbar_rm.release();
     ctx->magnus_scratch.release();
     DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
@@ -656,124 +658,136 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
 
-    // Pipelined schedule. The serial sweep of a seed is latency bound (one wave, 2(N-1)
-    // dependent steps), so each memory chunk is cut into `pipe` sub-chunks: the compute stream
-    // runs pade_pq + lu of every sub-chunk back to back, each sub-chunk's sweep runs on its own
-    // side stream behind its lu, and krylov_grad + scatter of sub-chunk i follow on the compute
-    // stream once sweep i is done - the sweeps hide behind the other sub-chunks' kernels.
-    const int max_pipe = (int)ctx->sweep_streams.size();
+    // Time-segmented pipeline. The serial sweep of a seed is latency bound (one wave, 2(N-1)
+    // dependent steps, <= B waves on the whole chip), the other kernels are throughput bound.
+    // The steps are therefore cut into `nseg` time segments: the compute stream factors segment
+    // after segment (Magnus, K1a, K1b), the high-priority sweep stream follows one segment
+    // behind with the forward sweep, then walks back with the adjoint sweep while the compute
+    // stream runs K3 on the segments the adjoint sweep has already left.
+    const int max_seg = (int)ctx->ev_factored.size();
+    if (ctx->lam_buf.ensure((size_t)chunk * S * np)) return QOCX_ERR_HIP;
+    hipStream_t cs = ctx->stream;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
-        // default: 2 sub-chunks (measured best on MI355X: a running sweep wave blocks its SIMD for
-        // the 382-VGPR pade_pq waves, so more overlap costs more than it hides)
-        const int want_pipe = ctx->pipe_user > 0 ? ctx->pipe_user : (bc >= 64 ? 2 : 1);
-        const int pipe = std::max(1, std::min(std::min(max_pipe, want_pipe), bc));
-        std::vector<int> sub_lo(pipe + 1);
-        for (int i = 0; i <= pipe; ++i) sub_lo[i] = (int)((long long)bc * i / pipe);
-        for (int i = 0; i < pipe; ++i) {
-            const int lo = sub_lo[i], nb_ = sub_lo[i + 1] - sub_lo[i];  // seeds lo.. within chunk
-            const size_t mo = (size_t)lo * nsteps;
-            qocx::FactorArgs fa;
-            fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)(b0 + lo) * ctx->nc * K : nullptr;
-            fa.interp = ctx->interp.p;
-            fa.h0_cimg = ctx->h0_cimg.p;
-            fa.g_cimg = ctx->g_cimg.p;
-            fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
-            fa.q_img = ctx->q_img.p + mo * mat; fa.lu_img = ctx->lu_img.p + mo * mat;
-            fa.s_arr = ctx->s_arr.p + mo; fa.status = ctx->status.p;
-            qocx::MagnusArgs ma;
-            if (nodes > 1) {
-                ma.controls = fa.controls; ma.interp = ctx->interp.p;
-                ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
-                ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
-                ma.dt = ctx->dt;
-                ma.m_rm = ctx->m_rm.p + mo * mat; ma.mbar_rm = nullptr; ma.gstep = nullptr;
-                ma.scratch = ctx->magnus_scratch.p; ma.total = (size_t)nb_ * nsteps;
-            }
-            time_begin(ctx, 0, ctx->stream);
-            if (nodes > 1) {
-                qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks),
-                                        ctx->stream);
-                qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, nb_ * nsteps, ctx->stream);
-            } else {
-                qocx::launch_pq(ctx->nb, fa, nsteps, nb_, ctx->stream);
-            }
-            time_end(ctx, ctx->stream);
-            qocx::LuArgs la;
-            la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p + mo * np; la.perm = ctx->perm.p + mo * np;
-            la.iperm = ctx->iperm.p + mo * np; la.status = ctx->status.p;
-            time_begin(ctx, 4, ctx->stream);
-            qocx::launch_lu(ctx->nb, la, (size_t)nb_ * nsteps, ctx->stream);
-            time_end(ctx, ctx->stream);
-            HIP_TRY(hipEventRecord(ctx->ev_factored[i], ctx->stream));
+        int nseg = ctx->pipe_user > 0 ? ctx->pipe_user
+                                      : ((size_t)bc * nsteps >= 16384 && nsteps >= 64 ? 8 : 1);
+        nseg = std::max(1, std::min(std::min(nseg, max_seg), nsteps));
+        hipStream_t ss = (nseg == 1) ? cs : ctx->sweep_streams[0];
+        std::vector<int> lo(nseg + 1);
+        for (int i = 0; i <= nseg; ++i) lo[i] = (int)((long long)nsteps * i / nseg);
 
-            hipStream_t ss = (pipe == 1) ? ctx->stream : ctx->sweep_streams[i];
-            if (pipe > 1) HIP_TRY(hipStreamWaitEvent(ss, ctx->ev_factored[i], 0));
-            qocx::SweepArgs sa;
-            sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;
-            sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
-            sa.psi0 = ctx->psi0.p;
-            sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
-            sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
-            sa.diag = 0;
-            sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
-            sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
-            sa.states = ctx->states.p + (size_t)lo * ctx->slot_cap * S * np;
-            sa.xs = ctx->xs.p + (want_grad ? (size_t)lo * ctx->slot_cap * S * np : 0);
-            sa.offs = ctx->offs.p + (size_t)lo * (nsteps + 1);
-            sa.cost_out = ctx->cost_out.p + b0 + lo;
-            sa.final_out = ctx->final_out.p + (size_t)(b0 + lo) * S * np;
-            sa.step_states = ctx->keep_step_states
-                                 ? ctx->step_states.p + (size_t)(b0 + lo) * (nsteps + 1) * S * np
-                                 : nullptr;
-            sa.status = ctx->status.p;
+        qocx::FactorArgs fa;
+        fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
+        fa.interp = ctx->interp.p;
+        fa.h0_cimg = ctx->h0_cimg.p;
+        fa.g_cimg = ctx->g_cimg.p;
+        fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+        fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
+        fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
+        qocx::LuArgs la;
+        la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
+        la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps;
+        qocx::MagnusArgs ma;
+        ma.controls = fa.controls; ma.interp = ctx->interp.p;
+        ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
+        ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
+        ma.dt = ctx->dt; ma.scratch = ctx->magnus_scratch.p;
+        qocx::SweepArgs sa;
+        sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;
+        sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
+        sa.psi0 = ctx->psi0.p;
+        sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
+        sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
+        sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
+        sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
+        sa.states = ctx->states.p;
+        sa.xs = ctx->xs.p;
+        sa.offs = ctx->offs.p;
+        sa.cost_out = ctx->cost_out.p + b0;
+        sa.final_out = ctx->final_out.p + (size_t)b0 * S * np;
+        sa.step_states = ctx->keep_step_states
+                             ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
+        sa.status = ctx->status.p;
+        sa.lam_buf = ctx->lam_buf.p;
+
+        // ---- factor + forward sweep, segment by segment ------------------------------------
+        for (int i = 0; i < nseg; ++i) {
+            const int len = lo[i + 1] - lo[i];
+            fa.step0 = lo[i]; fa.seg_len = len;
+            time_begin(ctx, 0, cs);
+            if (nodes > 1) {
+                ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
+                ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
+                qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
+                qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, bc * len, cs);
+            } else {
+                qocx::launch_pq(ctx->nb, fa, len, bc, cs);
+            }
+            time_end(ctx, cs);
+            la.step0 = lo[i]; la.seg_len = len;
+            time_begin(ctx, 4, cs);
+            qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
+            time_end(ctx, cs);
+            if (nseg > 1) {
+                HIP_TRY(hipEventRecord(ctx->ev_factored[i], cs));
+                HIP_TRY(hipStreamWaitEvent(ss, ctx->ev_factored[i], 0));
+            }
+            sa.j_begin = lo[i]; sa.j_end = lo[i + 1];
+            sa.phase = (nseg == 1) ? (want_grad ? 3 : 1) : 1;
             time_begin(ctx, 1, ss);
-            qocx::launch_sweep(ctx->nb, sa, nb_, ss);
+            qocx::launch_sweep(ctx->nb, sa, bc, ss);
             time_end(ctx, ss);
-            if (pipe > 1) HIP_TRY(hipEventRecord(ctx->ev_swept[i], ss));
         }
-        for (int i = 0; i < pipe; ++i) {
-            const int lo = sub_lo[i], nb_ = sub_lo[i + 1] - sub_lo[i];
-            const size_t mo = (size_t)lo * nsteps;
-            if (pipe > 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_swept[i], 0));
-            if (!want_grad) continue;
+        // ---- adjoint sweep walks back; K3 follows on the compute stream ----------------------
+        if (nseg > 1 && want_grad) {
+            for (int i = nseg - 1; i >= 0; --i) {
+                sa.j_begin = lo[i]; sa.j_end = lo[i + 1]; sa.phase = 2;
+                time_begin(ctx, 1, ss);
+                qocx::launch_sweep(ctx->nb, sa, bc, ss);
+                time_end(ctx, ss);
+                HIP_TRY(hipEventRecord(ctx->ev_swept[i], ss));
+            }
+        } else if (nseg > 1) {
+            HIP_TRY(hipEventRecord(ctx->ev_swept[0], ss));
+            HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[0], 0));
+        }
+        if (want_grad) {
             qocx::KrylovArgs ka;
-            ka.controls = ctx->controls.p + (size_t)(b0 + lo) * ctx->nc * K;
+            ka.controls = fa.controls;
             ka.interp = ctx->interp.p;
             ka.h0_rimg = ctx->h0_rimg.p; ka.h0_timg = ctx->h0_timg.p;
             ka.g_rimg = ctx->g_rimg.p; ka.g_timg = ctx->g_timg.p;
             ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
-            ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p + mo;
-            ka.offs = ctx->offs.p + (size_t)lo * (nsteps + 1);
-            ka.states = ctx->states.p + (size_t)lo * ctx->slot_cap * S * np;
-            ka.xs = ctx->xs.p + (size_t)lo * ctx->slot_cap * S * np;
+            ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
+            ka.offs = ctx->offs.p;
+            ka.states = ctx->states.p;
+            ka.xs = ctx->xs.p;
             ka.slot_cap = ctx->slot_cap;
-            ka.gstep = ctx->gstep.p + mo * nodes * K;
-            ka.m_rm = nodes > 1 ? ctx->m_rm.p + mo * mat : nullptr;
-            ka.mbar_rm = nodes > 1 ? ctx->mbar_rm.p + mo * mat : nullptr;
-            time_begin(ctx, 2, ctx->stream);
-            qocx::launch_krylov(ctx->nb, ka, nsteps, nb_, ctx->stream);
-            if (nodes > 1) {
-                qocx::MagnusArgs ma;
-                ma.controls = ka.controls; ma.interp = ctx->interp.p;
-                ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
-                ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
-                ma.dt = ctx->dt;
-                ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
-                ma.scratch = ctx->magnus_scratch.p; ma.total = (size_t)nb_ * nsteps;
-                qocx::launch_magnus_vjp(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks),
-                                        ctx->stream);
+            ka.gstep = ctx->gstep.p;
+            ka.m_rm = nodes > 1 ? ctx->m_rm.p : nullptr;
+            ka.mbar_rm = nodes > 1 ? ctx->mbar_rm.p : nullptr;
+            for (int i = nseg - 1; i >= 0; --i) {
+                const int len = lo[i + 1] - lo[i];
+                if (nseg > 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[i], 0));
+                ka.step0 = lo[i];
+                time_begin(ctx, 2, cs);
+                qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
+                if (nodes > 1) {
+                    ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
+                    ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
+                    qocx::launch_magnus_vjp(ctx->nb, ma,
+                                            (int)std::min<size_t>(ma.total, magnus_blocks), cs);
+                }
+                time_end(ctx, cs);
             }
-            time_end(ctx, ctx->stream);
-
             qocx::ScatterArgs sc;
             sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
             sc.weight = ctx->weight.p;
-            sc.grads = ctx->grads.p + (size_t)(b0 + lo) * ctx->nc * K;
-            sc.B = nb_; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * nodes;
-            time_begin(ctx, 3, ctx->stream);
-            qocx::launch_scatter(sc, ctx->stream);
-            time_end(ctx, ctx->stream);
+            sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
+            sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * nodes;
+            time_begin(ctx, 3, cs);
+            qocx::launch_scatter(sc, cs);
+            time_end(ctx, cs);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1384,10 +1398,12 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     qocx::FactorArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
+    fa.nsteps = count; fa.step0 = 0; fa.seg_len = count;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
     la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
     la.status = ctx->status.p;
+    la.nsteps = count; la.step0 = 0; la.seg_len = count;
     qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -37,6 +37,7 @@ struct FactorArgs {
     const double2* h0_cimg;    // [nt] C-images
     const double2* g_cimg;     // [nt][K] C-images
     int K, nc, nsteps, nt;
+    int step0, seg_len;        // this launch covers steps [step0, step0 + seg_len) of every seed
     double dt;
     // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
@@ -51,6 +52,7 @@ struct LuArgs {
     int* perm;        // [NP] perm[pos] = original row
     int* iperm;       // [NP] iperm[row] = pos
     int* status;
+    int nsteps, step0, seg_len;  // work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len
 };
 
 struct SweepArgs {
@@ -62,7 +64,11 @@ struct SweepArgs {
     const int* s_arr;
     const double2* psi0;  // [S][NP]
     int S, nsteps, cost_eval_step, want_grad, has_step_costs;
-    int diag;             // timing-only ablation bits (QOCX_SWEEP_DIAG); 0 in production
+    // Time segmentation: one launch runs the forward sweep over steps [j_begin, j_end) (phase
+    // bit 0) and / or the adjoint sweep from j_end back to j_begin (phase bit 1); state is carried
+    // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).
+    int phase, j_begin, j_end;
+    double2* lam_buf;     // [B][S][NP]
     size_t slot_cap;      // sub-step slots per seed
     // costs
     int cost_count;
@@ -87,6 +93,7 @@ struct KrylovArgs {
     const double2* g_rimg;
     const double2* g_timg;
     int K, nc, nsteps, nt, S;
+    int step0;  // grid.x covers steps [step0, step0 + gridDim.x)
     double dt;
     const int* s_arr;
     const int* offs;
@@ -107,12 +114,13 @@ struct MagnusArgs {
     const double2* h0_cimg;    // [nt] C-images, nt = 1 or nsteps * nodes
     const double2* g_cimg;     // [nt][K]
     int K, nc, nsteps, nt, nodes;
+    int step0, seg_len;        // work item w -> (seed w / seg_len, step step0 + w % seg_len)
     double dt;
     double2* m_rm;             // fwd out: [B][nsteps] row-major padded generators
     const double2* mbar_rm;    // vjp in : cotangents of the generators
     double* gstep;             // vjp out: [B][nsteps * nodes][K]
     double2* scratch;          // [blocks][11] lane-linear matrix dumps
-    size_t total;              // B * nsteps
+    size_t total;              // B * seg_len work items
 };
 
 struct ScatterArgs {

@@ -195,7 +195,7 @@ template <int NB>
 __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int step = blockIdx.x, b = blockIdx.y;
+    const int step = args.step0 + blockIdx.x, b = blockIdx.y;
     const int lane = lane_id();
     const size_t m = (size_t)b * args.nsteps + step;
     PqOut out;
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
                                                               FactorArgs args) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t m = blockIdx.x;
+    const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
+                     blockIdx.x % args.seg_len;
     const int lane = lane_id();
     const int q = lane >> 4, c = lane & 15;
     PqOut out;
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
     typedef Geo<NB> G;
     constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
     __shared__ __attribute__((aligned(16))) double2 prow[NP];
-    const size_t m = blockIdx.x;
+    const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
+                     blockIdx.x % args.seg_len;
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
     double2* img = args.lu_img + m * G::MAT;
     double pre[CPL], pim[CPL];
@@ -677,17 +679,30 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     const bool g0 = (h == 0);
     const size_t m0 = (size_t)b * nsteps;
 
-    for (int s = 0; s < S; ++s)
-        if (g0) {
-            const double2 p = args.psi0[s * NP + i];
-            vecs[s * NP + i] = p;
-            states_b[(size_t)s * NP + i] = p;
-        }
-    wave_sync();
+    const int jb = args.j_begin, je = args.j_end;
+    const bool do_fwd = (args.phase & 1) != 0, do_bwd = (args.phase & 2) != 0;
+    if (jb > 0 || !do_fwd)
+        if ((*(volatile int*)args.status) & 4) return;  // an earlier segment overflowed
 
     double cost = 0;
     int slot = 0;
     bool overflow = false;
+    if (do_fwd) {
+        if (jb == 0) {
+            for (int s = 0; s < S; ++s)
+                if (g0) {
+                    const double2 p = args.psi0[s * NP + i];
+                    vecs[s * NP + i] = p;
+                    states_b[(size_t)s * NP + i] = p;
+                }
+        } else {  // resume: states, slot counter and partial cost left by the previous segment
+            slot = offs_b[jb];
+            cost = args.cost_out[b];
+            for (int s = 0; s < S; ++s)
+                if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
+        }
+        wave_sync();
+    }
     StepRegs<NB> r;
 
     // Everything a step needs arrives by LDS-DMA one step ahead: Q and LU images (the adjoint
@@ -791,11 +806,11 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
 
     // ---- forward sweep: the next step's operands stream into LDS while the current step's
     // dependent chains run -------------------------------------------------------------------
-    {
-        issue_dma(m0, 0, false);
-        int nsub_next = 1 << min(max(args.s_arr[m0], 0), 30);
-        for (int step = 0; step < nsteps; ++step) {
-            const int par = step & 1;
+    if (do_fwd) {
+        issue_dma(m0 + jb, 0, false);
+        int nsub_next = 1 << min(max(args.s_arr[m0 + jb], 0), 30);
+        for (int step = jb; step < je; ++step) {
+            const int par = (step - jb) & 1;
             const int nsub = nsub_next;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
@@ -803,7 +818,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                    lane, i);
             wave_sync();
-            pf_due = (step + 1 < nsteps);
+            pf_due = (step + 1 < je);
             if (pf_due) {
                 pf_m = m0 + step + 1;
                 pf_par = par ^ 1;
@@ -820,20 +835,39 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         if (lane == 0) atomicOr(args.status, 4);
         return;
     }
-    before_step(nsteps);
-    cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
-    if (lane == 0) args.cost_out[b] = cost;
-    if (g0)
-        for (int s = 0; s < S; ++s) args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
-    if (!args.want_grad) return;
+    if (do_fwd) {
+        if (je == nsteps) {
+            before_step(nsteps);
+            cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
+            if (g0)
+                for (int s = 0; s < S; ++s)
+                    args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
+        } else if (lane == 0) {
+            offs_b[je] = slot;  // the next segment resumes from here
+        }
+        if (lane == 0) args.cost_out[b] = cost;
+    }
+    if (!do_bwd) return;
 
     // ---- adjoint sweep ---------------------------------------------------------------------
-    for (int s = 0; s < S; ++s)
-        if (g0) lam[s * NP + i] = make_double2(0, 0);
-    wave_sync();
-    // cotangent seeds on the final states: non-step costs, and step costs if the final step is
-    // a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
-    (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+    if (je == nsteps) {
+        if (!do_fwd) {  // final states of the forward segments
+            slot = offs_b[nsteps];
+            for (int s = 0; s < S; ++s)
+                if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
+        }
+        for (int s = 0; s < S; ++s)
+            if (g0) lam[s * NP + i] = make_double2(0, 0);
+        wave_sync();
+        // cotangent seeds on the final states: non-step costs, and step costs if the final step
+        // is a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
+        (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+    } else {  // resume the adjoint sweep below step je
+        slot = offs_b[je];
+        for (int s = 0; s < S; ++s)
+            if (g0) lam[s * NP + i] = args.lam_buf[((size_t)b * S + s) * NP + i];
+        wave_sync();
+    }
 
     auto adjoint_step = [&](const StepScalars& sc, int nsub, int step) {
         for (int sub = nsub - 1; sub >= 0; --sub) {
@@ -887,10 +921,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         }
     };
     {
-        const size_t ml = m0 + nsteps - 1;
+        const size_t ml = m0 + je - 1;
         issue_dma(ml, 0, true);
         int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
-        for (int step = nsteps - 1, it = 0; step >= 0; --step, ++it) {
+        for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
             const int par = it & 1;
             const int nsub = nsub_next;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -899,7 +933,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                   lane, i);
             wave_sync();
-            pf_due = (step - 1 >= 0);
+            pf_due = (step - 1 >= jb);
             if (pf_due) {
                 pf_m = m0 + step - 1;
                 pf_par = par ^ 1;
@@ -909,6 +943,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             adjoint_step(sc, nsub, step);
         }
     }
+    if (jb > 0 && g0)
+        for (int s = 0; s < S; ++s)
+            args.lam_buf[((size_t)b * S + s) * NP + i] = lam[s * NP + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -929,7 +966,7 @@ struct KrylovLds {
     static constexpr int BYTES = RHO_OFF + 13 * G::NP * 16;
 };
 
-template <int NB>
+template <int NB, bool EXPLICIT>
 __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
     typedef Geo<NB> G;
     typedef KrylovLds<NB> L;
@@ -938,7 +975,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
     double2* vv = reinterpret_cast<double2*>(smem + L::V_OFF);
     double2* part = reinterpret_cast<double2*>(smem + L::PART_OFF);
     double2* rho_l = reinterpret_cast<double2*>(smem + L::RHO_OFF);
-    const int step = blockIdx.x, b = blockIdx.y;
+    const int step = args.step0 + blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
     const int nsteps = args.nsteps, S = args.S, K = args.K;
     const size_t m = (size_t)b * nsteps + step;
@@ -954,8 +991,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
 
     // a (rows) and a^H (rows) of the scaled generator
     double are[CPL], aim[CPL], hre[CPL], him[CPL];
-    const bool explicit_gen = args.m_rm != nullptr;
-    if (explicit_gen) {
+    if (EXPLICIT) {
         // Magnus M4/M6: a = 2^-s M with M from magnus_fwd_kernel (row-major, padded)
         const double2* mm = args.m_rm + m * G::MAT;
         const double sc = ldexp(1.0, -sq);
@@ -1103,7 +1139,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
         }
     }
 
-    if (explicit_gen) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
+    if (EXPLICIT) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
         double2* mb = args.mbar_rm + m * G::MAT;
         const double sc = ldexp(1.0, -sq);
 #pragma unroll
@@ -1181,8 +1217,12 @@ static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
 }
 template <int NB>
 static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(krylov_grad_kernel<NB>, dim3(nsteps, batch), dim3(64),
-                       KrylovLds<NB>::BYTES, st, a);
+    if (a.m_rm != nullptr)
+        hipLaunchKernelGGL((krylov_grad_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
+                           KrylovLds<NB>::BYTES, st, a);
+    else
+        hipLaunchKernelGGL((krylov_grad_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
+                           KrylovLds<NB>::BYTES, st, a);
 }
 
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {

@@ -25,7 +25,6 @@ namespace {
 constexpr int LNB = 1;                 // n <= 16
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                 // 16 x 16 complex in C-layout: 16 VGPRs
-constexpr int LNP = LG::NP;            // 16
 constexpr int LPLANE = LG::PLANE;      // doubles per LDS plane
 constexpr int SLOT_BYTES = 2 * LPLANE * 8;  // planar left-operand slot
 constexpr int DUMP_BYTES = 256 * 16;        // C-layout dump of one matrix (lane-linear)

@@ -19,8 +19,6 @@ namespace qocx {
 
 namespace {
 
-constexpr double M4_C[2] = {0.21132486540518713, 0.7886751345948129};   // 1/2 -+ sqrt(3)/6
-constexpr double M6_C[3] = {0.1127016653792583, 0.5, 0.8872983346207417};  // 1/2 -+ sqrt(15)/10
 constexpr double M4_F0 = 0.14433756729740643;  // sqrt(3)/12
 constexpr double M6_F0 = 1.2909944487358056;   // sqrt(15)/3
 constexpr double M6_F1 = 10.0 / 3.0;
@@ -383,9 +381,10 @@ __global__ __launch_bounds__(64) void magnus_fwd_kernel(MagnusArgs args) {
     cx.bre = cx.aim + G::PLANE;
     cx.bim = cx.bre + G::PLANE;
     double2* scr = args.scratch + (size_t)blockIdx.x * S_COUNT * G::MAT;
-    for (size_t m = blockIdx.x; m < args.total; m += gridDim.x) {
-        const int step = (int)(m % args.nsteps);
-        const size_t b = m / args.nsteps;
+    for (size_t w = blockIdx.x; w < args.total; w += gridDim.x) {
+        const int step = args.step0 + (int)(w % args.seg_len);
+        const size_t b = w / args.seg_len;
+        const size_t m = b * args.nsteps + step;
         const double* ctl_b = args.controls + b * args.nc * args.K;
         Mat mm;
         if (args.nodes == 2) {
@@ -416,9 +415,10 @@ __global__ __launch_bounds__(64) void magnus_vjp_kernel(MagnusArgs args) {
     cx.bim = cx.bre + G::PLANE;
     double2* scr = args.scratch + (size_t)blockIdx.x * S_COUNT * G::MAT;
     const double dt = args.dt;
-    for (size_t m = blockIdx.x; m < args.total; m += gridDim.x) {
-        const int step = (int)(m % args.nsteps);
-        const size_t b = m / args.nsteps;
+    for (size_t w = blockIdx.x; w < args.total; w += gridDim.x) {
+        const int step = args.step0 + (int)(w % args.seg_len);
+        const size_t b = w / args.seg_len;
+        const size_t m = b * args.nsteps + step;
         const double* ctl_b = args.controls + b * args.nc * args.K;
         if (args.nodes == 2) {
             // a1bar = dt/2 mbar + d[a2,a1]/da1 ; a2bar likewise (cbar = F0 dt^2 mbar)
