@@ -142,6 +142,7 @@ struct qocx_ctx {
     // ---- Lindblad problem / evaluation state ----
     // ---- Magnus M4/M6 ----
     int nodes = 1;
+    int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
     struct Lindblad {
         bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
@@ -170,6 +171,8 @@ struct qocx_ctx {
     // ---- timing ----
     int timing = 0;
     std::vector<TimingRec> pending;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
     int64_t t_launch[6] = {0, 0, 0, 0, 0, 0};
     double t_ms[6] = {0, 0, 0, 0, 0, 0};
     // ---- comm ----
@@ -222,12 +225,23 @@ void from_image(const double2* img, int n, int np, const int* row_map, double* o
         }
 }
 
+// timing events come from a grow-only pool: creating and destroying ~100 events per evaluation
+// makes the runtime stall for tens of milliseconds every few evaluations
+hipEvent_t pooled_event(qocx_ctx* ctx) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
+}
+
 void time_begin(qocx_ctx* ctx, int which, hipStream_t st) {
     if (!ctx->timing) return;
     TimingRec r;
     r.which = which;
-    (void)hipEventCreate(&r.a);
-    (void)hipEventCreate(&r.b);
+    r.a = pooled_event(ctx);
+    r.b = pooled_event(ctx);
     (void)hipEventRecord(r.a, st);
     ctx->pending.push_back(r);
 }
@@ -244,10 +258,9 @@ void time_collect(qocx_ctx* ctx) {
             ctx->t_ms[r.which] += ms;
             ctx->t_launch[r.which] += 1;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
     }
     ctx->pending.clear();
+    ctx->ev_used = 0;
 }
 
 int load_rccl(qocx_ctx* ctx) {
@@ -369,6 +382,7 @@ int qocx_destroy(qocx_ctx* ctx) {
             kv.second.weight.release();
         }
     }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
     for (auto e : ctx->ev_factored) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_swept) (void)hipEventDestroy(e);
@@ -415,6 +429,23 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     ctx->T = p->evolution_time;
     ctx->dt = p->evolution_time / (N - 1);  // programstate.py:44
 
+    {
+        auto is_hermitian = [n](const double* m) {
+            for (int r = 0; r < n; ++r)
+                for (int c = r; c < n; ++c)
+                    if (m[2 * ((size_t)r * n + c)] != m[2 * ((size_t)c * n + r)] ||
+                        m[2 * ((size_t)r * n + c) + 1] != -m[2 * ((size_t)c * n + r) + 1])
+                        return false;
+            return true;
+        };
+        bool herm = true;
+        for (int t = 0; t < p->nt && herm; ++t) {
+            herm = is_hermitian(p->h0 + (size_t)t * n * n * 2);
+            for (int k = 0; k < K && herm; ++k)
+                herm = is_hermitian(p->g + ((size_t)t * K + k) * n * n * 2);
+        }
+        ctx->hermitian = herm ? 1 : 0;
+    }
     // Hamiltonian images + norms for the squaring bound
     std::vector<double2> img((size_t)nt * mat);
     ctx->h0_norm_max = 0;
@@ -770,6 +801,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 const int len = lo[i + 1] - lo[i];
                 if (nseg > 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[i], 0));
                 ka.step0 = lo[i];
+            ka.skew = ctx->hermitian;
                 time_begin(ctx, 2, cs);
                 qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
                 if (nodes > 1) {

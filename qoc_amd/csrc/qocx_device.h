@@ -94,6 +94,7 @@ struct KrylovArgs {
     const double2* g_timg;
     int K, nc, nsteps, nt, S;
     int step0;  // grid.x covers steps [step0, step0 + gridDim.x)
+    int skew;   // 1: every H0(t), G_k(t) is exactly Hermitian (a^H = -a)
     double dt;
     const int* s_arr;
     const int* offs;

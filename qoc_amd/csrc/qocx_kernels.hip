@@ -960,20 +960,35 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
 template <int NB>
 struct KrylovLds {
     typedef Geo<NB> G;
-    static constexpr int V_OFF = 0;                        // 3 vectors (sigma, delta, tau)
-    static constexpr int PART_OFF = V_OFF + 3 * G::NP * 16;  // 3 * 64 partial sums
-    static constexpr int RHO_OFF = PART_OFF + 3 * 64 * 16;   // 13 rho vectors
+    static constexpr int V_OFF = 0;                          // 2 vectors (sigma_j, delta_j)
+    static constexpr int TAU_OFF = V_OFF + 2 * G::NP * 16;   // 13 tau vectors
+    static constexpr int RHO_OFF = TAU_OFF + 13 * G::NP * 16;  // 13 rho vectors
     static constexpr int BYTES = RHO_OFF + 13 * G::NP * 16;
 };
 
-template <int NB, bool EXPLICIT>
-__global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
+// sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
+template <int NB>
+__device__ __forceinline__ double sum_groups(double v) {
+    if (Geo<NB>::H == 2) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
+    }
+#pragma unroll
+    for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// SKEW: every H0(t), G_k(t) is Hermitian, so a^H = -a exactly and the rows of a^H need no
+// registers (the common physical case; the host checks it bit for bit).
+template <int NB, bool EXPLICIT, bool SKEW>
+__device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* smem) {
     typedef Geo<NB> G;
     typedef KrylovLds<NB> L;
     constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* vv = reinterpret_cast<double2*>(smem + L::V_OFF);
-    double2* part = reinterpret_cast<double2*>(smem + L::PART_OFF);
+    double2* tau_l = reinterpret_cast<double2*>(smem + L::TAU_OFF);
     double2* rho_l = reinterpret_cast<double2*>(smem + L::RHO_OFF);
     const int step = args.step0 + blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
@@ -990,7 +1005,8 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
     const double2* gt = args.g_timg + tsel * K * G::MAT;
 
     // a (rows) and a^H (rows) of the scaled generator
-    double are[CPL], aim[CPL], hre[CPL], him[CPL];
+    constexpr int HC = SKEW ? 1 : CPL;
+    double are[CPL], aim[CPL], hre[HC], him[HC];
     if (EXPLICIT) {
         // Magnus M4/M6: a = 2^-s M with M from magnus_fwd_kernel (row-major, padded)
         const double2* mm = args.m_rm + m * G::MAT;
@@ -1005,15 +1021,17 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
             him[cc] = -sc * f.y;
         }
     } else {
-        double xr[CPL], xi[CPL], tr_[CPL], ti_[CPL];
+        double xr[CPL], xi[CPL], tr_[HC], ti_[HC];
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
             const double2 e = h0r[cc * 64 + lane];
             xr[cc] = e.x;
             xi[cc] = e.y;
-            const double2 f = h0t[cc * 64 + lane];
-            tr_[cc] = f.x;
-            ti_[cc] = f.y;
+            if (!SKEW) {
+                const double2 f = h0t[cc * 64 + lane];
+                tr_[cc] = f.x;
+                ti_[cc] = f.y;
+            }
         }
         for (int k = 0; k < K; ++k) {
             const double uk = control_at(ctl_b, si, K, k);
@@ -1022,17 +1040,21 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
                 const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
                 xr[cc] += uk * e.x;
                 xi[cc] += uk * e.y;
-                const double2 f = gt[(size_t)k * G::MAT + cc * 64 + lane];
-                tr_[cc] += uk * f.x;
-                ti_[cc] += uk * f.y;
+                if (!SKEW) {
+                    const double2 f = gt[(size_t)k * G::MAT + cc * 64 + lane];
+                    tr_[cc] += uk * f.x;
+                    ti_[cc] += uk * f.y;
+                }
             }
         }
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
             are[cc] = dts * xi[cc];   // a = -i dts H
             aim[cc] = -dts * xr[cc];
-            hre[cc] = dts * ti_[cc];  // a^H[i][c] = conj(a[c][i]) = conj(-i dts H[c][i])
-            him[cc] = dts * tr_[cc];
+            if (!SKEW) {
+                hre[cc] = dts * ti_[cc];  // a^H[i][c] = conj(a[c][i]) = conj(-i dts H[c][i])
+                him[cc] = dts * tr_[cc];
+            }
         }
     }
 
@@ -1058,7 +1080,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
             double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
             double dlr = p0.x - p1.x, dli = p0.y - p1.y;
             double tar = x.x, tai = x.y;
-            double rhr[13], rhi[13], tvr[13], tvi[13];
+            double rhr[13], rhi[13];
 #pragma unroll
             for (int ii = 0; ii < 13; ++ii) {
                 rhr[ii] = 0;
@@ -1078,45 +1100,42 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
                         rhi[ii] += coef * dli;
                     }
                 }
-                tvr[jj] = tar;
-                tvi[jj] = tai;
-                if (jj < 12) {
-                    if (h == 0) {
+                // tau_jj stays in LDS: it is the broadcast source of the next matvec and the
+                // left factor of the rank-1 update below
+                if (h == 0) {
+                    tau_l[jj * NP + i] = make_double2(tar, tai);
+                    if (jj < 12) {
                         vv[i] = make_double2(sgr, sgi);
                         vv[NP + i] = make_double2(dlr, dli);
-                        vv[2 * NP + i] = make_double2(tar, tai);
                     }
+                }
+                if (jj < 12) {
                     wave_sync();
                     double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0;
 #pragma unroll
                     for (int cc = 0; cc < CPL; ++cc) {
                         const double2 v0 = vv[cc * H + h];
                         const double2 v1 = vv[NP + cc * H + h];
-                        const double2 v2 = vv[2 * NP + cc * H + h];
+                        const double2 v2 = tau_l[jj * NP + cc * H + h];
                         s0r += are[cc] * v0.x - aim[cc] * v0.y;
                         s0i += are[cc] * v0.y + aim[cc] * v0.x;
                         s1r += are[cc] * v1.x - aim[cc] * v1.y;
                         s1i += are[cc] * v1.y + aim[cc] * v1.x;
-                        s2r += hre[cc] * v2.x - him[cc] * v2.y;
-                        s2i += hre[cc] * v2.y + him[cc] * v2.x;
+                        if (SKEW) {  // a^H = -a
+                            s2r -= are[cc] * v2.x - aim[cc] * v2.y;
+                            s2i -= are[cc] * v2.y + aim[cc] * v2.x;
+                        } else {
+                            s2r += hre[cc] * v2.x - him[cc] * v2.y;
+                            s2i += hre[cc] * v2.y + him[cc] * v2.x;
+                        }
                     }
-                    part[lane] = make_double2(s0r, s0i);
-                    part[64 + lane] = make_double2(s1r, s1i);
-                    part[128 + lane] = make_double2(s2r, s2i);
-                    wave_sync();
-                    sgr = sgi = dlr = dli = tar = tai = 0;
-#pragma unroll
-                    for (int hh = 0; hh < H; ++hh) {
-                        const double2 q0 = part[hh * NP + i];
-                        const double2 q1 = part[64 + hh * NP + i];
-                        const double2 q2 = part[128 + hh * NP + i];
-                        sgr += q0.x;
-                        sgi += q0.y;
-                        dlr += q1.x;
-                        dli += q1.y;
-                        tar += q2.x;
-                        tai += q2.y;
-                    }
+                    sgr = sum_groups<NB>(s0r);
+                    sgi = sum_groups<NB>(s0i);
+                    dlr = sum_groups<NB>(s1r);
+                    dli = sum_groups<NB>(s1i);
+                    tar = sum_groups<NB>(s2r);
+                    tai = sum_groups<NB>(s2i);
+                    wave_sync();  // vv is rewritten by the next chain step
                 }
             }
             // abar += sum_t tau_t rho_t^H
@@ -1127,12 +1146,13 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
             wave_sync();
 #pragma unroll
             for (int tt = 0; tt < 13; ++tt) {
+                const double2 tv = tau_l[tt * NP + i];
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     const double2 r = rho_l[tt * NP + cc * H + h];
                     // tau * conj(rho)
-                    abr[cc] += tvr[tt] * r.x + tvi[tt] * r.y;
-                    abi[cc] += tvi[tt] * r.x - tvr[tt] * r.y;
+                    abr[cc] += tv.x * r.x + tv.y * r.y;
+                    abi[cc] += tv.y * r.x - tv.x * r.y;
                 }
             }
             wave_sync();
@@ -1158,6 +1178,19 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
         acc = wave_sum(acc);
         if (lane == 0) args.gstep[m * K + k] = acc;
     }
+}
+
+template <int NB, bool EXPLICIT>
+__global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    krylov_grad_body<NB, EXPLICIT, false>(args, smem);
+}
+
+// Hermitian-generator variant: half the generator registers, so two waves share a SIMD.
+template <int NB>
+__global__ __launch_bounds__(64, 2) void krylov_grad_skew_kernel(KrylovArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    krylov_grad_body<NB, false, true>(args, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1219,6 +1252,9 @@ template <int NB>
 static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
     if (a.m_rm != nullptr)
         hipLaunchKernelGGL((krylov_grad_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
+                           KrylovLds<NB>::BYTES, st, a);
+    else if (a.skew)
+        hipLaunchKernelGGL(krylov_grad_skew_kernel<NB>, dim3(nsteps, batch), dim3(64),
                            KrylovLds<NB>::BYTES, st, a);
     else
         hipLaunchKernelGGL((krylov_grad_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
