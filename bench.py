@@ -55,16 +55,18 @@ def make_controls(first_seed, count):
 def pmc_traffic_bytes(kernel, units_per_launch):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/r01_v3_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, gfx950
-    correction applied), rescaled to this run's units per launch. PMC counters cannot be
-    collected from inside the timed run; None if the summary is absent.
+    (profiles/r01_v4_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this
+    bench command, gfx950 correction applied; tools/pmc_summary.py), rescaled to this run's
+    units per launch. PMC counters cannot be collected from inside the timed run; None if the
+    summary is absent.
     """
-    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_v4_pmc_hbm.json")
     try:
         with open(path) as f:
-            entry = json.load(f)["kernels"][kernel]
-        measured_units = 128 * (N_EVAL - 1)
-        return entry["hbm_bytes_per_dispatch_corrected"] * units_per_launch / measured_units
+            summary = json.load(f)
+        entry = summary["kernels"][kernel]
+        return (entry["hbm_bytes_per_dispatch_corrected"] * units_per_launch
+                / summary["units_per_dispatch"])
     except (OSError, KeyError, ValueError):
         return None
 

@@ -200,8 +200,20 @@ def case_magnus_big(magnus):
     return c
 
 
+def case_non_hermitian():
+    """A non-Hermitian generator (effective Hamiltonian with loss): the reference takes any
+    matrix; on the device this selects the general (a^H != -a) adjoint kernel. n = 24, S = 2."""
+    c = case_random("nonhermitian_n24", n=24, N=17, seeds=2, h_seed=808, S=2, K=2, dt=0.2,
+                    sigma=0.8, full_unitary=True)
+    rng = np.random.default_rng(809)
+    c.h0 = c.h0 * 2.0 - 0.15j * np.diag(rng.uniform(0, 1, 24))
+    c.g_re = [c.g_re[0], c.g_re[1] + 0.2j * gue(rng, 24)]
+    return c
+
+
 def all_cases():
     cases = [case_iswap(m) for m in ("M2", "M4", "M6")]
+    cases.append(case_non_hermitian())
     cases.extend(case_magnus_big(m) for m in ("M4", "M6"))
     cases.append(case_c2_transmon())
     cases.append(case_random("c2_random", n=8, N=501, seeds=1, h_seed=2002))
