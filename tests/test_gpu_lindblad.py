@@ -66,7 +66,7 @@ def test_lindblad_engine_matches_golden_and_model(engine, name):
         assert abs(cost[b] - m_err) < 1e-12
         assert np.max(np.abs(final[b] - m_final)) < 1e-12
         assert np.max(np.abs(grads[b] - m_grads)) / np.max(np.abs(m_grads)) < 1e-10
-        assert abs(np.trace(final[b, 0]) - 1) < 1e-10
+        assert abs(np.trace(final[b, 0]) - 1) < 1e-12  # trace preservation
 
 
 def test_lindblad_forward_only_and_step_densities(engine):
@@ -92,7 +92,7 @@ def test_lindblad_forward_only_and_step_densities(engine):
                                  lindblad_data=case.lindblad_data(), control_eval_count=case.Nc,
                                  control_count=case.K)
     traces = np.trace(steps, axis1=-2, axis2=-1)
-    assert np.max(np.abs(traces - 1)) < 1e-10
+    assert np.max(np.abs(traces - 1)) < 1e-12
     herm = steps - np.conj(np.swapaxes(steps, -1, -2))
     assert np.max(np.abs(herm)) < 1e-12
     del problem
