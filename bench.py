@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 
 DIM, N_EVAL, SEEDS_PER_GPU, K_CTRL, DT = 32, 1001, 256, 2, 0.05
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (spec; SURVEY.md 8d / BASELINE.md 3)
+# The rate a register-only loop of v_mfma_f64_16x16x4_f64 sustains on the box is measured live
+# (qocx_debug_mfma_peak) and reported as roofline.peak_sustained_measured: ~48 TFLOP/s.
 
 
 def gue(rng, n):
@@ -177,9 +179,10 @@ def main():
         avg_s = total_ms / launches * 1e-3
         units_per_launch = seeds * (N_EVAL - 1) * args.steps / launches
         achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
-        roofline = dict(bound="mfma", kernel="pade_pq_kernel<2>", achieved=achieved,
+        roofline = dict(bound="mfma", kernel="pade_pq_kernel<2, hermitian>", achieved=achieved,
                         peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS,
+                        peak_sustained_measured=engine.mfma_peak(2, 20000),
                         traffic=pmc_traffic_bytes("qocx::pade_pq_kernel<2>", units_per_launch),
                         avg_launch_ms=total_ms / launches)
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}

@@ -211,6 +211,10 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
                            double* q_out, double* lu_out, int32_t* perm_out,
                            double* dinv_out, int32_t* s_out);
 int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
+/* Sustained FP64 MFMA rate of the device: waves_per_simd x 4 x CUs waves issue `iters` rounds of
+ * 8 independent v_mfma_f64_16x16x4_f64 from registers (no memory traffic). bench.py reports it
+ * next to the spec peak. */
+int qocx_debug_mfma_peak(qocx_ctx* ctx, int32_t waves_per_simd, int32_t iters, double* tflops);
 
 #ifdef __cplusplus
 }

@@ -729,6 +729,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.h0_cimg = ctx->h0_cimg.p;
         fa.g_cimg = ctx->g_cimg.p;
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+        fa.hermitian = ctx->hermitian;
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         qocx::LuArgs la;
@@ -1503,6 +1504,32 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
     if (status & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");
+    return 0;
+}
+
+int qocx_debug_mfma_peak(qocx_ctx* ctx, int32_t waves_per_simd, int32_t iters, double* tflops) {
+    if (!ctx || !tflops || waves_per_simd < 1 || iters < 1) return fail(QOCX_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 4 * waves_per_simd;
+    DevBuf<double> out;
+    if (out.ensure(8)) return QOCX_ERR_HIP;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    qocx::launch_mfma_peak(out.p, blocks, 64, ctx->stream);  // warm-up
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    qocx::launch_mfma_peak(out.p, blocks, iters, ctx->stream);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    out.release();
+    // one v_mfma_f64_16x16x4_f64 = 16*16*4 multiply-adds = 2048 flop per wave
+    *tflops = (double)blocks * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
     return 0;
 }
 

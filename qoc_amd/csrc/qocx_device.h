@@ -38,6 +38,7 @@ struct FactorArgs {
     const double2* g_cimg;     // [nt][K] C-images
     int K, nc, nsteps, nt;
     int step0, seg_len;        // this launch covers steps [step0, step0 + seg_len) of every seed
+    int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
     double dt;
     // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
@@ -179,6 +180,7 @@ void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);
+void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 size_t magnus_scratch_elems(int nb, int blocks);

@@ -44,15 +44,142 @@ struct PqOut {
 
 template <int NB>
 struct PqLds {
-    static constexpr int BYTES = 2 * Geo<NB>::PLANE * 8;  // planar A-operand slot
+    static constexpr int SLOT = 3 * Geo<NB>::PLANE * 8;   // planar A-operand slot: re | im | re+im
+    static constexpr int BYTES = SLOT + 2 * 16 * 18 * 8;  // + one 16 x 16 complex tile (mirror)
 };
 
-// The body of K1a; `gen(a)` builds the unscaled generator in C-layout.
-template <int NB, class Gen>
+// Complex products by the 3M scheme: with T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi),
+//   Re(AB) = T1 - T2,  Im(AB) = T3 - T1 - T2,
+// i.e. three real MFMA chains per complex product instead of four. The rounding error stays
+// normwise O(eps ||A|| ||B||) (Higham, Accuracy and Stability, 23.2.4) - the parity tests hold
+// the result to the same 1e-10 / 1e-8 gates as before.
+template <int NB>
+struct CAcc3 {
+    d4 t1[NB][NB], t2[NB][NB], t3[NB][NB];
+};
+
+template <int NB>
+__device__ __forceinline__ void acc3_init(CAcc3<NB>& a, const CMat<NB>& c) {
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {
+            a.t1[ti][tj] = c.re[ti][tj];
+            a.t2[ti][tj] = d4{0, 0, 0, 0};
+            a.t3[ti][tj] = c.re[ti][tj] + c.im[ti][tj];
+        }
+}
+template <int NB>
+__device__ __forceinline__ void acc3_zero(CAcc3<NB>& a) {
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {
+            a.t1[ti][tj] = d4{0, 0, 0, 0};
+            a.t2[ti][tj] = d4{0, 0, 0, 0};
+            a.t3[ti][tj] = d4{0, 0, 0, 0};
+        }
+}
+template <int NB>
+__device__ __forceinline__ void acc3_finish(CMat<NB>& c, const CAcc3<NB>& a) {
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {
+            c.re[ti][tj] = a.t1[ti][tj] - a.t2[ti][tj];
+            c.im[ti][tj] = a.t3[ti][tj] - a.t1[ti][tj] - a.t2[ti][tj];
+        }
+}
+
+// C-layout registers -> three planes (re, im, re + im) of the planar A-operand slot
+template <int NB>
+__device__ __forceinline__ void cmat_to_lds3(const CMat<NB>& m, double* lre, double* lim,
+                                             double* lsum) {
+    typedef Geo<NB> G;
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (16 * ti + 4 * r + q) * G::PITCH + 16 * tj + c;
+                lre[off] = m.re[ti][tj][r];
+                lim[off] = m.im[ti][tj][r];
+                lsum[off] = m.re[ti][tj][r] + m.im[ti][tj][r];
+            }
+}
+
+// acc += A * B (3M). A from the three planes, B fragment (re, im) from `bf`. UPPER: only the
+// tiles on and above the diagonal (the product is known to be Hermitian or skew-Hermitian).
+template <int NB, bool UPPER, class BFrag>
+__device__ __forceinline__ void zgemm3_acc(CAcc3<NB>& acc, const double* lre, const double* lim,
+                                           const double* lsum, BFrag bf) {
+    typedef Geo<NB> G;
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int kk = 0; kk < 4 * NB; ++kk) {
+        double are[NB], aim[NB], asum[NB];
+#pragma unroll
+        for (int ti = 0; ti < NB; ++ti) {
+            const int off = (16 * ti + c) * G::PITCH + 4 * kk + q;
+            are[ti] = lre[off];
+            aim[ti] = lim[off];
+            asum[ti] = lsum[off];
+        }
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {
+            double bre, bim;
+            bf(kk, tj, bre, bim);
+            const double bsum = bre + bim;
+#pragma unroll
+            for (int ti = 0; ti < NB; ++ti) {
+                if (UPPER && ti > tj) continue;
+                acc.t1[ti][tj] = mfma_f64(are[ti], bre, acc.t1[ti][tj]);
+                acc.t2[ti][tj] = mfma_f64(aim[ti], bim, acc.t2[ti][tj]);
+                acc.t3[ti][tj] = mfma_f64(asum[ti], bsum, acc.t3[ti][tj]);
+            }
+        }
+    }
+}
+
+// Lower tiles of a (skew-)Hermitian product from the upper ones: tile (ti, tj), ti > tj, is
+// sign * conj(tile (tj, ti))^T; the 16 x 16 transposition goes through an LDS scratch tile.
+template <int NB>
+__device__ __forceinline__ void mirror_lower(CMat<NB>& m, double sign, double* scratch) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+    double* sre = scratch;
+    double* sim = scratch + 16 * 18;
+#pragma unroll
+    for (int ti = 1; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < ti; ++tj) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // element (4r+q, c) of the upper tile -> slot [c][4r+q]
+                sre[c * 18 + 4 * r + q] = m.re[tj][ti][r];
+                sim[c * 18 + 4 * r + q] = m.im[tj][ti][r];
+            }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                m.re[ti][tj][r] = sign * sre[(4 * r + q) * 18 + c];
+                m.im[ti][tj][r] = -sign * sim[(4 * r + q) * 18 + c];
+            }
+        }
+}
+
+// The body of K1a; `gen(a)` builds the unscaled generator in C-layout. HERM: the generator is
+// exactly skew-Hermitian (Hermitian H), so a^2, a^4, a^6, w2 and v are Hermitian and u = a w2 is
+// skew-Hermitian: only the upper tiles of the six products are computed.
+template <int NB, bool HERM, class Gen>
 __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* smem) {
     typedef Geo<NB> G;
+    constexpr bool UP = HERM && NB > 1;
     double* lre = reinterpret_cast<double*>(smem);
     double* lim = lre + G::PLANE;
+    double* lsum = lim + G::PLANE;
+    double* mscr = lsum + G::PLANE;
     const int lane = lane_id();
 
     // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
@@ -90,31 +217,46 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
 
     // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
     CMat<NB> x2, x4, x6;
-    cmat_to_lds<NB>(a, lre, lim);
+    cmat_to_lds3<NB>(a, lre, lim, lsum);
     wave_sync();
-    cmat_zero<NB>(x2);
-    zgemm_acc<NB>(x2, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        bre = a.re[kk >> 2][tj][kk & 3];
-        bim = a.im[kk >> 2][tj][kk & 3];
-    });
+    {
+        CAcc3<NB> acc;
+        acc3_zero<NB>(acc);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            bre = a.re[kk >> 2][tj][kk & 3];
+            bim = a.im[kk >> 2][tj][kk & 3];
+        });
+        acc3_finish<NB>(x2, acc);
+        if (UP) mirror_lower<NB>(x2, 1.0, mscr);
+    }
     wave_sync();
-    cmat_to_lds<NB>(x2, lre, lim);
+    cmat_to_lds3<NB>(x2, lre, lim, lsum);
     wave_sync();
-    cmat_zero<NB>(x4);
-    zgemm_acc<NB>(x4, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        bre = x2.re[kk >> 2][tj][kk & 3];
-        bim = x2.im[kk >> 2][tj][kk & 3];
-    });
-    cmat_zero<NB>(x6);
-    zgemm_acc<NB>(x6, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        bre = x4.re[kk >> 2][tj][kk & 3];
-        bim = x4.im[kk >> 2][tj][kk & 3];
-    });
+    {
+        CAcc3<NB> acc;
+        acc3_zero<NB>(acc);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            bre = x2.re[kk >> 2][tj][kk & 3];
+            bim = x2.im[kk >> 2][tj][kk & 3];
+        });
+        acc3_finish<NB>(x4, acc);
+        if (UP) mirror_lower<NB>(x4, 1.0, mscr);
+    }
+    {
+        CAcc3<NB> acc;
+        acc3_zero<NB>(acc);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            bre = x4.re[kk >> 2][tj][kk & 3];
+            bim = x4.im[kk >> 2][tj][kk & 3];
+        });
+        acc3_finish<NB>(x6, acc);
+        if (UP) mirror_lower<NB>(x6, 1.0, mscr);
+    }
     wave_sync();
 
     // ---- w2 = a6 (b13 a6 + b11 a4 + b9 a2) + b7 a6 + b5 a4 + b3 a2 (expm.py:157) ---------
     // ---- v  = a6 (b12 a6 + b10 a4 + b8 a2) + b6 a6 + b4 a4 + b2 a2 + b0 I (expm.py:158) --
-    cmat_to_lds<NB>(x6, lre, lim);
+    cmat_to_lds3<NB>(x6, lre, lim, lsum);
     wave_sync();
     const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
                  b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
@@ -135,22 +277,34 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
                     if (4 * r + q == c) v.re[ti][tj][r] += b0;
             }
         }
-    zgemm_acc<NB>(w2, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        const int tb = kk >> 2, r = kk & 3;
-        bre = b13 * x6.re[tb][tj][r] + b11 * x4.re[tb][tj][r] + b9 * x2.re[tb][tj][r];
-        bim = b13 * x6.im[tb][tj][r] + b11 * x4.im[tb][tj][r] + b9 * x2.im[tb][tj][r];
-    });
-    zgemm_acc<NB>(v, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        const int tb = kk >> 2, r = kk & 3;
-        bre = b12 * x6.re[tb][tj][r] + b10 * x4.re[tb][tj][r] + b8 * x2.re[tb][tj][r];
-        bim = b12 * x6.im[tb][tj][r] + b10 * x4.im[tb][tj][r] + b8 * x2.im[tb][tj][r];
-    });
+    {
+        CAcc3<NB> acc;
+        acc3_init<NB>(acc, w2);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            const int tb = kk >> 2, r = kk & 3;
+            bre = b13 * x6.re[tb][tj][r] + b11 * x4.re[tb][tj][r] + b9 * x2.re[tb][tj][r];
+            bim = b13 * x6.im[tb][tj][r] + b11 * x4.im[tb][tj][r] + b9 * x2.im[tb][tj][r];
+        });
+        acc3_finish<NB>(w2, acc);
+        if (UP) mirror_lower<NB>(w2, 1.0, mscr);
+    }
+    {
+        CAcc3<NB> acc;
+        acc3_init<NB>(acc, v);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            const int tb = kk >> 2, r = kk & 3;
+            bre = b12 * x6.re[tb][tj][r] + b10 * x4.re[tb][tj][r] + b8 * x2.re[tb][tj][r];
+            bim = b12 * x6.im[tb][tj][r] + b10 * x4.im[tb][tj][r] + b8 * x2.im[tb][tj][r];
+        });
+        acc3_finish<NB>(v, acc);
+        if (UP) mirror_lower<NB>(v, 1.0, mscr);
+    }
     wave_sync();
 
     // ---- u = a w2 + b1 a (expm.py:157) ; P = v - u ; Q = v + u (expm.py:246) ---------------
     gen(a);
     if (sq > 0) cmat_scale<NB>(a, scale);
-    cmat_to_lds<NB>(a, lre, lim);
+    cmat_to_lds3<NB>(a, lre, lim, lsum);
     wave_sync();
     CMat<NB> u;
 #pragma unroll
@@ -160,10 +314,16 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
             u.re[ti][tj] = b1 * a.re[ti][tj];
             u.im[ti][tj] = b1 * a.im[ti][tj];
         }
-    zgemm_acc<NB>(u, lre, lim, [&](int kk, int tj, double& bre, double& bim) {
-        bre = w2.re[kk >> 2][tj][kk & 3];
-        bim = w2.im[kk >> 2][tj][kk & 3];
-    });
+    {
+        CAcc3<NB> acc;
+        acc3_init<NB>(acc, u);
+        zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+            bre = w2.re[kk >> 2][tj][kk & 3];
+            bim = w2.im[kk >> 2][tj][kk & 3];
+        });
+        acc3_finish<NB>(u, acc);
+        if (UP) mirror_lower<NB>(u, -1.0, mscr);
+    }
     wave_sync();
 
     // C-layout -> LDS -> R-layout -> column-major images (one contiguous KiB per store)
@@ -191,7 +351,7 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
     lds_to_image<NB>(lre, lim, out.p_img);
 }
 
-template <int NB>
+template <int NB, bool HERM>
 __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -246,7 +406,7 @@ __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
                 a.im[ti][tj] = -dt * hm.re[ti][tj];
             }
     };
-    pade_pq_body<NB>(gen, out, smem);
+    pade_pq_body<NB, HERM>(gen, out, smem);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
@@ -280,7 +440,7 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
                     a.im[ti][tj][r] = e.y;
                 }
     };
-    pade_pq_body<NB>(gen, out, smem);
+    pade_pq_body<NB, false>(gen, out, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1227,12 +1387,36 @@ __global__ __launch_bounds__(64) void selftest_kernel(double* out) {
     out[448 + lane] = dpp_f64<0x140>(v);
 }
 
+// Sustained FP64 MFMA rate: every wave issues `iters` rounds of 8 independent
+// v_mfma_f64_16x16x4_f64 chains from registers, nothing else. Calibrates the roofline peak.
+__global__ __launch_bounds__(64) void mfma_peak_kernel(double* out, int iters) {
+    const double a = 1.0 + 1e-9 * lane_id(), b = 1.0 - 1e-9 * lane_id();
+    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    for (int it = 0; it < iters; ++it) {
+        c0 = mfma_f64(a, b, c0);
+        c1 = mfma_f64(a, b, c1);
+        c2 = mfma_f64(a, b, c2);
+        c3 = mfma_f64(a, b, c3);
+        c4 = mfma_f64(a, b, c4);
+        c5 = mfma_f64(a, b, c5);
+        c6 = mfma_f64(a, b, c6);
+        c7 = mfma_f64(a, b, c7);
+    }
+    const d4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = 1.0;  // keeps the chains alive
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int NB>
 static void launch_pq_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(pade_pq_kernel<NB>, dim3(nsteps, batch), dim3(64), PqLds<NB>::BYTES, st, a);
+    if (a.hermitian)
+        hipLaunchKernelGGL((pade_pq_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
+                           PqLds<NB>::BYTES, st, a);
+    else
+        hipLaunchKernelGGL((pade_pq_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
+                           PqLds<NB>::BYTES, st, a);
 }
 template <int NB>
 static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
@@ -1287,6 +1471,9 @@ void launch_scatter(const ScatterArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.B * a.nc * a.K;
     if (total == 0) return;
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(64), 0, st, out, iters);
 }
 void launch_selftest(double* out, hipStream_t st) {
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, out);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "qocx_debug_pade_factor": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p, _c_double_p,
                                               _c_double_p, _c_int_p, _c_double_p, _c_int_p]),
     "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
+    "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
 }
 
 _lib = None
@@ -395,6 +396,13 @@ class Engine(object):
             self._ctx, count, n, _dp(a), _dp(q), _dp(lu), perm.ctypes.data_as(_c_int_p),
             _dp(dinv), s.ctypes.data_as(_c_int_p)))
         return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s)
+
+    def mfma_peak(self, waves_per_simd=1, iters=20000):
+        """Sustained FP64 MFMA TFLOP/s of a register-only MFMA loop (roofline calibration)."""
+        out = ctypes.c_double(0)
+        self._check(self._lib.qocx_debug_mfma_peak(self._ctx, int(waves_per_simd), int(iters),
+                                                   ctypes.byref(out)))
+        return out.value
 
     def selftest(self):
         failures = ctypes.c_int32(0)
