@@ -720,8 +720,22 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                                       : ((size_t)bc * nsteps >= 16384 && nsteps >= 64 ? 8 : 1);
         nseg = std::max(1, std::min(std::min(nseg, max_seg), nsteps));
         hipStream_t ss = (nseg == 1) ? cs : ctx->sweep_streams[0];
+        // segment boundaries; the last two segments are shorter, because the forward sweep of the
+        // last segment and the adjoint sweep of the first one it revisits are exposed
         std::vector<int> lo(nseg + 1);
-        for (int i = 0; i <= nseg; ++i) lo[i] = (int)((long long)nsteps * i / nseg);
+        {
+            std::vector<double> wgt(nseg, 1.0);
+            if (nseg >= 4) { wgt[nseg - 2] = 0.6; wgt[nseg - 1] = 0.35; }
+            double tot = 0, run = 0;
+            for (double w : wgt) tot += w;
+            lo[0] = 0;
+            for (int i = 0; i < nseg; ++i) {
+                run += wgt[i];
+                lo[i + 1] = std::max(lo[i] + 1, (int)llround(nsteps * run / tot));
+            }
+            lo[nseg] = nsteps;
+            for (int i = nseg - 1; i > 0; --i) lo[i] = std::min(lo[i], lo[i + 1] - 1);
+        }
 
         qocx::FactorArgs fa;
         fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
