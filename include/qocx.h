@@ -163,6 +163,16 @@ int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep); /* before the evalua
 int qocx_download_step_states(qocx_ctx* ctx, double* states_out);
 
 /*
+ * Cotangents of the states supplied by the host, for Cost plugins whose derivative the engine
+ * does not know (the reference obtains it from autograd, schroedingerdiscrete.py:412-416,
+ * :429-432): bars [B][count][S][n] complex = d cost / d Re(psi) + i d cost / d Im(psi) of the
+ * states at system steps steps[c] (1..N-1; N-1 = final states). They are added to the adjoint
+ * sweep of every following evaluation of the same batch size; count = 0 clears them.
+ */
+int qocx_set_state_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
+                              const double* bars);
+
+/*
  * Lindblad path: B calls of _evaluate_lindblad_discrete (+ gradient), lindbladdiscrete.py:321-322,
  * :357-441. The device integrates the same master equation with a fixed-step DOP853 scheme
  * and its exact discrete adjoint (parity tolerances there).

@@ -28,6 +28,62 @@ def make_backend(device=-1):
     return Engine(device)
 
 
+_FD_STEP = 1e-6
+
+
+def user_states_bar(cost, controls, states, step):
+    """
+    d cost / d Re(states) + i d cost / d Im(states) of a user Cost: its states_bar() hook when it
+    has one, else central differences of cost() (4 evaluations per state component; the
+    reference gets this from autograd).
+    """
+    hook = getattr(cost, "states_bar", None)
+    if hook is not None:
+        out = hook(controls, states, step)
+        if out is not None:
+            return np.asarray(out, dtype=np.complex128).reshape(states.shape)
+    states = np.array(states, dtype=np.complex128)
+    out = np.zeros_like(states)
+    flat, oflat = states.reshape(-1), out.reshape(-1)
+    for idx in range(flat.size):
+        keep = flat[idx]
+        h = _FD_STEP * max(1.0, abs(keep))
+        vals = []
+        for delta in (h, -h, 1j * h, -1j * h):
+            flat[idx] = keep + delta
+            vals.append(cost.cost(controls, states, step))
+        flat[idx] = keep
+        oflat[idx] = (vals[0] - vals[1]) / (2 * h) + 1j * (vals[2] - vals[3]) / (2 * h)
+    return out
+
+
+def user_controls_bar(cost, controls, states, step):
+    """The same for the explicit dependence of a user Cost on the controls (`uses_controls = False`
+    on the class skips it; a controls_bar() hook replaces the finite differences)."""
+    if getattr(cost, "uses_controls", True) is False:
+        return 0.0
+    hook = getattr(cost, "controls_bar", None)
+    if hook is not None:
+        out = hook(controls, states, step)
+        if out is not None:
+            return np.asarray(out)
+    controls = np.array(controls)
+    out = np.zeros(controls.shape, dtype=np.complex128)
+    flat, oflat = controls.reshape(-1), out.reshape(-1)
+    deltas = (1.0, 1j) if np.iscomplexobj(controls) else (1.0,)
+    for idx in range(flat.size):
+        keep = flat[idx]
+        h = _FD_STEP * max(1.0, abs(keep))
+        for d in deltas:
+            flat[idx] = keep + d * h
+            up = cost.cost(controls, states, step)
+            flat[idx] = keep - d * h
+            down = cost.cost(controls, states, step)
+            oflat[idx] += d * (up - down) / (2 * h)
+        flat[idx] = keep
+    return out
+
+
 class SchroedingerEvaluator(object):
     def __init__(self, evolution_time, hamiltonian, initial_states, system_eval_count,
                  control_count=0, control_eval_count=0, complex_controls=False, costs=(),
@@ -65,13 +121,6 @@ class SchroedingerEvaluator(object):
                 self.host_costs.append(cost)
             else:
                 self.opaque_costs.append(cost)
-        if need_gradients:
-            for cost in self.opaque_costs:
-                raise NotImplementedError(
-                    "cost {} provides neither device_descriptor() nor a controls-only "
-                    "controls_bar(): the reference differentiates it with autograd, which this "
-                    "engine replaces by hand-derived adjoints (see qoc_amd.models.Cost)."
-                    "".format(cost))
         self.backend = backend if backend is not None else make_backend()
         self.kr = control_count * (2 if complex_controls else 1)
         self.backend.set_schroedinger_problem(
@@ -108,27 +157,64 @@ class SchroedingerEvaluator(object):
         if need_steps:
             self.backend.set_keep_step_states(True)
         self.backend.upload_controls(device_controls)
-        self.backend.eval_resident(want_grad)
-        cost, grads, final = self.backend.download_results(want_grad=want_grad)
+        two_pass = want_grad and bool(self.opaque_costs)
+        self.backend.eval_resident(want_grad and not two_pass)
+        cost, grads, final = self.backend.download_results(want_grad=want_grad and not two_pass)
         step_states = None
         if need_steps:
             step_states = self.backend.download_step_states()[..., None]
             self.backend.set_keep_step_states(False)
+        opaque_grads = None
+        if two_pass:
+            # User costs without a device descriptor: the host supplies the cotangent of the
+            # states at every cost step (the cost's own states_bar() hook, else central
+            # differences of its cost()), the engine's adjoint sweep carries it back.
+            steps, bars, opaque_grads = self._opaque_cotangents(controls_batch, step_states)
+            self.backend.set_state_cotangents(steps, bars)
+            try:
+                self.backend.eval_resident(True)
+                cost, grads, final = self.backend.download_results(want_grad=True)
+            finally:
+                self.backend.set_state_cotangents(None, None)
         errors = np.array(cost, dtype=np.float64)
         final = final[..., None]
         if grads is not None:
             grads = structure.from_real_gradients(grads, self.complex_controls)
             if not self.complex_controls:
                 grads = np.array(grads, dtype=np.float64)
+            if opaque_grads is not None:
+                grads = grads + (opaque_grads if self.complex_controls
+                                 else np.real(opaque_grads))
         for b in range(batch):
             controls = None if self.control_count == 0 else controls_batch[b]
             value, host_grad = self._host_terms(controls, want_grad)
             errors[b] += value
             if host_grad is not None:
                 grads[b] = grads[b] + host_grad
-            for cost in self.opaque_costs:  # forward only: host evaluates the user's cost()
+            for cost in self.opaque_costs:  # the host evaluates the user's cost()
                 errors[b] += self._opaque_value(cost, controls, step_states[b])
         return errors, grads, final, step_states
+
+    def _cost_steps(self, cost):
+        if not cost.requires_step_evaluation:
+            return [self.final_system_eval_step]
+        return list(range(self.cost_eval_step, self.system_eval_count, self.cost_eval_step))
+
+    def _opaque_cotangents(self, controls_batch, step_states):
+        """(steps, bars[B, len(steps), S, n], control_grads[B, Nc, K] complex) of the user costs."""
+        steps = sorted({st for c in self.opaque_costs for st in self._cost_steps(c)})
+        row = {st: r for r, st in enumerate(steps)}
+        batch = controls_batch.shape[0]
+        bars = np.zeros((batch, len(steps), self.state_count, self.hilbert_size),
+                        dtype=np.complex128)
+        cgrads = np.zeros(controls_batch.shape, dtype=np.complex128)
+        for b in range(batch):
+            for cost in self.opaque_costs:
+                for st in self._cost_steps(cost):
+                    states = step_states[b][st]
+                    bars[b, row[st]] += user_states_bar(cost, controls_batch[b], states, st)[:, :, 0]
+                    cgrads[b] += user_controls_bar(cost, controls_batch[b], states, st)
+        return steps, bars, cgrads
 
     def _opaque_value(self, cost, controls, states_by_step):
         if not cost.requires_step_evaluation:

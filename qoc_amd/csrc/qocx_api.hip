@@ -147,6 +147,10 @@ struct qocx_ctx {
     int split_lu = 0;   // QOCX_SPLIT_LU=1 moves K1b to its own stream (measured: no gain)
     int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
+    // ---- host-supplied state cotangents ----
+    int inj_count = 0, inj_batch = 0;
+    DevBuf<int> inj_index;
+    DevBuf<double2> inj_bars;
     struct Lindblad {
         bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
         int n = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nops = 0;
@@ -364,6 +368,8 @@ int qocx_destroy(qocx_ctx* ctx) {
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     ctx->m_rm.release();
     ctx->lam_buf.release();
+    ctx->inj_index.release();
+    ctx->inj_bars.release();
     ctx->mbar_rm.release();
     ctx->magnus_scratch.release();
     DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
@@ -600,6 +606,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     ctx->has_problem = true;
     ctx->have_results = false;
     ctx->B = 0;
+    ctx->inj_count = 0;
     return 0;
 }
 
@@ -645,6 +652,34 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
     return 0;
 }
 
+int qocx_set_state_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
+                              const double* bars) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (!ctx->has_problem) return fail(QOCX_ERR_STATE, "no problem set");
+    if (count <= 0) {
+        ctx->inj_count = 0;
+        return 0;
+    }
+    if (batch < 1 || !steps || !bars) return fail(QOCX_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->n, np = ctx->np, S = ctx->S, nsteps = ctx->nsteps;
+    std::vector<int> index(nsteps + 1, -1);
+    for (int c = 0; c < count; ++c) {
+        if (steps[c] < 1 || steps[c] > nsteps || index[steps[c]] >= 0)
+            return fail(QOCX_ERR_ARG, "cotangent steps must be distinct and in 1..N-1");
+        index[steps[c]] = c;
+    }
+    std::vector<double2> padded((size_t)batch * count * S * np, make_double2(0, 0));
+    for (size_t v = 0; v < (size_t)batch * count * S; ++v)
+        for (int i = 0; i < n; ++i)
+            padded[v * np + i] = make_double2(bars[2 * (v * n + i)], bars[2 * (v * n + i) + 1]);
+    if (ctx->inj_index.upload(index, ctx->stream) || ctx->inj_bars.upload(padded, ctx->stream))
+        return QOCX_ERR_HIP;
+    ctx->inj_count = count;
+    ctx->inj_batch = batch;
+    return 0;
+}
+
 int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
     ctx->chunk_user = seeds_per_chunk < 0 ? 0 : seeds_per_chunk;
@@ -669,6 +704,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     HIP_TRY(hipSetDevice(ctx->device));
     const int B = ctx->B, np = ctx->np, mat = np * np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
     want_grad = (want_grad && K > 0) ? 1 : 0;
+    if (ctx->inj_count > 0 && ctx->inj_batch != B)
+        return fail(QOCX_ERR_STATE, "state cotangents were set for a different batch size");
 
     // chunk size from the memory budget
     const size_t per_seed = (size_t)nsteps * ((size_t)mat * 32 + (size_t)np * 20 + 4) +
@@ -771,6 +808,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                              ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
         sa.status = ctx->status.p;
         sa.lam_buf = ctx->lam_buf.p;
+        sa.inj_count = ctx->inj_count;
+        sa.inj_index = ctx->inj_count > 0 ? ctx->inj_index.p : nullptr;
+        sa.inj_bars = ctx->inj_count > 0
+                          ? ctx->inj_bars.p + (size_t)b0 * ctx->inj_count * S * np : nullptr;
 
         // ---- factor + forward sweep, segment by segment ------------------------------------
         for (int i = 0; i < nseg; ++i) {

@@ -70,6 +70,12 @@ struct SweepArgs {
     // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).
     int phase, j_begin, j_end;
     double2* lam_buf;     // [B][S][NP]
+    // Externally supplied state cotangents (user Cost plugins whose derivative the host
+    // provides): inj_index[step] = row of inj_bars or -1; added to lambda at system step `step`
+    // (the states before evolving from it; step N-1 = the final states).
+    const int* inj_index;     // [nsteps + 1] or nullptr
+    const double2* inj_bars;  // [B][inj_count][S][NP]
+    int inj_count;
     size_t slot_cap;      // sub-step slots per seed
     // costs
     int cost_count;

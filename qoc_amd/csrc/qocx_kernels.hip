@@ -1012,6 +1012,22 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     }
     if (!do_bwd) return;
 
+    // lambda += host-supplied cotangent of the states at system step `step`, if there is one
+    auto inject = [&](int step) {
+        if (args.inj_index == nullptr) return;
+        const int row = args.inj_index[step];
+        if (row < 0) return;
+        if (g0)
+            for (int s = 0; s < S; ++s) {
+                const double2 e = args.inj_bars[(((size_t)b * args.inj_count + row) * S + s) * NP + i];
+                double2 l = lam[s * NP + i];
+                l.x += e.x;
+                l.y += e.y;
+                lam[s * NP + i] = l;
+            }
+        wave_sync();
+    };
+
     // ---- adjoint sweep ---------------------------------------------------------------------
     if (je == nsteps) {
         if (!do_fwd) {  // final states of the forward segments
@@ -1025,6 +1041,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         // cotangent seeds on the final states: non-step costs, and step costs if the final step
         // is a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
         (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+        inject(nsteps);
     } else {  // resume the adjoint sweep below step je
         slot = offs_b[je];
         for (int s = 0; s < S; ++s)
@@ -1082,6 +1099,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             wave_sync();
             (void)eval_costs<NB>(args, true, false, vecs, lam, h, i);
         }
+        if (step != 0) inject(step);
     };
     {
         const size_t ml = m0 + je - 1;

@@ -85,6 +85,7 @@ SIGNATURES = {
     "qocx_eval_lindblad": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
                                           _c_double_p, _c_double_p]),
     "qocx_download_step_densities": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_set_state_cotangents": (ctypes.c_int, [_VP, _I32, _I32, _c_int_p, _c_double_p]),
     "qocx_set_timing": (ctypes.c_int, [_VP, _I32]),
     "qocx_get_timing": (ctypes.c_int, [_VP, _I32, ctypes.POINTER(_I64), _c_double_p]),
     "qocx_reset_timing": (ctypes.c_int, [_VP]),
@@ -328,6 +329,18 @@ class Engine(object):
         out = np.empty((B, pr["N"], pr["S"], pr["n"], pr["n"]), dtype=np.complex128)
         self._check(self._lib.qocx_download_step_densities(self._ctx, _dp(out)))
         return out
+
+    def set_state_cotangents(self, steps, bars):
+        """bars :: (B, len(steps), S, n) complex cotangents of the states at system steps `steps`;
+        steps = None or empty clears them."""
+        if steps is None or len(steps) == 0:
+            self._check(self._lib.qocx_set_state_cotangents(self._ctx, 0, 0, None, None))
+            return
+        pr = self._problem
+        steps = np.ascontiguousarray(steps, dtype=np.int32)
+        bars = _as_complex(bars).reshape(-1, len(steps), pr["S"], pr["n"])
+        self._check(self._lib.qocx_set_state_cotangents(
+            self._ctx, bars.shape[0], len(steps), steps.ctypes.data_as(_c_int_p), _dp(bars)))
 
     def set_chunk(self, seeds_per_chunk):
         self._check(self._lib.qocx_set_chunk(self._ctx, int(seeds_per_chunk)))

@@ -6,16 +6,22 @@ Same contract as qoc/models/cost.py:5-51: class attributes `name`,
 `cost(controls, states, system_eval_step) -> scalar`, called with the WHOLE control array, the
 current (state_count x hilbert_size x 1) states and the integer system step.
 
-The reference differentiates `cost` with autograd. This package has no AD engine, so a cost
-that takes part in GRAPE also describes its derivative in one of two ways:
+The reference differentiates `cost` with autograd. This package has no AD engine; the
+derivative of a cost reaches the engine in one of these ways:
 
 * `device_descriptor(state_count, hilbert_size)` -> dict for the HIP engine (built-in state
-  costs: the value AND the cotangent are then evaluated on the GPU), or
+  costs: the value AND the cotangent are evaluated on the GPU);
 * `controls_bar(controls, states, system_eval_step)` -> d cost / d Re(controls) + i d cost /
-  d Im(controls) for costs that depend on the controls only (`uses_states = False`).
-
-A user subclass that provides neither can be used with evolve_* (forward only); grape_*
-rejects it with a clear error.
+  d Im(controls) for costs that depend on the controls only (`uses_states = False`);
+* any other subclass (a user's own cost of the states) works unchanged in the Schroedinger
+  GRAPE: the host evaluates `cost()` on the states the device returns and hands the engine the
+  cotangent of the states at every cost step - from the optional hook
+  `states_bar(controls, states, system_eval_step)` (d cost / d Re(states) + i d cost /
+  d Im(states)), else by central differences of `cost()`. The explicit dependence on the
+  controls is differentiated the same way (`controls_bar()` hook, or `uses_controls = False`
+  to declare there is none). The finite-difference route costs 4 * state_count * hilbert_size
+  evaluations of `cost()` per cost step and is accurate to ~1e-8; write the hooks for speed.
+  (The Lindblad GRAPE takes only the built-in density costs and controls-only costs so far.)
 """
 
 
@@ -23,6 +29,7 @@ class Cost(object):
     name = "parent_cost"
     requires_step_evaluation = False
     uses_states = True
+    uses_controls = True
 
     def __init__(self, cost_multiplier=1.):
         super().__init__()
@@ -43,4 +50,7 @@ class Cost(object):
         return None
 
     def controls_bar(self, controls, states, system_eval_step):
+        return None
+
+    def states_bar(self, controls, states, system_eval_step):
         return None

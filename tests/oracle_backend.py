@@ -59,6 +59,23 @@ class _DescriptorCost(onp.OracleCost):
         return out[:, :, None]
 
 
+class _InjectedCotangent(onp.OracleCost):
+    """Host-supplied state cotangents of one seed (qocx_set_state_cotangents): contributes no
+    cost, only states_bar at the given system steps."""
+
+    def __init__(self, by_step, step_cost):
+        super().__init__(1.0)
+        self.requires_step_evaluation = step_cost
+        self.by_step = by_step
+
+    def cost(self, controls, states, step):
+        return 0.0
+
+    def states_bar(self, controls, states, step):
+        bar = self.by_step.get(step)
+        return None if bar is None else bar[:, :, None]
+
+
 class _DensityDescriptorCost(object):
     """Oracle-side evaluation of a density cost descriptor (qocx.h kinds 3 and 4)."""
 
@@ -132,6 +149,32 @@ class OracleBackend(object):
     def set_keep_step_states(self, keep):
         self.keep = bool(keep)
 
+    def set_state_cotangents(self, steps, bars):
+        if steps is None or len(steps) == 0:
+            self.inj = None
+            return
+        n, S, K, Nc, N = self.dims
+        self.inj = (list(int(x) for x in steps),
+                    np.asarray(bars, dtype=np.complex128).reshape(-1, len(steps), S, n))
+
+    def _problem_for_seed(self, b):
+        inj = getattr(self, "inj", None)
+        if inj is None:
+            return self.problem
+        import copy
+        n, S, K, Nc, N = self.dims
+        steps, bars = inj
+        assert bars.shape[0] == self.batch
+        ces = self.problem.cost_eval_step
+        on_grid = {st: bars[b, r] for r, st in enumerate(steps) if st % ces == 0}
+        off_grid = {st: bars[b, r] for r, st in enumerate(steps) if st % ces != 0}
+        assert all(st == N - 1 for st in off_grid), "off-grid cotangents only at the final step"
+        p = copy.copy(self.problem)
+        p.costs = list(self.problem.costs) + [_InjectedCotangent(on_grid, True),
+                                              _InjectedCotangent(off_grid, False)]
+        p.step_costs = [c for c in p.costs if c.requires_step_evaluation]
+        return p
+
     def upload_controls(self, controls):
         n, S, K, Nc, N = self.dims
         if K == 0:
@@ -144,9 +187,9 @@ class OracleBackend(object):
         n, S, K, Nc, N = self.dims
         self.calls += 1
         self.cost, self.grads, self.final, self.steps = [], [], [], []
-        for u in self.controls:
+        for b, u in enumerate(self.controls):
             if want_grad and K > 0:
-                err, gr, fin = onp.evaluate_with_grad(self.problem, u)
+                err, gr, fin = onp.evaluate_with_grad(self._problem_for_seed(b), u)
                 self.grads.append(gr)
             else:
                 err, fin = onp.evaluate(self.problem, u)

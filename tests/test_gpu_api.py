@@ -97,3 +97,32 @@ def test_transmon_pi_pulse_example():
         optimizer=Adam(learning_rate=2e-2), max_control_norms=np.array([0.5]))
     assert result.best_error < 1e-3
     assert np.all(np.abs(result.best_controls) <= 0.5 + 1e-12)
+
+
+@pytest.mark.parametrize("with_hook", [True, False])
+def test_user_cost_in_grape_on_gpu(with_hook):
+    """Host-supplied state cotangents (qocx_set_state_cotangents) against the built-in cost."""
+    from qoc_amd.standard import ForbidStates
+    from tests.test_host_api import _UserOccupation
+    case = cases_mod.case_by_name("nc10_n101")
+    ces = 10
+    count = (case.N - 1) // ces
+    forb = np.zeros((1, 1, case.n, 1), dtype=np.complex128)
+    forb[0, 0, 1, 0] = 1
+    target = product_cost_list(case)
+    args = dict(control_count=case.K, control_eval_count=case.Nc, cost_eval_step=ces)
+    ev_ref = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N,
+        costs=target + [ForbidStates(forb, case.N, cost_eval_step=ces, cost_multiplier=0.7)],
+        **args)
+    ev_user = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N,
+        costs=target + [_UserOccupation(count, with_hook, cost_multiplier=0.7)], **args)
+    batch = np.stack(list(case.controls) + [0.5 * case.controls[0]])
+    e0, g0, f0, _ = ev_ref.evaluate_batch(batch)
+    e1, g1, f1, _ = ev_user.evaluate_batch(batch)
+    assert np.max(np.abs(e0 - e1)) < 1e-12 and rel_err(f1, f0) < 1e-12
+    assert rel_err(g1, g0) < (1e-11 if with_hook else 1e-7)
+    # a later evaluation without user costs is not affected by stale cotangents
+    e2, g2, _, _ = ev_ref.evaluate_batch(batch)
+    assert np.array_equal(e2, e0) and np.array_equal(g2, g0)

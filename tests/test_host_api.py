@@ -212,10 +212,6 @@ def test_evolve_with_user_cost_and_errors():
     expected = sum(abs(inter[s][0, 0, 0]) ** 2 * 1e-3 for s in range(10, case.N, 10))
     assert abs(r.error - expected) < 1e-12
     with pytest.raises(NotImplementedError):
-        qoc_amd.grape_schroedinger_discrete(case.K, case.Nc, [Population()], case.T,
-                                            case.hamiltonian(), case.initial_states, case.N,
-                                            iteration_count=1, log_iteration_step=0)
-    with pytest.raises(NotImplementedError):
         qoc_amd.evolve_schroedinger_discrete(case.T, case.hamiltonian(), case.initial_states,
                                              case.N, controls=case.controls[0],
                                              interpolation_policy="cubic")
@@ -301,3 +297,84 @@ def test_batch_evaluator_matches_single():
     g = golden(case.name)
     assert rel_err(errors, g["error"]) < 1e-11 and rel_err(grads, g["grads_ad"]) < 1e-9
     assert rel_err(final, g["final_states"]) < 1e-11
+
+
+# ---- user Cost plugins in GRAPE: host-supplied state cotangents ----------------------------------
+
+class _UserOccupation(Cost):
+    """What ForbidStates computes for one forbidden basis state, written as a user plugin."""
+    name = "user_occupation"
+    requires_step_evaluation = True
+    uses_controls = False
+
+    def __init__(self, count, with_hook, cost_multiplier=1.):
+        super().__init__(cost_multiplier)
+        self.count = count
+        self.with_hook = with_hook
+        self.calls = 0
+
+    def cost(self, controls, states, step):
+        self.calls += 1
+        return self.cost_multiplier / self.count * float(np.abs(states[0, 1, 0]) ** 2)
+
+    def states_bar(self, controls, states, step):
+        if not self.with_hook:
+            return None
+        out = np.zeros_like(states)
+        out[0, 1, 0] = 2 * self.cost_multiplier / self.count * states[0, 1, 0]
+        return out
+
+
+class _UserFinalPlusControls(Cost):
+    """A final-time cost that also depends on the controls explicitly (no hooks at all)."""
+    name = "user_final"
+    requires_step_evaluation = False
+
+    def cost(self, controls, states, step):
+        return float(np.real(states[0, 0, 0] * np.conj(states[0, 2, 0]))) + 0.01 * float(
+            np.sum(np.abs(controls) ** 2))
+
+
+@pytest.mark.parametrize("with_hook", [True, False])
+def test_grape_with_user_state_cost_matches_builtin(with_hook):
+    case = cases_mod.case_by_name("nc10_n101")
+    ces = 10
+    count = (case.N - 1) // ces
+    forb = np.zeros((1, 1, case.n, 1), dtype=np.complex128)
+    forb[0, 0, 1, 0] = 1
+    target = product_cost_list(case)
+    builtin = target + [ForbidStates(forb, case.N, cost_eval_step=ces, cost_multiplier=0.7)]
+    user = _UserOccupation(count, with_hook, cost_multiplier=0.7)
+    ev_ref = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N, control_count=case.K,
+        control_eval_count=case.Nc, costs=builtin, cost_eval_step=ces)
+    ev_user = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N, control_count=case.K,
+        control_eval_count=case.Nc, costs=target + [user], cost_eval_step=ces)
+    e0, g0, f0, _ = ev_ref.evaluate(case.controls[0])
+    e1, g1, f1, _ = ev_user.evaluate(case.controls[0])
+    assert abs(e0 - e1) < 1e-13 and rel_err(f1, f0) < 1e-13
+    assert rel_err(g1, g0) < (1e-12 if with_hook else 1e-7)
+    if not with_hook:
+        assert user.calls > 4 * case.n * count  # finite differences of cost()
+    # and the whole entry point runs with it
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, target + [user], case.T, case.hamiltonian(), case.initial_states,
+        case.N, cost_eval_step=ces, initial_controls=case.controls[0], iteration_count=3,
+        log_iteration_step=0, max_control_norms=np.array([5.0, 5.0]))
+    assert result.best_error <= e1 + 1e-12
+
+
+def test_user_cost_with_explicit_control_dependence():
+    case = cases_mod.case_by_name("ctrlcosts_r")
+    cost = _UserFinalPlusControls()
+    ev = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N, control_count=case.K,
+        control_eval_count=case.Nc, costs=[cost])
+    u = case.controls[0]
+    err, grads, _, _ = ev.evaluate(u)
+    rng = np.random.default_rng(2)
+    d = rng.standard_normal(u.shape)
+    h = 1e-5
+    fd = (ev.evaluate(u + h * d, want_grad=False)[0] - ev.evaluate(u - h * d, want_grad=False)[0]) / (2 * h)
+    assert abs(fd - np.sum(grads * d)) < 1e-7 * max(1.0, abs(fd))
