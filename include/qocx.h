@@ -183,6 +183,9 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* proble
 int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
                        double* cost_out, double* grad_out, double* final_out);
 int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out);
+/* The Lindblad twin of qocx_set_state_cotangents: bars [B][count][S][n][n] complex. */
+int qocx_set_density_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
+                                const double* bars);
 
 /* Per-kernel timing, measured with HIP events on the context's stream.
  * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`

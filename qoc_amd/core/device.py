@@ -278,12 +278,6 @@ class LindbladEvaluator(object):
                 self.host_costs.append(cost)
             else:
                 self.opaque_costs.append(cost)
-        if need_gradients and self.opaque_costs:
-            raise NotImplementedError(
-                "cost {} provides neither device_descriptor() nor a controls-only "
-                "controls_bar(): the reference differentiates it with autograd, which this "
-                "engine replaces by hand-derived adjoints (see qoc_amd.models.Cost)."
-                "".format(self.opaque_costs[0]))
         self.backend = backend if backend is not None else make_backend()
         self.kr = control_count * (2 if complex_controls else 1)
         self.backend.set_lindblad_problem(
@@ -305,20 +299,33 @@ class LindbladEvaluator(object):
             batch = controls_batch.shape[0]
             device_controls = structure.to_real_controls(controls_batch, self.complex_controls)
         need_steps = want_step_densities or bool(self.opaque_costs)
+        two_pass = want_grad and bool(self.opaque_costs)
         if need_steps:
             self.backend.set_keep_step_states(True)
         try:
-            cost, grads, final = self.backend.evaluate_lindblad(device_controls,
-                                                                want_grad=want_grad)
+            cost, grads, final = self.backend.evaluate_lindblad(
+                device_controls, want_grad=want_grad and not two_pass)
             step_densities = self.backend.download_step_densities() if need_steps else None
         finally:
             if need_steps:
                 self.backend.set_keep_step_states(False)
+        opaque_grads = None
+        if two_pass:  # user costs: host-supplied density cotangents (see SchroedingerEvaluator)
+            steps, bars, opaque_grads = self._opaque_cotangents(controls_batch, step_densities)
+            self.backend.set_density_cotangents(steps, bars)
+            try:
+                cost, grads, final = self.backend.evaluate_lindblad(device_controls,
+                                                                    want_grad=True)
+            finally:
+                self.backend.set_density_cotangents(None, None)
         errors = np.array(cost, dtype=np.float64)
         if grads is not None:
             grads = structure.from_real_gradients(grads, self.complex_controls)
             if not self.complex_controls:
                 grads = np.array(grads, dtype=np.float64)
+            if opaque_grads is not None:
+                grads = grads + (opaque_grads if self.complex_controls
+                                 else np.real(opaque_grads))
         for b in range(batch):
             controls = None if self.control_count == 0 else controls_batch[b]
             for cost_ in self.host_costs:
@@ -328,15 +335,30 @@ class LindbladEvaluator(object):
                     if bar is None:
                         raise NotImplementedError("cost {} has no controls_bar()".format(cost_))
                     grads[b] = grads[b] + bar
-            for cost_ in self.opaque_costs:  # forward only: host evaluates the user's cost()
-                if not cost_.requires_step_evaluation:
-                    errors[b] += cost_.cost(controls, step_densities[b][-1],
-                                            self.final_system_eval_step)
-                else:
-                    for step in range(self.cost_eval_step, self.system_eval_count,
-                                      self.cost_eval_step):
-                        errors[b] += cost_.cost(controls, step_densities[b][step], step)
+            for cost_ in self.opaque_costs:  # the host evaluates the user's cost()
+                for step in self._cost_steps(cost_):
+                    errors[b] += cost_.cost(controls, step_densities[b][step], step)
         return errors, grads, final, step_densities
+
+    def _cost_steps(self, cost):
+        if not cost.requires_step_evaluation:
+            return [self.final_system_eval_step]
+        return list(range(self.cost_eval_step, self.system_eval_count, self.cost_eval_step))
+
+    def _opaque_cotangents(self, controls_batch, step_densities):
+        steps = sorted({st for c in self.opaque_costs for st in self._cost_steps(c)})
+        row = {st: r for r, st in enumerate(steps)}
+        batch = controls_batch.shape[0]
+        bars = np.zeros((batch, len(steps), self.density_count, self.hilbert_size,
+                         self.hilbert_size), dtype=np.complex128)
+        cgrads = np.zeros(controls_batch.shape, dtype=np.complex128)
+        for b in range(batch):
+            for cost in self.opaque_costs:
+                for st in self._cost_steps(cost):
+                    dens = step_densities[b][st]
+                    bars[b, row[st]] += user_states_bar(cost, controls_batch[b], dens, st)
+                    cgrads[b] += user_controls_bar(cost, controls_batch[b], dens, st)
+        return steps, bars, cgrads
 
     def evaluate(self, controls, want_grad=True, want_step_densities=False):
         batch = None if controls is None else np.asarray(controls)[None]

@@ -172,6 +172,12 @@ struct qocx_ctx {
         // per evaluation
         int B = 0;
         std::vector<int> order;  // device position -> seed
+        // host-supplied density cotangents
+        int inj_count = 0, inj_batch = 0;
+        std::vector<int> inj_steps;
+        std::vector<double> inj_host;  // [B][count][S][n][n] complex
+        DevBuf<int> inj_index;
+        DevBuf<double2> inj_bars;
         DevBuf<double> gsub, cost_out, grads, controls;
         DevBuf<double2> checkpoints, final_out, step_densities;
     } lb;
@@ -401,6 +407,8 @@ int qocx_destroy(qocx_ctx* ctx) {
             kv.second.col.release();
             kv.second.weight.release();
         }
+        lb.inj_index.release();
+        lb.inj_bars.release();
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_pq) (void)hipEventDestroy(e);
@@ -1194,6 +1202,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     lb.grids.clear();
     lb.has_problem = true;
     lb.have_results = false;
+    lb.inj_count = 0;
     return 0;
 }
 
@@ -1339,6 +1348,22 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         HIP_TRY(hipMemcpyAsync(lb.controls.p, gathered.data(), gathered.size() * sizeof(double),
                                hipMemcpyHostToDevice, ctx->stream));
     }
+    if (lb.inj_count > 0) {
+        if (lb.inj_batch != B)
+            return fail(QOCX_ERR_STATE, "density cotangents were set for a different batch size");
+        std::vector<int> index(nsteps + 1, -1);
+        for (int c = 0; c < lb.inj_count; ++c) index[lb.inj_steps[c]] = c;
+        const size_t per_seed = (size_t)lb.inj_count * S;
+        std::vector<double2> dumps((size_t)B * per_seed * 256);
+        for (int pos = 0; pos < B; ++pos)
+            for (size_t v = 0; v < per_seed; ++v) {
+                cmat m(lb.inj_host.begin() + (((size_t)lb.order[pos] * per_seed + v) * n * n * 2),
+                       lb.inj_host.begin() + (((size_t)lb.order[pos] * per_seed + v + 1) * n * n * 2));
+                c_dump(m, n, dumps.data() + ((size_t)pos * per_seed + v) * 256);
+            }
+        if (lb.inj_index.upload(index, ctx->stream) || lb.inj_bars.upload(dumps, ctx->stream))
+            return QOCX_ERR_HIP;
+    }
     size_t pos0 = 0, ckpt_off = 0, gsub_off = 0;
     for (auto& kv : groups) {
         const auto& gr = lb.grids[kv.first];
@@ -1357,6 +1382,9 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         la.final_out = lb.final_out.p + pos0 * S * 256;
         la.step_densities = ctx->keep_step_states
                                 ? lb.step_densities.p + pos0 * (nsteps + 1) * S * 256 : nullptr;
+        la.inj_count = lb.inj_count;
+        la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
+        la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * 256 : nullptr;
         time_begin(ctx, 5, ctx->stream);
         qocx::launch_lindblad(la, Bg, ctx->stream);
         time_end(ctx, ctx->stream);
@@ -1399,6 +1427,29 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     lb.B = B;
     lb.have_results = true;
     lb.have_steps = ctx->keep_step_states != 0;
+    return 0;
+}
+
+int qocx_set_density_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
+                                const double* bars) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    auto& lb = ctx->lb;
+    if (!lb.has_problem) return fail(QOCX_ERR_STATE, "no Lindblad problem set");
+    if (count <= 0) {
+        lb.inj_count = 0;
+        return 0;
+    }
+    if (batch < 1 || !steps || !bars) return fail(QOCX_ERR_ARG, "bad argument");
+    std::vector<bool> seen(lb.nsteps + 1, false);
+    for (int c = 0; c < count; ++c) {
+        if (steps[c] < 1 || steps[c] > lb.nsteps || seen[steps[c]])
+            return fail(QOCX_ERR_ARG, "cotangent steps must be distinct and in 1..N-1");
+        seen[steps[c]] = true;
+    }
+    lb.inj_steps.assign(steps, steps + count);
+    lb.inj_host.assign(bars, bars + (size_t)batch * count * lb.S * lb.n * lb.n * 2);
+    lb.inj_count = count;
+    lb.inj_batch = batch;
     return 0;
 }
 

@@ -173,6 +173,9 @@ struct LindbladArgs {
     double* cost_out;          // [B]
     double2* final_out;        // [B][S] C-dumps
     double2* step_densities;   // [B][nsteps+1][S] C-dumps or nullptr
+    const int* inj_index;      // host-supplied density cotangents (see SweepArgs): [nsteps + 1]
+    const double2* inj_bars;   // [B][inj_count][S] C-dumps
+    int inj_count;
 };
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);

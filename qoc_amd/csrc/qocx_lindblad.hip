@@ -463,6 +463,21 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     }
     wave_sync();
     (void)density_costs(a, (a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+    // lambda += host-supplied cotangent of the densities at system step `step`, if there is one
+    auto inject = [&](int step) {
+        if (a.inj_index == nullptr) return;
+        const int row = a.inj_index[step];
+        if (row < 0) return;
+        for (int s = 0; s < S; ++s) {
+            Mat l, e;
+            dump_load(l, lam + (size_t)s * 256);
+            dump_load(e, a.inj_bars + (((size_t)b * a.inj_count + row) * S + s) * 256);
+            mat_axpy(l, 1.0, e);
+            dump_store(l, lam + (size_t)s * 256);
+        }
+        wave_sync();
+    };
+    inject(a.nsteps);
 
     for (int q = nsub - 1; q >= 0; --q) {
         const SubStep ss = a.substeps[q];
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
             wave_sync();
             (void)density_costs(a, true, false, dens, lam);
         }
+        if (ss.first_of_step && ss.step != 0) inject(ss.step);
     }
 }
 

@@ -85,6 +85,7 @@ SIGNATURES = {
     "qocx_eval_lindblad": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
                                           _c_double_p, _c_double_p]),
     "qocx_download_step_densities": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_set_density_cotangents": (ctypes.c_int, [_VP, _I32, _I32, _c_int_p, _c_double_p]),
     "qocx_set_state_cotangents": (ctypes.c_int, [_VP, _I32, _I32, _c_int_p, _c_double_p]),
     "qocx_set_timing": (ctypes.c_int, [_VP, _I32]),
     "qocx_get_timing": (ctypes.c_int, [_VP, _I32, ctypes.POINTER(_I64), _c_double_p]),
@@ -323,6 +324,17 @@ class Engine(object):
             _dp(cost), _dp(grads) if want_grad else None, _dp(final) if want_final else None))
         self._lindblad_batch = B
         return cost, grads, final
+
+    def set_density_cotangents(self, steps, bars):
+        """bars :: (B, len(steps), S, n, n) complex cotangents of the densities at `steps`."""
+        if steps is None or len(steps) == 0:
+            self._check(self._lib.qocx_set_density_cotangents(self._ctx, 0, 0, None, None))
+            return
+        pr = self._lindblad
+        steps = np.ascontiguousarray(steps, dtype=np.int32)
+        bars = _as_complex(bars).reshape(-1, len(steps), pr["S"], pr["n"], pr["n"])
+        self._check(self._lib.qocx_set_density_cotangents(
+            self._ctx, bars.shape[0], len(steps), steps.ctypes.data_as(_c_int_p), _dp(bars)))
 
     def download_step_densities(self):
         pr, B = self._lindblad, self._lindblad_batch

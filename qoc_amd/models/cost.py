@@ -13,15 +13,15 @@ derivative of a cost reaches the engine in one of these ways:
   costs: the value AND the cotangent are evaluated on the GPU);
 * `controls_bar(controls, states, system_eval_step)` -> d cost / d Re(controls) + i d cost /
   d Im(controls) for costs that depend on the controls only (`uses_states = False`);
-* any other subclass (a user's own cost of the states) works unchanged in the Schroedinger
-  GRAPE: the host evaluates `cost()` on the states the device returns and hands the engine the
+* any other subclass (a user's own cost of the states or densities) works unchanged in both
+  GRAPE entry points: the host evaluates `cost()` on the states the device returns and hands the engine the
   cotangent of the states at every cost step - from the optional hook
   `states_bar(controls, states, system_eval_step)` (d cost / d Re(states) + i d cost /
   d Im(states)), else by central differences of `cost()`. The explicit dependence on the
   controls is differentiated the same way (`controls_bar()` hook, or `uses_controls = False`
   to declare there is none). The finite-difference route costs 4 * state_count * hilbert_size
-  evaluations of `cost()` per cost step and is accurate to ~1e-8; write the hooks for speed.
-  (The Lindblad GRAPE takes only the built-in density costs and controls-only costs so far.)
+  evaluations of `cost()` per cost step (x hilbert_size for densities) and is accurate to
+  ~1e-8; write the hooks for speed.
 """
 
 

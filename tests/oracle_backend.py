@@ -220,6 +220,37 @@ class OracleBackend(object):
         self.lb = dict(n=n, S=S, K=K, Nc=Nc, N=N, T=T, ces=cost_eval_step,
                        rho0=np.asarray(initial_densities, dtype=np.complex128).reshape(S, n, n))
 
+    def set_density_cotangents(self, steps, bars):
+        if steps is None or len(steps) == 0:
+            self.lb_inj = None
+            return
+        p = self.lb
+        self.lb_inj = (list(int(x) for x in steps), np.asarray(bars, dtype=np.complex128).reshape(
+            -1, len(steps), p["S"], p["n"], p["n"]))
+
+    def _lindblad_costs_for_seed(self, b):
+        inj = getattr(self, "lb_inj", None)
+        if inj is None:
+            return self.lb_costs
+        steps, bars = inj
+        p = self.lb
+        ces = p["ces"]
+
+        class Injected(object):
+            def __init__(self, by_step, step_cost):
+                self.by_step, self.requires_step_evaluation = by_step, step_cost
+
+            def cost(self, controls, densities, step):
+                return 0.0
+
+            def states_bar(self, controls, densities, step):
+                return self.by_step.get(step, np.zeros_like(densities))
+
+        on_grid = {st: bars[b, r] for r, st in enumerate(steps) if st % ces == 0}
+        off_grid = {st: bars[b, r] for r, st in enumerate(steps) if st % ces != 0}
+        assert all(st == p["N"] - 1 for st in off_grid)
+        return list(self.lb_costs) + [Injected(on_grid, True), Injected(off_grid, False)]
+
     def evaluate_lindblad(self, controls, want_grad=True, want_final=True):
         from tests import lindblad_model as lm
         p = self.lb
@@ -230,9 +261,10 @@ class OracleBackend(object):
         want_grad = want_grad and p["K"] > 0
         cost, grads, final, self.lb_steps = [], [], [], []
         self.calls += 1
-        for u in batch:
+        for b, u in enumerate(batch):
+            costs = self._lindblad_costs_for_seed(b) if want_grad else self.lb_costs
             err, gr, fin = lm.evaluate_with_grad(self.lb_system, u, p["rho0"], p["T"], p["N"],
-                                                 self.lb_costs, p["ces"], want_grad=want_grad)
+                                                 costs, p["ces"], want_grad=want_grad)
             cost.append(err)
             grads.append(gr)
             final.append(fin)

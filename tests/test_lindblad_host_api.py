@@ -158,11 +158,58 @@ def test_user_cost_forward_only():
     expected = 1e-2 * (np.real(np.trace(mid[0] @ mid[0])) + np.real(np.trace(end[0] @ end[0])))
     assert abs(r.error - expected) < 1e-9
     del problem, xs
-    with pytest.raises(NotImplementedError):
-        qoc_amd.grape_lindblad_discrete(case.K, case.Nc, [Purity()], case.T,
-                                        case.initial_densities, case.N,
-                                        hamiltonian=case.hamiltonian(), iteration_count=1,
-                                        log_iteration_step=0)
+
+
+class _UserDensityOverlap(Cost):
+    """ForbidDensities for one forbidden density per evolving density, as a user plugin."""
+    name = "user_density_overlap"
+    requires_step_evaluation = True
+    uses_controls = False
+
+    def __init__(self, forbidden, count, with_hook, cost_multiplier=1.):
+        super().__init__(cost_multiplier)
+        self.forbidden, self.count, self.with_hook = forbidden, count, with_hook
+
+    def cost(self, controls, densities, step):
+        n = densities.shape[-1]
+        ip = np.einsum("sij,sij->s", self.forbidden.conj(), densities) / n
+        return self.cost_multiplier / (self.count * len(self.forbidden)) * float(np.sum(np.abs(ip) ** 2))
+
+    def states_bar(self, controls, densities, step):
+        if not self.with_hook:
+            return None
+        n = densities.shape[-1]
+        ip = np.einsum("sij,sij->s", self.forbidden.conj(), densities) / n
+        scale = 2 * self.cost_multiplier / (self.count * len(self.forbidden) * n)
+        return scale * ip[:, None, None] * self.forbidden
+
+
+@pytest.mark.parametrize("with_hook", [True, False])
+def test_grape_with_user_density_cost_matches_builtin(with_hook):
+    case = cases_mod.lindblad_case_by_name("lindblad_n4")
+    rng = np.random.default_rng(11)
+    S = case.initial_densities.shape[0]
+    forb = np.stack([cases_mod.random_density(rng, case.n) for _ in range(S)])
+    count = (case.N - 1) // case.cost_eval_step
+    base = product_cost_list(case)[:1]
+    builtin = base + [ForbidDensities(forb[:, None], case.N, cost_eval_step=case.cost_eval_step,
+                                      cost_multiplier=0.9)]
+    user = base + [_UserDensityOverlap(forb, count, with_hook, cost_multiplier=0.9)]
+    args = dict(hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data(),
+                control_count=case.K, control_eval_count=case.Nc,
+                cost_eval_step=case.cost_eval_step)
+    ev0 = device.LindbladEvaluator(case.T, case.initial_densities, case.N, costs=builtin, **args)
+    ev1 = device.LindbladEvaluator(case.T, case.initial_densities, case.N, costs=user, **args)
+    e0, g0, f0, _ = ev0.evaluate(case.controls[0])
+    e1, g1, f1, _ = ev1.evaluate(case.controls[0])
+    assert abs(e0 - e1) < 1e-13 and np.max(np.abs(f0 - f1)) < 1e-13
+    assert np.max(np.abs(g0 - g1)) / np.max(np.abs(g0)) < (1e-12 if with_hook else 1e-7)
+    result = qoc_amd.grape_lindblad_discrete(
+        case.K, case.Nc, user, case.T, case.initial_densities, case.N,
+        cost_eval_step=case.cost_eval_step, hamiltonian=case.hamiltonian(),
+        lindblad_data=case.lindblad_data(), initial_controls=case.controls[0],
+        iteration_count=2, log_iteration_step=0, max_control_norms=np.array([5.0, 5.0]))
+    assert result.best_error <= e1 + 1e-12
 
 
 def run_grape(case, optimizer, iterations, **kw):
