@@ -114,3 +114,41 @@ def test_chunked_equals_unchunked(engine):
         for a, b in zip(ref, out):
             assert np.array_equal(a, b)
     engine.set_pipeline(0)
+
+
+def test_error_paths(engine):
+    """The C ABI reports misuse and numerical trouble loudly (include/qocx.h error codes)."""
+    from qoc_amd.engine import Engine, QocxError
+    from tests import gpu_helpers as gh
+    fresh = Engine(0)
+    try:
+        with pytest.raises(QocxError) as err:  # no problem set
+            fresh.eval_resident(True)
+        assert err.value.code == -3
+        with pytest.raises(QocxError) as err:  # unsupported size
+            fresh.set_schroedinger_problem(33, 1, 0, 0, 5, 1.0, np.eye(33), None, np.eye(33)[:1])
+        assert err.value.code == -1 and "hilbert_size" in err.value.message
+        with pytest.raises(QocxError):  # nt neither 1 nor (N-1) * nodes
+            fresh.set_schroedinger_problem(4, 1, 0, 0, 5, 1.0, np.stack([np.eye(4)] * 3), None,
+                                           np.eye(4)[:1])
+    finally:
+        fresh.close()
+    case = cases_mod.case_by_name("scaled_n8")
+    gh.setup_engine(engine, case)
+    bad = gh.real_controls(case, case.controls).copy()
+    bad[0, 3, 0] = np.nan
+    with pytest.raises(QocxError) as err:
+        engine.evaluate(bad, want_grad=True)
+    assert "non-finite" in err.value.message
+    huge = gh.real_controls(case, case.controls) * 1e6  # ||dt H|| needs > 2^10 sub-steps
+    with pytest.raises(QocxError) as err:
+        engine.evaluate(huge, want_grad=True)
+    assert err.value.code == -5
+    with pytest.raises(QocxError):  # cotangents for another batch size
+        engine.upload_controls(gh.real_controls(case, case.controls))
+        engine.set_state_cotangents([1], np.zeros((5, 1, case.S, case.n), dtype=np.complex128))
+        engine.eval_resident(True)
+    engine.set_state_cotangents(None, None)
+    # the engine is still usable afterwards
+    cost, grads, final = engine.evaluate(gh.real_controls(case, case.controls), want_grad=True)
+    assert np.all(np.isfinite(cost)) and np.all(np.isfinite(grads))
