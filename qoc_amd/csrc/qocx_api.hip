@@ -179,7 +179,7 @@ struct qocx_ctx {
         DevBuf<int> inj_index;
         DevBuf<double2> inj_bars;
         DevBuf<double> gsub, cost_out, grads, controls;
-        DevBuf<double2> checkpoints, final_out, step_densities;
+        DevBuf<double2> checkpoints, final_out, step_densities, ystages;
     } lb;
     // ---- timing ----
     int timing = 0;
@@ -409,6 +409,7 @@ int qocx_destroy(qocx_ctx* ctx) {
         }
         lb.inj_index.release();
         lb.inj_bars.release();
+        lb.ystages.release();
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_pq) (void)hipEventDestroy(e);
@@ -1332,6 +1333,24 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         gsub_total += kv.second.size() * (size_t)it->second.nsub * 2 * std::max(K, 1);
         for (int b : kv.second) lb.order.push_back(b);
     }
+    // The stage values of the forward pass are kept for the adjoint (12 x the checkpoints of the
+    // seeds in flight); a group of seeds that does not fit is launched in pieces that do, and
+    // only if a piece would fall below 256 seeds does the adjoint recompute the stages instead.
+    size_t stage_budget = 0;  // double2 elements
+    if (want_grad) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        stage_budget = (size_t)(0.45 * (double)(free_b + lb.ystages.count * sizeof(double2))) /
+                       sizeof(double2);
+        size_t want = 0;
+        for (auto& kv : groups) {
+            const size_t per_seed = (size_t)lb.grids[kv.first].nsub * S * 256 * 12;
+            const size_t piece = std::min<size_t>(kv.second.size(),
+                                                  std::max<size_t>(1, stage_budget / per_seed));
+            if (piece == kv.second.size() || piece >= 256) want = std::max(want, piece * per_seed);
+        }
+        if (want > 0 && lb.ystages.ensure(want)) return QOCX_ERR_HIP;
+    }
     const size_t csz = (size_t)nc * K;
     if (lb.controls.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.cost_out.ensure(B) ||
         lb.grads.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.gsub.ensure(gsub_total) ||
@@ -1368,38 +1387,50 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     for (auto& kv : groups) {
         const auto& gr = lb.grids[kv.first];
         const int Bg = (int)kv.second.size(), nsub = gr.nsub;
-        qocx::LindbladArgs la;
-        la.controls = lb.controls.p + pos0 * csz; la.substeps = gr.substeps.p;
-        la.a0l_cimg = lb.a0l.p; la.a0r_cimg = lb.a0r.p; la.a0ld_cimg = lb.a0ld.p; la.a0rd_cimg = lb.a0rd.p;
-        la.gp_cimg = lb.gp.p; la.gpd_cimg = lb.gpd.p; la.gpt_cimg = lb.gpt.p; la.op_cimg = lb.ops.p;
-        la.gammas = lb.gammas.p; la.rho0_cimg = lb.rho0.p;
-        la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
-        la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
-        la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;
-        la.cost_counts = lb.cost_counts.p;
-        la.checkpoints = lb.checkpoints.p + ckpt_off; la.gsub = lb.gsub.p + gsub_off;
-        la.cost_out = lb.cost_out.p + pos0;
-        la.final_out = lb.final_out.p + pos0 * S * 256;
-        la.step_densities = ctx->keep_step_states
-                                ? lb.step_densities.p + pos0 * (nsteps + 1) * S * 256 : nullptr;
-        la.inj_count = lb.inj_count;
-        la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
-        la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * 256 : nullptr;
-        time_begin(ctx, 5, ctx->stream);
-        qocx::launch_lindblad(la, Bg, ctx->stream);
-        time_end(ctx, ctx->stream);
+        const size_t per_seed_stage = (size_t)nsub * S * 256 * 12;
+        int piece = Bg;
+        bool keep_stages = false;
         if (want_grad) {
-            qocx::ScatterArgs sc;
-            sc.gstep = la.gsub; sc.row_ptr = gr.row_ptr.p; sc.col_step = gr.col.p;
-            sc.weight = gr.weight.p; sc.grads = lb.grads.p + pos0 * csz;
-            sc.B = Bg; sc.nc = nc; sc.K = K; sc.nsteps = 2 * nsub;
-            time_begin(ctx, 3, ctx->stream);
-            qocx::launch_scatter(sc, ctx->stream);
-            time_end(ctx, ctx->stream);
+            const size_t fit = std::max<size_t>(1, stage_budget / per_seed_stage);
+            if (fit >= (size_t)Bg) { keep_stages = true; }
+            else if (fit >= 256) { keep_stages = true; piece = (int)fit; }
         }
-        pos0 += Bg;
-        ckpt_off += (size_t)Bg * nsub * S * 256;
-        gsub_off += (size_t)Bg * nsub * 2 * std::max(K, 1);
+        for (int p0 = 0; p0 < Bg; p0 += piece) {
+            const int Bp = std::min(piece, Bg - p0);
+            qocx::LindbladArgs la;
+            la.controls = lb.controls.p + pos0 * csz; la.substeps = gr.substeps.p;
+            la.a0l_cimg = lb.a0l.p; la.a0r_cimg = lb.a0r.p; la.a0ld_cimg = lb.a0ld.p; la.a0rd_cimg = lb.a0rd.p;
+            la.gp_cimg = lb.gp.p; la.gpd_cimg = lb.gpd.p; la.gpt_cimg = lb.gpt.p; la.op_cimg = lb.ops.p;
+            la.gammas = lb.gammas.p; la.rho0_cimg = lb.rho0.p;
+            la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
+            la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
+            la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;
+            la.cost_counts = lb.cost_counts.p;
+            la.checkpoints = lb.checkpoints.p + ckpt_off; la.gsub = lb.gsub.p + gsub_off;
+            la.ystages = keep_stages ? lb.ystages.p : nullptr;  // reused piece after piece
+            la.cost_out = lb.cost_out.p + pos0;
+            la.final_out = lb.final_out.p + pos0 * S * 256;
+            la.step_densities = ctx->keep_step_states
+                                    ? lb.step_densities.p + pos0 * (nsteps + 1) * S * 256 : nullptr;
+            la.inj_count = lb.inj_count;
+            la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
+            la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * 256 : nullptr;
+            time_begin(ctx, 5, ctx->stream);
+            qocx::launch_lindblad(la, Bp, ctx->stream);
+            time_end(ctx, ctx->stream);
+            if (want_grad) {
+                qocx::ScatterArgs sc;
+                sc.gstep = la.gsub; sc.row_ptr = gr.row_ptr.p; sc.col_step = gr.col.p;
+                sc.weight = gr.weight.p; sc.grads = lb.grads.p + pos0 * csz;
+                sc.B = Bp; sc.nc = nc; sc.K = K; sc.nsteps = 2 * nsub;
+                time_begin(ctx, 3, ctx->stream);
+                qocx::launch_scatter(sc, ctx->stream);
+                time_end(ctx, ctx->stream);
+            }
+            pos0 += Bp;
+            ckpt_off += (size_t)Bp * nsub * S * 256;
+            gsub_off += (size_t)Bp * nsub * 2 * std::max(K, 1);
+        }
     }
     HIP_TRY(hipGetLastError());
     std::vector<double2> fin(final_out ? (size_t)B * S * 256 : 0);

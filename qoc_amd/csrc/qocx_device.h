@@ -169,6 +169,8 @@ struct LindbladArgs {
     const double2* cost_matrices;  // pooled C-dumps
     const int* cost_counts;
     double2* checkpoints;      // [B][nsub][S] C-dumps: densities at the start of each sub-interval
+    double2* ystages;          // [B][nsub][S][12] C-dumps of the stage values, or nullptr: the
+                               // adjoint then recomputes them from the checkpoints
     double* gsub;              // [B][nsub][2][K] control cotangents at t_a / t_b
     double* cost_out;          // [B]
     double2* final_out;        // [B][S] C-dumps

@@ -292,10 +292,12 @@ struct Wave {
         }
     }
     // all stage derivatives of the sub-interval starting at y0 -> kdump; optionally advance y0
-    __device__ __forceinline__ void substep(const SubStep& ss, Mat& y0, bool advance) const {
+    __device__ __forceinline__ void substep(const SubStep& ss, Mat& y0, bool advance,
+                                            double2* ystore = nullptr) const {
         for (int i = 0; i < STAGES; ++i) {
             Mat y, k, gl, gr;
             stage_value(y, y0, i, ss.h);
+            if (ystore != nullptr) dump_store(y, ystore + (size_t)i * 256);  // for the adjoint
             build_generator(ss, RK_C_DEV[i], false, gl, gr);
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
@@ -321,7 +323,8 @@ struct Wave {
     __device__ __forceinline__ void adjoint_substep(const SubStep& ss, const Mat& y0,
                                                     const Mat& lambda, Mat& lambda_new,
                                                     double (&ga)[QOCX_LINDBLAD_MAX_K],
-                                                    double (&gb)[QOCX_LINDBLAD_MAX_K]) const {
+                                                    double (&gb)[QOCX_LINDBLAD_MAX_K],
+                                                    const double2* ystore = nullptr) const {
         for (int i = STAGES - 1; i >= 0; --i) {
             // kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j)
             Mat kb;
@@ -346,7 +349,8 @@ struct Wave {
             // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
             // Z = Y kbar^H - kbar^H Y  (slot_y still holds kbar as a planar image)
             Mat y, kbd, z, z2;
-            stage_value(y, y0, i, ss.h);  // the stage value Y_i again
+            if (ystore != nullptr) dump_load(y, ystore + (size_t)i * 256);
+            else stage_value(y, y0, i, ss.h);  // the stage value Y_i again
             wave_sync();
             dump_store(ybar, kdump + (size_t)i * 256);  // k_i is no longer needed
             load_adjoint(kbd, slot_y);
@@ -437,7 +441,10 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
             Mat y0;
             dump_load(y0, dens + (size_t)s * 256);
             dump_store(y0, ckpt_b + ((size_t)q * S + s) * 256);
-            w.substep(ss, y0, true);
+            w.substep(ss, y0, true,
+                      a.ystages != nullptr
+                          ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * 256
+                          : nullptr);
             wave_sync();
             dump_store(y0, dens + (size_t)s * 256);
             wave_sync();
@@ -490,11 +497,14 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
         for (int s = 0; s < S; ++s) {
             Mat y0;
             dump_load(y0, ckpt_b + ((size_t)q * S + s) * 256);
-            w.substep(ss, y0, false);  // recompute the stage derivatives -> kdump
+            const double2* ys = a.ystages != nullptr
+                                    ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * 256
+                                    : nullptr;
+            if (ys == nullptr) w.substep(ss, y0, false);  // recompute the stage derivatives
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * 256);
             lambda_new = lambda;
-            w.adjoint_substep(ss, y0, lambda, lambda_new, ga, gb);
+            w.adjoint_substep(ss, y0, lambda, lambda_new, ga, gb, ys);
             dump_store(lambda_new, lam + (size_t)s * 256);
             wave_sync();
         }
