@@ -1002,6 +1002,7 @@ int qocx_reset_timing(qocx_ctx* ctx) {
 
 // ---- Lindblad ----------------------------------------------------------------------------
 
+extern "C++" {
 namespace {
 
 typedef std::vector<double> cmat;  // row-major n x n complex, interleaved
@@ -1100,6 +1101,7 @@ int upload_dumps(DevBuf<double2>& dst, const std::vector<cmat>& mats, int n, hip
 }
 
 }  // namespace
+}  // extern "C++"
 
 int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     if (!ctx || !p) return fail(QOCX_ERR_ARG, "NULL argument");
