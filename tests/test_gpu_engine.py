@@ -152,3 +152,61 @@ def test_error_paths(engine):
     # the engine is still usable afterwards
     cost, grads, final = engine.evaluate(gh.real_controls(case, case.controls), want_grad=True)
     assert np.all(np.isfinite(cost)) and np.all(np.isfinite(grads))
+
+
+EDGE_CASES = [
+    # n, N, Nc, K, S, dt, cost_eval_step, sigma
+    dict(n=1, N=5, Nc=5, K=1, S=1, dt=0.3, ces=1, sigma=1.0),     # scalar "matrix"
+    dict(n=2, N=2, Nc=2, K=2, S=2, dt=0.7, ces=1, sigma=1.0),     # a single propagator step
+    dict(n=17, N=6, Nc=3, K=3, S=3, dt=0.2, ces=2, sigma=0.8),    # two tiles, 15 padded rows
+    dict(n=16, N=9, Nc=2, K=1, S=16, dt=0.1, ces=3, sigma=2.0),   # full tile, Nc = 2 (one line)
+    dict(n=32, N=4, Nc=7, K=2, S=64, dt=0.4, ces=1, sigma=0.5),   # maximum state count
+    dict(n=5, N=12, Nc=12, K=4, S=1, dt=0.9, ces=20, sigma=3.0),  # cost_eval_step > N, squarings
+    dict(n=31, N=5, Nc=9, K=8, S=2, dt=0.05, ces=1, sigma=0.1),   # Nc > N, many controls
+]
+
+
+@pytest.mark.parametrize("spec", EDGE_CASES, ids=lambda s: "n{n}_N{N}_Nc{Nc}_K{K}_S{S}".format(**s))
+def test_edge_shapes_against_oracle(engine, spec):
+    """Engine vs the oracle (itself pinned by the reference fixtures) on the corner shapes."""
+    from qoc_amd.engine import COST_FORBID, COST_TARGET_COHERENT, COST_TARGET_INCOHERENT
+    n, N, Nc, K, S = spec["n"], spec["N"], spec["Nc"], spec["K"], spec["S"]
+    rng = np.random.default_rng(1000 * n + N)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 2.0
+    g = [gue(rng, n) for _ in range(K)]
+    S_eff = min(S, 64)
+    init = rng.standard_normal((S_eff, n)) + 1j * rng.standard_normal((S_eff, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S_eff, n)) + 1j * rng.standard_normal((S_eff, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    forb = rng.standard_normal((S_eff, 2, n)) + 1j * rng.standard_normal((S_eff, 2, n))
+    forb /= np.linalg.norm(forb, axis=2, keepdims=True)
+    T = spec["dt"] * (N - 1)
+    ces = spec["ces"]
+    count = max((N - 1) // ces, 1)
+    controls = spec["sigma"] * rng.standard_normal((3, Nc, K))
+    descs = [dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=0.7, vectors=targ),
+             dict(kind=COST_TARGET_INCOHERENT, step_cost=1, scale=1.3 / count, vectors=targ),
+             dict(kind=COST_FORBID, step_cost=1, scale=0.9 / (count * S_eff),
+                  vectors=forb.reshape(-1, n), counts=[2] * S_eff)]
+    engine.set_schroedinger_problem(n, S_eff, K, Nc, N, T, h0[None], np.stack(g)[None], init,
+                                    costs=descs, cost_eval_step=ces)
+    cost, grads, final = engine.evaluate(controls, want_grad=True)
+    ocosts = [onp.TargetStateInfidelity(targ[:, :, None], cost_multiplier=0.7),
+              onp.TargetStateInfidelityTime(N, targ[:, :, None], neglect_relative_pahse=True,
+                                            cost_eval_step=ces, cost_multiplier=1.3)
+              if (N - 1) // ces > 0 else None,
+              onp.ForbidStates(forb[:, :, :, None], N, cost_eval_step=ces, cost_multiplier=0.9)
+              if (N - 1) // ces > 0 else None]
+    ocosts = [c for c in ocosts if c is not None]
+    problem = onp.SchroedingerProblem(
+        T, lambda u, t: h0 + sum(u[k] * g[k] for k in range(K)), init[:, :, None], N,
+        control_eval_count=Nc, costs=ocosts, cost_eval_step=ces, control_count=K)
+    for b in range(controls.shape[0]):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        if (N - 1) // ces > 0:
+            assert abs(err - cost[b]) < 1e-10 * max(1.0, abs(err)), (err, cost[b])
+            # (n = 1: every cost is phase invariant, the gradient is zero up to rounding)
+            assert np.max(np.abs(grads[b] - gr)) < 1e-8 * max(np.max(np.abs(gr)), 1e-3)
+        assert rel_err(final[b][:, :, None], fin) < 1e-10

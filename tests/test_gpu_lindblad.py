@@ -162,3 +162,47 @@ def test_lindblad_rejects_unsupported(engine):
     with pytest.raises(QocxError):
         engine.set_lindblad_problem(17, 1, 0, 0, 2, 1.0, np.zeros((17, 17)), None, None, None,
                                     np.eye(17)[None] / 17)
+
+
+LINDBLAD_EDGES = [
+    dict(n=1, S=1, K=1, L=1, N=3, Nc=3),    # scalar density
+    dict(n=2, S=8, K=2, L=4, N=4, Nc=2),    # maximum densities and operators, Nc = 2
+    dict(n=16, S=2, K=8, L=0, N=3, Nc=5),   # full tile, maximum controls, no dissipation
+    dict(n=7, S=1, K=0, L=2, N=5, Nc=0),    # no controls at all
+    dict(n=5, S=3, K=1, L=1, N=2, Nc=9),    # one system step, many control knots inside it
+]
+
+
+@pytest.mark.parametrize("spec", LINDBLAD_EDGES,
+                         ids=lambda s: "n{n}_S{S}_K{K}_L{L}_N{N}_Nc{Nc}".format(**s))
+def test_lindblad_edge_shapes_against_model(engine, spec):
+    from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY
+    n, S, K, L, N, Nc = (spec[k] for k in ("n", "S", "K", "L", "N", "Nc"))
+    rng = np.random.default_rng(77 * n + S)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 1.5
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)]) if L else None
+    gam = rng.uniform(0.05, 0.3, L) if L else None
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    forb = np.stack([cases_mod.random_density(rng, n) for _ in range(2 * S)])
+    T = 0.3 * (N - 1)
+    count = N - 1
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ),
+             dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=1.5 / (count * S), vectors=forb,
+                  counts=[2] * S)]
+    engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs)
+    controls = 0.7 * rng.standard_normal((2, Nc, K)) if K else None
+    cost, grads, final = engine.evaluate_lindblad(controls if K else 2, want_grad=K > 0)
+    costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8),
+             ol.ForbidDensities(forb.reshape(S, 2, n, n), N, cost_multiplier=1.5)]
+    system = lm.StructuredLindblad(h0, g, gam, ops)
+    for b in range(2):
+        u = controls[b] if K else np.zeros((2, 0))
+        m_err, m_grads, m_final = lm.evaluate_with_grad(system, u, rho0, T, N, costs, 1,
+                                                        want_grad=K > 0)
+        assert abs(cost[b] - m_err) < 1e-12
+        assert np.max(np.abs(final[b] - m_final)) < 1e-12
+        if K:
+            assert np.max(np.abs(grads[b] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
