@@ -210,3 +210,24 @@ def test_edge_shapes_against_oracle(engine, spec):
             # (n = 1: every cost is phase invariant, the gradient is zero up to rounding)
             assert np.max(np.abs(grads[b] - gr)) < 1e-8 * max(np.max(np.abs(gr)), 1e-3)
         assert rel_err(final[b][:, :, None], fin) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["magnus_n20_M6", "small_complex_M4", "nonhermitian_n24"])
+def test_segments_and_chunks_with_other_kernel_variants(engine, name):
+    """Time segments / memory chunks through the Magnus kernels, the explicit-generator K3 and
+    the general (non-Hermitian) kernels give bit-identical results."""
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_by_name(name)
+    gh.setup_engine(engine, case)
+    u = gh.real_controls(case, np.concatenate([case.controls, 0.5 * case.controls]))
+    ref = engine.evaluate(u, True)
+    try:
+        for chunk, pipe in ((1, 3), (3, 2), (0, 5)):
+            engine.set_chunk(chunk)
+            engine.set_pipeline(pipe)
+            out = engine.evaluate(u, True)
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), (chunk, pipe)
+    finally:
+        engine.set_chunk(0)
+        engine.set_pipeline(0)
