@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
 // the form a Magnus M4/M6 generator kernel would feed).
-template <int NB>
+template <int NB, bool HERM>
 __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_in, int n,
                                                               FactorArgs args) {
     typedef Geo<NB> G;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
                     a.im[ti][tj][r] = e.y;
                 }
     };
-    pade_pq_body<NB, false>(gen, out, smem);
+    pade_pq_body<NB, HERM>(gen, out, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1197,9 +1197,11 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
             const double2 e = mm[(size_t)i * NP + cc * H + h];
             are[cc] = sc * e.x;
             aim[cc] = sc * e.y;
-            const double2 f = mm[(size_t)(cc * H + h) * NP + i];
-            hre[cc] = sc * f.x;
-            him[cc] = -sc * f.y;
+            if (!SKEW) {
+                const double2 f = mm[(size_t)(cc * H + h) * NP + i];
+                hre[cc] = sc * f.x;
+                him[cc] = -sc * f.y;
+            }
         }
     } else {
         double xr[CPL], xi[CPL], tr_[HC], ti_[HC];
@@ -1368,10 +1370,10 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
 }
 
 // Hermitian-generator variant: half the generator registers, so two waves share a SIMD.
-template <int NB>
+template <int NB, bool EXPLICIT>
 __global__ __launch_bounds__(64, 2) void krylov_grad_skew_kernel(KrylovArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    krylov_grad_body<NB, false, true>(args, smem);
+    krylov_grad_body<NB, EXPLICIT, true>(args, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1442,8 +1444,12 @@ static void launch_pq_t(const FactorArgs& a, int nsteps, int batch, hipStream_t 
 template <int NB>
 static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
                                  hipStream_t st) {
-    hipLaunchKernelGGL(pade_pq_explicit_kernel<NB>, dim3(count), dim3(64), PqLds<NB>::BYTES, st,
-                       a_in, n, a);
+    if (a.hermitian)
+        hipLaunchKernelGGL((pade_pq_explicit_kernel<NB, true>), dim3(count), dim3(64),
+                           PqLds<NB>::BYTES, st, a_in, n, a);
+    else
+        hipLaunchKernelGGL((pade_pq_explicit_kernel<NB, false>), dim3(count), dim3(64),
+                           PqLds<NB>::BYTES, st, a_in, n, a);
 }
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
@@ -1455,11 +1461,16 @@ static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
 }
 template <int NB>
 static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
-    if (a.m_rm != nullptr)
+    // a.skew: Hermitian H. The Magnus generators of skew-Hermitian node generators are
+    // skew-Hermitian too (up to rounding), so the explicit path may use the same variant.
+    if (a.m_rm != nullptr && a.skew)
+        hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
+                           KrylovLds<NB>::BYTES, st, a);
+    else if (a.m_rm != nullptr)
         hipLaunchKernelGGL((krylov_grad_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
                            KrylovLds<NB>::BYTES, st, a);
     else if (a.skew)
-        hipLaunchKernelGGL(krylov_grad_skew_kernel<NB>, dim3(nsteps, batch), dim3(64),
+        hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
                            KrylovLds<NB>::BYTES, st, a);
     else
         hipLaunchKernelGGL((krylov_grad_kernel<NB, false>), dim3(nsteps, batch), dim3(64),

@@ -370,7 +370,7 @@ __device__ __forceinline__ void contract_node(const CMat<NB>& abar, const Magnus
 
 }  // namespace
 
-template <int NB>
+template <int NB, int NODES>
 __global__ __launch_bounds__(64) void magnus_fwd_kernel(MagnusArgs args) {
     typedef Geo<NB> G;
     typedef CMat<NB> Mat;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void magnus_fwd_kernel(MagnusArgs args) {
         const size_t m = b * args.nsteps + step;
         const double* ctl_b = args.controls + b * args.nc * args.K;
         Mat mm;
-        if (args.nodes == 2) {
+        if (NODES == 2) {
             // m4 = dt/2 (a1 + a2) + F0 dt^2 [a2, a1]   (mathmethods.py:119-121)
             Mat a1, a2;
             node_generator<NB>(a1, args, step, 0, ctl_b);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void magnus_fwd_kernel(MagnusArgs args) {
     }
 }
 
-template <int NB>
+template <int NB, int NODES>
 __global__ __launch_bounds__(64) void magnus_vjp_kernel(MagnusArgs args) {
     typedef Geo<NB> G;
     typedef CMat<NB> Mat;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void magnus_vjp_kernel(MagnusArgs args) {
         const size_t b = w / args.seg_len;
         const size_t m = b * args.nsteps + step;
         const double* ctl_b = args.controls + b * args.nc * args.K;
-        if (args.nodes == 2) {
+        if (NODES == 2) {
             // a1bar = dt/2 mbar + d[a2,a1]/da1 ; a2bar likewise (cbar = F0 dt^2 mbar)
             {
                 Mat a;
@@ -523,18 +523,33 @@ size_t magnus_scratch_elems(int nb, int blocks) {
     return (size_t)blocks * S_COUNT * (size_t)(256 * nb * nb);
 }
 
-void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
-    if (nb == 1)
-        hipLaunchKernelGGL(magnus_fwd_kernel<1>, dim3(blocks), dim3(64), MagnusLds<1>::BYTES, st, a);
+template <int NB>
+static void launch_fwd_t(const MagnusArgs& a, int blocks, hipStream_t st) {
+    if (a.nodes == 2)
+        hipLaunchKernelGGL((magnus_fwd_kernel<NB, 2>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
+                           st, a);
     else
-        hipLaunchKernelGGL(magnus_fwd_kernel<2>, dim3(blocks), dim3(64), MagnusLds<2>::BYTES, st, a);
+        hipLaunchKernelGGL((magnus_fwd_kernel<NB, 3>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
+                           st, a);
+}
+template <int NB>
+static void launch_vjp_t(const MagnusArgs& a, int blocks, hipStream_t st) {
+    if (a.nodes == 2)
+        hipLaunchKernelGGL((magnus_vjp_kernel<NB, 2>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
+                           st, a);
+    else
+        hipLaunchKernelGGL((magnus_vjp_kernel<NB, 3>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
+                           st, a);
+}
+
+void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
+    if (nb == 1) launch_fwd_t<1>(a, blocks, st);
+    else launch_fwd_t<2>(a, blocks, st);
 }
 
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
-    if (nb == 1)
-        hipLaunchKernelGGL(magnus_vjp_kernel<1>, dim3(blocks), dim3(64), MagnusLds<1>::BYTES, st, a);
-    else
-        hipLaunchKernelGGL(magnus_vjp_kernel<2>, dim3(blocks), dim3(64), MagnusLds<2>::BYTES, st, a);
+    if (nb == 1) launch_vjp_t<1>(a, blocks, st);
+    else launch_vjp_t<2>(a, blocks, st);
 }
 
 }  // namespace qocx
