@@ -113,8 +113,6 @@ struct ncclUniqueIdBytes {
 struct qocx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t lu_stream = nullptr;  // K1b of segment i runs beside K1a of segment i + 1
-    std::vector<hipEvent_t> ev_pq;
     // ---- problem ----
     bool has_problem = false;
     int n = 0, nb = 0, np = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nt = 1;
@@ -144,7 +142,6 @@ struct qocx_ctx {
     // ---- Lindblad problem / evaluation state ----
     // ---- Magnus M4/M6 ----
     int nodes = 1;
-    int split_lu = 0;   // QOCX_SPLIT_LU=1 moves K1b to its own stream (measured: no gain)
     int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
     // ---- host-supplied state cotangents ----
@@ -348,19 +345,8 @@ int qocx_create(int device, qocx_ctx** out) {
             return QOCX_ERR_HIP;
         }
         if (i == 0) ctx->sweep_streams.push_back(st);
-        hipEvent_t e3;
-        if (hipEventCreateWithFlags(&e3, hipEventDisableTiming) != hipSuccess) {
-            g_error = "cannot create the pipeline events";
-            return QOCX_ERR_HIP;
-        }
-        ctx->ev_pq.push_back(e3);
         ctx->ev_factored.push_back(e1);
         ctx->ev_swept.push_back(e2);
-    }
-    if (const char* e = getenv("QOCX_SPLIT_LU")) ctx->split_lu = atoi(e) != 0;
-    if (hipStreamCreateWithFlags(&ctx->lu_stream, hipStreamNonBlocking) != hipSuccess) {
-        g_error = "cannot create the LU stream";
-        return QOCX_ERR_HIP;
     }
     *out = ctx;
     return 0;
@@ -412,8 +398,6 @@ int qocx_destroy(qocx_ctx* ctx) {
         lb.ystages.release();
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
-    for (auto e : ctx->ev_pq) (void)hipEventDestroy(e);
-    if (ctx->lu_stream) (void)hipStreamDestroy(ctx->lu_stream);
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
     for (auto e : ctx->ev_factored) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_swept) (void)hipEventDestroy(e);
@@ -837,16 +821,13 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             }
             time_end(ctx, cs);
             la.step0 = lo[i]; la.seg_len = len;
-            hipStream_t ls = (nseg > 1 && ctx->split_lu) ? ctx->lu_stream : cs;
-            if (ls != cs) {
-                HIP_TRY(hipEventRecord(ctx->ev_pq[i], cs));
-                HIP_TRY(hipStreamWaitEvent(ls, ctx->ev_pq[i], 0));
-            }
-            time_begin(ctx, 4, ls);
-            qocx::launch_lu(ctx->nb, la, (size_t)bc * len, ls);
-            time_end(ctx, ls);
+            // (K1b on a stream of its own, beside the next segment's K1a, was measured: no gain -
+            // the two kernels cannot share a SIMD's register file)
+            time_begin(ctx, 4, cs);
+            qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
+            time_end(ctx, cs);
             if (nseg > 1) {
-                HIP_TRY(hipEventRecord(ctx->ev_factored[i], ls));
+                HIP_TRY(hipEventRecord(ctx->ev_factored[i], cs));
                 HIP_TRY(hipStreamWaitEvent(ss, ctx->ev_factored[i], 0));
             }
             sa.j_begin = lo[i]; sa.j_end = lo[i + 1];
