@@ -108,7 +108,7 @@ typedef struct qocx_schroedinger_problem {
  * lindblad_data(t) = (dissipators, operators) must not depend on time explicitly.
  */
 typedef struct qocx_lindblad_problem {
-    int32_t hilbert_size;         /* n, 1..16                                                      */
+    int32_t hilbert_size;         /* n, 1..32 (n > 16: four tiles per matrix, HBM scratch)         */
     int32_t density_count;        /* S >= 1                                                        */
     int32_t control_count;        /* K real controls, 0..8                                         */
     int32_t control_eval_count;   /* Nc                                                            */

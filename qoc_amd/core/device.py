@@ -238,7 +238,7 @@ class LindbladEvaluator(object):
     (qoc/core/lindbladdiscrete.py:321-322, :357-441) through qocx_eval_lindblad.
     """
 
-    MAX_HILBERT_SIZE = 16
+    MAX_HILBERT_SIZE = 32
 
     def __init__(self, evolution_time, initial_densities, system_eval_count, hamiltonian=None,
                  lindblad_data=None, control_count=0, control_eval_count=0,

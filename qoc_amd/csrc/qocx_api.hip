@@ -176,7 +176,8 @@ struct qocx_ctx {
         DevBuf<int> inj_index;
         DevBuf<double2> inj_bars;
         DevBuf<double> gsub, cost_out, grads, controls;
-        DevBuf<double2> checkpoints, final_out, step_densities, ystages;
+        DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
+        int global_scratch = 0;
     } lb;
     // ---- timing ----
     int timing = 0;
@@ -396,6 +397,7 @@ int qocx_destroy(qocx_ctx* ctx) {
         lb.inj_index.release();
         lb.inj_bars.release();
         lb.ystages.release();
+        lb.scratch.release();
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
@@ -1040,29 +1042,40 @@ void cm_axpy(cmat& y, double alpha, const cmat& x) {
     for (size_t e = 0; e < y.size(); ++e) y[e] += alpha * x[e];
 }
 
-// C-layout dump (NB = 1): reg r of lane l <-> element (row 4r + (l >> 4), col l & 15), index r*64+l
+// C-layout dump of an n x n matrix padded to 16 nb: reg r of tile (ti, tj) of lane l <-> element
+// (row 16 ti + 4 r + (l >> 4), col 16 tj + (l & 15)), index ((ti nb + tj) 4 + r) 64 + l
+int dump_tiles(int n) { return n <= 16 ? 1 : 2; }
+int dump_elems(int n) { return 256 * dump_tiles(n) * dump_tiles(n); }
+
 void c_dump(const cmat& m, int n, double2* out) {
-    for (int r = 0; r < 4; ++r)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int row = 4 * r + (lane >> 4), col = lane & 15;
-            double2 e = make_double2(0, 0);
-            if (row < n && col < n) {
-                e.x = m[2 * ((size_t)row * n + col)];
-                e.y = m[2 * ((size_t)row * n + col) + 1];
-            }
-            out[r * 64 + lane] = e;
-        }
+    const int nb = dump_tiles(n);
+    for (int ti = 0; ti < nb; ++ti)
+        for (int tj = 0; tj < nb; ++tj)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = 16 * ti + 4 * r + (lane >> 4), col = 16 * tj + (lane & 15);
+                    double2 e = make_double2(0, 0);
+                    if (row < n && col < n) {
+                        e.x = m[2 * ((size_t)row * n + col)];
+                        e.y = m[2 * ((size_t)row * n + col) + 1];
+                    }
+                    out[((ti * nb + tj) * 4 + r) * 64 + lane] = e;
+                }
 }
 
 void from_c_dump(const double2* d, int n, double* out) {
-    for (int r = 0; r < 4; ++r)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int row = 4 * r + (lane >> 4), col = lane & 15;
-            if (row < n && col < n) {
-                out[2 * ((size_t)row * n + col)] = d[r * 64 + lane].x;
-                out[2 * ((size_t)row * n + col) + 1] = d[r * 64 + lane].y;
-            }
-        }
+    const int nb = dump_tiles(n);
+    for (int ti = 0; ti < nb; ++ti)
+        for (int tj = 0; tj < nb; ++tj)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = 16 * ti + 4 * r + (lane >> 4), col = 16 * tj + (lane & 15);
+                    if (row < n && col < n) {
+                        const double2 e = d[((ti * nb + tj) * 4 + r) * 64 + lane];
+                        out[2 * ((size_t)row * n + col)] = e.x;
+                        out[2 * ((size_t)row * n + col) + 1] = e.y;
+                    }
+                }
 }
 
 double cm_norm_inf(const cmat& m, int n) {
@@ -1076,8 +1089,9 @@ double cm_norm_inf(const cmat& m, int n) {
 }
 
 int upload_dumps(DevBuf<double2>& dst, const std::vector<cmat>& mats, int n, hipStream_t st) {
-    std::vector<double2> img(mats.size() * 256);
-    for (size_t i = 0; i < mats.size(); ++i) c_dump(mats[i], n, img.data() + i * 256);
+    const size_t md = dump_elems(n);
+    std::vector<double2> img(mats.size() * md);
+    for (size_t i = 0; i < mats.size(); ++i) c_dump(mats[i], n, img.data() + i * md);
     return dst.upload(img, st);
 }
 
@@ -1089,9 +1103,9 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->density_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count, L = p->operator_count;
-    if (n < 1 || n > 16)
-        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..16 for the Lindblad engine");
-    if (S < 1 || S > 8) return fail(QOCX_ERR_ARG, "density_count must be in 1..8");
+    if (n < 1 || n > 32)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..32 for the Lindblad engine");
+    if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "density_count must be in 1..64");
     if (K < 0 || K > QOCX_LINDBLAD_MAX_K) return fail(QOCX_ERR_ARG, "control_count must be in 0..8");
     if (L < 0 || L > 4) return fail(QOCX_ERR_ARG, "operator_count must be in 0..4");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
@@ -1099,8 +1113,11 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     if (p->cost_eval_step < 1) return fail(QOCX_ERR_ARG, "cost_eval_step must be >= 1");
     if (!p->initial_densities || (K > 0 && !p->g) || (L > 0 && (!p->operators || !p->dissipators)))
         return fail(QOCX_ERR_ARG, "missing problem arrays");
-    if (qocx::lindblad_lds_size(S, L) > 160 * 1024)
-        return fail(QOCX_ERR_ARG, "too many densities / operators for the kernel's LDS");
+    // densities, cotangents and stage derivatives live in LDS when they fit (n <= 16), else in
+    // per-seed HBM scratch
+    ctx->lb.global_scratch = (n > 16 || qocx::lindblad_lds_size(n, S, L, 0) > 160 * 1024) ? 1 : 0;
+    if (qocx::lindblad_lds_size(n, S, L, ctx->lb.global_scratch) > 160 * 1024)
+        return fail(QOCX_ERR_ARG, "too many operators for the kernel's LDS");
     auto& lb = ctx->lb;
     lb.has_problem = false;
     lb.n = n; lb.S = S; lb.K = K; lb.nc = nc; lb.N = N; lb.nsteps = N - 1; lb.ces = p->cost_eval_step;
@@ -1270,6 +1287,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     if (batch < 1) return fail(QOCX_ERR_ARG, "batch must be >= 1");
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = lb.n, S = lb.S, K = lb.K, nc = lb.nc, nsteps = lb.nsteps, B = batch;
+    const size_t md = dump_elems(n);
     want_grad = (want_grad && K > 0) ? 1 : 0;
     if (K > 0 && !controls) return fail(QOCX_ERR_ARG, "controls is NULL");
 
@@ -1312,7 +1330,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             if (rc) return rc;
             it = lb.grids.find(kv.first);
         }
-        ckpt_total += kv.second.size() * (size_t)it->second.nsub * S * 256;
+        ckpt_total += kv.second.size() * (size_t)it->second.nsub * S * md;
         gsub_total += kv.second.size() * (size_t)it->second.nsub * 2 * std::max(K, 1);
         for (int b : kv.second) lb.order.push_back(b);
     }
@@ -1327,20 +1345,23 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                        sizeof(double2);
         size_t want = 0;
         for (auto& kv : groups) {
-            const size_t per_seed = (size_t)lb.grids[kv.first].nsub * S * 256 * 12;
+            const size_t per_seed = (size_t)lb.grids[kv.first].nsub * S * md * 12;
             const size_t piece = std::min<size_t>(kv.second.size(),
                                                   std::max<size_t>(1, stage_budget / per_seed));
             if (piece == kv.second.size() || piece >= 256) want = std::max(want, piece * per_seed);
         }
         if (want > 0 && lb.ystages.ensure(want)) return QOCX_ERR_HIP;
     }
+    if (lb.global_scratch &&
+        lb.scratch.ensure((size_t)B * qocx::lindblad_scratch_elems(n, S)))
+        return QOCX_ERR_HIP;
     const size_t csz = (size_t)nc * K;
     if (lb.controls.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.cost_out.ensure(B) ||
         lb.grads.ensure((size_t)B * std::max<size_t>(csz, 1)) || lb.gsub.ensure(gsub_total) ||
-        lb.checkpoints.ensure(ckpt_total) || lb.final_out.ensure((size_t)B * S * 256))
+        lb.checkpoints.ensure(ckpt_total) || lb.final_out.ensure((size_t)B * S * md))
         return QOCX_ERR_HIP;
     if (ctx->keep_step_states)
-        if (lb.step_densities.ensure((size_t)B * (nsteps + 1) * S * 256)) return QOCX_ERR_HIP;
+        if (lb.step_densities.ensure((size_t)B * (nsteps + 1) * S * md)) return QOCX_ERR_HIP;
     std::vector<double> gathered;
     if (K > 0) {
         gathered.resize((size_t)B * csz);
@@ -1356,12 +1377,12 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         std::vector<int> index(nsteps + 1, -1);
         for (int c = 0; c < lb.inj_count; ++c) index[lb.inj_steps[c]] = c;
         const size_t per_seed = (size_t)lb.inj_count * S;
-        std::vector<double2> dumps((size_t)B * per_seed * 256);
+        std::vector<double2> dumps((size_t)B * per_seed * md);
         for (int pos = 0; pos < B; ++pos)
             for (size_t v = 0; v < per_seed; ++v) {
                 cmat m(lb.inj_host.begin() + (((size_t)lb.order[pos] * per_seed + v) * n * n * 2),
                        lb.inj_host.begin() + (((size_t)lb.order[pos] * per_seed + v + 1) * n * n * 2));
-                c_dump(m, n, dumps.data() + ((size_t)pos * per_seed + v) * 256);
+                c_dump(m, n, dumps.data() + ((size_t)pos * per_seed + v) * md);
             }
         if (lb.inj_index.upload(index, ctx->stream) || lb.inj_bars.upload(dumps, ctx->stream))
             return QOCX_ERR_HIP;
@@ -1370,7 +1391,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     for (auto& kv : groups) {
         const auto& gr = lb.grids[kv.first];
         const int Bg = (int)kv.second.size(), nsub = gr.nsub;
-        const size_t per_seed_stage = (size_t)nsub * S * 256 * 12;
+        const size_t per_seed_stage = (size_t)nsub * S * md * 12;
         int piece = Bg;
         bool keep_stages = false;
         if (want_grad) {
@@ -1391,13 +1412,14 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.cost_counts = lb.cost_counts.p;
             la.checkpoints = lb.checkpoints.p + ckpt_off; la.gsub = lb.gsub.p + gsub_off;
             la.ystages = keep_stages ? lb.ystages.p : nullptr;  // reused piece after piece
+            la.scratch = lb.global_scratch ? lb.scratch.p : nullptr;  // likewise
             la.cost_out = lb.cost_out.p + pos0;
-            la.final_out = lb.final_out.p + pos0 * S * 256;
+            la.final_out = lb.final_out.p + pos0 * S * md;
             la.step_densities = ctx->keep_step_states
-                                    ? lb.step_densities.p + pos0 * (nsteps + 1) * S * 256 : nullptr;
+                                    ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
             la.inj_count = lb.inj_count;
             la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
-            la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * 256 : nullptr;
+            la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * md : nullptr;
             time_begin(ctx, 5, ctx->stream);
             qocx::launch_lindblad(la, Bp, ctx->stream);
             time_end(ctx, ctx->stream);
@@ -1411,12 +1433,12 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 time_end(ctx, ctx->stream);
             }
             pos0 += Bp;
-            ckpt_off += (size_t)Bp * nsub * S * 256;
+            ckpt_off += (size_t)Bp * nsub * S * md;
             gsub_off += (size_t)Bp * nsub * 2 * std::max(K, 1);
         }
     }
     HIP_TRY(hipGetLastError());
-    std::vector<double2> fin(final_out ? (size_t)B * S * 256 : 0);
+    std::vector<double2> fin(final_out ? (size_t)B * S * md : 0);
     std::vector<double> cst(B), grd(want_grad && grad_out ? (size_t)B * csz : 0);
     HIP_TRY(hipMemcpyAsync(cst.data(), lb.cost_out.p, (size_t)B * sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream));
@@ -1435,7 +1457,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             memcpy(grad_out + (size_t)b * csz, grd.data() + (size_t)pos * csz, csz * sizeof(double));
         if (final_out)
             for (int s = 0; s < S; ++s)
-                from_c_dump(fin.data() + ((size_t)pos * S + s) * 256, n,
+                from_c_dump(fin.data() + ((size_t)pos * S + s) * md, n,
                             final_out + ((size_t)b * S + s) * n * n * 2);
     }
     lb.B = B;
@@ -1474,12 +1496,13 @@ int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out) {
         return fail(QOCX_ERR_STATE, "step densities were not kept (qocx_set_keep_step_states)");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t per_seed = (size_t)(lb.nsteps + 1) * lb.S;
-    std::vector<double2> tmp((size_t)lb.B * per_seed * 256);
+    const size_t md = dump_elems(lb.n);
+    std::vector<double2> tmp((size_t)lb.B * per_seed * md);
     HIP_TRY(hipMemcpy(tmp.data(), lb.step_densities.p, tmp.size() * sizeof(double2),
                       hipMemcpyDeviceToHost));
     for (int pos = 0; pos < lb.B; ++pos)
         for (size_t v = 0; v < per_seed; ++v)
-            from_c_dump(tmp.data() + ((size_t)pos * per_seed + v) * 256, lb.n,
+            from_c_dump(tmp.data() + ((size_t)pos * per_seed + v) * md, lb.n,
                         densities_out + ((size_t)lb.order[pos] * per_seed + v) * lb.n * lb.n * 2);
     return 0;
 }

@@ -169,6 +169,8 @@ struct LindbladArgs {
     const double2* cost_matrices;  // pooled C-dumps
     const int* cost_counts;
     double2* checkpoints;      // [B][nsub][S] C-dumps: densities at the start of each sub-interval
+    double2* scratch;          // [B][2 S + 12] dumps when densities / cotangents / stage
+                               // derivatives do not live in LDS (always for n > 16), else nullptr
     double2* ystages;          // [B][nsub][S][12] C-dumps of the stage values, or nullptr: the
                                // adjoint then recomputes them from the checkpoints
     double* gsub;              // [B][nsub][2][K] control cotangents at t_a / t_b
@@ -181,7 +183,8 @@ struct LindbladArgs {
 };
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
-int lindblad_lds_size(int S, int nops);
+int lindblad_lds_size(int n, int S, int nops, int global_scratch);
+size_t lindblad_scratch_elems(int n, int S);
 
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,

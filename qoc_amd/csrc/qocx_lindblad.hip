@@ -22,12 +22,6 @@ namespace qocx {
 
 namespace {
 
-constexpr int LNB = 1;                 // n <= 16
-typedef Geo<LNB> LG;
-typedef CMat<LNB> Mat;                 // 16 x 16 complex in C-layout: 16 VGPRs
-constexpr int LPLANE = LG::PLANE;      // doubles per LDS plane
-constexpr int SLOT_BYTES = 2 * LPLANE * 8;  // planar left-operand slot
-constexpr int DUMP_BYTES = 256 * 16;        // C-layout dump of one matrix (lane-linear)
 constexpr int STAGES = QOCX_RK_STAGES;
 
 // the Butcher tableau in constant memory (runtime-indexed by the rolled stage loops)
@@ -52,71 +46,118 @@ struct Slot {
     double* im;
 };
 
-__device__ __forceinline__ Slot slot_at(char* base) {
+// Everything is a member of this template: LNB = 1 (n <= 16, one MFMA tile per matrix) or
+// LNB = 2 (n <= 32, four tiles). GS: the stage derivatives, the densities and the cotangents
+// live in per-seed HBM scratch instead of LDS (always for LNB = 2: 12 x 16 KB do not fit).
+template <int LNB, bool GS>
+struct LB {
+typedef Geo<LNB> LG;
+typedef CMat<LNB> Mat;                               // C-layout register tiles
+static constexpr int MAT = 256 * LNB * LNB;          // complex elements of one matrix dump
+static constexpr int LPLANE = LG::PLANE;             // doubles per LDS plane
+static constexpr int SLOT_BYTES = 2 * LPLANE * 8;    // planar left-operand slot
+static constexpr int DUMP_BYTES = MAT * 16;          // C-layout dump of one matrix (lane-linear)
+
+static __device__ __forceinline__ Slot slot_at(char* base) {
     Slot s;
     s.re = reinterpret_cast<double*>(base);
     s.im = s.re + LPLANE;
     return s;
 }
 
-// C-layout dump: reg r of lane l <-> complex index r*64 + l (conflict free, coalesced)
-__device__ __forceinline__ void dump_store(const Mat& m, double2* d) {
+// C-layout dump: reg r of tile (ti, tj) of lane l <-> complex index ((ti LNB + tj) 4 + r) 64 + l
+static __device__ __forceinline__ void dump_store(const Mat& m, double2* d) {
     const int lane = lane_id();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r * 64 + lane] = make_double2(m.re[0][0][r], m.im[0][0][r]);
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d[((ti * LNB + tj) * 4 + r) * 64 + lane] =
+                    make_double2(m.re[ti][tj][r], m.im[ti][tj][r]);
 }
-__device__ __forceinline__ void dump_load(Mat& m, const double2* d) {
+static __device__ __forceinline__ void dump_load(Mat& m, const double2* d) {
     const int lane = lane_id();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double2 e = d[r * 64 + lane];
-        m.re[0][0][r] = e.x;
-        m.im[0][0][r] = e.y;
-    }
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = d[((ti * LNB + tj) * 4 + r) * 64 + lane];
+                m.re[ti][tj][r] = e.x;
+                m.im[ti][tj][r] = e.y;
+            }
 }
 
 // C-layout registers of M^H from the planar image of M
-__device__ __forceinline__ void load_adjoint(Mat& m, const Slot& s) {
+static __device__ __forceinline__ void load_adjoint(Mat& m, const Slot& s) {
     const int q = lane_id() >> 4, c = lane_id() & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int off = c * LG::PITCH + 4 * r + q;  // element (row 4r+q, col c) of M^H = conj M[c][4r+q]
-        m.re[0][0][r] = s.re[off];
-        m.im[0][0][r] = -s.im[off];
-    }
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // element (R, C) of M^H = conj M[C][R], R = 16 ti + 4 r + q, C = 16 tj + c
+                const int off = (16 * tj + c) * LG::PITCH + 16 * ti + 4 * r + q;
+                m.re[ti][tj][r] = s.re[off];
+                m.im[ti][tj][r] = -s.im[off];
+            }
 }
 
 // C-layout registers of M from the planar image of M
-__device__ __forceinline__ void load_plain(Mat& m, const Slot& s) {
+static __device__ __forceinline__ void load_plain(Mat& m, const Slot& s) {
     const int q = lane_id() >> 4, c = lane_id() & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int off = (4 * r + q) * LG::PITCH + c;
-        m.re[0][0][r] = s.re[off];
-        m.im[0][0][r] = s.im[off];
-    }
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (16 * ti + 4 * r + q) * LG::PITCH + 16 * tj + c;
+                m.re[ti][tj][r] = s.re[off];
+                m.im[ti][tj][r] = s.im[off];
+            }
 }
 
-__device__ __forceinline__ void mat_zero(Mat& m) { cmat_zero<LNB>(m); }
-__device__ __forceinline__ void mat_axpy(Mat& y, double a, const Mat& x) {
-    y.re[0][0] += a * x.re[0][0];
-    y.im[0][0] += a * x.im[0][0];
+static __device__ __forceinline__ void mat_zero(Mat& m) { cmat_zero<LNB>(m); }
+static __device__ __forceinline__ void mat_axpy(Mat& y, double a, const Mat& x) {
+#pragma unroll
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj) {
+            y.re[ti][tj] += a * x.re[ti][tj];
+            y.im[ti][tj] += a * x.im[ti][tj];
+        }
 }
 
 // acc += Left * right, Left = the planar slot (or its conjugate transpose), right in registers
 template <bool LEFT_ADJ>
-__device__ __forceinline__ void gemm(Mat& acc, const Slot& left, const Mat& right) {
+static __device__ __forceinline__ void gemm(Mat& acc, const Slot& left, const Mat& right) {
     const int q = lane_id() >> 4, c = lane_id() & 15;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int off = LEFT_ADJ ? ((4 * kk + q) * LG::PITCH + c) : (c * LG::PITCH + 4 * kk + q);
-        const double are = left.re[off];
-        const double aim = LEFT_ADJ ? -left.im[off] : left.im[off];
-        const double bre = right.re[0][0][kk], bim = right.im[0][0][kk];
-        acc.re[0][0] = mfma_f64(are, bre, acc.re[0][0]);
-        acc.re[0][0] = mfma_f64(-aim, bim, acc.re[0][0]);
-        acc.im[0][0] = mfma_f64(are, bim, acc.im[0][0]);
-        acc.im[0][0] = mfma_f64(aim, bre, acc.im[0][0]);
+    for (int kk = 0; kk < 4 * LNB; ++kk) {
+        double are[LNB], aim[LNB];
+#pragma unroll
+        for (int ti = 0; ti < LNB; ++ti) {
+            const int off = LEFT_ADJ ? ((4 * kk + q) * LG::PITCH + 16 * ti + c)
+                                     : ((16 * ti + c) * LG::PITCH + 4 * kk + q);
+            are[ti] = left.re[off];
+            aim[ti] = LEFT_ADJ ? -left.im[off] : left.im[off];
+        }
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj) {
+            const double bre = right.re[kk >> 2][tj][kk & 3], bim = right.im[kk >> 2][tj][kk & 3];
+#pragma unroll
+            for (int ti = 0; ti < LNB; ++ti) {
+                acc.re[ti][tj] = mfma_f64(are[ti], bre, acc.re[ti][tj]);
+                acc.re[ti][tj] = mfma_f64(-aim[ti], bim, acc.re[ti][tj]);
+                acc.im[ti][tj] = mfma_f64(are[ti], bim, acc.im[ti][tj]);
+                acc.im[ti][tj] = mfma_f64(aim[ti], bre, acc.im[ti][tj]);
+            }
+        }
     }
 }
 
@@ -129,7 +170,7 @@ struct Operands {     // LDS addresses of one direction (forward or adjoint) of 
 
 // out = Gen y + y GenRight + sum_i gamma_i Op_i y Op_i^H   (ADJ: Op_i^H y Op_i)
 template <bool ADJ>
-__device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen_right,
+static __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen_right,
                                           const Operands& o, int nops, const double* gammas) {
     cmat_to_lds<LNB>(y, o.y_left.re, o.y_left.im);
     wave_sync();
@@ -142,8 +183,7 @@ __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen
         const Slot op = slot_at(o.op_planar + (size_t)i * SLOT_BYTES);
         gemm<ADJ>(t, op, y);
         const double gm = gammas[i];
-        t.re[0][0] *= gm;
-        t.im[0][0] *= gm;
+        cmat_scale<LNB>(t, gm);
         wave_sync();
         cmat_to_lds<LNB>(t, o.tmp.re, o.tmp.im);
         wave_sync();
@@ -154,21 +194,36 @@ __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen
     wave_sync();
 }
 
+// l += (zr + i zi) * t
+static __device__ __forceinline__ void add_scaled(Mat& l, double zr, double zi, const Mat& t) {
+#pragma unroll
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj) {
+            l.re[ti][tj] += zr * t.re[ti][tj] - zi * t.im[ti][tj];
+            l.im[ti][tj] += zr * t.im[ti][tj] + zi * t.re[ti][tj];
+        }
+}
+
 // <X, Y> = sum conj(X) Y over the whole matrix, wave-uniform
-__device__ __forceinline__ void frob_inner(const Mat& x, const Mat& y, double& re, double& im) {
+static __device__ __forceinline__ void frob_inner(const Mat& x, const Mat& y, double& re, double& im) {
     double pr = 0, pi = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        pr += x.re[0][0][r] * y.re[0][0][r] + x.im[0][0][r] * y.im[0][0][r];
-        pi += x.re[0][0][r] * y.im[0][0][r] - x.im[0][0][r] * y.re[0][0][r];
-    }
+    for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr += x.re[ti][tj][r] * y.re[ti][tj][r] + x.im[ti][tj][r] * y.im[ti][tj][r];
+                pi += x.re[ti][tj][r] * y.im[ti][tj][r] - x.im[ti][tj][r] * y.re[ti][tj][r];
+            }
     re = wave_sum(pr);
     im = wave_sum(pi);
 }
 
 // Density costs on the S densities in `dens` (LDS dumps); optionally adds the cotangents into
 // `lam`. qoc/standard/costs/targetdensityinfidelity.py:41-69, forbiddensities.py:53-85.
-__device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step_pass,
+static __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step_pass,
                                                 bool final_pass, const double2* dens,
                                                 double2* lam) {
     const int S = a.S, n = a.n;
@@ -177,13 +232,13 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
         const DevCost c = a.costs[ci];
         const bool on = c.step_cost ? step_pass : final_pass;
         if (!on) continue;
-        const double2* pool = a.cost_matrices + (size_t)c.vec_offset * 256;
+        const double2* pool = a.cost_matrices + (size_t)c.vec_offset * MAT;
         if (c.kind == QOCX_DEV_COST_TARGET_DENSITY) {
             double fid = 0;
             for (int s = 0; s < S; ++s) {
                 Mat t, rho;
-                dump_load(t, pool + (size_t)s * 256);
-                dump_load(rho, dens + (size_t)s * 256);
+                dump_load(t, pool + (size_t)s * MAT);
+                dump_load(rho, dens + (size_t)s * MAT);
                 double zr, zi;
                 frob_inner(t, rho, zr, zi);  // tr(T^H rho)
                 const double mag = sqrt(zr * zr + zi * zi);
@@ -191,13 +246,9 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
                 if (lam != nullptr && mag > 0) {
                     const double f = -c.scale / ((double)S * n * mag);
                     Mat l;
-                    dump_load(l, lam + (size_t)s * 256);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        l.re[0][0][r] += f * (zr * t.re[0][0][r] - zi * t.im[0][0][r]);
-                        l.im[0][0][r] += f * (zr * t.im[0][0][r] + zi * t.re[0][0][r]);
-                    }
-                    dump_store(l, lam + (size_t)s * 256);
+                    dump_load(l, lam + (size_t)s * MAT);
+                    add_scaled(l, f * zr, f * zi, t);
+                    dump_store(l, lam + (size_t)s * MAT);
                 }
             }
             total += c.scale * (1.0 - fid / ((double)S * n));
@@ -207,11 +258,11 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
             for (int s = 0; s < S; ++s) {
                 const int fs = a.cost_counts[c.cnt_offset + s];
                 Mat rho, l;
-                dump_load(rho, dens + (size_t)s * 256);
-                if (lam != nullptr) dump_load(l, lam + (size_t)s * 256);
+                dump_load(rho, dens + (size_t)s * MAT);
+                if (lam != nullptr) dump_load(l, lam + (size_t)s * MAT);
                 for (int f = 0; f < fs; ++f) {
                     Mat t;
-                    dump_load(t, pool + (size_t)(base + f) * 256);
+                    dump_load(t, pool + (size_t)(base + f) * MAT);
                     double zr, zi;
                     frob_inner(t, rho, zr, zi);
                     zr /= n;
@@ -219,14 +270,10 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
                     acc += (zr * zr + zi * zi) / fs;
                     if (lam != nullptr) {
                         const double g = 2.0 * c.scale / ((double)fs * n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            l.re[0][0][r] += g * (zr * t.re[0][0][r] - zi * t.im[0][0][r]);
-                            l.im[0][0][r] += g * (zr * t.im[0][0][r] + zi * t.re[0][0][r]);
-                        }
+                        add_scaled(l, g * zr, g * zi, t);
                     }
                 }
-                if (lam != nullptr) dump_store(l, lam + (size_t)s * 256);
+                if (lam != nullptr) dump_store(l, lam + (size_t)s * MAT);
                 base += fs;
             }
             total += c.scale * acc;
@@ -236,15 +283,12 @@ __device__ __forceinline__ double density_costs(const LindbladArgs& a, bool step
     return total;
 }
 
-}  // namespace
-
-// LDS carve (bytes): 3 planar work slots | per operator: planar L | S density dumps |
-// S lambda dumps | STAGES stage-derivative dumps.  80 KB at S = 1, L = 2: two seeds per CU.
-__host__ __device__ inline int lindblad_lds_bytes(int S, int nops) {
-    return 3 * SLOT_BYTES + nops * SLOT_BYTES + 2 * S * DUMP_BYTES + STAGES * DUMP_BYTES;
+// LDS carve (bytes): 3 planar work slots | per operator: planar L | and unless GS: S density
+// dumps | S lambda dumps | STAGES stage-derivative dumps. 80 KB at LNB = 1, S = 1, L = 2: two
+// seeds per CU.
+static __host__ __device__ int lds_bytes(int S, int nops) {
+    return 3 * SLOT_BYTES + nops * SLOT_BYTES + (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES);
 }
-
-namespace {
 
 // Everything one wave needs; the stage loops are template recursions over the (compile-time)
 // Butcher tableau so that the stage derivatives stay in registers.
@@ -270,7 +314,7 @@ struct Wave {
             const double ub = ss.wb1 * ctl_b[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl_b[(size_t)ss.ib2 * K + k];
             const double u = (1.0 - c) * ua + c * ub;  // u(t) is linear inside a sub-interval
             Mat g;
-            dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * 256);
+            dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
             mat_axpy(left, u, g);
             mat_axpy(right, -u, g);
         }
@@ -286,7 +330,7 @@ struct Wave {
             const double aij = RK_A_DEV[i * STAGES + j];
             if (aij != 0.0) {
                 Mat k;
-                dump_load(k, kdump + (size_t)j * 256);
+                dump_load(k, kdump + (size_t)j * MAT);
                 mat_axpy(y, h * aij, k);
             }
         }
@@ -297,13 +341,13 @@ struct Wave {
         for (int i = 0; i < STAGES; ++i) {
             Mat y, k, gl, gr;
             stage_value(y, y0, i, ss.h);
-            if (ystore != nullptr) dump_store(y, ystore + (size_t)i * 256);  // for the adjoint
+            if (ystore != nullptr) dump_store(y, ystore + (size_t)i * MAT);  // for the adjoint
             build_generator(ss, RK_C_DEV[i], false, gl, gr);
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
             wave_sync();
             rhs_apply<false>(k, y, gr, fwd, a.nops, a.gammas);
-            dump_store(k, kdump + (size_t)i * 256);
+            dump_store(k, kdump + (size_t)i * MAT);
             wave_sync();
         }
         if (advance)
@@ -311,7 +355,7 @@ struct Wave {
                 const double bi = RK_B_DEV[i];
                 if (bi != 0.0) {
                     Mat k;
-                    dump_load(k, kdump + (size_t)i * 256);
+                    dump_load(k, kdump + (size_t)i * MAT);
                     mat_axpy(y0, ss.h * bi, k);
                 }
             }
@@ -335,7 +379,7 @@ struct Wave {
                 const double aji = RK_A_DEV[j * STAGES + i];
                 if (aji != 0.0) {
                     Mat yb;
-                    dump_load(yb, kdump + (size_t)j * 256);
+                    dump_load(yb, kdump + (size_t)j * MAT);
                     mat_axpy(kb, ss.h * aji, yb);
                 }
             }
@@ -349,10 +393,10 @@ struct Wave {
             // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
             // Z = Y kbar^H - kbar^H Y  (slot_y still holds kbar as a planar image)
             Mat y, kbd, z, z2;
-            if (ystore != nullptr) dump_load(y, ystore + (size_t)i * 256);
+            if (ystore != nullptr) dump_load(y, ystore + (size_t)i * MAT);
             else stage_value(y, y0, i, ss.h);  // the stage value Y_i again
             wave_sync();
-            dump_store(ybar, kdump + (size_t)i * 256);  // k_i is no longer needed
+            dump_store(ybar, kdump + (size_t)i * MAT);  // k_i is no longer needed
             load_adjoint(kbd, slot_y);
             mat_zero(z2);
             gemm<true>(z2, slot_y, y);  // kbar^H Y
@@ -365,11 +409,16 @@ struct Wave {
             const int K = a.K;
             for (int k = 0; k < K; ++k) {
                 Mat gt;
-                dump_load(gt, a.gpt_cimg + (size_t)k * 256);  // C-image of Gp_k^T
+                dump_load(gt, a.gpt_cimg + (size_t)k * MAT);  // C-image of Gp_k^T
                 double pr = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                for (int ti = 0; ti < LNB; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < LNB; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pr += z.re[ti][tj][r] * gt.re[ti][tj][r] -
+                                  z.im[ti][tj][r] * gt.im[ti][tj][r];
                 const double g = wave_sum(pr);
 #pragma unroll
                 for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
@@ -383,10 +432,8 @@ struct Wave {
     }
 };
 
-}  // namespace
-
-__global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// the kernel body: one wavefront = one seed
+static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     const int lane = lane_id();
     const int S = a.S, K = a.K, nops = a.nops, nsub = a.nsub;
     const int b = blockIdx.x;
@@ -395,22 +442,29 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     const Slot slot_y = slot_at(p); p += SLOT_BYTES;
     const Slot slot_tmp = slot_at(p); p += SLOT_BYTES;
     char* op_planar = p; p += (size_t)nops * SLOT_BYTES;     // L_i
-    double2* dens = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
-    double2* lam = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
-    double2* kdump = reinterpret_cast<double2*>(p);
+    double2 *dens, *lam, *kdump;
+    if (GS) {  // per-seed HBM scratch: S densities | S cotangents | STAGES stage derivatives
+        dens = a.scratch + (size_t)b * (2 * S + STAGES) * MAT;
+        lam = dens + (size_t)S * MAT;
+        kdump = lam + (size_t)S * MAT;
+    } else {
+        dens = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
+        lam = reinterpret_cast<double2*>(p); p += (size_t)S * DUMP_BYTES;
+        kdump = reinterpret_cast<double2*>(p);
+    }
 
     // static operators into LDS (planar: left operand directly, right operand by a
     // transposing read)
     for (int i = 0; i < nops; ++i) {
         Mat op;
-        dump_load(op, a.op_cimg + (size_t)i * 256);
+        dump_load(op, a.op_cimg + (size_t)i * MAT);
         cmat_to_lds<LNB>(op, slot_at(op_planar + (size_t)i * SLOT_BYTES).re,
                          slot_at(op_planar + (size_t)i * SLOT_BYTES).im);
     }
     for (int s = 0; s < S; ++s) {
         Mat rho;
-        dump_load(rho, a.rho0_cimg + (size_t)s * 256);
-        dump_store(rho, dens + (size_t)s * 256);
+        dump_load(rho, a.rho0_cimg + (size_t)s * MAT);
+        dump_store(rho, dens + (size_t)s * MAT);
     }
     wave_sync();
 
@@ -420,7 +474,7 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     adj = fwd;
     const Wave w{a, slot_gen, slot_y, slot_tmp, fwd, adj, kdump,
                  a.controls + (size_t)b * a.nc * K};
-    double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * 256;
+    double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
 
     // ---- forward ------------------------------------------------------------------------
     double cost = 0;
@@ -432,21 +486,21 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
             if (a.step_densities != nullptr)
                 for (int s = 0; s < S; ++s) {
                     Mat rho;
-                    dump_load(rho, dens + (size_t)s * 256);
+                    dump_load(rho, dens + (size_t)s * MAT);
                     dump_store(rho, a.step_densities +
-                                        (((size_t)b * (a.nsteps + 1) + ss.step) * S + s) * 256);
+                                        (((size_t)b * (a.nsteps + 1) + ss.step) * S + s) * MAT);
                 }
         }
         for (int s = 0; s < S; ++s) {
             Mat y0;
-            dump_load(y0, dens + (size_t)s * 256);
-            dump_store(y0, ckpt_b + ((size_t)q * S + s) * 256);
+            dump_load(y0, dens + (size_t)s * MAT);
+            dump_store(y0, ckpt_b + ((size_t)q * S + s) * MAT);
             w.substep(ss, y0, true,
                       a.ystages != nullptr
-                          ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * 256
+                          ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                           : nullptr);
             wave_sync();
-            dump_store(y0, dens + (size_t)s * 256);
+            dump_store(y0, dens + (size_t)s * MAT);
             wave_sync();
         }
     }
@@ -455,10 +509,10 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     if (lane == 0) a.cost_out[b] = cost;
     for (int s = 0; s < S; ++s) {
         Mat rho;
-        dump_load(rho, dens + (size_t)s * 256);
-        dump_store(rho, a.final_out + ((size_t)b * S + s) * 256);
+        dump_load(rho, dens + (size_t)s * MAT);
+        dump_store(rho, a.final_out + ((size_t)b * S + s) * MAT);
         if (a.step_densities != nullptr)
-            dump_store(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * 256);
+            dump_store(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
     }
     if (!a.want_grad) return;
 
@@ -466,7 +520,7 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     {
         Mat zero;
         mat_zero(zero);
-        for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * 256);
+        for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * MAT);
     }
     wave_sync();
     (void)density_costs(a, (a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
@@ -477,10 +531,10 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
         if (row < 0) return;
         for (int s = 0; s < S; ++s) {
             Mat l, e;
-            dump_load(l, lam + (size_t)s * 256);
-            dump_load(e, a.inj_bars + (((size_t)b * a.inj_count + row) * S + s) * 256);
+            dump_load(l, lam + (size_t)s * MAT);
+            dump_load(e, a.inj_bars + (((size_t)b * a.inj_count + row) * S + s) * MAT);
             mat_axpy(l, 1.0, e);
-            dump_store(l, lam + (size_t)s * 256);
+            dump_store(l, lam + (size_t)s * MAT);
         }
         wave_sync();
     };
@@ -496,16 +550,16 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
         }
         for (int s = 0; s < S; ++s) {
             Mat y0;
-            dump_load(y0, ckpt_b + ((size_t)q * S + s) * 256);
+            dump_load(y0, ckpt_b + ((size_t)q * S + s) * MAT);
             const double2* ys = a.ystages != nullptr
-                                    ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * 256
+                                    ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                                     : nullptr;
             if (ys == nullptr) w.substep(ss, y0, false);  // recompute the stage derivatives
             Mat lambda, lambda_new;
-            dump_load(lambda, lam + (size_t)s * 256);
+            dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
             w.adjoint_substep(ss, y0, lambda, lambda_new, ga, gb, ys);
-            dump_store(lambda_new, lam + (size_t)s * 256);
+            dump_store(lambda_new, lam + (size_t)s * MAT);
             wave_sync();
         }
         if (lane == 0)
@@ -518,8 +572,8 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
             a.has_step_costs) {
             for (int s = 0; s < S; ++s) {
                 Mat rho;
-                dump_load(rho, ckpt_b + ((size_t)q * S + s) * 256);
-                dump_store(rho, dens + (size_t)s * 256);
+                dump_load(rho, ckpt_b + ((size_t)q * S + s) * MAT);
+                dump_store(rho, dens + (size_t)s * MAT);
             }
             wave_sync();
             (void)density_costs(a, true, false, dens, lam);
@@ -528,13 +582,39 @@ __global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
     }
 }
 
-void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
-    const int bytes = lindblad_lds_bytes(a.S, a.nops);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(lindblad_kernel, dim3(batch), dim3(64), bytes, st, a);
+};  // struct LB
+
+template <int LNB, bool GS>
+__global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LB<LNB, GS>::run(a, smem);
 }
 
-int lindblad_lds_size(int S, int nops) { return lindblad_lds_bytes(S, nops); }
+template <int LNB, bool GS>
+void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
+    const int bytes = LB<LNB, GS>::lds_bytes(a.S, a.nops);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS>), dim3(batch), dim3(64), bytes, st, a);
+}
+
+}  // namespace
+
+void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
+    if (a.n > 16) launch_t<2, true>(a, batch, st);
+    else if (a.scratch != nullptr) launch_t<1, true>(a, batch, st);
+    else launch_t<1, false>(a, batch, st);
+}
+
+// LDS bytes of one seed; global_scratch: stage derivatives, densities and cotangents in HBM
+int lindblad_lds_size(int n, int S, int nops, int global_scratch) {
+    if (n > 16) return LB<2, true>::lds_bytes(S, nops);
+    return global_scratch ? LB<1, true>::lds_bytes(S, nops) : LB<1, false>::lds_bytes(S, nops);
+}
+
+// complex elements of per-seed HBM scratch when it is used
+size_t lindblad_scratch_elems(int n, int S) {
+    return (size_t)(2 * S + STAGES) * (n > 16 ? 1024 : 256);
+}
 
 }  // namespace qocx

@@ -299,6 +299,9 @@ def lindblad_cases():
         lindblad_case("lindblad_n4_complex", n=4, N=9, S=1, K=1, seeds=2, h_seed=72, Nc=5, T=0.9,
                       complex_controls=True, ops="random"),
         lindblad_case("lindblad_c4_short", n=16, N=6, S=1, K=2, seeds=2, h_seed=2004, sigma=0.1),
+        # two MFMA tiles per side (n > 16): densities, cotangents and stages in HBM scratch
+        lindblad_case("lindblad_n20", n=20, N=4, S=2, K=2, seeds=2, h_seed=2020, Nc=3, T=0.24,
+                      sigma=0.3, with_forbid=True),
     ]
 
 

@@ -160,8 +160,8 @@ def test_lindblad_batch_independent_of_neighbours(engine):
 def test_lindblad_rejects_unsupported(engine):
     from qoc_amd.engine import QocxError
     with pytest.raises(QocxError):
-        engine.set_lindblad_problem(17, 1, 0, 0, 2, 1.0, np.zeros((17, 17)), None, None, None,
-                                    np.eye(17)[None] / 17)
+        engine.set_lindblad_problem(33, 1, 0, 0, 2, 1.0, np.zeros((33, 33)), None, None, None,
+                                    np.eye(33)[None] / 33)
 
 
 LINDBLAD_EDGES = [
@@ -170,6 +170,9 @@ LINDBLAD_EDGES = [
     dict(n=16, S=2, K=8, L=0, N=3, Nc=5),   # full tile, maximum controls, no dissipation
     dict(n=7, S=1, K=0, L=2, N=5, Nc=0),    # no controls at all
     dict(n=5, S=3, K=1, L=1, N=2, Nc=9),    # one system step, many control knots inside it
+    dict(n=3, S=12, K=1, L=4, N=3, Nc=3),   # one tile, but too many densities for LDS: HBM scratch
+    dict(n=32, S=1, K=2, L=4, N=2, Nc=2),   # largest supported Hilbert space and operator count
+    dict(n=17, S=2, K=1, L=1, N=3, Nc=4),   # two tiles with 15 padded rows
 ]
 
 

@@ -118,8 +118,8 @@ def test_structure_rejects_time_dependence_and_size():
             case.T, case.initial_densities, case.N, controls=case.controls[0],
             hamiltonian=lambda u, t: case.h0 + u[0] ** 2 * case.g_re[0])
     with pytest.raises(NotImplementedError):
-        qoc_amd.evolve_lindblad_discrete(1.0, np.eye(17)[None] / 17, 2,
-                                         hamiltonian=lambda u, t: np.eye(17))
+        qoc_amd.evolve_lindblad_discrete(1.0, np.eye(33)[None] / 33, 2,
+                                         hamiltonian=lambda u, t: np.eye(33))
     with pytest.raises(NotImplementedError):
         qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N,
                                          controls=case.controls[0], hamiltonian=h,
