@@ -123,6 +123,12 @@ typedef struct qocx_lindblad_problem {
     const double* initial_densities; /* [S][n][n] complex                                          */
     int32_t cost_count;
     const qocx_cost_desc* costs;  /* kinds QOCX_COST_TARGET_DENSITY / QOCX_COST_FORBID_DENSITY     */
+    /* Hamiltonian with explicit time dependence: every seed then uses `fixed_subdivision` pieces
+     * per system step and h0 / g are given at the stage times of that grid
+     * (qocx_lindblad_stage_times, same order). 0: time independent, sub-division chosen per seed. */
+    int32_t fixed_subdivision;
+    const double* h0_stages;      /* [count][n][n] complex                                         */
+    const double* g_stages;       /* [count][K][n][n] complex, or NULL when g is constant          */
 } qocx_lindblad_problem;
 
 const char* qocx_last_error(void);
@@ -180,6 +186,13 @@ int qocx_set_state_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const
  * qocx_download_step_densities: [B][N][S][n][n] complex after qocx_set_keep_step_states(ctx, 1).
  */
 int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* problem);
+/* The times at which a time-dependent Hamiltonian must be sampled for `subdivision` pieces per
+ * system step: for every sub-interval [t_a, t_b] (uniform pieces cut at the control knots) the 12
+ * DOP853 stage times t_a + c_i (t_b - t_a). times_out may be NULL to query *count_out. */
+int qocx_lindblad_stage_times(double evolution_time, int32_t system_eval_count,
+                              int32_t control_eval_count, int32_t control_count,
+                              int32_t subdivision, double* times_out, int64_t capacity,
+                              int64_t* count_out);
 int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
                        double* cost_out, double* grad_out, double* final_out);
 int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out);

@@ -244,7 +244,7 @@ class LindbladEvaluator(object):
                  lindblad_data=None, control_count=0, control_eval_count=0,
                  complex_controls=False, costs=(), cost_eval_step=1,
                  interpolation_policy=InterpolationPolicy.LINEAR, need_gradients=True,
-                 backend=None):
+                 backend=None, control_bounds=None):
         if interpolation_policy != InterpolationPolicy.LINEAR:
             raise NotImplementedError("This operation does not yet support the interpolation "
                                       "policy {}.".format(interpolation_policy))
@@ -262,9 +262,10 @@ class LindbladEvaluator(object):
         self.final_system_eval_step = system_eval_count - 1
         self.cost_eval_step = cost_eval_step
         self.costs = list(costs)
-        h0, g, dissipators, operators = structure.probe_static_lindblad_system(
-            hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
-            evolution_time)
+        h0, g, dissipators, operators, self.time_dependent = \
+            structure.probe_static_lindblad_system(
+                hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
+                evolution_time)
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
         descriptors = []
         for cost in self.costs:
@@ -280,10 +281,50 @@ class LindbladEvaluator(object):
                 self.opaque_costs.append(cost)
         self.backend = backend if backend is not None else make_backend()
         self.kr = control_count * (2 if complex_controls else 1)
-        self.backend.set_lindblad_problem(
-            self.hilbert_size, self.density_count, self.kr, control_eval_count,
-            system_eval_count, evolution_time, h0, g, dissipators, operators, initial_densities,
-            costs=descriptors, cost_eval_step=cost_eval_step)
+        self._problem_args = (self.hilbert_size, self.density_count, self.kr, control_eval_count,
+                              system_eval_count, evolution_time, h0, g, dissipators, operators,
+                              initial_densities)
+        self._problem_kw = dict(costs=descriptors, cost_eval_step=cost_eval_step)
+        self._hamiltonian = hamiltonian
+        self._table_bounds = None
+        if not self.time_dependent:
+            self.backend.set_lindblad_problem(*self._problem_args, **self._problem_kw)
+        elif control_bounds is not None:  # GRAPE: max_control_norms bound the controls for good
+            bounds = np.repeat(np.asarray(control_bounds, dtype=np.float64),
+                               2 if complex_controls else 1)
+            self._set_time_dependent_problem(bounds)
+
+    def _set_time_dependent_problem(self, bounds):
+        """Sample the time-dependent Hamiltonian at the stage times of a sub-division fine
+        enough for controls up to `bounds` and hand the samples to the engine."""
+        (n, _, kr, nc, n_eval, evolution_time, h0, g, dissipators, operators, _) = \
+            self._problem_args
+        dt = evolution_time / (n_eval - 1)
+        probe_times = [evolution_time * q / 16 for q in range(17)]
+        h_probe, g_probe = structure.probe_hamiltonian(
+            self._hamiltonian, n, self.control_count, self.complex_controls, probe_times)
+        h_norm = max(np.linalg.norm(m, 1) for m in h_probe)
+        g_norms = [max(np.linalg.norm(g_probe[t, k], 1) for t in range(g_probe.shape[0]))
+                   for k in range(kr)]
+        ksub = structure.lindblad_subdivision(h_norm, g_norms, bounds, dissipators, operators, dt)
+        times = self.backend.lindblad_stage_times(evolution_time, n_eval, nc, kr, ksub)
+        h0_stages, g_stages = structure.sample_lindblad_hamiltonian(
+            self._hamiltonian, n, self.control_count, self.complex_controls, times)
+        self.backend.set_lindblad_problem(*self._problem_args, fixed_subdivision=ksub,
+                                          h0_stages=h0_stages, g_stages=g_stages,
+                                          **self._problem_kw)
+        self._table_bounds = np.asarray(bounds, dtype=np.float64)
+
+    def _ensure_time_table(self, device_controls):
+        if not self.time_dependent:
+            return
+        if self.control_count == 0:
+            need = np.zeros(0)
+        else:
+            need = np.max(np.abs(device_controls.reshape(-1, self.kr)), axis=0)
+        if self._table_bounds is None or np.any(need > self._table_bounds):
+            old = np.zeros_like(need) if self._table_bounds is None else self._table_bounds
+            self._set_time_dependent_problem(np.maximum(old, need))
 
     def evaluate_batch(self, controls_batch, want_grad=True, want_step_densities=False):
         """
@@ -298,6 +339,7 @@ class LindbladEvaluator(object):
             controls_batch = np.asarray(controls_batch)
             batch = controls_batch.shape[0]
             device_controls = structure.to_real_controls(controls_batch, self.complex_controls)
+        self._ensure_time_table(device_controls if self.control_count else None)
         need_steps = want_step_densities or bool(self.opaque_costs)
         two_pass = want_grad and bool(self.opaque_costs)
         if need_steps:

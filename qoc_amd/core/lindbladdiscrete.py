@@ -84,7 +84,7 @@ def grape_lindblad_discrete(control_count, control_eval_count, costs, evolution_
         lindblad_data=lindblad_data, control_count=control_count,
         control_eval_count=control_eval_count, complex_controls=complex_controls, costs=costs,
         cost_eval_step=cost_eval_step, interpolation_policy=interpolation_policy,
-        need_gradients=True)
+        need_gradients=True, control_bounds=max_control_norms)
     pstate.log_and_save_initial()
     reporter = Dummy()
     reporter.iteration = 0

@@ -85,8 +85,9 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
     Structure of the Lindblad path's inputs (qoc/core/lindbladdiscrete.py:444-493):
     hamiltonian(controls, time) and lindblad_data(time) -> (dissipators, operators).
     Returns (h0 (n, n), g (Kr, n, n), dissipators (L,) or None, operators (L, n, n) or None).
-    The engine integrates time-independent H0, G_k, gamma_i, L_i; explicit time dependence
-    (sampled at `probe_count` times across the evolution) is rejected loudly.
+    Returns (..., time_dependent): explicit time dependence of the Hamiltonian (probed at
+    `probe_count` times) is handled by sampling it at the integrator's stage times
+    (sample_lindblad_hamiltonian); a time-dependent lindblad_data is rejected loudly.
     """
     n = hilbert_size
     times = [evolution_time * q / (probe_count - 1) for q in range(probe_count)]
@@ -96,11 +97,7 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
         g = np.zeros((1, kr, n, n), dtype=np.complex128)
     else:
         h0, g = probe_hamiltonian(hamiltonian, n, control_count, complex_controls, times)
-    if h0.shape[0] != 1:
-        raise TimeDependentSystemError(
-            "hamiltonian(controls, time) depends on time explicitly: the MI355X Lindblad engine "
-            "integrates H = H0 + sum_k u_k(t) G_k with constant H0, G_k. There is no CPU "
-            "fallback.")
+    time_dependent = h0.shape[0] != 1
     dissipators, operators = None, None
     if lindblad_data is not None:
         first = lindblad_data(times[0])
@@ -122,7 +119,32 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
                 raise TimeDependentSystemError(
                     "lindblad_data(time) depends on time: the MI355X Lindblad engine needs "
                     "constant dissipators and operators. There is no CPU fallback.")
-    return h0[0], g[0], dissipators, operators
+    return h0[0], g[0], dissipators, operators, time_dependent
+
+
+def sample_lindblad_hamiltonian(hamiltonian, hilbert_size, control_count, complex_controls, times):
+    """(h0 (nt, n, n), g (nt, Kr, n, n) or None if constant) at the given stage times."""
+    h0, g = probe_hamiltonian(hamiltonian, hilbert_size, control_count, complex_controls,
+                              list(times))
+    nt = len(times)
+    if h0.shape[0] == 1:  # turned out constant on this grid
+        h0 = np.repeat(h0, nt, axis=0)
+        g = np.repeat(g, nt, axis=0)
+    g_constant = bool(np.all(g == g[:1]))
+    return h0, (None if g_constant else g)
+
+
+def lindblad_subdivision(h0_norm, g_norms, control_bounds, dissipators, operators, dt,
+                         margin=1.25, max_phase=0.4):
+    """Sub-division count for a time-dependent Hamiltonian: the engine's per-seed rule
+    (||Liouvillian|| * piece <= max_phase) evaluated for the largest controls, with a margin for
+    the norm of H between the probe times."""
+    bound = h0_norm + sum(b * g for b, g in zip(control_bounds, g_norms))
+    diss = 0.0
+    if dissipators is not None:
+        for gm, op in zip(dissipators, operators):
+            diss += abs(gm) * np.linalg.norm(op, 1) * np.linalg.norm(op, np.inf)
+    return max(1, int(np.ceil(margin * (2 * bound + 2 * diss) * abs(dt) / max_phase)))
 
 
 def to_real_controls(controls, complex_controls):

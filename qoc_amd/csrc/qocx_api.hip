@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/qocx.h"
+#include "dop853_tableau.h"
 #include "qocx_device.h"
 
 namespace {
@@ -178,6 +179,8 @@ struct qocx_ctx {
         DevBuf<double> gsub, cost_out, grads, controls;
         DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
         int global_scratch = 0;
+        int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
+        DevBuf<double2> a0_tab, gp_tab;
     } lb;
     // ---- timing ----
     int timing = 0;
@@ -398,6 +401,8 @@ int qocx_destroy(qocx_ctx* ctx) {
         lb.inj_bars.release();
         lb.ystages.release();
         lb.scratch.release();
+        lb.a0_tab.release();
+        lb.gp_tab.release();
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
@@ -1155,6 +1160,49 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         upload_dumps(lb.gpt, gpt, n, ctx->stream) || upload_dumps(lb.ops, ops, n, ctx->stream) ||
         lb.gammas.upload(gammas, ctx->stream))
         return QOCX_ERR_HIP;
+    // Time-dependent Hamiltonian: samples at the stage times of the fixed sub-division
+    // (qocx_lindblad_stage_times), turned into per-stage generator dumps.
+    lb.fixed_ksub = 0;
+    lb.a0_tab.release();
+    lb.gp_tab.release();
+    if (p->fixed_subdivision > 0) {
+        if (!p->h0_stages) return fail(QOCX_ERR_ARG, "h0_stages missing");
+        int64_t count = 0;
+        int rc = qocx_lindblad_stage_times(p->evolution_time, N, nc, K, p->fixed_subdivision, nullptr,
+                                           0, &count);
+        if (rc) return rc;
+        const size_t md = dump_elems(n);
+        std::vector<double2> tab((size_t)count * 4 * md);
+        lb.h0_norm = 0;
+        for (int64_t st = 0; st < count; ++st) {
+            const cmat h = cm_from(p->h0_stages + (size_t)st * n * n * 2, n);
+            lb.h0_norm = std::max(lb.h0_norm, one_norm(h.data(), n));
+            cmat l = cm_scale(h, 0.0, -1.0), r = cm_scale(h, 0.0, 1.0);
+            cm_axpy(l, -0.5, decay);
+            cm_axpy(r, -0.5, decay);
+            c_dump(l, n, tab.data() + ((size_t)st * 4 + 0) * md);
+            c_dump(r, n, tab.data() + ((size_t)st * 4 + 1) * md);
+            c_dump(cm_adjoint(l, n), n, tab.data() + ((size_t)st * 4 + 2) * md);
+            c_dump(cm_adjoint(r, n), n, tab.data() + ((size_t)st * 4 + 3) * md);
+        }
+        if (lb.a0_tab.upload(tab, ctx->stream)) return QOCX_ERR_HIP;
+        if (p->g_stages && K > 0) {
+            std::vector<double2> gtab((size_t)count * K * 3 * md);
+            lb.g_norm.assign(K, 0.0);
+            for (int64_t st = 0; st < count; ++st)
+                for (int k = 0; k < K; ++k) {
+                    const cmat gk = cm_from(p->g_stages + ((size_t)st * K + k) * n * n * 2, n);
+                    lb.g_norm[k] = std::max(lb.g_norm[k], one_norm(gk.data(), n));
+                    const cmat gpk = cm_scale(gk, 0.0, -1.0);
+                    double2* dst = gtab.data() + (((size_t)st * K + k) * 3) * md;
+                    c_dump(gpk, n, dst);
+                    c_dump(cm_adjoint(gpk, n), n, dst + md);
+                    c_dump(cm_transpose(gpk, n), n, dst + 2 * md);
+                }
+            if (lb.gp_tab.upload(gtab, ctx->stream)) return QOCX_ERR_HIP;
+        }
+        lb.fixed_ksub = p->fixed_subdivision;
+    }
     std::vector<cmat> rho0;
     for (int s = 0; s < S; ++s) rho0.push_back(cm_from(p->initial_densities + (size_t)s * n * n * 2, n));
     if (upload_dumps(lb.rho0, rho0, n, ctx->stream)) return QOCX_ERR_HIP;
@@ -1209,6 +1257,24 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
 
 namespace {
 
+// End points of the sub-intervals of system step `step`: `ksub` uniform pieces, cut at the
+// control knots that fall inside the step.
+std::vector<double> lindblad_points(double T, int nsteps, int nc, int K, int ksub, int step) {
+    const double dt = T / nsteps;
+    const double t0 = step * dt, t1 = (step + 1) * dt;
+    std::vector<double> pts;
+    for (int q = 0; q < ksub; ++q) pts.push_back(t0 + (t1 - t0) * q / ksub);
+    pts.push_back(t1);
+    if (K > 0)
+        for (int i = 0; i < nc; ++i) {
+            const double kn = (i == nc - 1) ? T : i * (T / (nc - 1));
+            if (kn > t0 + 1e-12 * dt && kn < t1 - 1e-12 * dt) pts.push_back(kn);
+        }
+    std::sort(pts.begin(), pts.end());
+    pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+    return pts;
+}
+
 // Sub-interval table of one sub-division count: uniform pieces per system step, cut at control
 // knots, with the interpolation weights of both ends and the CSR of their transpose.
 int build_lindblad_grid(qocx_ctx* ctx, int ksub, qocx_ctx::Lindblad::Grid& gr) {
@@ -1219,14 +1285,7 @@ int build_lindblad_grid(qocx_ctx* ctx, int ksub, qocx_ctx::Lindblad::Grid& gr) {
     if (!knots.empty()) knots.back() = lb.T;
     std::vector<qocx::SubStep> subs;
     for (int step = 0; step < nsteps; ++step) {
-        const double t0 = step * lb.dt, t1 = (step + 1) * lb.dt;
-        std::vector<double> pts;
-        for (int q = 0; q < ksub; ++q) pts.push_back(t0 + (t1 - t0) * q / ksub);
-        pts.push_back(t1);
-        for (double kn : knots)
-            if (kn > t0 + 1e-12 * lb.dt && kn < t1 - 1e-12 * lb.dt) pts.push_back(kn);
-        std::sort(pts.begin(), pts.end());
-        pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+        const std::vector<double> pts = lindblad_points(lb.T, nsteps, nc, K, ksub, step);
         for (size_t i = 0; i + 1 < pts.size(); ++i) {
             qocx::SubStep ss;
             ss.h = pts[i + 1] - pts[i];
@@ -1279,6 +1338,29 @@ int build_lindblad_grid(qocx_ctx* ctx, int ksub, qocx_ctx::Lindblad::Grid& gr) {
 
 }  // namespace
 
+int qocx_lindblad_stage_times(double evolution_time, int32_t system_eval_count,
+                              int32_t control_eval_count, int32_t control_count,
+                              int32_t subdivision, double* times_out, int64_t capacity,
+                              int64_t* count_out) {
+    if (system_eval_count < 2 || subdivision < 1 || !count_out ||
+        (control_count > 0 && control_eval_count < 2))
+        return fail(QOCX_ERR_ARG, "bad argument");
+    const int nsteps = system_eval_count - 1;
+    int64_t count = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const std::vector<double> pts = lindblad_points(evolution_time, nsteps, control_eval_count,
+                                                        control_count, subdivision, step);
+        for (size_t i = 0; i + 1 < pts.size(); ++i)
+            for (int st = 0; st < QOCX_RK_STAGES; ++st) {
+                if (times_out && count < capacity)
+                    times_out[count] = pts[i] + QOCX_RK_C[st] * (pts[i + 1] - pts[i]);
+                ++count;
+            }
+    }
+    *count_out = count;
+    return 0;
+}
+
 int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
                        double* cost_out, double* grad_out, double* final_out) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
@@ -1311,6 +1393,13 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         if (pieces * nsteps > (double)(1 << 24))
             return fail(QOCX_ERR_CAPACITY, "too many sub-intervals");
         ksub_of[b] = std::max(1, (int)pieces);
+        if (lb.fixed_ksub > 0) {
+            // the time samples of the Hamiltonian exist for one grid only
+            if (ksub_of[b] > lb.fixed_ksub)
+                return fail(QOCX_ERR_CAPACITY,
+                            "controls need a finer sub-division than the Hamiltonian was sampled for");
+            ksub_of[b] = lb.fixed_ksub;
+        }
     }
     std::map<int, std::vector<int>> groups;
     for (int b = 0; b < B; ++b) groups[ksub_of[b]].push_back(b);
@@ -1406,6 +1495,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.a0l_cimg = lb.a0l.p; la.a0r_cimg = lb.a0r.p; la.a0ld_cimg = lb.a0ld.p; la.a0rd_cimg = lb.a0rd.p;
             la.gp_cimg = lb.gp.p; la.gpd_cimg = lb.gpd.p; la.gpt_cimg = lb.gpt.p; la.op_cimg = lb.ops.p;
             la.gammas = lb.gammas.p; la.rho0_cimg = lb.rho0.p;
+            la.a0_tab = lb.fixed_ksub > 0 ? lb.a0_tab.p : nullptr;
+            la.gp_tab = (lb.fixed_ksub > 0 && lb.gp_tab.p) ? lb.gp_tab.p : nullptr;
             la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
             la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
             la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;

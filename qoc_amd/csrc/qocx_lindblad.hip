@@ -304,17 +304,29 @@ struct Wave {
     // of each other only for Hermitian H):
     //   forward : left = A_L = A0L + sum u_k Gp_k ,  right = A_R = A0R - sum u_k Gp_k , Gp = -i G
     //   adjoint : left = A_L^H,  right = A_R^H  (images of the conjugate transposes)
-    __device__ __forceinline__ void build_generator(const SubStep& ss, double c, bool adjoint,
-                                                    Mat& left, Mat& right) const {
-        dump_load(left, adjoint ? a.a0ld_cimg : a.a0l_cimg);
-        dump_load(right, adjoint ? a.a0rd_cimg : a.a0r_cimg);
+    // `stage` = sub-interval index * STAGES + stage index: selects the time samples of a
+    // time-dependent Hamiltonian (a0_tab: A0L, A0R, A0L^H, A0R^H per stage; gp_tab: Gp, Gp^H, Gp^T
+    // per stage and control) when the host supplied them.
+    __device__ __forceinline__ void build_generator(const SubStep& ss, size_t stage, double c,
+                                                    bool adjoint, Mat& left, Mat& right) const {
+        if (a.a0_tab != nullptr) {
+            const double2* t = a.a0_tab + stage * 4 * MAT;
+            dump_load(left, t + (adjoint ? 2 : 0) * (size_t)MAT);
+            dump_load(right, t + (adjoint ? 3 : 1) * (size_t)MAT);
+        } else {
+            dump_load(left, adjoint ? a.a0ld_cimg : a.a0l_cimg);
+            dump_load(right, adjoint ? a.a0rd_cimg : a.a0r_cimg);
+        }
         const int K = a.K;
         for (int k = 0; k < K; ++k) {
             const double ua = ss.wa1 * ctl_b[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl_b[(size_t)ss.ia2 * K + k];
             const double ub = ss.wb1 * ctl_b[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl_b[(size_t)ss.ib2 * K + k];
             const double u = (1.0 - c) * ua + c * ub;  // u(t) is linear inside a sub-interval
             Mat g;
-            dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
+            if (a.gp_tab != nullptr)
+                dump_load(g, a.gp_tab + ((stage * K + k) * 3 + (adjoint ? 1 : 0)) * MAT);
+            else
+                dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
             mat_axpy(left, u, g);
             mat_axpy(right, -u, g);
         }
@@ -336,13 +348,13 @@ struct Wave {
         }
     }
     // all stage derivatives of the sub-interval starting at y0 -> kdump; optionally advance y0
-    __device__ __forceinline__ void substep(const SubStep& ss, Mat& y0, bool advance,
+    __device__ __forceinline__ void substep(const SubStep& ss, int q, Mat& y0, bool advance,
                                             double2* ystore = nullptr) const {
         for (int i = 0; i < STAGES; ++i) {
             Mat y, k, gl, gr;
             stage_value(y, y0, i, ss.h);
             if (ystore != nullptr) dump_store(y, ystore + (size_t)i * MAT);  // for the adjoint
-            build_generator(ss, RK_C_DEV[i], false, gl, gr);
+            build_generator(ss, (size_t)q * STAGES + i, RK_C_DEV[i], false, gl, gr);
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
             wave_sync();
@@ -364,7 +376,7 @@ struct Wave {
     // ---- adjoint stages -------------------------------------------------------------------
     // Going down in i, slot i of kdump is turned from k_i into Ybar_i once Y_i has been rebuilt
     // (Y_i needs only k_j, j < i; kbar_i needs only Ybar_j, j > i).
-    __device__ __forceinline__ void adjoint_substep(const SubStep& ss, const Mat& y0,
+    __device__ __forceinline__ void adjoint_substep(const SubStep& ss, int q, const Mat& y0,
                                                     const Mat& lambda, Mat& lambda_new,
                                                     double (&ga)[QOCX_LINDBLAD_MAX_K],
                                                     double (&gb)[QOCX_LINDBLAD_MAX_K],
@@ -384,7 +396,7 @@ struct Wave {
                 }
             }
             Mat gl, gr, ybar;
-            build_generator(ss, ci, true, gl, gr);
+            build_generator(ss, (size_t)q * STAGES + i, ci, true, gl, gr);
             wave_sync();
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);  // A_L^H is the left operand now
             wave_sync();
@@ -409,7 +421,10 @@ struct Wave {
             const int K = a.K;
             for (int k = 0; k < K; ++k) {
                 Mat gt;
-                dump_load(gt, a.gpt_cimg + (size_t)k * MAT);  // C-image of Gp_k^T
+                if (a.gp_tab != nullptr)  // C-image of Gp_k^T
+                    dump_load(gt, a.gp_tab + ((((size_t)q * STAGES + i) * K + k) * 3 + 2) * MAT);
+                else
+                    dump_load(gt, a.gpt_cimg + (size_t)k * MAT);
                 double pr = 0;
 #pragma unroll
                 for (int ti = 0; ti < LNB; ++ti)
@@ -495,7 +510,7 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             Mat y0;
             dump_load(y0, dens + (size_t)s * MAT);
             dump_store(y0, ckpt_b + ((size_t)q * S + s) * MAT);
-            w.substep(ss, y0, true,
+            w.substep(ss, q, y0, true,
                       a.ystages != nullptr
                           ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                           : nullptr);
@@ -554,11 +569,11 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             const double2* ys = a.ystages != nullptr
                                     ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                                     : nullptr;
-            if (ys == nullptr) w.substep(ss, y0, false);  // recompute the stage derivatives
+            if (ys == nullptr) w.substep(ss, q, y0, false);  // recompute the stage derivatives
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
-            w.adjoint_substep(ss, y0, lambda, lambda_new, ga, gb, ys);
+            w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
             dump_store(lambda_new, lam + (size_t)s * MAT);
             wave_sync();
         }

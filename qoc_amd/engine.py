@@ -58,7 +58,9 @@ class _LindbladProblem(ctypes.Structure):
                 ("operator_count", ctypes.c_int32), ("evolution_time", ctypes.c_double),
                 ("h0", _c_double_p), ("g", _c_double_p), ("dissipators", _c_double_p),
                 ("operators", _c_double_p), ("initial_densities", _c_double_p),
-                ("cost_count", ctypes.c_int32), ("costs", ctypes.POINTER(_CostDesc))]
+                ("cost_count", ctypes.c_int32), ("costs", ctypes.POINTER(_CostDesc)),
+                ("fixed_subdivision", ctypes.c_int32), ("h0_stages", _c_double_p),
+                ("g_stages", _c_double_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/qocx.h
@@ -82,6 +84,8 @@ SIGNATURES = {
     "qocx_set_keep_step_states": (ctypes.c_int, [_VP, _I32]),
     "qocx_download_step_states": (ctypes.c_int, [_VP, _c_double_p]),
     "qocx_set_lindblad_problem": (ctypes.c_int, [_VP, ctypes.POINTER(_LindbladProblem)]),
+    "qocx_lindblad_stage_times": (ctypes.c_int, [ctypes.c_double, _I32, _I32, _I32, _I32,
+                                                 _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_eval_lindblad": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
                                           _c_double_p, _c_double_p]),
     "qocx_download_step_densities": (ctypes.c_int, [_VP, _c_double_p]),
@@ -259,10 +263,29 @@ class Engine(object):
         return out
 
     # -- Lindblad -------------------------------------------------------------------------------
+    @staticmethod
+    def lindblad_stage_times(evolution_time, system_eval_count, control_eval_count, control_count,
+                             subdivision):
+        """Times at which a time-dependent Hamiltonian is sampled for `subdivision` pieces per
+        system step (no GPU needed)."""
+        lib = load_library()
+        count = _I64(0)
+        args = (float(evolution_time), int(system_eval_count), int(control_eval_count),
+                int(control_count), int(subdivision))
+        code = lib.qocx_lindblad_stage_times(*args, None, 0, ctypes.byref(count))
+        if code:
+            raise QocxError(code, lib.qocx_last_error().decode("utf-8", "replace"))
+        times = np.empty(count.value, dtype=np.float64)
+        code = lib.qocx_lindblad_stage_times(*args, _dp(times), count.value, ctypes.byref(count))
+        if code:
+            raise QocxError(code, lib.qocx_last_error().decode("utf-8", "replace"))
+        return times
+
     def set_lindblad_problem(self, hilbert_size, density_count, control_count,
                              control_eval_count, system_eval_count, evolution_time,
                              h0, g, dissipators, operators, initial_densities, costs=(),
-                             cost_eval_step=1):
+                             cost_eval_step=1, fixed_subdivision=0, h0_stages=None,
+                             g_stages=None):
         """
         h0 :: (n, n), g :: (K, n, n), dissipators :: (L,), operators :: (L, n, n),
         initial_densities :: (S, n, n); costs :: dicts {kind (3|4), step_cost, scale,
@@ -299,6 +322,15 @@ class Engine(object):
         p.dissipators, p.operators = _dp(gam), _dp(ops)
         p.cost_count = len(costs)
         p.costs = descs
+        p.fixed_subdivision = int(fixed_subdivision)
+        if fixed_subdivision:
+            hs = _as_complex(h0_stages).reshape(-1, n, n)
+            keep.append(hs)
+            p.h0_stages = _dp(hs)
+            if g_stages is not None and K > 0:
+                gs = _as_complex(g_stages).reshape(-1, K, n, n)
+                keep.append(gs)
+                p.g_stages = _dp(gs)
         self._check(self._lib.qocx_set_lindblad_problem(self._ctx, ctypes.byref(p)))
         self._lindblad = dict(n=n, S=S, K=K, Nc=int(control_eval_count),
                               N=int(system_eval_count))

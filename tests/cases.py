@@ -254,7 +254,7 @@ def random_density(rng, n):
 
 
 def lindblad_case(name, n, N, S, K, seeds, h_seed, Nc=None, T=None, complex_controls=False,
-                  sigma=0.4, cost_eval_step=1, with_forbid=False, ops="ladder"):
+                  sigma=0.4, cost_eval_step=1, with_forbid=False, ops="ladder", time_mod=None):
     rng = np.random.default_rng(h_seed)
     a = annihilation(n)
     ad = a.conj().T
@@ -286,6 +286,7 @@ def lindblad_case(name, n, N, S, K, seeds, h_seed, Nc=None, T=None, complex_cont
                      complex_controls=complex_controls, initial_states=None,
                      cost_specs=specs, cost_eval_step=cost_eval_step,
                      controls=_controls(500, seeds, Nc, K, complex_controls, sigma))
+    c.time_mod = time_mod
     c.initial_densities = init
     c.dissipators = dissipators
     c.operators = operators
@@ -299,6 +300,9 @@ def lindblad_cases():
         lindblad_case("lindblad_n4_complex", n=4, N=9, S=1, K=1, seeds=2, h_seed=72, Nc=5, T=0.9,
                       complex_controls=True, ops="random"),
         lindblad_case("lindblad_c4_short", n=16, N=6, S=1, K=2, seeds=2, h_seed=2004, sigma=0.1),
+        # Hamiltonian with explicit time dependence: sampled at the integrator's stage times
+        lindblad_case("lindblad_timedep", n=5, N=7, S=1, K=2, seeds=2, h_seed=88, Nc=4, T=0.9,
+                      sigma=0.6, time_mod=3.1),
         # two MFMA tiles per side (n > 16): densities, cotangents and stages in HBM scratch
         lindblad_case("lindblad_n20", n=20, N=4, S=2, K=2, seeds=2, h_seed=2020, Nc=3, T=0.24,
                       sigma=0.3, with_forbid=True),

@@ -30,7 +30,7 @@ def h(x):
 
 
 def substep_grid(evolution_time, system_eval_count, control_eval_count, norm_bound,
-                 max_phase=0.4):
+                 max_phase=0.4, subdivision=None):
     """
     Sub-intervals of every system step: uniform pieces short enough that
     norm_bound * length <= max_phase, further cut at control knots. Returns a list (per system
@@ -41,6 +41,9 @@ def substep_grid(evolution_time, system_eval_count, control_eval_count, norm_bou
     knots = (np.linspace(0, evolution_time, control_eval_count) if control_eval_count > 1
              else np.array([]))
     ksub = max(1, int(np.ceil(norm_bound * dt / max_phase)))
+    if subdivision is not None:  # time-dependent Hamiltonian: the grid it was sampled for
+        assert ksub <= subdivision
+        ksub = subdivision
     out = []
     for step in range(n_steps):
         t0, t1 = step * dt, (step + 1) * dt
@@ -52,19 +55,26 @@ def substep_grid(evolution_time, system_eval_count, control_eval_count, norm_bou
 
 
 class StructuredLindblad(object):
-    """h0, g (real controls: list of K matrices), gammas (L,), ops (L x n x n)."""
+    """h0, g (real controls: list of K matrices), gammas (L,), ops (L x n x n). A Hamiltonian
+    with explicit time dependence is given by the callables h0_of_t(t) -> (n x n) and
+    g_of_t(t) -> list of K matrices; h0 / g then only provide shapes and norm bounds."""
 
-    def __init__(self, h0, g, gammas, ops):
+    def __init__(self, h0, g, gammas, ops, h0_of_t=None, g_of_t=None):
         self.h0 = np.asarray(h0, dtype=np.complex128)
         self.g = [np.asarray(x, dtype=np.complex128) for x in g]
+        self.h0_of_t, self.g_of_t = h0_of_t, g_of_t
         self.gammas = np.zeros(0) if gammas is None else np.asarray(gammas, dtype=np.float64)
         self.ops = (np.zeros((0,) + self.h0.shape, dtype=np.complex128) if ops is None
                     else np.asarray(ops, dtype=np.complex128))
         self.decay = sum((gm * (h(op) @ op) for gm, op in zip(self.gammas, self.ops)),
                          np.zeros_like(self.h0))
 
-    def generator(self, u):
-        ham = self.h0 + sum((uk * gk for uk, gk in zip(u, self.g)), np.zeros_like(self.h0))
+    def g_at(self, t):
+        return self.g if self.g_of_t is None else self.g_of_t(t)
+
+    def generator(self, u, t=None):
+        h0 = self.h0 if self.h0_of_t is None else self.h0_of_t(t)
+        ham = h0 + sum((uk * gk for uk, gk in zip(u, self.g_at(t))), np.zeros_like(self.h0))
         return -1j * ham - 0.5 * self.decay
 
     def rhs(self, a, rho):
@@ -89,7 +99,8 @@ class StructuredLindblad(object):
 
 
 def evaluate_with_grad(system, controls, initial_densities, evolution_time, system_eval_count,
-                       costs, cost_eval_step=1, want_grad=True, stop_step=None):
+                       costs, cost_eval_step=1, want_grad=True, stop_step=None,
+                       subdivision=None):
     """
     controls :: (Nc x K) real. costs :: oracle cost objects (cost / states_bar on
     (S x n x n) densities). Returns (error, grads (Nc x K), final_densities).
@@ -99,7 +110,8 @@ def evaluate_with_grad(system, controls, initial_densities, evolution_time, syst
     xs = np.linspace(0, evolution_time, nc)
     n_steps = system_eval_count - 1
     umax = np.max(np.abs(controls), axis=0) if k else []
-    grid = substep_grid(evolution_time, system_eval_count, nc, system.norm_bound(umax))
+    grid = substep_grid(evolution_time, system_eval_count, nc, system.norm_bound(umax),
+                        subdivision=subdivision)
     step_costs = [c for c in costs if c.requires_step_evaluation]
 
     def control(t):
@@ -111,7 +123,7 @@ def evaluate_with_grad(system, controls, initial_densities, evolution_time, syst
         ks, ys, gens = [], [], []
         for i in range(STAGES):
             u = (1 - RK_C[i]) * ua + RK_C[i] * ub  # linear inside a sub-interval
-            a = system.generator(u)
+            a = system.generator(u, ta + RK_C[i] * hh)
             yi = rho + hh * sum((RK_A[i, j] * ks[j] for j in range(i)), np.zeros_like(rho))
             ks.append(system.rhs(a, yi))
             ys.append(yi)
@@ -161,10 +173,11 @@ def evaluate_with_grad(system, controls, initial_densities, evolution_time, syst
             ybar_stage[i] = system.rhs_adjoint(gens[i], kb)
             lam_new = lam_new + ybar_stage[i]
             # d rhs / d u_k = -i [G_k, Y_i]  ->  ubar_k = sum_s Re tr(kb_s^H (-i)(G_k Y_s - Y_s G_k))
+            g_now = system.g_at(ta + RK_C[i] * hh)
             for kk in range(k):
                 val = 0.0
                 for s in range(ys[i].shape[0]):
-                    comm = system.g[kk] @ ys[i][s] - ys[i][s] @ system.g[kk]
+                    comm = g_now[kk] @ ys[i][s] - ys[i][s] @ g_now[kk]
                     val += np.real(np.trace(h(kb[s]) @ (-1j * comm)))
                 ca, cb = (1 - RK_C[i]) * val, RK_C[i] * val
                 grads[ia1, kk] += wa1 * ca

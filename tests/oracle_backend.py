@@ -210,12 +210,31 @@ class OracleBackend(object):
         return np.stack(self.steps)
 
     # -- Lindblad: the NumPy model of the device algorithm (tests/lindblad_model.py) -----------
+    @staticmethod
+    def lindblad_stage_times(*args):
+        from qoc_amd.engine import Engine  # a host-only function of libqocx, no GPU involved
+        return Engine.lindblad_stage_times(*args)
+
     def set_lindblad_problem(self, n, S, K, Nc, N, T, h0, g, dissipators, operators,
-                             initial_densities, costs=(), cost_eval_step=1):
+                             initial_densities, costs=(), cost_eval_step=1, fixed_subdivision=0,
+                             h0_stages=None, g_stages=None):
         from tests import lindblad_model as lm
         g = np.asarray(g if K > 0 else np.zeros((0, n, n)), dtype=np.complex128).reshape(K, n, n)
+        h0_of_t = g_of_t = None
+        self.lb_subdivision = None
+        if fixed_subdivision:
+            times = self.lindblad_stage_times(T, N, Nc, K, fixed_subdivision)
+            hs = np.asarray(h0_stages, dtype=np.complex128).reshape(len(times), n, n)
+            h0_of_t = lambda t: hs[int(np.argmin(np.abs(times - t)))]
+            if g_stages is not None:
+                gs = np.asarray(g_stages, dtype=np.complex128).reshape(len(times), K, n, n)
+                g_of_t = lambda t: list(gs[int(np.argmin(np.abs(times - t)))])
+                g = np.max(np.abs(gs), axis=0) * 0 + gs[np.argmax(
+                    [np.linalg.norm(x.reshape(K * n, n), 1) for x in gs])]
+            h0 = hs[int(np.argmax([np.linalg.norm(x, 1) for x in hs]))]
+            self.lb_subdivision = int(fixed_subdivision)
         self.lb_system = lm.StructuredLindblad(np.asarray(h0).reshape(n, n), list(g),
-                                               dissipators, operators)
+                                               dissipators, operators, h0_of_t, g_of_t)
         self.lb_costs = [_DensityDescriptorCost(c, S, n) for c in costs]
         self.lb = dict(n=n, S=S, K=K, Nc=Nc, N=N, T=T, ces=cost_eval_step,
                        rho0=np.asarray(initial_densities, dtype=np.complex128).reshape(S, n, n))
@@ -264,7 +283,8 @@ class OracleBackend(object):
         for b, u in enumerate(batch):
             costs = self._lindblad_costs_for_seed(b) if want_grad else self.lb_costs
             err, gr, fin = lm.evaluate_with_grad(self.lb_system, u, p["rho0"], p["T"], p["N"],
-                                                 costs, p["ces"], want_grad=want_grad)
+                                                 costs, p["ces"], want_grad=want_grad,
+                                                 subdivision=self.lb_subdivision)
             cost.append(err)
             grads.append(gr)
             final.append(fin)
@@ -273,7 +293,7 @@ class OracleBackend(object):
                 for step in range(1, p["N"]):
                     _, _, rho = lm.evaluate_with_grad(
                         self.lb_system, u, p["rho0"], p["T"], p["N"], [], 1, want_grad=False,
-                        stop_step=step)
+                        stop_step=step, subdivision=self.lb_subdivision)
                     steps.append(rho)
                 self.lb_steps.append(np.stack(steps))
         return (np.array(cost, dtype=np.float64), np.stack(grads) if want_grad else None,

@@ -46,7 +46,11 @@ def structured(case):
     g = list(case.g_re)
     if case.complex_controls:
         g = [case.g_re[0], case.g_im[0]]
-    return lm.StructuredLindblad(case.h0, g, case.dissipators, case.operators)
+    if getattr(case, "time_mod", None) is None:
+        return lm.StructuredLindblad(case.h0, g, case.dissipators, case.operators)
+    omega = case.time_mod  # tests/cases.py Case.hamiltonian: h0 (1 + 0.3 cos(omega t))
+    return lm.StructuredLindblad(1.3 * case.h0, g, case.dissipators, case.operators,
+                                 h0_of_t=lambda t: case.h0 * (1 + 0.3 * np.cos(omega * t)))
 
 
 def test_get_lindbladian_known_answer():
@@ -141,9 +145,6 @@ def test_device_model_matches_fixtures(name):
         assert np.max(np.abs(dens - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
         assert np.max(np.abs(grads - ref)) / np.max(np.abs(ref)) < 1e-6
-        traced = real_form(case, g["grads_ad_traced_controller"][b])
-        # for the record: the controller-traced AD is NOT a usable gradient oracle
-        assert np.max(np.abs(traced - ref)) / np.max(np.abs(ref)) > 1e-6
 
 
 def test_device_model_gradient_vs_own_finite_differences():
@@ -171,3 +172,16 @@ def test_substeps_never_straddle_control_knots():
         for ta, tb in pieces:
             assert tb > ta and (tb - ta) * 30.0 <= 0.4 + 1e-12
             assert not any(ta + 1e-12 < k < tb - 1e-12 for k in knots)
+
+
+def test_controller_traced_gradient_is_not_a_usable_oracle():
+    """For the record: AD that differentiates the step-size controller, as
+    autograd does in the reference, deviates from the gradient of the integrated quantity."""
+    worst = 0.0
+    for case in cases_mod.lindblad_cases():
+        g = golden(case.name)
+        for b in range(len(case.controls)):
+            ref = real_form(case, g["grads_ad"][b])
+            traced = real_form(case, g["grads_ad_traced_controller"][b])
+            worst = max(worst, np.max(np.abs(traced - ref)) / np.max(np.abs(ref)))
+    assert worst > 1e-4

@@ -51,6 +51,8 @@ def ad_eval(case, controls_np, freeze_mesh=False):
     def rhs(t, rho):
         u = interp(t, xs, controls)
         h = h0
+        if getattr(case, "time_mod", None) is not None:  # tests/cases.py Case.hamiltonian
+            h = h0 * (1 + 0.3 * torch.cos(case.time_mod * torch.as_tensor(t)))
         for k in range(case.K):
             if case.complex_controls:
                 h = h + torch.real(u[k]) * g_re[k] + torch.imag(u[k]) * g_im[k]
