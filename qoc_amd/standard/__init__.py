@@ -6,9 +6,10 @@ from .costs import (ControlArea, ControlBandwidthMax, ControlNorm, ControlVariat
                     ForbidDensities, ForbidStates, TargetDensityInfidelity,
                     TargetDensityInfidelityTime, TargetStateInfidelity,
                     TargetStateInfidelityTime)
-from .functions import (column_vector_list_to_matrix, commutator, conjugate_transpose, krons,
-                        matmuls, matrix_to_column_vector_list, rms_norm)
+from .functions import (column_vector_list_to_matrix, commutator, conjugate_transpose, expm,
+                        krons, matmuls, matrix_to_column_vector_list, rms_norm)
 from .optimizers import LBFGSB, SGD, Adam
+from .utils import CustomJSONEncoder, generate_save_file_path
 
 __all__ = [
     "get_annihilation_operator", "get_creation_operator", "get_eij",
@@ -16,7 +17,8 @@ __all__ = [
     "ControlArea", "ControlBandwidthMax", "ControlNorm", "ControlVariation",
     "ForbidDensities", "ForbidStates", "TargetDensityInfidelity", "TargetDensityInfidelityTime",
     "TargetStateInfidelity", "TargetStateInfidelityTime",
-    "commutator", "conjugate_transpose", "krons", "rms_norm", "matmuls",
+    "commutator", "conjugate_transpose", "expm", "krons", "rms_norm", "matmuls",
     "column_vector_list_to_matrix", "matrix_to_column_vector_list",
     "Adam", "LBFGSB", "SGD",
+    "generate_save_file_path", "CustomJSONEncoder",
 ]

@@ -1,6 +1,7 @@
 """
 functions.py - small dense helpers with the names of qoc/standard/functions/convenience.py
-(:16-104). Plain NumPy: nothing here is traced.
+(:16-104), plain NumPy (nothing here is traced), and `expm`, the public name of the reference's
+Pade-13 matrix exponential (qoc/standard/functions/expm.py:210-252), evaluated by the HIP engine.
 """
 
 from functools import reduce
@@ -35,3 +36,31 @@ def column_vector_list_to_matrix(column_vector_list):
 
 def matrix_to_column_vector_list(matrix):
     return np.stack([np.vstack(matrix[:, i]) for i in range(matrix.shape[1])])
+
+
+_EXPM_ENGINE = []
+
+
+def expm(a):
+    """
+    Matrix exponential of one square complex matrix (n <= 32) by the engine's Pade-13 scaling
+    and squaring path - the same kernels the propagation uses: exp(a) is the one-step propagator
+    of H = i a over dt = 1 applied to the identity columns. There is no CPU implementation in
+    this package; without the HIP library / a GPU the call raises.
+    """
+    from qoc_amd.core import device
+    a = np.asarray(a, dtype=np.complex128)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError("expm expects one square matrix, got shape {}".format(a.shape))
+    n = a.shape[0]
+    if n > 32:
+        raise NotImplementedError("expm on the MI355X engine handles n <= 32 (got {})".format(n))
+    if not _EXPM_ENGINE:
+        _EXPM_ENGINE.append(device.make_backend())
+    engine = _EXPM_ENGINE[0]
+    engine.set_schroedinger_problem(n, n, 0, 0, 2, 1.0, (1j * a)[None], None,
+                                    np.eye(n, dtype=np.complex128), costs=())
+    engine.upload_controls(1)
+    engine.eval_resident(False)
+    _, _, final = engine.download_results(want_grad=False)
+    return np.ascontiguousarray(final[0].T)  # final[s] = U e_s is column s of U

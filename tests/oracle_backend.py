@@ -126,7 +126,8 @@ class OracleBackend(object):
                                  cost_eval_step=1, magnus_policy="M2"):
         h0 = np.asarray(h0, dtype=np.complex128).reshape(-1, n, n)
         nt = h0.shape[0]
-        g = np.asarray(g, dtype=np.complex128).reshape(nt, K, n, n)
+        g = np.asarray(g if K > 0 else np.zeros((nt, 0, n, n)),
+                       dtype=np.complex128).reshape(nt, K, n, n)
         dt = T / (N - 1)
         nodes = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
                  "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}[magnus_policy]

@@ -126,3 +126,25 @@ def test_user_cost_in_grape_on_gpu(with_hook):
     # a later evaluation without user costs is not affected by stale cotangents
     e2, g2, _, _ = ev_ref.evaluate_batch(batch)
     assert np.array_equal(e2, e0) and np.array_equal(g2, g0)
+
+
+def test_expm_and_example_on_gpu(capsys):
+    import importlib.util
+    import os
+    import scipy.linalg
+    from oracle import qoc_numpy as onp
+    from qoc_amd.standard import expm
+    rng = np.random.default_rng(9)
+    for n, scale in ((1, 0.3), (2, 0.5), (16, 4.0), (17, 9.0), (32, 40.0)):
+        a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * scale / n
+        out = expm(a)
+        assert rel_err(out, onp.expm_pade(a)) < 1e-11
+        assert rel_err(out, scipy.linalg.expm(a)) < 1e-9
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "transmon_pi.py")
+    spec = importlib.util.spec_from_file_location("example_transmon_pi", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    result = module.main()
+    assert result.best_error < 1e-2
+    assert "best error" in capsys.readouterr().out

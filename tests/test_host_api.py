@@ -378,3 +378,31 @@ def test_user_cost_with_explicit_control_dependence():
     h = 1e-5
     fd = (ev.evaluate(u + h * d, want_grad=False)[0] - ev.evaluate(u - h * d, want_grad=False)[0]) / (2 * h)
     assert abs(fd - np.sum(grads * d)) < 1e-7 * max(1.0, abs(fd))
+
+
+def test_file_and_json_helpers(tmp_path):
+    import json
+    from qoc_amd.standard import CustomJSONEncoder, generate_save_file_path
+    first = generate_save_file_path("run", str(tmp_path / "out"))
+    assert first.endswith("out/00000_run.h5")
+    open(first, "w").close()
+    open(str(tmp_path / "out" / "00007_run.h5"), "w").close()
+    open(str(tmp_path / "out" / "00003_other.h5"), "w").close()
+    assert generate_save_file_path("run", str(tmp_path / "out")).endswith("00008_run.h5")
+    assert generate_save_file_path("other", str(tmp_path / "out")).endswith("00004_other.h5")
+    text = json.dumps({"a": np.arange(3), "b": np.float64(0.5), "c": np.int32(7)},
+                      cls=CustomJSONEncoder)
+    assert json.loads(text) == {"a": [0, 1, 2], "b": 0.5, "c": 7}
+
+
+def test_expm_through_the_engine():
+    # reference tests/test_standard.py:228-247 intends this comparison with scipy
+    import scipy.linalg
+    from qoc_amd.standard import expm
+    rng = np.random.default_rng(9)
+    for n, scale in ((2, 0.5), (5, 3.0), (17, 9.0)):
+        a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * scale / n
+        assert rel_err(expm(a), onp.expm_pade(a)) < 1e-12
+        assert rel_err(expm(a), scipy.linalg.expm(a)) < 1e-10
+    with pytest.raises(ValueError):
+        expm(np.zeros((2, 3)))
