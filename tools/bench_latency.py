@@ -1,0 +1,42 @@
+"""
+bench_latency.py - secondary measurement: single-seed evaluation latency (what one GRAPE
+iteration of an ordinary qoc script costs), BASELINE.json configs[1]: n = 8 transmon, 500
+steps, one seed; plus the C3 shape with one seed.
+
+    python tools/bench_latency.py
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qoc_amd.engine import Engine, COST_TARGET_COHERENT  # noqa: E402
+from tests import cases as cases_mod  # noqa: E402
+from tests import gpu_helpers as gh  # noqa: E402
+
+
+def main():
+    eng = Engine(0)
+    for name in ("c2_transmon", "c3_subset"):
+        case = cases_mod.case_by_name(name)
+        gh.setup_engine(eng, case)
+        u = gh.real_controls(case, case.controls[:1])
+        for _ in range(5):
+            eng.evaluate(u, True)
+        for want_grad in (False, True):
+            t0 = time.perf_counter()
+            reps = 50
+            for _ in range(reps):
+                eng.evaluate(u, want_grad)
+            wall = (time.perf_counter() - t0) / reps
+            print(json.dumps(dict(case=name, n=case.n, steps=case.N - 1, want_grad=want_grad,
+                                  ms_per_eval=round(wall * 1e3, 3),
+                                  us_per_step=round(wall * 1e6 / (case.N - 1), 2))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
