@@ -606,8 +606,8 @@ __device__ __forceinline__ void masked_cfma(double& zre, double& zim, double cre
             "s_mov_b32 exec_lo, %[lo]\n\t"
             "s_mov_b32 exec_hi, %[hi]\n\t"
             "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
-            "v_fma_f64 %[zr], -%[ci], %[ki], %[zr]\n\t"
             "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
+            "v_fma_f64 %[zr], -%[ci], %[ki], %[zr]\n\t"
             "v_fma_f64 %[zi], %[ci], %[kr], %[zi]\n\t"
             "s_mov_b64 exec, -1"
             : [zr] "+v"(zre), [zi] "+v"(zim)
@@ -618,8 +618,8 @@ __device__ __forceinline__ void masked_cfma(double& zre, double& zim, double cre
             "s_mov_b32 exec_lo, %[lo]\n\t"
             "s_mov_b32 exec_hi, %[hi]\n\t"
             "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
-            "v_fma_f64 %[zr], %[ci], %[ki], %[zr]\n\t"
             "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
+            "v_fma_f64 %[zr], %[ci], %[ki], %[zr]\n\t"
             "v_fma_f64 %[zi], -%[ci], %[kr], %[zi]\n\t"
             "s_mov_b64 exec, -1"
             : [zr] "+v"(zre), [zi] "+v"(zim)

@@ -9,9 +9,10 @@
 //     A_L = -i H(u(t)) - 1/2 sum_i gamma_i L_i^H L_i,   A_R = +i H(u(t)) - 1/2 sum_i gamma_i L_i^H L_i,
 // with the FIXED-step 12-stage Dormand-Prince 8(5,3) scheme on host-chosen sub-intervals that
 // never straddle a control knot (so u(t) is linear inside each), and applies the exact discrete
-// adjoint of that scheme, recomputing each sub-interval from a checkpoint (tests/lindblad_model.py
-// is the NumPy model of exactly this). All products are n x n (n <= 16: ONE MFMA tile):
-// every right-hand side is 2 + 2L complex 16^3 GEMMs on v_mfma_f64_16x16x4_f64.
+// adjoint of that scheme from per-sub-interval checkpoints and (when they fit HBM) the stored
+// stage values (tests/lindblad_model.py is the NumPy model of exactly this). All products are
+// n x n: one MFMA tile for n <= 16, four for n <= 32; every right-hand side is 2 + 2L complex
+// GEMMs on v_mfma_f64_16x16x4_f64.
 //
 // One wavefront per seed; the S densities of a seed advance together, sub-interval by
 // sub-interval (the recursion in time is serial).
@@ -290,8 +291,8 @@ static __host__ __device__ int lds_bytes(int S, int nops) {
     return 3 * SLOT_BYTES + nops * SLOT_BYTES + (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES);
 }
 
-// Everything one wave needs; the stage loops are template recursions over the (compile-time)
-// Butcher tableau so that the stage derivatives stay in registers.
+// Everything one wave needs. The stage loops are plain runtime loops over the Butcher tableau
+// (constant memory); the stage derivatives live in `kdump`, not in registers.
 struct Wave {
     const LindbladArgs& a;
     Slot slot_gen, slot_y, slot_tmp;
