@@ -300,6 +300,8 @@ def lindblad_cases():
         lindblad_case("lindblad_n4_complex", n=4, N=9, S=1, K=1, seeds=2, h_seed=72, Nc=5, T=0.9,
                       complex_controls=True, ops="random"),
         lindblad_case("lindblad_c4_short", n=16, N=6, S=1, K=2, seeds=2, h_seed=2004, sigma=0.1),
+        # BASELINE.json configs[3] at its full length (n = 16, 500 system steps), one seed
+        lindblad_case("lindblad_c4_full", n=16, N=501, S=1, K=2, seeds=1, h_seed=2004, sigma=0.1),
         # Hamiltonian with explicit time dependence: sampled at the integrator's stage times
         lindblad_case("lindblad_timedep", n=5, N=7, S=1, K=2, seeds=2, h_seed=88, Nc=4, T=0.9,
                       sigma=0.6, time_mod=3.1),

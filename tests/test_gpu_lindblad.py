@@ -17,7 +17,7 @@ import pytest
 from oracle import qoc_lindblad_numpy as ol
 from tests import cases as cases_mod
 from tests import lindblad_model as lm
-from tests.helpers import golden
+from tests.helpers import golden, lindblad_grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +61,7 @@ def test_lindblad_engine_matches_golden_and_model(engine, name):
         assert abs(cost[b] - g["error"][b]) < 1e-9
         assert np.max(np.abs(final[b] - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
-        assert np.max(np.abs(grads[b] - ref)) / np.max(np.abs(ref)) < 1e-6
+        assert lindblad_grad_close(grads[b], ref)
         m_err, m_grads, m_final = lm.evaluate_with_grad(
             system, controls[b], case.initial_densities, case.T, case.N, costs,
             case.cost_eval_step)

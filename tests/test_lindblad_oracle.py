@@ -22,7 +22,7 @@ import pytest
 from oracle import qoc_lindblad_numpy as ol
 from tests import cases as cases_mod
 from tests import lindblad_model as lm
-from tests.helpers import golden
+from tests.helpers import golden, lindblad_grad_close
 
 NAMES = [c.name for c in cases_mod.lindblad_cases()]
 
@@ -144,7 +144,7 @@ def test_device_model_matches_fixtures(name):
         assert abs(err - g["error"][b]) < 1e-9
         assert np.max(np.abs(dens - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
-        assert np.max(np.abs(grads - ref)) / np.max(np.abs(ref)) < 1e-6
+        assert lindblad_grad_close(grads, ref)
 
 
 def test_device_model_gradient_vs_own_finite_differences():
