@@ -50,7 +50,10 @@ struct Slot {
 // Everything is a member of this template: LNB = 1 (n <= 16, one MFMA tile per matrix) or
 // LNB = 2 (n <= 32, four tiles). GS: the stage derivatives, the densities and the cotangents
 // live in per-seed HBM scratch instead of LDS (always for LNB = 2: 12 x 16 KB do not fit).
-template <int LNB, bool GS>
+// MW: several wavefronts work on one seed - wave 0 the generator terms A_L y + y A_R, wave 1 + i
+// the term of Lindblad operator i, the last wave the control cotangents of the adjoint - and
+// exchange their partial right-hand sides through LDS (two workgroup barriers per stage).
+template <int LNB, bool GS, bool MW>
 struct LB {
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                               // C-layout register tiles
@@ -162,39 +165,6 @@ static __device__ __forceinline__ void gemm(Mat& acc, const Slot& left, const Ma
     }
 }
 
-struct Operands {     // LDS addresses of one direction (forward or adjoint) of the RHS
-    Slot gen_left;    // A_L (forward) or A_L^H (adjoint), rebuilt per stage
-    Slot y_left;      // the argument, as a left operand
-    Slot tmp;         // gamma_i L_i Y
-    char* op_planar;  // [L] planar slots of L_i; both directions read L_i and L_i^H from them
-};
-
-// out = Gen y + y GenRight + sum_i gamma_i Op_i y Op_i^H   (ADJ: Op_i^H y Op_i)
-template <bool ADJ>
-static __device__ __forceinline__ void rhs_apply(Mat& out, const Mat& y, const Mat& gen_right,
-                                          const Operands& o, int nops, const double* gammas) {
-    cmat_to_lds<LNB>(y, o.y_left.re, o.y_left.im);
-    wave_sync();
-    mat_zero(out);
-    gemm<false>(out, o.gen_left, y);
-    gemm<false>(out, o.y_left, gen_right);
-    for (int i = 0; i < nops; ++i) {
-        Mat t, opr;
-        mat_zero(t);
-        const Slot op = slot_at(o.op_planar + (size_t)i * SLOT_BYTES);
-        gemm<ADJ>(t, op, y);
-        const double gm = gammas[i];
-        cmat_scale<LNB>(t, gm);
-        wave_sync();
-        cmat_to_lds<LNB>(t, o.tmp.re, o.tmp.im);
-        wave_sync();
-        if (ADJ) load_plain(opr, op);
-        else load_adjoint(opr, op);
-        gemm<false>(out, o.tmp, opr);
-    }
-    wave_sync();
-}
-
 // l += (zr + i zi) * t
 static __device__ __forceinline__ void add_scaled(Mat& l, double zr, double zi, const Mat& t) {
 #pragma unroll
@@ -287,18 +257,34 @@ static __device__ __forceinline__ double density_costs(const LindbladArgs& a, bo
 // LDS carve (bytes): 3 planar work slots | per operator: planar L | and unless GS: S density
 // dumps | S lambda dumps | STAGES stage-derivative dumps. 80 KB at LNB = 1, S = 1, L = 2: two
 // seeds per CU.
+static __host__ __device__ int waves(int nops) { return MW ? nops + 2 : 1; }
 static __host__ __device__ int lds_bytes(int S, int nops) {
-    return 3 * SLOT_BYTES + nops * SLOT_BYTES + (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES);
+    // work slots: single wave gen | y | tmp; MW: gen | y | tmp per operator | zk | zy ; then the
+    // operator images, MW: one partial-result dump per wave, and the per-seed dumps
+    const int slots = MW ? (2 + nops + 2) : 3;
+    return slots * SLOT_BYTES + nops * SLOT_BYTES + (MW ? waves(nops) * DUMP_BYTES : 0) +
+           (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES);
+}
+static __device__ __forceinline__ void block_sync() {
+    if (MW) __syncthreads();
+    else wave_sync();
 }
 
 // Everything one wave needs. The stage loops are plain runtime loops over the Butcher tableau
 // (constant memory); the stage derivatives live in `kdump`, not in registers.
 struct Wave {
     const LindbladArgs& a;
-    Slot slot_gen, slot_y, slot_tmp;
-    Operands fwd, adj;
+    int wv, nwaves;                   // this wave's index in the block, waves per seed
+    Slot slot_gen, slot_y;            // wave 0: A_L (or A_L^H) and the argument as left operands
+    Slot slot_tmp;                    // this wave's gamma_i L_i Y
+    Slot slot_zk, slot_zy;            // control-cotangent wave: kbar and Y as left operands
+    char* op_planar;                  // [L] planar images of L_i
+    double2* parts;                   // MW: [nwaves] partial right-hand sides
     double2* kdump;  // STAGES dumps: stage derivatives k_j, then (adjoint) Ybar_j
     const double* ctl_b;
+
+    __device__ __forceinline__ bool first() const { return !MW || wv == 0; }
+    __device__ __forceinline__ bool z_wave() const { return !MW || wv == nwaves - 1; }
 
     // Generators of one stage. The reference applies -i[H, rho] with the SAME H on both sides
     // (mathmethods.py:188), so the left and right factors are kept separate (they are adjoints
@@ -333,8 +319,56 @@ struct Wave {
         }
     }
 
+    // out = Gen y + y GenRight + sum_i gamma_i Op_i y Op_i^H   (ADJ: Gen^H, GenRight^H,
+    // Op_i^H y Op_i). Single wave: everything; MW: each wave its share, summed through `parts`
+    // (one workgroup barrier inside; every wave returns the full result).
+    template <bool ADJ>
+    __device__ __forceinline__ void rhs_split(Mat& out, const Mat& y, const SubStep& ss,
+                                              size_t stage, double c) const {
+        Mat acc;
+        mat_zero(acc);
+        if (first()) {
+            Mat gl, gr;
+            build_generator(ss, stage, c, ADJ, gl, gr);
+            wave_sync();
+            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
+            cmat_to_lds<LNB>(y, slot_y.re, slot_y.im);
+            wave_sync();
+            gemm<false>(acc, slot_gen, y);
+            gemm<false>(acc, slot_y, gr);
+        }
+        for (int i = 0; i < a.nops; ++i) {
+            if (MW && wv != 1 + i) continue;
+            Mat t, opr;
+            mat_zero(t);
+            const Slot op = slot_at(op_planar + (size_t)i * SLOT_BYTES);
+            gemm<ADJ>(t, op, y);
+            cmat_scale<LNB>(t, a.gammas[i]);
+            wave_sync();
+            cmat_to_lds<LNB>(t, slot_tmp.re, slot_tmp.im);
+            wave_sync();
+            if (ADJ) load_plain(opr, op);
+            else load_adjoint(opr, op);
+            gemm<false>(acc, slot_tmp, opr);
+        }
+        wave_sync();
+        if (MW) {
+            // (the last wave - control cotangents - has no share of the right-hand side)
+            if (wv < nwaves - 1) dump_store(acc, parts + (size_t)wv * MAT);
+            __syncthreads();
+            mat_zero(out);
+            for (int w = 0; w < nwaves - 1; ++w) {
+                Mat p;
+                dump_load(p, parts + (size_t)w * MAT);
+                mat_axpy(out, 1.0, p);
+            }
+        } else {
+            out = acc;
+        }
+    }
+
     // ---- forward stages -------------------------------------------------------------------
-    // The stage derivatives k_j live in slot j of `kdump` (LDS). Plain runtime loops over the
+    // The stage derivatives k_j live in slot j of `kdump`. Plain runtime loops over the
     // tableau (in constant memory): the body is GEMM bound, and rolled loops keep the register
     // allocation small.
     __device__ __forceinline__ void stage_value(Mat& y, const Mat& y0, int i, double h) const {
@@ -349,19 +383,16 @@ struct Wave {
         }
     }
     // all stage derivatives of the sub-interval starting at y0 -> kdump; optionally advance y0
+    // (every wave ends with the same y0)
     __device__ __forceinline__ void substep(const SubStep& ss, int q, Mat& y0, bool advance,
                                             double2* ystore = nullptr) const {
         for (int i = 0; i < STAGES; ++i) {
-            Mat y, k, gl, gr;
+            Mat y, k;
             stage_value(y, y0, i, ss.h);
-            if (ystore != nullptr) dump_store(y, ystore + (size_t)i * MAT);  // for the adjoint
-            build_generator(ss, (size_t)q * STAGES + i, RK_C_DEV[i], false, gl, gr);
-            wave_sync();
-            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
-            wave_sync();
-            rhs_apply<false>(k, y, gr, fwd, a.nops, a.gammas);
-            dump_store(k, kdump + (size_t)i * MAT);
-            wave_sync();
+            if (ystore != nullptr && first()) dump_store(y, ystore + (size_t)i * MAT);
+            rhs_split<false>(k, y, ss, (size_t)q * STAGES + i, RK_C_DEV[i]);
+            if (first()) dump_store(k, kdump + (size_t)i * MAT);
+            block_sync();
         }
         if (advance)
             for (int i = 0; i < STAGES; ++i) {
@@ -376,7 +407,8 @@ struct Wave {
 
     // ---- adjoint stages -------------------------------------------------------------------
     // Going down in i, slot i of kdump is turned from k_i into Ybar_i once Y_i has been rebuilt
-    // (Y_i needs only k_j, j < i; kbar_i needs only Ybar_j, j > i).
+    // (Y_i needs only k_j, j < i; kbar_i needs only Ybar_j, j > i). ga / gb accumulate in the
+    // control-cotangent wave only.
     __device__ __forceinline__ void adjoint_substep(const SubStep& ss, int q, const Mat& y0,
                                                     const Mat& lambda, Mat& lambda_new,
                                                     double (&ga)[QOCX_LINDBLAD_MAX_K],
@@ -396,68 +428,85 @@ struct Wave {
                     mat_axpy(kb, ss.h * aji, yb);
                 }
             }
-            Mat gl, gr, ybar;
-            build_generator(ss, (size_t)q * STAGES + i, ci, true, gl, gr);
-            wave_sync();
-            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);  // A_L^H is the left operand now
-            wave_sync();
-            rhs_apply<true>(ybar, kb, gr, adj, a.nops, a.gammas);
+            Mat ybar;
+            rhs_split<true>(ybar, kb, ss, (size_t)q * STAGES + i, ci);
             mat_axpy(lambda_new, 1.0, ybar);
-            // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
-            // Z = Y kbar^H - kbar^H Y  (slot_y still holds kbar as a planar image)
-            Mat y, kbd, z, z2;
-            if (ystore != nullptr) dump_load(y, ystore + (size_t)i * MAT);
-            else stage_value(y, y0, i, ss.h);  // the stage value Y_i again
-            wave_sync();
-            dump_store(ybar, kdump + (size_t)i * MAT);  // k_i is no longer needed
-            load_adjoint(kbd, slot_y);
-            mat_zero(z2);
-            gemm<true>(z2, slot_y, y);  // kbar^H Y
-            wave_sync();
-            cmat_to_lds<LNB>(y, slot_tmp.re, slot_tmp.im);
-            wave_sync();
-            mat_zero(z);
-            gemm<false>(z, slot_tmp, kbd);  // Y kbar^H
-            mat_axpy(z, -1.0, z2);
-            const int K = a.K;
-            for (int k = 0; k < K; ++k) {
-                Mat gt;
-                if (a.gp_tab != nullptr)  // C-image of Gp_k^T
-                    dump_load(gt, a.gp_tab + ((((size_t)q * STAGES + i) * K + k) * 3 + 2) * MAT);
-                else
-                    dump_load(gt, a.gpt_cimg + (size_t)k * MAT);
-                double pr = 0;
+            if (z_wave()) {
+                // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
+                // Z = Y kbar^H - kbar^H Y
+                Mat y, kbd, z, z2;
+                if (ystore != nullptr) dump_load(y, ystore + (size_t)i * MAT);
+                else stage_value(y, y0, i, ss.h);  // the stage value Y_i again
+                wave_sync();
+                if (MW) cmat_to_lds<LNB>(kb, slot_zk.re, slot_zk.im);  // (single wave: slot_y
+                wave_sync();                                          //  still holds kbar)
+                load_adjoint(kbd, slot_zk);
+                mat_zero(z2);
+                gemm<true>(z2, slot_zk, y);  // kbar^H Y
+                wave_sync();
+                cmat_to_lds<LNB>(y, slot_zy.re, slot_zy.im);
+                wave_sync();
+                mat_zero(z);
+                gemm<false>(z, slot_zy, kbd);  // Y kbar^H
+                mat_axpy(z, -1.0, z2);
+                const int K = a.K;
+                for (int k = 0; k < K; ++k) {
+                    Mat gt;
+                    if (a.gp_tab != nullptr)  // C-image of Gp_k^T
+                        dump_load(gt, a.gp_tab + ((((size_t)q * STAGES + i) * K + k) * 3 + 2) * MAT);
+                    else
+                        dump_load(gt, a.gpt_cimg + (size_t)k * MAT);
+                    double pr = 0;
 #pragma unroll
-                for (int ti = 0; ti < LNB; ++ti)
+                    for (int ti = 0; ti < LNB; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < LNB; ++tj)
+                        for (int tj = 0; tj < LNB; ++tj)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            pr += z.re[ti][tj][r] * gt.re[ti][tj][r] -
-                                  z.im[ti][tj][r] * gt.im[ti][tj][r];
-                const double g = wave_sum(pr);
+                            for (int r = 0; r < 4; ++r)
+                                pr += z.re[ti][tj][r] * gt.re[ti][tj][r] -
+                                      z.im[ti][tj][r] * gt.im[ti][tj][r];
+                    const double g = wave_sum(pr);
 #pragma unroll
-                for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
-                    if (kk == k) {
-                        ga[kk] += (1.0 - ci) * g;
-                        gb[kk] += ci * g;
-                    }
+                    for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                        if (kk == k) {
+                            ga[kk] += (1.0 - ci) * g;
+                            gb[kk] += ci * g;
+                        }
+                }
+                wave_sync();
             }
-            wave_sync();
+            // k_i is no longer needed (Y_i is rebuilt from k_j, j < i, or read from ystore)
+            if (first()) dump_store(ybar, kdump + (size_t)i * MAT);
+            block_sync();  // Ybar_i visible to every wave; `parts` free again
         }
     }
 };
 
-// the kernel body: one wavefront = one seed
+// the kernel body: one workgroup (1 or nops + 2 wavefronts) = one seed
 static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     const int lane = lane_id();
     const int S = a.S, K = a.K, nops = a.nops, nsub = a.nsub;
     const int b = blockIdx.x;
+    const int wv = MW ? (int)(threadIdx.x >> 6) : 0, nwaves = waves(nops);
+    const bool lead = !MW || wv == 0;  // the wave that owns the shared bookkeeping
     char* p = smem;
     const Slot slot_gen = slot_at(p); p += SLOT_BYTES;
     const Slot slot_y = slot_at(p); p += SLOT_BYTES;
-    const Slot slot_tmp = slot_at(p); p += SLOT_BYTES;
+    Slot slot_tmp, slot_zk, slot_zy;
+    if (MW) {
+        // one private slot per operator wave, two for the control-cotangent wave
+        slot_tmp = slot_at(p + (size_t)(wv >= 1 && wv <= nops ? wv - 1 : 0) * SLOT_BYTES);
+        p += (size_t)nops * SLOT_BYTES;
+        slot_zk = slot_at(p); p += SLOT_BYTES;
+        slot_zy = slot_at(p); p += SLOT_BYTES;
+    } else {
+        slot_tmp = slot_at(p); p += SLOT_BYTES;
+        slot_zk = slot_y;   // rhs_split leaves kbar there
+        slot_zy = slot_tmp;
+    }
     char* op_planar = p; p += (size_t)nops * SLOT_BYTES;     // L_i
+    double2* parts = reinterpret_cast<double2*>(p);
+    if (MW) p += (size_t)nwaves * DUMP_BYTES;
     double2 *dens, *lam, *kdump;
     if (GS) {  // per-seed HBM scratch: S densities | S cotangents | STAGES stage derivatives
         dens = a.scratch + (size_t)b * (2 * S + STAGES) * MAT;
@@ -471,32 +520,30 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 
     // static operators into LDS (planar: left operand directly, right operand by a
     // transposing read)
-    for (int i = 0; i < nops; ++i) {
-        Mat op;
-        dump_load(op, a.op_cimg + (size_t)i * MAT);
-        cmat_to_lds<LNB>(op, slot_at(op_planar + (size_t)i * SLOT_BYTES).re,
-                         slot_at(op_planar + (size_t)i * SLOT_BYTES).im);
+    if (lead) {
+        for (int i = 0; i < nops; ++i) {
+            Mat op;
+            dump_load(op, a.op_cimg + (size_t)i * MAT);
+            cmat_to_lds<LNB>(op, slot_at(op_planar + (size_t)i * SLOT_BYTES).re,
+                             slot_at(op_planar + (size_t)i * SLOT_BYTES).im);
+        }
+        for (int s = 0; s < S; ++s) {
+            Mat rho;
+            dump_load(rho, a.rho0_cimg + (size_t)s * MAT);
+            dump_store(rho, dens + (size_t)s * MAT);
+        }
     }
-    for (int s = 0; s < S; ++s) {
-        Mat rho;
-        dump_load(rho, a.rho0_cimg + (size_t)s * MAT);
-        dump_store(rho, dens + (size_t)s * MAT);
-    }
-    wave_sync();
+    block_sync();
 
-    Operands fwd, adj;
-    fwd.gen_left = slot_gen; fwd.y_left = slot_y; fwd.tmp = slot_tmp;
-    fwd.op_planar = op_planar;
-    adj = fwd;
-    const Wave w{a, slot_gen, slot_y, slot_tmp, fwd, adj, kdump,
-                 a.controls + (size_t)b * a.nc * K};
+    const Wave w{a, wv, nwaves, slot_gen, slot_y, slot_tmp, slot_zk, slot_zy, op_planar, parts,
+                 kdump, a.controls + (size_t)b * a.nc * K};
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
 
     // ---- forward ------------------------------------------------------------------------
     double cost = 0;
     for (int q = 0; q < nsub; ++q) {
         const SubStep ss = a.substeps[q];
-        if (ss.first_of_step) {
+        if (ss.first_of_step && lead) {
             if (ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
                 cost += density_costs(a, true, false, dens, nullptr);
             if (a.step_densities != nullptr)
@@ -510,36 +557,32 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         for (int s = 0; s < S; ++s) {
             Mat y0;
             dump_load(y0, dens + (size_t)s * MAT);
-            dump_store(y0, ckpt_b + ((size_t)q * S + s) * MAT);
+            if (lead) dump_store(y0, ckpt_b + ((size_t)q * S + s) * MAT);
             w.substep(ss, q, y0, true,
                       a.ystages != nullptr
                           ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                           : nullptr);
             wave_sync();
-            dump_store(y0, dens + (size_t)s * MAT);
-            wave_sync();
+            if (lead) dump_store(y0, dens + (size_t)s * MAT);
+            block_sync();
         }
     }
-    if ((a.nsteps % a.cost_eval_step) == 0) cost += density_costs(a, true, false, dens, nullptr);
-    cost += density_costs(a, false, true, dens, nullptr);
-    if (lane == 0) a.cost_out[b] = cost;
-    for (int s = 0; s < S; ++s) {
-        Mat rho;
-        dump_load(rho, dens + (size_t)s * MAT);
-        dump_store(rho, a.final_out + ((size_t)b * S + s) * MAT);
-        if (a.step_densities != nullptr)
-            dump_store(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
+    if (lead) {
+        if ((a.nsteps % a.cost_eval_step) == 0) cost += density_costs(a, true, false, dens, nullptr);
+        cost += density_costs(a, false, true, dens, nullptr);
+        if (lane == 0) a.cost_out[b] = cost;
+        for (int s = 0; s < S; ++s) {
+            Mat rho;
+            dump_load(rho, dens + (size_t)s * MAT);
+            dump_store(rho, a.final_out + ((size_t)b * S + s) * MAT);
+            if (a.step_densities != nullptr)
+                dump_store(rho, a.step_densities +
+                                    (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
+        }
     }
     if (!a.want_grad) return;
 
     // ---- discrete adjoint ----------------------------------------------------------------
-    {
-        Mat zero;
-        mat_zero(zero);
-        for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * MAT);
-    }
-    wave_sync();
-    (void)density_costs(a, (a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
     // lambda += host-supplied cotangent of the densities at system step `step`, if there is one
     auto inject = [&](int step) {
         if (a.inj_index == nullptr) return;
@@ -554,7 +597,15 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         }
         wave_sync();
     };
-    inject(a.nsteps);
+    if (lead) {
+        Mat zero;
+        mat_zero(zero);
+        for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * MAT);
+        wave_sync();
+        (void)density_costs(a, (a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+        inject(a.nsteps);
+    }
+    block_sync();
 
     for (int q = nsub - 1; q >= 0; --q) {
         const SubStep ss = a.substeps[q];
@@ -575,57 +626,67 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
             w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
-            dump_store(lambda_new, lam + (size_t)s * MAT);
-            wave_sync();
+            block_sync();  // every wave has read lambda
+            if (lead) dump_store(lambda_new, lam + (size_t)s * MAT);
+            block_sync();
         }
-        if (lane == 0)
+        if (w.z_wave() && lane == 0)
             for (int k = 0; k < K; ++k) {
                 a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + k] = ga[k];
                 a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + k] = gb[k];
             }
-        // step costs are evaluated on the densities at the START of their system step
-        if (ss.first_of_step && ss.step != 0 && (ss.step % a.cost_eval_step) == 0 &&
-            a.has_step_costs) {
-            for (int s = 0; s < S; ++s) {
-                Mat rho;
-                dump_load(rho, ckpt_b + ((size_t)q * S + s) * MAT);
-                dump_store(rho, dens + (size_t)s * MAT);
+        if (ss.first_of_step && ss.step != 0) {
+            if (lead) {
+                // step costs are evaluated on the densities at the START of their system step
+                if ((ss.step % a.cost_eval_step) == 0 && a.has_step_costs) {
+                    for (int s = 0; s < S; ++s) {
+                        Mat rho;
+                        dump_load(rho, ckpt_b + ((size_t)q * S + s) * MAT);
+                        dump_store(rho, dens + (size_t)s * MAT);
+                    }
+                    wave_sync();
+                    (void)density_costs(a, true, false, dens, lam);
+                }
+                inject(ss.step);
             }
-            wave_sync();
-            (void)density_costs(a, true, false, dens, lam);
+            block_sync();
         }
-        if (ss.first_of_step && ss.step != 0) inject(ss.step);
     }
 }
-
 };  // struct LB
 
-template <int LNB, bool GS>
-__global__ __launch_bounds__(64) void lindblad_kernel(LindbladArgs a) {
+template <int LNB, bool GS, bool MW>
+__global__ __launch_bounds__(MW ? 384 : 64) void lindblad_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LB<LNB, GS>::run(a, smem);
+    LB<LNB, GS, MW>::run(a, smem);
 }
 
-template <int LNB, bool GS>
+template <int LNB, bool GS, bool MW>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
-    const int bytes = LB<LNB, GS>::lds_bytes(a.S, a.nops);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS>),
+    typedef LB<LNB, GS, MW> I;
+    const int bytes = I::lds_bytes(a.S, a.nops);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((lindblad_kernel<LNB, GS>), dim3(batch), dim3(64), bytes, st, a);
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW>), dim3(batch), dim3(64 * I::waves(a.nops)),
+                       bytes, st, a);
 }
 
 }  // namespace
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
-    if (a.n > 16) launch_t<2, true>(a, batch, st);
-    else if (a.scratch != nullptr) launch_t<1, true>(a, batch, st);
-    else launch_t<1, false>(a, batch, st);
+    if (a.n > 16) launch_t<2, true, false>(a, batch, st);
+    else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
+    else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
+    else launch_t<1, false, false>(a, batch, st);
 }
 
-// LDS bytes of one seed; global_scratch: stage derivatives, densities and cotangents in HBM
-int lindblad_lds_size(int n, int S, int nops, int global_scratch) {
-    if (n > 16) return LB<2, true>::lds_bytes(S, nops);
-    return global_scratch ? LB<1, true>::lds_bytes(S, nops) : LB<1, false>::lds_bytes(S, nops);
+// LDS bytes of one seed. mode 0: one wave, everything in LDS; 1: one wave, stage derivatives /
+// densities / cotangents in HBM scratch (always for n > 16); 2: nops + 2 waves per seed
+int lindblad_lds_size(int n, int S, int nops, int mode) {
+    if (n > 16) return LB<2, true, false>::lds_bytes(S, nops);
+    if (mode == 1) return LB<1, true, false>::lds_bytes(S, nops);
+    if (mode == 2) return LB<1, false, true>::lds_bytes(S, nops);
+    return LB<1, false, false>::lds_bytes(S, nops);
 }
 
 // complex elements of per-seed HBM scratch when it is used
