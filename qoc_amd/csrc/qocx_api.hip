@@ -179,7 +179,7 @@ struct qocx_ctx {
         DevBuf<double2> inj_bars;
         DevBuf<double> gsub, cost_out, grads, controls;
         DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
-        int global_scratch = 0, multi_wave = 0;
+        int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
         DevBuf<double2> a0_tab, gp_tab;
     } lb;
@@ -1127,14 +1127,16 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         return fail(QOCX_ERR_ARG, "missing problem arrays");
     // densities, cotangents and stage derivatives live in LDS when they fit (n <= 16), else in
     // per-seed HBM scratch
-    ctx->lb.global_scratch = (n > 16 || qocx::lindblad_lds_size(n, S, L, 0) > 160 * 1024) ? 1 : 0;
-    if (qocx::lindblad_lds_size(n, S, L, ctx->lb.global_scratch) > 160 * 1024)
+    ctx->lb.global_scratch = (n > 16 || qocx::lindblad_lds_size(n, S, L, 0, K) > 160 * 1024) ? 1 : 0;
+    if (qocx::lindblad_lds_size(n, S, L, ctx->lb.global_scratch, K) > 160 * 1024)
         return fail(QOCX_ERR_ARG, "too many operators for the kernel's LDS");
     // several waves per seed (generator terms | one per operator | control cotangents) whenever
     // that layout fits LDS: the recursion in time is serial, this shortens every stage
     ctx->lb.multi_wave = (!ctx->lb.global_scratch && L > 0 &&
-                          qocx::lindblad_lds_size(n, S, L, 2) <= 160 * 1024 &&
+                          qocx::lindblad_lds_size(n, S, L, 2, K) <= 160 * 1024 &&
                           !getenv("QOCX_LINDBLAD_SINGLE_WAVE")) ? 1 : 0;
+    ctx->lb.cache_gen = (ctx->lb.multi_wave && p->fixed_subdivision <= 0 &&
+                         qocx::lindblad_lds_size(n, S, L, 3, K) <= 160 * 1024) ? 1 : 0;
     auto& lb = ctx->lb;
     lb.has_problem = false;
     lb.n = n; lb.S = S; lb.K = K; lb.nc = nc; lb.N = N; lb.nsteps = N - 1; lb.ces = p->cost_eval_step;
@@ -1519,6 +1521,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             // several waves per seed shorten a seed's serial chain by ~1.4x but hold one seed
             // per CU instead of two: worth it while the batch leaves CUs idle
             la.multi_wave = (lb.multi_wave && B <= ctx->cu_count) ? 1 : 0;
+            la.cache_gen = (la.multi_wave && lb.cache_gen) ? 1 : 0;
             la.cost_out = lb.cost_out.p + pos0;
             la.final_out = lb.final_out.p + pos0 * S * md;
             la.step_densities = ctx->keep_step_states

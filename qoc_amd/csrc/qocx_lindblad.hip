@@ -258,12 +258,15 @@ static __device__ __forceinline__ double density_costs(const LindbladArgs& a, bo
 // dumps | S lambda dumps | STAGES stage-derivative dumps. 80 KB at LNB = 1, S = 1, L = 2: two
 // seeds per CU.
 static __host__ __device__ int waves(int nops) { return MW ? nops + 2 : 1; }
-static __host__ __device__ int lds_bytes(int S, int nops) {
+static __host__ __device__ int lds_bytes(int S, int nops, int cached_controls = -1) {
     // work slots: single wave gen | y | tmp; MW: gen | y | tmp per operator | zk | zy ; then the
-    // operator images, MW: one partial-result dump per wave, and the per-seed dumps
+    // operator images, MW: one partial-result dump per wave, the per-seed dumps, and (MW,
+    // cached_controls = K >= 0) copies of the constant generator dumps A0L A0R A0L^H A0R^H and
+    // Gp Gp^H Gp^T per control
     const int slots = MW ? (2 + nops + 2) : 3;
     return slots * SLOT_BYTES + nops * SLOT_BYTES + (MW ? waves(nops) * DUMP_BYTES : 0) +
-           (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES);
+           (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES) +
+           (cached_controls >= 0 ? (4 + 3 * cached_controls) * DUMP_BYTES : 0);
 }
 static __device__ __forceinline__ void block_sync() {
     if (MW) __syncthreads();
@@ -282,6 +285,8 @@ struct Wave {
     double2* parts;                   // MW: [nwaves] partial right-hand sides
     double2* kdump;  // STAGES dumps: stage derivatives k_j, then (adjoint) Ybar_j
     const double* ctl_b;
+    // constant generator dumps: the HBM images, or their copies in LDS (MW with room to spare)
+    const double2 *c_a0l, *c_a0r, *c_a0ld, *c_a0rd, *c_gp, *c_gpd, *c_gpt;
 
     __device__ __forceinline__ bool first() const { return !MW || wv == 0; }
     __device__ __forceinline__ bool z_wave() const { return !MW || wv == nwaves - 1; }
@@ -301,8 +306,8 @@ struct Wave {
             dump_load(left, t + (adjoint ? 2 : 0) * (size_t)MAT);
             dump_load(right, t + (adjoint ? 3 : 1) * (size_t)MAT);
         } else {
-            dump_load(left, adjoint ? a.a0ld_cimg : a.a0l_cimg);
-            dump_load(right, adjoint ? a.a0rd_cimg : a.a0r_cimg);
+            dump_load(left, adjoint ? c_a0ld : c_a0l);
+            dump_load(right, adjoint ? c_a0rd : c_a0r);
         }
         const int K = a.K;
         for (int k = 0; k < K; ++k) {
@@ -313,7 +318,7 @@ struct Wave {
             if (a.gp_tab != nullptr)
                 dump_load(g, a.gp_tab + ((stage * K + k) * 3 + (adjoint ? 1 : 0)) * MAT);
             else
-                dump_load(g, (adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
+                dump_load(g, (adjoint ? c_gpd : c_gp) + (size_t)k * MAT);
             mat_axpy(left, u, g);
             mat_axpy(right, -u, g);
         }
@@ -455,7 +460,7 @@ struct Wave {
                     if (a.gp_tab != nullptr)  // C-image of Gp_k^T
                         dump_load(gt, a.gp_tab + ((((size_t)q * STAGES + i) * K + k) * 3 + 2) * MAT);
                     else
-                        dump_load(gt, a.gpt_cimg + (size_t)k * MAT);
+                        dump_load(gt, c_gpt + (size_t)k * MAT);
                     double pr = 0;
 #pragma unroll
                     for (int ti = 0; ti < LNB; ++ti)
@@ -535,8 +540,38 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     }
     block_sync();
 
+    // constant generator dumps into LDS when the host found room (a.cache_gen): every stage
+    // then builds its generator without a trip to L2
+    const double2 *c_a0l = a.a0l_cimg, *c_a0r = a.a0r_cimg, *c_a0ld = a.a0ld_cimg,
+                  *c_a0rd = a.a0rd_cimg, *c_gp = a.gp_cimg, *c_gpd = a.gpd_cimg,
+                  *c_gpt = a.gpt_cimg;
+    if (MW && a.cache_gen) {
+        double2* cache = kdump + (size_t)STAGES * MAT;
+        const double2* src[4] = {a.a0l_cimg, a.a0r_cimg, a.a0ld_cimg, a.a0rd_cimg};
+        if (lead) {
+            for (int m = 0; m < 4; ++m) {
+                Mat t;
+                dump_load(t, src[m]);
+                dump_store(t, cache + (size_t)m * MAT);
+            }
+            for (int k = 0; k < K; ++k) {
+                Mat t;
+                dump_load(t, a.gp_cimg + (size_t)k * MAT);
+                dump_store(t, cache + (size_t)(4 + k) * MAT);
+                dump_load(t, a.gpd_cimg + (size_t)k * MAT);
+                dump_store(t, cache + (size_t)(4 + K + k) * MAT);
+                dump_load(t, a.gpt_cimg + (size_t)k * MAT);
+                dump_store(t, cache + (size_t)(4 + 2 * K + k) * MAT);
+            }
+        }
+        c_a0l = cache; c_a0r = cache + MAT; c_a0ld = cache + 2 * (size_t)MAT;
+        c_a0rd = cache + 3 * (size_t)MAT;
+        c_gp = cache + 4 * (size_t)MAT; c_gpd = c_gp + (size_t)K * MAT; c_gpt = c_gpd + (size_t)K * MAT;
+        block_sync();
+    }
     const Wave w{a, wv, nwaves, slot_gen, slot_y, slot_tmp, slot_zk, slot_zy, op_planar, parts,
-                 kdump, a.controls + (size_t)b * a.nc * K};
+                 kdump, a.controls + (size_t)b * a.nc * K,
+                 c_a0l, c_a0r, c_a0ld, c_a0rd, c_gp, c_gpd, c_gpt};
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
 
     // ---- forward ------------------------------------------------------------------------
@@ -664,7 +699,7 @@ __global__ __launch_bounds__(MW ? 384 : 64) void lindblad_kernel(LindbladArgs a)
 template <int LNB, bool GS, bool MW>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
     typedef LB<LNB, GS, MW> I;
-    const int bytes = I::lds_bytes(a.S, a.nops);
+    const int bytes = I::lds_bytes(a.S, a.nops, (MW && a.cache_gen) ? a.K : -1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW>), dim3(batch), dim3(64 * I::waves(a.nops)),
@@ -681,11 +716,13 @@ void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
 }
 
 // LDS bytes of one seed. mode 0: one wave, everything in LDS; 1: one wave, stage derivatives /
-// densities / cotangents in HBM scratch (always for n > 16); 2: nops + 2 waves per seed
-int lindblad_lds_size(int n, int S, int nops, int mode) {
+// densities / cotangents in HBM scratch (always for n > 16); 2: nops + 2 waves per seed; 3: as 2
+// with the constant generator dumps of K controls cached in LDS
+int lindblad_lds_size(int n, int S, int nops, int mode, int K) {
     if (n > 16) return LB<2, true, false>::lds_bytes(S, nops);
     if (mode == 1) return LB<1, true, false>::lds_bytes(S, nops);
     if (mode == 2) return LB<1, false, true>::lds_bytes(S, nops);
+    if (mode == 3) return LB<1, false, true>::lds_bytes(S, nops, K);
     return LB<1, false, false>::lds_bytes(S, nops);
 }
 
