@@ -208,10 +208,11 @@ int qocx_set_timing(qocx_ctx* ctx, int32_t enable);
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms);
 int qocx_reset_timing(qocx_ctx* ctx);
 
-/* Seeds per memory chunk (0 = auto from free HBM) and number of pipelined sub-chunks per chunk
- * (0 = auto, 1 = no overlap of the sweep with the other kernels). */
+/* Seeds per memory chunk (0 = auto from free HBM) and number of time segments of the pipeline
+ * (0 = auto: 8 for large evaluations; 1 = no overlap of the sweep with the other kernels). Results
+ * do not depend on either. */
 int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk);
-int qocx_set_pipeline(qocx_ctx* ctx, int32_t sub_chunks);
+int qocx_set_pipeline(qocx_ctx* ctx, int32_t time_segments);
 
 /*
  * Multi-GPU: one process per GPU; the seed axis is sharded by the caller, the summed

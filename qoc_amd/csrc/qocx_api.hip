@@ -693,9 +693,9 @@ int qocx_set_chunk(qocx_ctx* ctx, int32_t seeds_per_chunk) {
     return 0;
 }
 
-int qocx_set_pipeline(qocx_ctx* ctx, int32_t sub_chunks) {
+int qocx_set_pipeline(qocx_ctx* ctx, int32_t time_segments) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
-    ctx->pipe_user = sub_chunks < 0 ? 0 : sub_chunks;
+    ctx->pipe_user = time_segments < 0 ? 0 : time_segments;
     return 0;
 }
 

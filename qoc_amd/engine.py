@@ -389,8 +389,9 @@ class Engine(object):
     def set_chunk(self, seeds_per_chunk):
         self._check(self._lib.qocx_set_chunk(self._ctx, int(seeds_per_chunk)))
 
-    def set_pipeline(self, sub_chunks):
-        self._check(self._lib.qocx_set_pipeline(self._ctx, int(sub_chunks)))
+    def set_pipeline(self, time_segments):
+        """Number of time segments the evaluation pipeline is cut into (0 = automatic)."""
+        self._check(self._lib.qocx_set_pipeline(self._ctx, int(time_segments)))
 
     # -- timing --------------------------------------------------------------------------------
     def set_timing(self, enable):
