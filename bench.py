@@ -179,7 +179,7 @@ def main():
         avg_s = total_ms / launches * 1e-3
         units_per_launch = seeds * (N_EVAL - 1) * args.steps / launches
         achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
-        roofline = dict(bound="mfma", kernel="pade_pq_kernel<2, hermitian>", achieved=achieved,
+        roofline = dict(bound="mfma", kernel="qocx::pade_pq_kernel<2, true>", achieved=achieved,
                         peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS,
                         peak_sustained_measured=engine.mfma_peak(2, 20000),
