@@ -231,3 +231,18 @@ def test_segments_and_chunks_with_other_kernel_variants(engine, name):
     finally:
         engine.set_chunk(0)
         engine.set_pipeline(0)
+
+
+def test_random_shapes_fuzz(engine):
+    """tools/fuzz_parity.py: 80 random problems (sizes, grids, Magnus policies, Hermitian or not,
+    time dependent or not, 0..4 squarings) against the oracle at the parity tolerances."""
+    from tools import fuzz_parity
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for index in range(80):
+        worst, tag = fuzz_parity.one(engine, rng, index)
+        if worst is None:
+            continue
+        checked += 1
+        assert worst < 1.0, tag
+    assert checked > 60

@@ -1,0 +1,118 @@
+"""
+fuzz_parity.py - BUILD TOOLING: random problem shapes, engine (through the C ABI) against the
+oracle. Complements the fixed fixtures: sizes 1..32, random step counts / control grids / state
+counts / time steps (so that 0..4 squarings occur), all three Magnus policies, Hermitian and
+non-Hermitian generators, all state-cost kinds at once.
+
+    python tools/fuzz_parity.py [count] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qoc_numpy as onp  # noqa: E402
+from qoc_amd.engine import (Engine, QocxError, COST_FORBID, COST_TARGET_COHERENT,  # noqa: E402
+                            COST_TARGET_INCOHERENT)
+from tests.cases import gue  # noqa: E402
+
+NODES = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
+         "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}
+
+
+def one(engine, rng, index):
+    n = int(rng.integers(1, 33))
+    N = int(rng.integers(2, 14))
+    K = int(rng.integers(1, 4))
+    Nc = int(rng.integers(2, 16))
+    S = int(rng.integers(1, 5))
+    ces = int(rng.integers(1, 4))
+    policy = ("M2", "M2", "M4", "M6")[int(rng.integers(0, 4))]
+    hermitian = rng.random() < 0.7
+    time_dep = rng.random() < 0.3
+    dt = float(10 ** rng.uniform(-2, 0.3))
+    scale = float(10 ** rng.uniform(-0.5, 0.8))
+    h0 = gue(rng, n) * scale
+    g = [gue(rng, n) for _ in range(K)]
+    if not hermitian:
+        h0 = h0 + 0.3j * scale * gue(rng, n)
+        g[0] = g[0] + 0.2j * gue(rng, n)
+    omega = float(rng.uniform(0.5, 4.0))
+    T = dt * (N - 1)
+
+    def hamiltonian(u, t):
+        base = h0 * (1 + 0.3 * np.cos(omega * t)) if time_dep else h0
+        return base + sum(u[k] * g[k] for k in range(K))
+
+    init = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    forb = rng.standard_normal((S, 2, n)) + 1j * rng.standard_normal((S, 2, n))
+    forb /= np.linalg.norm(forb, axis=2, keepdims=True)
+    count = (N - 1) // ces
+    descs = [dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=0.7, vectors=targ)]
+    ocosts = [onp.TargetStateInfidelity(targ[:, :, None], cost_multiplier=0.7)]
+    if count > 0:
+        descs += [dict(kind=COST_TARGET_INCOHERENT, step_cost=1, scale=1.3 / count, vectors=targ),
+                  dict(kind=COST_FORBID, step_cost=1, scale=0.9 / (count * S),
+                       vectors=forb.reshape(-1, n), counts=[2] * S)]
+        ocosts += [onp.TargetStateInfidelityTime(N, targ[:, :, None], neglect_relative_pahse=True,
+                                                 cost_eval_step=ces, cost_multiplier=1.3),
+                   onp.ForbidStates(forb[:, :, :, None], N, cost_eval_step=ces,
+                                    cost_multiplier=0.9)]
+    if time_dep:
+        times = [j * dt + c * dt for j in range(N - 1) for c in NODES[policy]]
+        h0s = np.stack([h0 * (1 + 0.3 * np.cos(omega * t)) for t in times])
+        gs = np.stack([np.stack(g) for _ in times])
+    else:
+        h0s, gs = h0[None], np.stack(g)[None]
+    engine.set_schroedinger_problem(n, S, K, Nc, N, T, h0s, gs, init, costs=descs,
+                                    cost_eval_step=ces, magnus_policy=policy)
+    controls = float(10 ** rng.uniform(-1, 0.5)) * rng.standard_normal((2, Nc, K))
+    tag = "n={} N={} Nc={} K={} S={} ces={} {} herm={} tdep={} dt={:.3g} |H|={:.3g}".format(
+        n, N, Nc, K, S, ces, policy, hermitian, time_dep, dt, scale)
+    try:
+        cost, grads, final = engine.evaluate(controls, want_grad=True)
+    except QocxError as exc:
+        if exc.code == -5:  # more than 2^10 squarings per step: rejected by design
+            return None, tag
+        raise
+    problem = onp.SchroedingerProblem(T, hamiltonian, init[:, :, None], N, control_eval_count=Nc,
+                                      costs=ocosts, cost_eval_step=ces, magnus_policy=policy,
+                                      control_count=K)
+    worst = 0.0
+    for b in range(2):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        e_cost = abs(err - cost[b]) / max(1.0, abs(err))
+        e_fin = np.max(np.abs(fin[:, :, 0] - final[b])) / max(np.max(np.abs(fin)), 1e-300)
+        e_grad = np.max(np.abs(gr - grads[b])) / max(np.max(np.abs(gr)), 1e-3)
+        worst = max(worst, e_cost / 1e-10, e_fin / 1e-10, e_grad / 1e-8)
+    return worst, tag
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    engine = Engine(0)
+    bad = skipped = 0
+    overall = 0.0
+    for index in range(count):
+        worst, tag = one(engine, rng, index)
+        if worst is None:
+            skipped += 1
+            continue
+        overall = max(overall, worst)
+        if worst > 1.0:
+            bad += 1
+            print("FAIL x{:.2f} of tolerance: {}".format(worst, tag), flush=True)
+    print("{} cases ({} rejected for capacity), {} failures, worst {:.2e} of tolerance "
+          "(cost/states 1e-10, grads 1e-8)".format(count, skipped, bad, overall))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
