@@ -211,3 +211,13 @@ def test_lindblad_edge_shapes_against_model(engine, spec):
         assert np.max(np.abs(final[b] - m_final)) < 1e-12
         if K:
             assert np.max(np.abs(grads[b] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+
+
+def test_lindblad_random_shapes_fuzz(engine):
+    """tools/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
+    several densities, batches that mix sub-division counts) against the device model."""
+    from tools import fuzz_lindblad
+    rng = np.random.default_rng(2025)
+    for index in range(40):
+        worst, tag = fuzz_lindblad.one(engine, rng, index)
+        assert worst < 1.0, tag

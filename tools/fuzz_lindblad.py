@@ -1,0 +1,83 @@
+"""
+fuzz_lindblad.py - BUILD TOOLING: random Lindblad problem shapes, engine (through the C ABI)
+against the NumPy model of the device algorithm (tests/lindblad_model.py), which the CPU suite
+holds against the reference fixtures.
+
+    python tools/fuzz_lindblad.py [count] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qoc_lindblad_numpy as ol  # noqa: E402
+from qoc_amd.engine import Engine, COST_FORBID_DENSITY, COST_TARGET_DENSITY  # noqa: E402
+from tests import lindblad_model as lm  # noqa: E402
+from tests.cases import gue, random_density  # noqa: E402
+
+
+def one(engine, rng, index):
+    n = int(rng.integers(1, 33)) if rng.random() < 0.5 else int(rng.integers(1, 17))
+    S = int(rng.integers(1, 4))
+    K = int(rng.integers(0, 4))
+    L = int(rng.integers(0, 4))
+    N = int(rng.integers(2, 6))
+    Nc = int(rng.integers(2, 9)) if K else 0
+    ces = int(rng.integers(1, 3))
+    batch = int(rng.integers(1, 4))
+    h0 = gue(rng, n) * float(10 ** rng.uniform(-0.3, 0.5))
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)]) if L else None
+    gam = rng.uniform(0.02, 0.4, L) if L else None
+    rho0 = np.stack([random_density(rng, n) for _ in range(S)])
+    targ = np.stack([random_density(rng, n) for _ in range(S)])
+    forb = np.stack([random_density(rng, n) for _ in range(2 * S)])
+    T = float(10 ** rng.uniform(-1.2, -0.2)) * (N - 1)
+    count = (N - 1) // ces
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ)]
+    costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8)]
+    if count > 0:
+        descs.append(dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=1.5 / (count * S),
+                          vectors=forb, counts=[2] * S))
+        costs.append(ol.ForbidDensities(forb.reshape(S, 2, n, n), N, cost_eval_step=ces,
+                                        cost_multiplier=1.5))
+    engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs,
+                                cost_eval_step=ces)
+    controls = (float(10 ** rng.uniform(-1, 0.3)) * rng.standard_normal((batch, Nc, K))
+                if K else None)
+    cost, grads, final = engine.evaluate_lindblad(controls if K else batch, want_grad=K > 0)
+    system = lm.StructuredLindblad(h0, g, gam, ops)
+    worst = 0.0
+    for b in range(batch):
+        u = controls[b] if K else np.zeros((2, 0))
+        m_err, m_grads, m_final = lm.evaluate_with_grad(system, u, rho0, T, N, costs, ces,
+                                                        want_grad=K > 0)
+        worst = max(worst, abs(cost[b] - m_err) / 1e-11, np.max(np.abs(final[b] - m_final)) / 1e-11)
+        if K:
+            worst = max(worst, np.max(np.abs(grads[b] - m_grads))
+                        / (1e-9 * max(np.max(np.abs(m_grads)), 1e-3)))
+    tag = "n={} S={} K={} L={} N={} Nc={} ces={} B={}".format(n, S, K, L, N, Nc, ces, batch)
+    return worst, tag
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    engine = Engine(0)
+    bad, overall = 0, 0.0
+    for index in range(count):
+        worst, tag = one(engine, rng, index)
+        overall = max(overall, worst)
+        if worst > 1.0:
+            bad += 1
+            print("FAIL x{:.2f} of tolerance: {}".format(worst, tag), flush=True)
+    print("{} cases, {} failures, worst {:.2e} of tolerance (cost/densities 1e-11, grads 1e-9)"
+          "".format(count, bad, overall))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
