@@ -558,8 +558,8 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
                 const double2 pv = prow[cc * H + h];
                 const bool on = (cc * H + h > k);
                 const double ure = on ? mre : 0.0, uim = on ? mim : 0.0;
-                pre[cc] -= ure * pv.x - uim * pv.y;
-                pim[cc] -= ure * pv.y + uim * pv.x;
+                pre[cc] = fma(uim, pv.y, fma(-ure, pv.x, pre[cc]));
+                pim[cc] = fma(-uim, pv.x, fma(-ure, pv.y, pim[cc]));
             }
         }
         wave_sync();
@@ -1300,16 +1300,18 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                         const double2 v0 = vv[cc * H + h];
                         const double2 v1 = vv[NP + cc * H + h];
                         const double2 v2 = tau_l[jj * NP + cc * H + h];
-                        s0r += are[cc] * v0.x - aim[cc] * v0.y;
-                        s0i += are[cc] * v0.y + aim[cc] * v0.x;
-                        s1r += are[cc] * v1.x - aim[cc] * v1.y;
-                        s1i += are[cc] * v1.y + aim[cc] * v1.x;
+                        // explicit FMA chains: two per complex component (the compiler may not
+                        // re-associate "s += x*y - z*w" into them; it costs a third more VALU)
+                        s0r = fma(-aim[cc], v0.y, fma(are[cc], v0.x, s0r));
+                        s0i = fma(aim[cc], v0.x, fma(are[cc], v0.y, s0i));
+                        s1r = fma(-aim[cc], v1.y, fma(are[cc], v1.x, s1r));
+                        s1i = fma(aim[cc], v1.x, fma(are[cc], v1.y, s1i));
                         if (SKEW) {  // a^H = -a
-                            s2r -= are[cc] * v2.x - aim[cc] * v2.y;
-                            s2i -= are[cc] * v2.y + aim[cc] * v2.x;
+                            s2r = fma(aim[cc], v2.y, fma(-are[cc], v2.x, s2r));
+                            s2i = fma(-aim[cc], v2.x, fma(-are[cc], v2.y, s2i));
                         } else {
-                            s2r += hre[cc] * v2.x - him[cc] * v2.y;
-                            s2i += hre[cc] * v2.y + him[cc] * v2.x;
+                            s2r = fma(-him[cc], v2.y, fma(hre[cc], v2.x, s2r));
+                            s2i = fma(him[cc], v2.x, fma(hre[cc], v2.y, s2i));
                         }
                     }
                     sgr = sum_groups<NB>(s0r);
@@ -1334,8 +1336,8 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                 for (int cc = 0; cc < CPL; ++cc) {
                     const double2 r = rho_l[tt * NP + cc * H + h];
                     // tau * conj(rho)
-                    abr[cc] += tv.x * r.x + tv.y * r.y;
-                    abi[cc] += tv.y * r.x - tv.x * r.y;
+                    abr[cc] = fma(tv.y, r.y, fma(tv.x, r.x, abr[cc]));
+                    abi[cc] = fma(-tv.x, r.y, fma(tv.y, r.x, abi[cc]));
                 }
             }
             wave_sync();
