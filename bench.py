@@ -57,12 +57,12 @@ def make_controls(first_seed, count):
 def pmc_traffic_bytes(kernel, units_per_launch):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/r01_v5_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this
+    (profiles/r01_v6_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this
     bench command, gfx950 correction applied; tools/pmc_summary.py), rescaled to this run's
     units per launch. PMC counters cannot be collected from inside the timed run; None if the
     summary is absent.
     """
-    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm.json")
     try:
         with open(path) as f:
             summary = json.load(f)
@@ -179,11 +179,11 @@ def main():
         avg_s = total_ms / launches * 1e-3
         units_per_launch = seeds * (N_EVAL - 1) * args.steps / launches
         achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
-        roofline = dict(bound="mfma", kernel="qocx::pade_pq_kernel<2, true>", achieved=achieved,
+        roofline = dict(bound="mfma", kernel="qocx::pade2::pade_pq2_kernel<true>", achieved=achieved,
                         peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS,
                         peak_sustained_measured=engine.mfma_peak(2, 20000),
-                        traffic=pmc_traffic_bytes("qocx::pade_pq_kernel<2", units_per_launch),
+                        traffic=pmc_traffic_bytes("qocx::pade2::pade_pq2_kernel<true", units_per_launch),
                         avg_launch_ms=total_ms / launches)
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}
     path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)

@@ -824,6 +824,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     typedef SweepLds<NB> L;
     constexpr int NP = G::NP, CPL = G::CPL, H = G::H, MAT = G::MAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the sweep is the serial chain of the evaluation: where it shares a SIMD with a wave of the
+    // throughput kernels (two-wave K1a, K3) its instructions go first
+    __builtin_amdgcn_s_setprio(3);
     double2* qbuf = reinterpret_cast<double2*>(smem + L::Q_OFF);
     double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
     double2* dbuf = reinterpret_cast<double2*>(smem + L::D_OFF);
@@ -1479,14 +1482,20 @@ static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStrea
                            KrylovLds<NB>::BYTES, st, a);
 }
 
+static bool one_wave_pq() {
+    static const bool v = getenv("QOCX_PQ1") != nullptr;
+    return v;
+}
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
-    else launch_pq_t<2>(a, nsteps, batch, st);
+    else if (one_wave_pq()) launch_pq_t<2>(a, nsteps, batch, st);
+    else launch_pq2(a, nsteps, batch, st);
 }
 void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
                         hipStream_t st) {
     if (nb == 1) launch_pq_explicit_t<1>(a_in, n, a, count, st);
-    else launch_pq_explicit_t<2>(a_in, n, a, count, st);
+    else if (one_wave_pq()) launch_pq_explicit_t<2>(a_in, n, a, count, st);
+    else launch_pq2_explicit(a_in, n, a, count, st);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);

@@ -1,0 +1,436 @@
+// qocx_pade2.hip - K1a for 17 <= n <= 32 as a TWO-wave workgroup per propagator step.
+//
+// The one-wave K1a (qocx_kernels.hip) needs ~410 registers, so a SIMD holds a single wave and
+// nothing overlaps its VALU / LDS phases (3M recombination, staging the next A operand, the B
+// combinations of the Paterson-Stockmeyer polynomials) with MFMA work: the matrix pipe is busy
+// about half of the time (rocprofv3 SQ counters). Here wave w of the workgroup owns
+// COLUMN BLOCK w (tiles (0,w), (1,w) of every 32 x 32 matrix, C-layout), which halves the
+// registers per wave; two waves of different workgroups then share a SIMD and the hardware
+// interleaves one wave's VALU / LDS phases with the other's MFMAs.
+//
+// A product C = A B needs all of A (from LDS, staged by both waves) and only B(:, w), which is
+// the wave's own column block of an earlier product. HERM (Hermitian H: a^2, a^4, a^6, w2, v
+// Hermitian, u skew-Hermitian): wave 0 computes tile (0,0) only, wave 1 tiles (0,1), (1,1) and
+// hands tile (1,0) = +-conj(tile (0,1))^T to wave 0 through LDS.
+//
+// LDS (22 KiB per workgroup, so that four workgroups and a sweep wave share a CU): one planar
+// A-operand slot holding a, a^2, a^6, w2 in turn, and M = one 16 x 16 complex tile for the
+// mirror hand-over of a^4. The Q / P images are stored straight from the C-layout registers.
+#include "qocx_wave.h"
+
+namespace qocx {
+
+namespace pade2 {
+
+constexpr int PITCH = Geo<2>::PITCH, PLANE = Geo<2>::PLANE, MAT = Geo<2>::MAT;
+constexpr int SLOT_F64 = 2 * PLANE;             // re | im planes
+constexpr int MPITCH = 18, MTILE_F64 = 2 * 16 * MPITCH;
+constexpr int LDS_BYTES = (SLOT_F64 + MTILE_F64 + 2) * 8;
+
+struct Col {  // tiles (0,w), (1,w) of a complex matrix, C-layout
+    d4 re[2], im[2];
+};
+
+// 3M accumulators of up to two tiles
+struct Acc3 {
+    d4 t1[2], t2[2], t3[2];
+};
+
+__device__ __forceinline__ void stage_tile(double* slot, int ti, int tj, const d4& re, const d4& im) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int off = (16 * ti + 4 * r + q) * PITCH + 16 * tj + c;
+        slot[off] = re[r];
+        slot[PLANE + off] = im[r];
+    }
+}
+// tile (ti, tj) of the slot := sign * conj(src)^T, src being tile (tj, ti)
+__device__ __forceinline__ void stage_mirror(double* slot, int ti, int tj, const d4& re, const d4& im,
+                                             double sign) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int off = (16 * ti + c) * PITCH + 16 * tj + 4 * r + q;
+        slot[off] = sign * re[r];
+        slot[PLANE + off] = -sign * im[r];
+    }
+}
+__device__ __forceinline__ void load_tile(const double* slot, int ti, int tj, d4& re, d4& im) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int off = (16 * ti + 4 * r + q) * PITCH + 16 * tj + c;
+        re[r] = slot[off];
+        im[r] = slot[PLANE + off];
+    }
+}
+// the mirror tile M: written transposed-conjugated by wave 1, read in C-layout by wave 0
+__device__ __forceinline__ void mirror_put(double* mt, const d4& re, const d4& im, double sign) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        mt[c * MPITCH + 4 * r + q] = sign * re[r];
+        mt[16 * MPITCH + c * MPITCH + 4 * r + q] = -sign * im[r];
+    }
+}
+__device__ __forceinline__ void mirror_get(const double* mt, d4& re, d4& im) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        re[r] = mt[(4 * r + q) * MPITCH + c];
+        im[r] = mt[16 * MPITCH + (4 * r + q) * MPITCH + c];
+    }
+}
+
+// acc(ti) += A(ti, :) B(:, w) for ti < NT, 3M scheme; A from the slot, B fragment from `bf`
+template <int NT, class BFrag>
+__device__ __forceinline__ void gemm3(Acc3& acc, const double* slot, BFrag bf) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        double are[NT], aim[NT], asum[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int off = (16 * ti + c) * PITCH + 4 * kk + q;
+            are[ti] = slot[off];
+            aim[ti] = slot[PLANE + off];
+            asum[ti] = are[ti] + aim[ti];
+        }
+        double bre, bim;
+        bf(kk, bre, bim);
+        const double bsum = bre + bim;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            acc.t1[ti] = mfma_f64(are[ti], bre, acc.t1[ti]);
+            acc.t2[ti] = mfma_f64(aim[ti], bim, acc.t2[ti]);
+            acc.t3[ti] = mfma_f64(asum[ti], bsum, acc.t3[ti]);
+        }
+        // keep the k-steps apart: hoisting every A fragment and B combination to the top of
+        // the product costs ~40 registers and spills
+        if (kk & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void acc_zero(Acc3& a) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        a.t1[ti] = d4{0, 0, 0, 0};
+        a.t2[ti] = d4{0, 0, 0, 0};
+        a.t3[ti] = d4{0, 0, 0, 0};
+    }
+}
+template <int NT>
+__device__ __forceinline__ void acc_init(Acc3& a, const Col& c) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        a.t1[ti] = c.re[ti];
+        a.t2[ti] = d4{0, 0, 0, 0};
+        a.t3[ti] = c.re[ti] + c.im[ti];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void acc_finish(Col& c, const Acc3& a) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        c.re[ti] = a.t1[ti] - a.t2[ti];
+        c.im[ti] = a.t3[ti] - a.t1[ti] - a.t2[ti];
+    }
+}
+
+struct Out {
+    double2* q_img;
+    double2* p_img;
+    int* s_out;
+    int* status;
+};
+
+// W: the wave's column block. Every wave executes the same number of barriers.
+template <bool HERM, int W, class Gen>
+__device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
+    // tiles this wave computes: rows [0, NT) of column block W
+    constexpr int NT = (HERM && W == 0) ? 1 : 2;
+    constexpr bool GIVE = HERM && W == 1;   // hands tile (1,0) to wave 0
+    constexpr bool TAKE = HERM && W == 0;
+    double* sl = smem;
+    double* mt = sl + SLOT_F64;
+    double* nrm = mt + MTILE_F64;
+    const int lane = lane_id();
+    const int q = lane >> 4, c = lane & 15;
+
+    // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
+    Col a;
+    gen(a, W);
+    {
+        double s = 0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        s = wave_max(s);
+        if (lane == 0) nrm[W] = s;
+    }
+    __syncthreads();  // 1
+    const double norm1 = fmax(nrm[0], nrm[1]);
+    int sq = 0;
+    {
+        double th = QOCX_THETA13;
+        while (norm1 > th && sq < 30) {
+            th *= 2.0;
+            ++sq;
+        }
+        if (!(norm1 <= th)) {  // inf / nan / absurd
+            if (W == 0 && lane == 0) atomicOr(out.status, 2);
+            sq = 0;
+        }
+    }
+    if (sq > 0) {
+        const double scale = ldexp(1.0, -sq);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    if (W == 0 && lane == 0) *out.s_out = sq;
+    stage_tile(sl, 0, W, a.re[0], a.im[0]);
+    stage_tile(sl, 1, W, a.re[1], a.im[1]);
+    __syncthreads();  // 2
+
+    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
+    Col x2, x4, x6;
+    Acc3 acc;
+    acc_zero<NT>(acc);
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    acc_finish<NT>(x2, acc);
+    __syncthreads();  // 3: every read of a is done
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x2.re[ti], x2.im[ti]);
+    if (GIVE) stage_mirror(sl, 1, 0, x2.re[0], x2.im[0], 1.0);
+    __syncthreads();  // 4
+    if (TAKE) load_tile(sl, 1, 0, x2.re[1], x2.im[1]);
+
+    acc_zero<NT>(acc);
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = x2.re[kk >> 2][kk & 3];
+        bim = x2.im[kk >> 2][kk & 3];
+    });
+    acc_finish<NT>(x4, acc);
+    if (GIVE) mirror_put(mt, x4.re[0], x4.im[0], 1.0);
+    __syncthreads();  // 5
+    if (TAKE) mirror_get(mt, x4.re[1], x4.im[1]);
+
+    acc_zero<NT>(acc);
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = x4.re[kk >> 2][kk & 3];
+        bim = x4.im[kk >> 2][kk & 3];
+    });
+    acc_finish<NT>(x6, acc);
+    __syncthreads();  // 6: every read of a2 is done
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x6.re[ti], x6.im[ti]);
+    if (GIVE) stage_mirror(sl, 1, 0, x6.re[0], x6.im[0], 1.0);
+    __syncthreads();  // 7
+    if (TAKE) load_tile(sl, 1, 0, x6.re[1], x6.im[1]);
+
+    // ---- w2 = a6 (b13 a6 + b11 a4 + b9 a2) + b7 a6 + b5 a4 + b3 a2 (expm.py:157) ---------
+    // ---- v  = a6 (b12 a6 + b10 a4 + b8 a2) + b6 a6 + b4 a4 + b2 a2 + b0 I (expm.py:158) --
+    const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
+                 b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
+                 b10 = PADE_B[10], b11 = PADE_B[11], b12 = PADE_B[12], b13 = PADE_B[13];
+    Col w2, v;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        w2.re[ti] = b7 * x6.re[ti] + b5 * x4.re[ti] + b3 * x2.re[ti];
+        w2.im[ti] = b7 * x6.im[ti] + b5 * x4.im[ti] + b3 * x2.im[ti];
+    }
+    acc_init<NT>(acc, w2);
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        const int tb = kk >> 2, r = kk & 3;
+        bre = b13 * x6.re[tb][r] + b11 * x4.re[tb][r] + b9 * x2.re[tb][r];
+        bim = b13 * x6.im[tb][r] + b11 * x4.im[tb][r] + b9 * x2.im[tb][r];
+    });
+    acc_finish<NT>(w2, acc);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        v.re[ti] = b6 * x6.re[ti] + b4 * x4.re[ti] + b2 * x2.re[ti];
+        v.im[ti] = b6 * x6.im[ti] + b4 * x4.im[ti] + b2 * x2.im[ti];
+        if (ti == W) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + q == c) v.re[ti][r] += b0;
+        }
+    }
+    acc_init<NT>(acc, v);
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        const int tb = kk >> 2, r = kk & 3;
+        bre = b12 * x6.re[tb][r] + b10 * x4.re[tb][r] + b8 * x2.re[tb][r];
+        bim = b12 * x6.im[tb][r] + b10 * x4.im[tb][r] + b8 * x2.im[tb][r];
+    });
+    acc_finish<NT>(v, acc);
+    __syncthreads();  // 8: every read of a6 is done
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, w2.re[ti], w2.im[ti]);
+    if (GIVE) stage_mirror(sl, 1, 0, w2.re[0], w2.im[0], 1.0);
+
+    // ---- u = a w2 + b1 a (expm.py:157), evaluated as w2 a + b1 a: w2 is a polynomial in a, the
+    // two commute, and this way the A operand is the product just finished while B is the
+    // wave's own column block of the generator (rebuilt: keeping it costs 32 registers).
+    gen(a, W);
+    if (sq > 0) {
+        const double scale = ldexp(1.0, -sq);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    Col u;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        u.re[ti] = b1 * a.re[ti];
+        u.im[ti] = b1 * a.im[ti];
+    }
+    acc_init<NT>(acc, u);
+    __syncthreads();  // 9
+    gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    acc_finish<NT>(u, acc);
+
+    // ---- P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers: for a
+    // fixed r the four q-lanes of a column hold rows 4r..4r+3, i.e. one 64-byte run of the
+    // column-major image. HERM: Q = P^H, so wave 1 also writes tile (1,0) of each image as the
+    // mirror of its tile (0,1) of the other one (256-byte runs).
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = (16 * W + c) * 32 + 16 * ti + 4 * r + q;
+            out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
+            out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
+        }
+    if (GIVE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = (4 * r + q) * 32 + 16 + c;  // element (16 + c, 4r + q)
+            out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
+            out.p_img[idx] = make_double2(v.re[0][r] + u.re[0][r], -(v.im[0][r] + u.im[0][r]));
+        }
+    }
+}
+
+template <bool HERM>
+__global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const int step = args.step0 + blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t m = (size_t)b * args.nsteps + step;
+    Out out;
+    out.q_img = args.q_img + m * MAT;
+    out.p_img = args.lu_img + m * MAT;
+    out.s_out = args.s_arr + m;
+    out.status = args.status;
+    const StepInterp si = args.interp[step];
+    const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
+    const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
+    const double2* h0 = args.h0_cimg + tsel * MAT;
+    const double2* g = args.g_cimg + tsel * args.K * MAT;
+    const double dt = args.dt;
+    const int K = args.K;
+    auto gen = [&](Col& a, int wcol) {
+        // H = h0 + sum_k u_k g_k ; a = dt * (-i H)  (schroedingerdiscrete.py:485-486,
+        // mathmethods.py:90-93); C-layout image index ((ti * 2 + tj) * 4 + r) * 64 + lane
+        d4 hre[2], him[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = h0[((ti * 2 + wcol) * 4 + r) * 64 + lane];
+                hre[ti][r] = e.x;
+                him[ti][r] = e.y;
+            }
+        for (int k = 0; k < K; ++k) {
+            const double uk = control_at(ctl_b, si, K, k);
+            const double2* gk = g + (size_t)k * MAT;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 e = gk[((ti * 2 + wcol) * 4 + r) * 64 + lane];
+                    hre[ti][r] += uk * e.x;
+                    him[ti][r] += uk * e.y;
+                }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            a.re[ti] = dt * him[ti];
+            a.im[ti] = -dt * hre[ti];
+        }
+    };
+    if (w == 0) body<HERM, 0>(gen, out, smem);
+    else body<HERM, 1>(gen, out, smem);
+}
+
+// Explicit-generator variant: a[count][n][n] row-major complex in HBM (Magnus M4/M6, debug)
+template <bool HERM>
+__global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2* a_in, int n,
+                                                                   FactorArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
+                     blockIdx.x % args.seg_len;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, c = lane & 15;
+    Out out;
+    out.q_img = args.q_img + m * MAT;
+    out.p_img = args.lu_img + m * MAT;
+    out.s_out = args.s_arr + m;
+    out.status = args.status;
+    const double2* am = a_in + m * (size_t)n * n;
+    auto gen = [&](Col& a, int wcol) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + q, col = 16 * wcol + c;
+                double2 e = make_double2(0, 0);
+                if (row < n && col < n) e = am[(size_t)row * n + col];
+                a.re[ti][r] = e.x;
+                a.im[ti][r] = e.y;
+            }
+    };
+    if (w == 0) body<HERM, 0>(gen, out, smem);
+    else body<HERM, 1>(gen, out, smem);
+}
+
+}  // namespace pade2
+
+void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    if (a.hermitian)
+        hipLaunchKernelGGL(pade2::pade_pq2_kernel<true>, dim3(nsteps, batch), dim3(128),
+                           pade2::LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(pade2::pade_pq2_kernel<false>, dim3(nsteps, batch), dim3(128),
+                           pade2::LDS_BYTES, st, a);
+}
+void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {
+    if (a.hermitian)
+        hipLaunchKernelGGL(pade2::pade_pq2_explicit_kernel<true>, dim3(count), dim3(128),
+                           pade2::LDS_BYTES, st, a_in, n, a);
+    else
+        hipLaunchKernelGGL(pade2::pade_pq2_explicit_kernel<false>, dim3(count), dim3(128),
+                           pade2::LDS_BYTES, st, a_in, n, a);
+}
+
+}  // namespace qocx
