@@ -867,6 +867,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             time_end(ctx, ss);
         }
         // ---- adjoint sweep walks back; K3 follows on the compute stream ----------------------
+        // (Measured and dropped: evaluating a chunk as two seed halves with sweep streams of
+        // their own, so that the first half's adjoint sweep runs under the second half's
+        // factorisation. Two sweeps then share the chip with half-size grids whose segments take
+        // as long as a sweep segment: 16.6 ms against 14.6 ms.)
         if (nseg > 1 && want_grad) {
             for (int i = nseg - 1; i >= 0; --i) {
                 sa.j_begin = lo[i]; sa.j_end = lo[i + 1]; sa.phase = 2;
@@ -897,8 +901,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             for (int i = nseg - 1; i >= 0; --i) {
                 const int len = lo[i + 1] - lo[i];
                 if (nseg > 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[i], 0));
-                ka.step0 = lo[i];
-            ka.skew = ctx->hermitian;
+                    ka.step0 = lo[i];
+                ka.skew = ctx->hermitian;
                 time_begin(ctx, 2, cs);
                 qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
                 if (nodes > 1) {

@@ -27,6 +27,8 @@
 //              per instruction. Every matrix in HBM (Q, LU, H0, G_k) is such a column-major
 //              image.
 //   F-layout : lane l (any group) holds the full row l % NP (index c*NP + i of the image).
+#include <type_traits>
+
 #include "qocx_wave.h"
 
 namespace qocx {
@@ -1144,10 +1146,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
 template <int NB>
 struct KrylovLds {
     typedef Geo<NB> G;
-    static constexpr int V_OFF = 0;                          // 2 vectors (sigma_j, delta_j)
-    static constexpr int TAU_OFF = V_OFF + 2 * G::NP * 16;   // 13 tau vectors
-    static constexpr int RHO_OFF = TAU_OFF + 13 * G::NP * 16;  // 13 rho vectors
-    static constexpr int BYTES = RHO_OFF + 13 * G::NP * 16;
+    static constexpr int TAU_OFF = 0;                            // 13 tau vectors
+    static constexpr int RHO_OFF = TAU_OFF + 13 * G::NP * 16;    // 13 rho vectors
+    static constexpr int V_OFF = RHO_OFF + 13 * G::NP * 16;      // 2 chain vectors (sigma_j, delta_j)
+    static constexpr int BYTES = V_OFF + 2 * G::NP * 16;
 };
 
 // sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
@@ -1166,6 +1168,12 @@ __device__ __forceinline__ double sum_groups(double v) {
 
 // SKEW: every H0(t), G_k(t) is Hermitian, so a^H = -a exactly and the rows of a^H need no
 // registers (the common physical case; the host checks it bit for bit).
+//
+// Measured and dropped: a variant that contracts abar with the G_k after every (sub-step, state)
+// and rebuilds the generator, so that the two never coexist and three waves share a SIMD
+// (<= 168 registers, 10 KiB LDS): no faster than two waves per SIMD of this form. What did pay
+// (16 %) was removing the exec-mask branches around the LDS stores: after sum_groups every lane
+// group holds the same values, so all of them store.
 template <int NB, bool EXPLICIT, bool SKEW>
 __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* smem) {
     typedef Geo<NB> G;
@@ -1190,66 +1198,154 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
 
     // a (rows) and a^H (rows) of the scaled generator
     constexpr int HC = SKEW ? 1 : CPL;
-    double are[CPL], aim[CPL], hre[HC], him[HC];
-    if (EXPLICIT) {
-        // Magnus M4/M6: a = 2^-s M with M from magnus_fwd_kernel (row-major, padded)
-        const double2* mm = args.m_rm + m * G::MAT;
-        const double sc = ldexp(1.0, -sq);
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const double2 e = mm[(size_t)i * NP + cc * H + h];
-            are[cc] = sc * e.x;
-            aim[cc] = sc * e.y;
-            if (!SKEW) {
-                const double2 f = mm[(size_t)(cc * H + h) * NP + i];
-                hre[cc] = sc * f.x;
-                him[cc] = -sc * f.y;
-            }
-        }
-    } else {
-        double xr[CPL], xi[CPL], tr_[HC], ti_[HC];
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const double2 e = h0r[cc * 64 + lane];
-            xr[cc] = e.x;
-            xi[cc] = e.y;
-            if (!SKEW) {
-                const double2 f = h0t[cc * 64 + lane];
-                tr_[cc] = f.x;
-                ti_[cc] = f.y;
-            }
-        }
-        for (int k = 0; k < K; ++k) {
-            const double uk = control_at(ctl_b, si, K, k);
+    auto build = [&](double (&are)[CPL], double (&aim)[CPL], double (&hre)[HC],
+                     double (&him)[HC]) __attribute__((always_inline)) {
+        if constexpr (EXPLICIT) {
+            // Magnus M4/M6: a = 2^-s M with M from magnus_fwd_kernel (row-major, padded)
+            const double2* mm = args.m_rm + m * G::MAT;
+            const double sc = ldexp(1.0, -sq);
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
-                const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
-                xr[cc] += uk * e.x;
-                xi[cc] += uk * e.y;
+                const double2 e = mm[(size_t)i * NP + cc * H + h];
+                are[cc] = sc * e.x;
+                aim[cc] = sc * e.y;
                 if (!SKEW) {
-                    const double2 f = gt[(size_t)k * G::MAT + cc * 64 + lane];
-                    tr_[cc] += uk * f.x;
-                    ti_[cc] += uk * f.y;
+                    const double2 f = mm[(size_t)(cc * H + h) * NP + i];
+                    hre[cc] = sc * f.x;
+                    him[cc] = -sc * f.y;
+                }
+            }
+        } else {
+            double xr[CPL], xi[CPL], tr_[HC], ti_[HC];
+            const unsigned off = (unsigned)lane;
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                const double2 e = (h0r + cc * 64)[off];
+                xr[cc] = e.x;
+                xi[cc] = e.y;
+                if (!SKEW) {
+                    const double2 f = (h0t + cc * 64)[off];
+                    tr_[cc] = f.x;
+                    ti_[cc] = f.y;
+                }
+            }
+            for (int k = 0; k < K; ++k) {
+                const double uk = control_at(ctl_b, si, K, k);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 e = (gr + (size_t)k * G::MAT + cc * 64)[off];
+                    xr[cc] += uk * e.x;
+                    xi[cc] += uk * e.y;
+                    if (!SKEW) {
+                        const double2 f = (gt + (size_t)k * G::MAT + cc * 64)[off];
+                        tr_[cc] += uk * f.x;
+                        ti_[cc] += uk * f.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                are[cc] = dts * xi[cc];   // a = -i dts H
+                aim[cc] = -dts * xr[cc];
+                if (!SKEW) {
+                    hre[cc] = dts * ti_[cc];  // a^H[i][c] = conj(a[c][i]) = conj(-i dts H[c][i])
+                    him[cc] = dts * tr_[cc];
                 }
             }
         }
+    };
+
+    // the chains of one (sub-step, state): tau_0..12 into LDS, rho_0..12 into registers
+    auto chains = [&](const double (&are)[CPL], const double (&aim)[CPL], const double (&hre)[HC],
+                      const double (&him)[HC], double2 x, double2 p0, double2 p1,
+                      double (&rhr)[13], double (&rhi)[13]) __attribute__((always_inline)) {
+        double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
+        double dlr = p0.x - p1.x, dli = p0.y - p1.y;
+        double tar = x.x, tai = x.y;
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            are[cc] = dts * xi[cc];   // a = -i dts H
-            aim[cc] = -dts * xr[cc];
-            if (!SKEW) {
-                hre[cc] = dts * ti_[cc];  // a^H[i][c] = conj(a[c][i]) = conj(-i dts H[c][i])
-                him[cc] = dts * tr_[cc];
+        for (int ii = 0; ii < 13; ++ii) {
+            rhr[ii] = 0;
+            rhi[ii] = 0;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 13; ++jj) {
+#pragma unroll
+            for (int ii = 0; ii + jj < 13; ++ii) {
+                const int mm = ii + jj + 1;
+                const double coef = PADE_B[mm];
+                if (mm & 1) {
+                    rhr[ii] += coef * sgr;
+                    rhi[ii] += coef * sgi;
+                } else {
+                    rhr[ii] += coef * dlr;
+                    rhi[ii] += coef * dli;
+                }
+            }
+            // tau_jj stays in LDS: it is the broadcast source of the next matvec and the
+            // left factor of the rank-1 update below
+            // (every lane group holds the same sums: all of them store, no exec-mask branch)
+            tau_l[jj * NP + i] = make_double2(tar, tai);
+            if (jj < 12) {
+                vv[i] = make_double2(sgr, sgi);
+                vv[NP + i] = make_double2(dlr, dli);
+            }
+            if (jj < 12) {
+                wave_sync();
+                double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 v0 = vv[cc * H + h];
+                    const double2 v1 = vv[NP + cc * H + h];
+                    const double2 v2 = tau_l[jj * NP + cc * H + h];
+                    // explicit FMA chains: two per complex component (the compiler may not
+                    // re-associate "s += x*y - z*w" into them; it costs a third more VALU)
+                    s0r = fma(-aim[cc], v0.y, fma(are[cc], v0.x, s0r));
+                    s0i = fma(aim[cc], v0.x, fma(are[cc], v0.y, s0i));
+                    s1r = fma(-aim[cc], v1.y, fma(are[cc], v1.x, s1r));
+                    s1i = fma(aim[cc], v1.x, fma(are[cc], v1.y, s1i));
+                    if (SKEW) {  // a^H = -a
+                        s2r = fma(aim[cc], v2.y, fma(-are[cc], v2.x, s2r));
+                        s2i = fma(-aim[cc], v2.x, fma(-are[cc], v2.y, s2i));
+                    } else {
+                        s2r = fma(-him[cc], v2.y, fma(hre[cc], v2.x, s2r));
+                        s2i = fma(him[cc], v2.x, fma(hre[cc], v2.y, s2i));
+                    }
+                }
+                sgr = sum_groups<NB>(s0r);
+                sgi = sum_groups<NB>(s0i);
+                dlr = sum_groups<NB>(s1r);
+                dli = sum_groups<NB>(s1i);
+                tar = sum_groups<NB>(s2r);
+                tai = sum_groups<NB>(s2i);
+                wave_sync();  // vv is rewritten by the next chain step
             }
         }
-    }
-
-    double abr[CPL], abi[CPL];
+    };
+    // abar += sum_t tau_t rho_t^H, the rho broadcast through LDS seven (six) at a time
+    auto rank1 = [&](const double (&rhr)[13], const double (&rhi)[13], double (&abr)[CPL],
+                     double (&abi)[CPL]) __attribute__((always_inline)) {
+        auto part = [&](auto T0, auto T1) __attribute__((always_inline)) {
+            constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value;
+            wave_sync();  // vv (first part) / the first seven rho (second part) are done with
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-        abr[cc] = 0;
-        abi[cc] = 0;
-    }
+            for (int tt = t0; tt < t1; ++tt)
+                rho_l[(tt - t0) * NP + i] = make_double2(rhr[tt], rhi[tt]);
+            wave_sync();
+#pragma unroll
+            for (int tt = t0; tt < t1; ++tt) {
+                const double2 tv = tau_l[tt * NP + i];
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 r = rho_l[(tt - t0) * NP + cc * H + h];
+                    // tau * conj(rho)
+                    abr[cc] = fma(tv.y, r.y, fma(tv.x, r.x, abr[cc]));
+                    abi[cc] = fma(-tv.x, r.y, fma(tv.y, r.x, abi[cc]));
+                }
+            }
+        };
+        part(std::integral_constant<int, 0>(), std::integral_constant<int, 13>());
+        wave_sync();
+    };
 
     const size_t cap = args.slot_cap;
     const double2* states_b = args.states + (size_t)b * cap * S * NP;
@@ -1257,114 +1353,41 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     const int t0 = args.offs[(size_t)b * (nsteps + 1) + step];
     const int nsub = 1 << sq;
     if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) return;  // sweep overflowed (status bit 2)
-    for (int sub = 0; sub < nsub; ++sub) {
+
+    double are[CPL], aim[CPL], hre[HC], him[HC];
+    build(are, aim, hre, him);
+    double abr[CPL], abi[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+        abr[cc] = 0;
+        abi[cc] = 0;
+    }
+    for (int sub = 0; sub < nsub; ++sub)
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
-            const double2 x = xs_b[(t * S + s) * NP + i];
-            const double2 p0 = states_b[(t * S + s) * NP + i];
-            const double2 p1 = states_b[((t + 1) * S + s) * NP + i];
-            double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
-            double dlr = p0.x - p1.x, dli = p0.y - p1.y;
-            double tar = x.x, tai = x.y;
             double rhr[13], rhi[13];
-#pragma unroll
-            for (int ii = 0; ii < 13; ++ii) {
-                rhr[ii] = 0;
-                rhi[ii] = 0;
-            }
-#pragma unroll
-            for (int jj = 0; jj < 13; ++jj) {
-#pragma unroll
-                for (int ii = 0; ii + jj < 13; ++ii) {
-                    const int mm = ii + jj + 1;
-                    const double coef = PADE_B[mm];
-                    if (mm & 1) {
-                        rhr[ii] += coef * sgr;
-                        rhi[ii] += coef * sgi;
-                    } else {
-                        rhr[ii] += coef * dlr;
-                        rhi[ii] += coef * dli;
-                    }
-                }
-                // tau_jj stays in LDS: it is the broadcast source of the next matvec and the
-                // left factor of the rank-1 update below
-                if (h == 0) {
-                    tau_l[jj * NP + i] = make_double2(tar, tai);
-                    if (jj < 12) {
-                        vv[i] = make_double2(sgr, sgi);
-                        vv[NP + i] = make_double2(dlr, dli);
-                    }
-                }
-                if (jj < 12) {
-                    wave_sync();
-                    double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0;
-#pragma unroll
-                    for (int cc = 0; cc < CPL; ++cc) {
-                        const double2 v0 = vv[cc * H + h];
-                        const double2 v1 = vv[NP + cc * H + h];
-                        const double2 v2 = tau_l[jj * NP + cc * H + h];
-                        // explicit FMA chains: two per complex component (the compiler may not
-                        // re-associate "s += x*y - z*w" into them; it costs a third more VALU)
-                        s0r = fma(-aim[cc], v0.y, fma(are[cc], v0.x, s0r));
-                        s0i = fma(aim[cc], v0.x, fma(are[cc], v0.y, s0i));
-                        s1r = fma(-aim[cc], v1.y, fma(are[cc], v1.x, s1r));
-                        s1i = fma(aim[cc], v1.x, fma(are[cc], v1.y, s1i));
-                        if (SKEW) {  // a^H = -a
-                            s2r = fma(aim[cc], v2.y, fma(-are[cc], v2.x, s2r));
-                            s2i = fma(-aim[cc], v2.x, fma(-are[cc], v2.y, s2i));
-                        } else {
-                            s2r = fma(-him[cc], v2.y, fma(hre[cc], v2.x, s2r));
-                            s2i = fma(him[cc], v2.x, fma(hre[cc], v2.y, s2i));
-                        }
-                    }
-                    sgr = sum_groups<NB>(s0r);
-                    sgi = sum_groups<NB>(s0i);
-                    dlr = sum_groups<NB>(s1r);
-                    dli = sum_groups<NB>(s1i);
-                    tar = sum_groups<NB>(s2r);
-                    tai = sum_groups<NB>(s2i);
-                    wave_sync();  // vv is rewritten by the next chain step
-                }
-            }
-            // abar += sum_t tau_t rho_t^H
-            if (h == 0) {
-#pragma unroll
-                for (int tt = 0; tt < 13; ++tt) rho_l[tt * NP + i] = make_double2(rhr[tt], rhi[tt]);
-            }
-            wave_sync();
-#pragma unroll
-            for (int tt = 0; tt < 13; ++tt) {
-                const double2 tv = tau_l[tt * NP + i];
-#pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 r = rho_l[tt * NP + cc * H + h];
-                    // tau * conj(rho)
-                    abr[cc] = fma(tv.y, r.y, fma(tv.x, r.x, abr[cc]));
-                    abi[cc] = fma(-tv.x, r.y, fma(tv.y, r.x, abi[cc]));
-                }
-            }
-            wave_sync();
+            chains(are, aim, hre, him, xs_b[(t * S + s) * NP + i], states_b[(t * S + s) * NP + i],
+                   states_b[((t + 1) * S + s) * NP + i], rhr, rhi);
+            rank1(rhr, rhi, abr, abi);
         }
-    }
-
-    if (EXPLICIT) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
+    if constexpr (EXPLICIT) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
         double2* mb = args.mbar_rm + m * G::MAT;
         const double sc = ldexp(1.0, -sq);
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc)
             mb[(size_t)i * NP + cc * H + h] = make_double2(sc * abr[cc], sc * abi[cc]);
-        return;
-    }
-    // g_k = Re <abar, E_k>, E_k = d a / d u_k = -i dts G_k  (H-bar = i dt M-bar, Appendix A)
-    for (int k = 0; k < K; ++k) {
-        double acc = 0;
+    } else {
+        // g_k = Re <abar, E_k>, E_k = d a / d u_k = -i dts G_k  (H-bar = i dt M-bar, Appendix A)
+        for (int k = 0; k < K; ++k) {
+            double acc = 0;
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-            const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
-            acc += abr[cc] * (dts * e.y) + abi[cc] * (-dts * e.x);
+            for (int cc = 0; cc < CPL; ++cc) {
+                const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
+                acc = fma(abi[cc], -dts * e.x, fma(abr[cc], dts * e.y, acc));
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) args.gstep[m * K + k] = acc;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) args.gstep[m * K + k] = acc;
     }
 }
 
@@ -1381,8 +1404,6 @@ __global__ __launch_bounds__(64, 2) void krylov_grad_skew_kernel(KrylovArgs args
     krylov_grad_body<NB, EXPLICIT, true>(args, smem);
 }
 
-// ------------------------------------------------------------------------------------------
-// K4: transpose of the linear interpolation: grads[b][ic][k] = sum_j W[j][ic] gstep[b][j][k]
 // ------------------------------------------------------------------------------------------
 __global__ void scatter_kernel(ScatterArgs args) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
