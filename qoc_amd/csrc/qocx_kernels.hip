@@ -456,15 +456,16 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
 // is final, which frees its registers); perm/iperm give the row order. Pivot choice = first
 // maximum of |re|+|im| (LAPACK izamax). Only the pivot row goes through LDS; the pivot element
 // comes from a dynamic v_readlane, the multipliers cross lane groups by ds_bpermute.
-// wave-wide max of a u32 (DPP folds into v_max_u32; rows combined on the scalar unit)
+// wave-wide max of a u32: four symmetric DPP exchanges inside each 16-lane row, then
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row results into lane 63
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
-    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
-    const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
-    return max(max(r0, r1), max(r2, r3));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // value of lane group `g` (static) of a double, replicated to every lane group
@@ -509,8 +510,12 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
             mine ? ((unsigned long long)__double_as_longlong(mag) + 1ull) : 0ull;
         const unsigned khi = (unsigned)(bits >> 32), klo = (unsigned)bits;
         const unsigned mh = wave_max_u32(khi);
-        const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
-        const unsigned long long ball = __ballot(khi == mh && klo == ml);
+        unsigned ml = 2u;  // only compared against 1 below unless the low words were needed
+        unsigned long long ball = __ballot(khi == mh);
+        if (__popcll(ball) > 1 || mh == 0u) {  // wave-uniform; rare: the high words tie
+            ml = wave_max_u32(khi == mh ? klo : 0u);
+            ball = __ballot(khi == mh && klo == ml);
+        }
         const int lp = __ffsll((long long)ball) - 1;  // a lane of group hk, never -1
         const int p = lp % NP;
         singular = singular || (mh == 0u && ml <= 1u);
