@@ -957,7 +957,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
                 finish_prefetch();
                 wave_sync();
-                if (g0) {
+                {   // every lane group holds the same z: all of them store (no exec-mask branch
+                    // in the serial chain)
                     const double2 p = make_double2(zre, zim);
                     vecs[s * NP + i] = p;
                     states_b[((size_t)(slot + 1) * S + s) * NP + i] = p;
@@ -1075,7 +1076,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
                 wave_sync();
-                if (g0) {
+                {
                     const double2 x = make_double2(xre, xim);
                     tmp[i] = x;
                     xs_b[((size_t)slot * S + s) * NP + i] = x;
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                     yim += __shfl_xor(yim, d);
                 }
                 wave_sync();
-                if (g0) lam[s * NP + i] = make_double2(yre, yim);
+                lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
             }
         }
