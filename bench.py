@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seeds-per-gpu", type=int, default=SEEDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-segments", type=int, default=0,
+                    help="tuning knob: time segments of the pipeline (0 = the engine's choice)")
     args = ap.parse_args()
 
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
@@ -137,6 +139,8 @@ def main():
         DIM, 1, K_CTRL, N_EVAL, N_EVAL, DT * (N_EVAL - 1), h0[None], np.stack(g)[None], psi0,
         costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
     controls = make_controls(rank * seeds, seeds)
+    if args.time_segments > 0:
+        engine.set_pipeline(args.time_segments)
     engine.upload_controls(controls)  # resident in HBM before the clock starts
 
     def one_step():
