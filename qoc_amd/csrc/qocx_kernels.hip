@@ -643,7 +643,7 @@ __device__ __forceinline__ void tri_step(const double (&tre)[Geo<NB>::NP],
     constexpr int k = LOWER ? KK : (NP - 1 - KK);
     constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
     const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
-    hook(KK);  // independent work issued into the bubble of the dependent chain
+    hook(std::integral_constant<int, KK>());  // independent work for the chain's bubbles
     masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
         zre, zim, tre[k], tim[k], kre, kim);
 }
@@ -785,14 +785,21 @@ __device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
         (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-// One KiB piece j of a column-major image into LDS. TRANSPOSE: gather so that LDS holds the image
-// of the transposed matrix (position r*NP + c <- element (r, c)).
-template <int NB, bool TRANSPOSE>
-__device__ __forceinline__ void dma_piece(const double2* img, double2* lds, int j, int lane) {
-    typedef Geo<NB> G;
-    const int q = j * 64 + lane;
-    const int src = TRANSPOSE ? ((q % G::NP) * G::NP + q / G::NP) : q;
-    dma16(img + src, lds + j * 64);
+// The same with an instruction offset IMM (13 bits, signed): the 16 bytes at g + IMM land at
+// lds_dst + 16*l. The hardware adds the offset to the global AND to the LDS address, so M0 gets
+// lds_dst - IMM. One per-lane base address then serves many pieces of an image.
+template <int IMM>
+__device__ __forceinline__ void dma16_imm(const char* g, char* lds_dst) {
+    static_assert(IMM >= -4096 && IMM <= 4095, "instruction offset range");
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)(lds_dst - IMM), 16, IMM, 0);
+}
+
+// f(integral_constant<int, P>) for every P of the sequence
+template <class F, int... P>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, P...>) {
+    (f(std::integral_constant<int, P>()), ...);
 }
 
 __device__ __forceinline__ void dma4(const int* g, int* lds_base) {
@@ -883,39 +890,71 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     // one per column of the current step's triangular solves, into the bubbles of the
     // dependent readlane -> fma chain (an in-order wave cannot fill them otherwise).
     constexpr int IMG_PIECES = MAT / 64, PIECES = 2 * IMG_PIECES + 2;
-    auto dma_one = [&](size_t m, int par, bool adjoint, int piece) {
-        if (piece < IMG_PIECES) {
-            if (adjoint) dma_piece<NB, true>(args.q_img + m * MAT, qbuf + par * MAT, piece, lane);
-            else dma_piece<NB, false>(args.q_img + m * MAT, qbuf + par * MAT, piece, lane);
-        } else if (piece < 2 * IMG_PIECES) {
-            if (adjoint) dma_piece<NB, true>(args.lu_img + m * MAT, lbuf + par * MAT, piece - IMG_PIECES, lane);
-            else dma_piece<NB, false>(args.lu_img + m * MAT, lbuf + par * MAT, piece - IMG_PIECES, lane);
-        } else if (piece == 2 * IMG_PIECES) {
-            dma16(args.dinv + m * NP + i, dbuf + par * 64);
-        } else if (piece == 2 * IMG_PIECES + 1) {
-            dma4((lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP, pbuf + par * 64);
+    // Per-lane global base addresses of the step being fetched; the pieces of an image are
+    // reached through the instruction offset (dma16_imm), so a step needs six addresses, not one
+    // per piece. Plain image: piece j is the KiB at j * 1024, two bases per image, each in the
+    // middle of eight pieces (offsets -4096 .. 3072). Transposed image (adjoint): lane l of
+    // piece j reads element ((l % NP) * NP + l / NP) + j * H, one base per image.
+    constexpr int GROUP = IMG_PIECES >= 8 ? 8 : IMG_PIECES, CENTER = IMG_PIECES >= 8 ? 4 : 0;
+    constexpr int NGROUP = IMG_PIECES / GROUP;
+    const char* pf_q[NGROUP];
+    const char* pf_l[NGROUP];
+    const double2* pf_d = nullptr;
+    const int* pf_p = nullptr;
+    int pf_par = 0;
+    bool pf_adjoint = false, pf_due = false;
+    auto set_prefetch = [&](size_t m, int par, bool adjoint) {
+        pf_par = par;
+        pf_adjoint = adjoint;
+        const size_t el = adjoint ? (size_t)(lane % NP) * NP + lane / NP : (size_t)lane;
+#pragma unroll
+        for (int g = 0; g < NGROUP; ++g) {
+            const size_t mid = adjoint ? 0 : (size_t)(g * GROUP + CENTER) * 64;
+            pf_q[g] = reinterpret_cast<const char*>(args.q_img + m * MAT + el + mid);
+            pf_l[g] = reinterpret_cast<const char*>(args.lu_img + m * MAT + el + mid);
+        }
+        pf_d = args.dinv + m * NP + i;
+        pf_p = (lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP;
+    };
+    auto dma_image = [&](auto J, const char* const (&base)[NGROUP], double2* buf) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        char* dst = reinterpret_cast<char*>(buf + pf_par * MAT + j * 64);
+        if (pf_adjoint) dma16_imm<j * H * 16>(base[0], dst);
+        else dma16_imm<(j - ((j / GROUP) * GROUP + CENTER)) * 1024>(base[j / GROUP], dst);
+    };
+    auto dma_one = [&](auto PIECE) __attribute__((always_inline)) {
+        constexpr int piece = decltype(PIECE)::value;
+        if constexpr (piece < IMG_PIECES) {
+            dma_image(std::integral_constant<int, piece>(), pf_q, qbuf);
+        } else if constexpr (piece < 2 * IMG_PIECES) {
+            dma_image(std::integral_constant<int, piece - IMG_PIECES>(), pf_l, lbuf);
+        } else if constexpr (piece == 2 * IMG_PIECES) {
+            dma16(pf_d, dbuf + pf_par * 64);
+        } else if constexpr (piece == 2 * IMG_PIECES + 1) {
+            dma4(pf_p, pbuf + pf_par * 64);
         }
     };
     auto issue_dma = [&](size_t m, int par, bool adjoint) {
-#pragma unroll
-        for (int piece = 0; piece < PIECES; ++piece) dma_one(m, par, adjoint, piece);
+        set_prefetch(m, par, adjoint);
+        for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
     };
-    // prefetch state of the step being computed: which step to fetch, and whether it is still due
-    size_t pf_m = 0;
-    int pf_par = 0;
-    bool pf_adjoint = false, pf_due = false;
-    auto hook_a = [&](int kk) {  // first solve of a step: pieces 0 .. NP-2
-        if (pf_due) dma_one(pf_m, pf_par, pf_adjoint, kk);
+    auto hook_a = [&](auto KK) __attribute__((always_inline)) {  // first solve: pieces 0 .. NP-2
+        if (pf_due) dma_one(KK);
     };
-    auto hook_b = [&](int kk) {  // second solve: the remaining pieces
-        if (pf_due && (NP - 1 + kk) < PIECES) dma_one(pf_m, pf_par, pf_adjoint, NP - 1 + kk);
+    auto hook_b = [&](auto KK) __attribute__((always_inline)) {  // second solve: the remaining pieces
+        constexpr int piece = NP - 1 + decltype(KK)::value;
+        if constexpr (piece < PIECES) {
+            if (pf_due) dma_one(std::integral_constant<int, piece>());
+        }
     };
     auto finish_prefetch = [&]() {  // pieces that did not fit into the two solves (NP = 16)
-        if (pf_due) {
-#pragma unroll
-            for (int piece = 2 * (NP - 1); piece < PIECES; ++piece)
-                dma_one(pf_m, pf_par, pf_adjoint, piece);
-        }
+        constexpr int DONE = 2 * (NP - 1), REST = PIECES > DONE ? PIECES - DONE : 0;
+        if (pf_due)
+            for_each_const(
+                [&](auto P) __attribute__((always_inline)) {
+                    dma_one(std::integral_constant<int, DONE + decltype(P)::value>());
+                },
+                std::make_integer_sequence<int, REST>{});
         pf_due = false;
     };
     auto scalars = [&](int par, bool adjoint) {
@@ -994,9 +1033,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             wave_sync();
             pf_due = (step + 1 < je);
             if (pf_due) {
-                pf_m = m0 + step + 1;
-                pf_par = par ^ 1;
-                pf_adjoint = false;
+                set_prefetch(m0 + step + 1, par ^ 1, false);
                 nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             }
             before_step(step);
@@ -1127,9 +1164,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             wave_sync();
             pf_due = (step - 1 >= jb);
             if (pf_due) {
-                pf_m = m0 + step - 1;
-                pf_par = par ^ 1;
-                pf_adjoint = true;
+                set_prefetch(m0 + step - 1, par ^ 1, true);
                 nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             }
             adjoint_step(sc, nsub, step);
