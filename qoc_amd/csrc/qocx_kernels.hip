@@ -815,9 +815,12 @@ template <int NB, bool ADJOINT>
 __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, const int* pb,
                                             StepRegs<NB>& r, int pm, int lane, int i) {
     typedef Geo<NB> G;
+    // forward: the lane at position i takes row perm[i] of Q, which folds the row permutation
+    // Pi of "z = Pi (Q psi)" into the operand (no cross-lane permute in the serial chain)
+    const int qlane = ADJOINT ? lane : (lane / G::NP) * G::NP + pm;
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
-        const double2 e = qb[cc * 64 + lane];
+        const double2 e = qb[cc * 64 + qlane];
         r.qre[cc] = e.x;
         r.qim[cc] = e.y;
     }
@@ -830,6 +833,20 @@ __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb
         r.lre[c] = e.x;
         r.lim[c] = e.y;
     }
+}
+
+// sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
+template <int NB>
+__device__ __forceinline__ double sum_groups(double v) {
+    if (Geo<NB>::H == 2) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
+    }
+#pragma unroll
+    for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
 }
 
 template <int NB>
@@ -972,7 +989,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 break;
             }
             for (int s = 0; s < S; ++s) {
-                // y = Q psi : partial sums over this lane group's columns, then combine
+                // y = (Pi Q) psi : partial sums over this lane group's columns
                 double yre = 0, yim = 0;
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -982,13 +999,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                     yim = fma(r.qre[cc], x.y, yim);
                     yim = fma(r.qim[cc], x.x, yim);
                 }
-#pragma unroll
-                for (int d = NP; d < 64; d <<= 1) {
-                    yre += __shfl_xor(yre, d);
-                    yim += __shfl_xor(yim, d);
-                }
-                // z = Pi y ; L z' = z ; z'' = D^-1 z' ; U' psi' = z''  (both solves unit-diagonal)
-                double zre = __shfl(yre, sc.pm), zim = __shfl(yim, sc.pm);
+                // z = Pi (Q psi) (the rows were permuted on load) ; L z' = z ; z'' = D^-1 z' ;
+                // U' psi' = z''  (both solves unit-diagonal)
+                double zre = sum_groups<NB>(yre), zim = sum_groups<NB>(yim);
                 tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
                 const double t = zre * sc.dv.x - zim * sc.dv.y;
                 zim = zre * sc.dv.y + zim * sc.dv.x;
@@ -1129,11 +1142,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                     yim = fma(r.qre[cc], x.y, yim);
                     yim = fma(-r.qim[cc], x.x, yim);
                 }
-#pragma unroll
-                for (int d = NP; d < 64; d <<= 1) {
-                    yre += __shfl_xor(yre, d);
-                    yim += __shfl_xor(yim, d);
-                }
+                yre = sum_groups<NB>(yre);
+                yim = sum_groups<NB>(yim);
                 wave_sync();
                 lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
@@ -1192,20 +1202,6 @@ struct KrylovLds {
     static constexpr int V_OFF = RHO_OFF + 13 * G::NP * 16;      // 2 chain vectors (sigma_j, delta_j)
     static constexpr int BYTES = V_OFF + 2 * G::NP * 16;
 };
-
-// sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
-template <int NB>
-__device__ __forceinline__ double sum_groups(double v) {
-    if (Geo<NB>::H == 2) {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
-    }
-#pragma unroll
-    for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
-    return v;
-}
 
 // SKEW: every H0(t), G_k(t) is Hermitian, so a^H = -a exactly and the rows of a^H need no
 // registers (the common physical case; the host checks it bit for bit).
