@@ -769,7 +769,6 @@ struct SweepLds {
 // Per-step operands of the sweep, in registers: Q in R-layout (matvec), LU in F-layout (solves).
 template <int NB>
 struct StepRegs {
-    double qre[Geo<NB>::CPL], qim[Geo<NB>::CPL];
     double lre[Geo<NB>::NP], lim[Geo<NB>::NP];
 };
 
@@ -815,15 +814,6 @@ template <int NB, bool ADJOINT>
 __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, const int* pb,
                                             StepRegs<NB>& r, int pm, int lane, int i) {
     typedef Geo<NB> G;
-    // forward: the lane at position i takes row perm[i] of Q, which folds the row permutation
-    // Pi of "z = Pi (Q psi)" into the operand (no cross-lane permute in the serial chain)
-    const int qlane = ADJOINT ? lane : (lane / G::NP) * G::NP + pm;
-#pragma unroll
-    for (int cc = 0; cc < G::CPL; ++cc) {
-        const double2 e = qb[cc * 64 + qlane];
-        r.qre[cc] = e.x;
-        r.qim[cc] = e.y;
-    }
 #pragma unroll
     for (int c = 0; c < G::NP; ++c) {
         int src;
@@ -847,6 +837,35 @@ __device__ __forceinline__ double sum_groups(double v) {
 #pragma unroll
     for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
     return v;
+}
+
+// Partial row sums of a matvec whose matrix sits in LDS as an R-layout image (`qlane` = the image
+// lane this lane takes: its own, or the one of a permuted row) and whose vector is broadcast from
+// LDS; BATCH (matrix, vector) pairs of LDS reads are in flight ahead of their FMAs.
+template <int NB, bool CONJ, int BATCH>
+__device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec, int qlane, int h,
+                                           double& yre, double& yim) {
+    typedef Geo<NB> G;
+    constexpr int CPL = G::CPL, H = G::H;
+    double ar = 0, ai = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < CPL; c0 += BATCH) {
+        double2 qv[BATCH], xv[BATCH];
+#pragma unroll
+        for (int cc = 0; cc < BATCH; ++cc) {
+            qv[cc] = qb[(c0 + cc) * 64 + qlane];
+            xv[cc] = vec[(c0 + cc) * H + h];
+        }
+#pragma unroll
+        for (int cc = 0; cc < BATCH; ++cc) {
+            const double qi = CONJ ? -qv[cc].y : qv[cc].y;
+            ar = fma(-qi, xv[cc].y, fma(qv[cc].x, xv[cc].x, ar));
+            ai = fma(qi, xv[cc].x, fma(qv[cc].x, xv[cc].y, ai));
+        }
+        asm volatile("" ::: "memory");
+    }
+    yre = sum_groups<NB>(ar);
+    yim = sum_groups<NB>(ai);
 }
 
 template <int NB>
@@ -901,6 +920,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         wave_sync();
     }
     StepRegs<NB> r;
+    const double2* qcur = qbuf;  // Q image of the step being computed
+    constexpr int MVB = Geo<NB>::CPL < 4 ? Geo<NB>::CPL : 4;  // (matrix, vector) LDS read pairs in flight
 
     // Everything a step needs arrives by LDS-DMA one step ahead: Q and LU images (the adjoint
     // gathers the transposed images), 1/U_kk, perm | iperm: 2*MAT/64 + 2 pieces. They are issued
@@ -989,19 +1010,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 break;
             }
             for (int s = 0; s < S; ++s) {
-                // y = (Pi Q) psi : partial sums over this lane group's columns
-                double yre = 0, yim = 0;
-#pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 x = vecs[s * NP + cc * H + h];
-                    yre = fma(r.qre[cc], x.x, yre);
-                    yre = fma(-r.qim[cc], x.y, yre);
-                    yim = fma(r.qre[cc], x.y, yim);
-                    yim = fma(r.qim[cc], x.x, yim);
-                }
-                // z = Pi (Q psi) (the rows were permuted on load) ; L z' = z ; z'' = D^-1 z' ;
-                // U' psi' = z''  (both solves unit-diagonal)
-                double zre = sum_groups<NB>(yre), zim = sum_groups<NB>(yim);
+                // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
+                double zre, zim;
+                lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
                 tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
                 const double t = zre * sc.dv.x - zim * sc.dv.y;
                 zim = zre * sc.dv.y + zim * sc.dv.x;
@@ -1043,6 +1054,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             const StepScalars sc = scalars(par, false);
             lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                    lane, i);
+            qcur = qbuf + par * MAT;
             wave_sync();
             pf_due = (step + 1 < je);
             if (pf_due) {
@@ -1132,18 +1144,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                     xs_b[((size_t)slot * S + s) * NP + i] = x;
                 }
                 wave_sync();
-                // lambda = Q^H x ; r.q holds rows of Q^T (lane (h,i): Q[cc*H+h][i])
-                double yre = 0, yim = 0;
-#pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 x = tmp[cc * H + h];
-                    yre = fma(r.qre[cc], x.x, yre);
-                    yre = fma(r.qim[cc], x.y, yre);
-                    yim = fma(r.qre[cc], x.y, yim);
-                    yim = fma(-r.qim[cc], x.x, yim);
-                }
-                yre = sum_groups<NB>(yre);
-                yim = sum_groups<NB>(yim);
+                // lambda = Q^H x ; the LDS image is that of Q^T (lane (h,i): Q[cc*H+h][i])
+                double yre, yim;
+                lds_matvec<NB, true, MVB>(qcur, tmp, lane, h, yre, yim);
                 wave_sync();
                 lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
@@ -1171,6 +1174,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             const StepScalars sc = scalars(par, true);
             lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                   lane, i);
+            qcur = qbuf + par * MAT;
             wave_sync();
             pf_due = (step - 1 >= jb);
             if (pf_due) {
