@@ -338,7 +338,7 @@ int qocx_create(int device, qocx_ctx** out) {
         return fail(QOCX_ERR_HIP, hipGetErrorString(e));
     }
     if (ctx->status.ensure(1)) {
-        delete ctx;
+        qocx_destroy(ctx);
         return QOCX_ERR_HIP;
     }
     // side streams of the latency-bound sweeps get the highest priority, so that their few
@@ -352,8 +352,8 @@ int qocx_create(int device, qocx_ctx** out) {
              hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) != hipSuccess) ||
             hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
-            g_error = "cannot create the pipeline streams";
-            return QOCX_ERR_HIP;
+            qocx_destroy(ctx);  // releases what has been created so far
+            return fail(QOCX_ERR_HIP, "cannot create the pipeline streams");
         }
         if (i == 0) ctx->sweep_streams.push_back(st);
         ctx->ev_factored.push_back(e1);
@@ -1277,6 +1277,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     return 0;
 }
 
+extern "C++" {
 namespace {
 
 // End points of the sub-intervals of system step `step`: `ksub` uniform pieces, cut at the
@@ -1296,6 +1297,7 @@ std::vector<double> lindblad_points(double T, int nsteps, int nc, int K, int ksu
     pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
     return pts;
 }
+}  // extern "C++"
 
 // Sub-interval table of one sub-division count: uniform pieces per system step, cut at control
 // knots, with the interpolation weights of both ends and the CSR of their transpose.
