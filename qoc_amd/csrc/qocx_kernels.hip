@@ -761,8 +761,9 @@ struct SweepLds {
     static constexpr int L_OFF = Q_OFF + 2 * BUF_BYTES;         // 2 x LU image
     static constexpr int D_OFF = L_OFF + 2 * BUF_BYTES;         // 2 x 64 complex: 1/U_kk
     static constexpr int P_OFF = D_OFF + 2 * 64 * 16;           // 2 x 64 int: perm | iperm
-    static constexpr int TMP_OFF = P_OFF + 2 * 64 * 4;          // NP complex scratch vector
-    static constexpr int VEC_OFF = TMP_OFF + G::NP * 16;        // [S][NP] states, [S][NP] lambda
+    static constexpr int MAX_WAVES = 4;                        // waves per seed (multi-state)
+    static constexpr int TMP_OFF = P_OFF + 2 * 64 * 4;          // NP complex scratch per wave
+    static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * G::NP * 16;  // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
 
@@ -868,8 +869,13 @@ __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec
     yim = sum_groups<NB>(ai);
 }
 
-template <int NB>
-__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
+// W waves per seed: the S states of a seed are dealt out to the waves of its workgroup (state s to
+// wave s % W). The operands of a step (Q, LU, 1/U_kk, perm) are fetched once, by wave 0, into LDS
+// buffers all waves read; a workgroup barrier at every step start says "the operands have landed
+// and every wave has left the previous step". The costs couple the states, so wave 0 evaluates
+// them on all S states between two barriers. W = 1 is the single-state form: no barrier at all.
+template <int NB, int W>
+__global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
     typedef SweepLds<NB> L;
     constexpr int NP = G::NP, CPL = G::CPL, H = G::H, MAT = G::MAT;
@@ -881,8 +887,13 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
     double2* dbuf = reinterpret_cast<double2*>(smem + L::D_OFF);
     int* pbuf = reinterpret_cast<int*>(smem + L::P_OFF);
-    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF);
+    const int w = W > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + w * NP;
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
+    auto block_sync = [&]() {
+        if constexpr (W > 1) __syncthreads();
+        else wave_sync();
+    };
     const int S = args.S;
     double2* lam = vecs + S * NP;
     const int b = blockIdx.x;
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     bool overflow = false;
     if (do_fwd) {
         if (jb == 0) {
-            for (int s = 0; s < S; ++s)
+            for (int s = w; s < S; s += W)
                 if (g0) {
                     const double2 p = args.psi0[s * NP + i];
                     vecs[s * NP + i] = p;
@@ -914,7 +925,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         } else {  // resume: states, slot counter and partial cost left by the previous segment
             slot = offs_b[jb];
             cost = args.cost_out[b];
-            for (int s = 0; s < S; ++s)
+            for (int s = w; s < S; s += W)
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
         }
         wave_sync();
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
                 overflow = true;
                 break;
             }
-            for (int s = 0; s < S; ++s) {
+            for (int s = w; s < S; s += W) {
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
                 lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
@@ -1031,36 +1042,36 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
             ++slot;
         }
     };
-    auto before_step = [&](int step) {
-        if (step != 0 && (step % args.cost_eval_step) == 0)
-            cost += eval_costs<NB>(args, true, false, vecs, nullptr, h, i);
+    auto before_step = [&](int step) {  // called behind a barrier: every state of `step` is in vecs
+        if (step != 0 && (step % args.cost_eval_step) == 0) {
+            if (w == 0) cost += eval_costs<NB>(args, true, false, vecs, nullptr, h, i);
+            if constexpr (W > 1) __syncthreads();  // the other waves overwrite their states next
+        }
         if (g0 && args.step_states != nullptr)
-            for (int s = 0; s < S; ++s)
+            for (int s = w; s < S; s += W)
                 args.step_states[(((size_t)b * (nsteps + 1) + step) * S + s) * NP + i] =
                     vecs[s * NP + i];
-        if (lane == 0) offs_b[step] = slot;
+        if (w == 0 && lane == 0) offs_b[step] = slot;
     };
 
     // ---- forward sweep: the next step's operands stream into LDS while the current step's
     // dependent chains run -------------------------------------------------------------------
     if (do_fwd) {
-        issue_dma(m0 + jb, 0, false);
+        if (w == 0) issue_dma(m0 + jb, 0, false);
         int nsub_next = 1 << min(max(args.s_arr[m0 + jb], 0), 30);
         for (int step = jb; step < je; ++step) {
             const int par = (step - jb) & 1;
             const int nsub = nsub_next;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_sync();
+            if (w == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            block_sync();
             const StepScalars sc = scalars(par, false);
             lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                    lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = (step + 1 < je);
-            if (pf_due) {
-                set_prefetch(m0 + step + 1, par ^ 1, false);
-                nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
-            }
+            pf_due = (w == 0) && (step + 1 < je);
+            if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
+            if (step + 1 < je) nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             before_step(step);
             forward_step(sc, nsub);
             if (overflow) break;
@@ -1068,20 +1079,21 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     }
     if (overflow) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) atomicOr(args.status, 4);
+        if (w == 0 && lane == 0) atomicOr(args.status, 4);
         return;
     }
     if (do_fwd) {
+        block_sync();  // every wave has finished the last step of the segment
         if (je == nsteps) {
             before_step(nsteps);
-            cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
+            if (w == 0) cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
             if (g0)
-                for (int s = 0; s < S; ++s)
+                for (int s = w; s < S; s += W)
                     args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
-        } else if (lane == 0) {
+        } else if (w == 0 && lane == 0) {
             offs_b[je] = slot;  // the next segment resumes from here
         }
-        if (lane == 0) args.cost_out[b] = cost;
+        if (w == 0 && lane == 0) args.cost_out[b] = cost;
     }
     if (!do_bwd) return;
 
@@ -1091,7 +1103,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         const int row = args.inj_index[step];
         if (row < 0) return;
         if (g0)
-            for (int s = 0; s < S; ++s) {
+            for (int s = w; s < S; s += W) {
                 const double2 e = args.inj_bars[(((size_t)b * args.inj_count + row) * S + s) * NP + i];
                 double2 l = lam[s * NP + i];
                 l.x += e.x;
@@ -1105,19 +1117,21 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     if (je == nsteps) {
         if (!do_fwd) {  // final states of the forward segments
             slot = offs_b[nsteps];
-            for (int s = 0; s < S; ++s)
+            for (int s = w; s < S; s += W)
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
         }
-        for (int s = 0; s < S; ++s)
+        for (int s = w; s < S; s += W)
             if (g0) lam[s * NP + i] = make_double2(0, 0);
-        wave_sync();
+        block_sync();
         // cotangent seeds on the final states: non-step costs, and step costs if the final step
         // is a cost step (schroedingerdiscrete.py:412-416 evaluates them before the loop ends).
-        (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+        if (w == 0)
+            (void)eval_costs<NB>(args, (nsteps % args.cost_eval_step) == 0, true, vecs, lam, h, i);
+        block_sync();
         inject(nsteps);
     } else {  // resume the adjoint sweep below step je
         slot = offs_b[je];
-        for (int s = 0; s < S; ++s)
+        for (int s = w; s < S; s += W)
             if (g0) lam[s * NP + i] = args.lam_buf[((size_t)b * S + s) * NP + i];
         wave_sync();
     }
@@ -1125,7 +1139,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
     auto adjoint_step = [&](const StepScalars& sc, int nsub, int step) {
         for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
-            for (int s = 0; s < S; ++s) {
+            for (int s = w; s < S; s += W) {
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
@@ -1155,37 +1169,36 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs args) {
         if (step != 0 && (step % args.cost_eval_step) == 0 && args.has_step_costs) {
             // step costs were evaluated on the states *before* evolving from `step`
             if (g0)
-                for (int s = 0; s < S; ++s)
+                for (int s = w; s < S; s += W)
                     vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
-            wave_sync();
-            (void)eval_costs<NB>(args, true, false, vecs, lam, h, i);
+            block_sync();
+            if (w == 0) (void)eval_costs<NB>(args, true, false, vecs, lam, h, i);
+            block_sync();
         }
         if (step != 0) inject(step);
     };
     {
         const size_t ml = m0 + je - 1;
-        issue_dma(ml, 0, true);
+        if (w == 0) issue_dma(ml, 0, true);
         int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
             const int par = it & 1;
             const int nsub = nsub_next;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_sync();
+            if (w == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            block_sync();
             const StepScalars sc = scalars(par, true);
             lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
                                   lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = (step - 1 >= jb);
-            if (pf_due) {
-                set_prefetch(m0 + step - 1, par ^ 1, true);
-                nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
-            }
+            pf_due = (w == 0) && (step - 1 >= jb);
+            if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
+            if (step - 1 >= jb) nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             adjoint_step(sc, nsub, step);
         }
     }
     if (jb > 0 && g0)
-        for (int s = 0; s < S; ++s)
+        for (int s = w; s < S; s += W)
             args.lam_buf[((size_t)b * S + s) * NP + i] = lam[s * NP + i];
 }
 
@@ -1518,13 +1531,21 @@ static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a
         hipLaunchKernelGGL((pade_pq_explicit_kernel<NB, false>), dim3(count), dim3(64),
                            PqLds<NB>::BYTES, st, a_in, n, a);
 }
-template <int NB>
-static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
+template <int NB, int W>
+static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
     const int bytes = SweepLds<NB>::bytes(a.S);
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(sweep_kernel<NB>, dim3(batch), dim3(64), bytes, st, a);
+    hipLaunchKernelGGL((sweep_kernel<NB, W>), dim3(batch), dim3(64 * W), bytes, st, a);
+}
+template <int NB>
+static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
+    // waves per seed: the states are independent chains, up to four of them run side by side
+    // (eight were measured at S = 32: no faster, the adjoint phase is K3 bound by then)
+    if (a.S >= 4) launch_sweep_w<NB, 4>(a, batch, st);
+    else if (a.S >= 2) launch_sweep_w<NB, 2>(a, batch, st);
+    else launch_sweep_w<NB, 1>(a, batch, st);
 }
 template <int NB>
 static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
