@@ -878,7 +878,7 @@ template <int NB, int W>
 __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
     typedef SweepLds<NB> L;
-    constexpr int NP = G::NP, CPL = G::CPL, H = G::H, MAT = G::MAT;
+    constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the sweep is the serial chain of the evaluation: where it shares a SIMD with a wave of the
     // throughput kernels (two-wave K1a, K3) its instructions go first
