@@ -163,6 +163,8 @@ EDGE_CASES = [
     dict(n=32, N=4, Nc=7, K=2, S=64, dt=0.4, ces=1, sigma=0.5),   # maximum state count
     dict(n=5, N=12, Nc=12, K=4, S=1, dt=0.9, ces=20, sigma=3.0),  # cost_eval_step > N, squarings
     dict(n=31, N=5, Nc=9, K=8, S=2, dt=0.05, ces=1, sigma=0.1),   # Nc > N, many controls
+    dict(n=20, N=14, Nc=5, K=2, S=6, dt=0.3, ces=2, sigma=1.5),   # 6 states on 4 sweep waves (2,2,1,1)
+    dict(n=9, N=10, Nc=10, K=2, S=5, dt=0.9, ces=3, sigma=3.0),   # multi-wave sweep with squarings
 ]
 
 
@@ -210,6 +212,42 @@ def test_edge_shapes_against_oracle(engine, spec):
             # (n = 1: every cost is phase invariant, the gradient is zero up to rounding)
             assert np.max(np.abs(grads[b] - gr)) < 1e-8 * max(np.max(np.abs(gr)), 1e-3)
         assert rel_err(final[b][:, :, None], fin) < 1e-10
+
+
+def test_multi_state_sweep_segments(engine):
+    """
+    S > 1 runs the sweep on several waves per seed (states dealt to the waves, costs evaluated by
+    wave 0 between workgroup barriers): the time-segmented pipeline, which resumes the sweep from
+    its saved states / lambda, must reproduce the single-launch result bit for bit.
+    """
+    from qoc_amd.engine import COST_FORBID, COST_TARGET_COHERENT, COST_TARGET_INCOHERENT
+    n, N, Nc, K, S, ces = 24, 41, 11, 2, 7, 4
+    rng = np.random.default_rng(99)
+    h0 = cases_mod.gue(rng, n) * 1.5
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    init = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    forb = rng.standard_normal((S, 1, n)) + 1j * rng.standard_normal((S, 1, n))
+    forb /= np.linalg.norm(forb, axis=2, keepdims=True)
+    count = (N - 1) // ces
+    descs = [dict(kind=COST_TARGET_COHERENT, step_cost=1, scale=0.5 / count, vectors=targ),
+             dict(kind=COST_TARGET_INCOHERENT, step_cost=0, scale=1.0, vectors=targ),
+             dict(kind=COST_FORBID, step_cost=1, scale=0.4 / (count * S), vectors=forb.reshape(-1, n),
+                  counts=[1] * S)]
+    engine.set_schroedinger_problem(n, S, K, Nc, N, 0.2 * (N - 1), h0[None], np.stack(g)[None], init,
+                                    costs=descs, cost_eval_step=ces)
+    controls = rng.standard_normal((5, Nc, K))
+    engine.set_pipeline(1)
+    ref = engine.evaluate(controls, True)
+    for pipe in (2, 5):
+        engine.set_pipeline(pipe)
+        out = engine.evaluate(controls, True)
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b)
+    engine.set_pipeline(0)
+    assert np.all(np.isfinite(ref[0])) and np.all(np.isfinite(ref[1]))
 
 
 @pytest.mark.parametrize("name", ["magnus_n20_M6", "small_complex_M4", "nonhermitian_n24"])
