@@ -835,8 +835,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             }
             time_end(ctx, cs);
             la.step0 = lo[i]; la.seg_len = len;
-            // (K1b on a stream of its own, beside the next segment's K1a, was measured: no gain -
-            // the two kernels cannot share a SIMD's register file)
+            // (K1b on a stream of its own, beside the next segment's K1a: with the v5 kernels no
+            // gain; with the two-wave K1a (240 registers) and K1b (160) sharing SIMDs 1 % - K1a
+            // then takes 1.08 ms per launch beside K1b instead of 0.80 + 0.32 ms in sequence.
+            // Not kept: one more stream and eight more events for 0.14 ms.)
             time_begin(ctx, 4, cs);
             qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
             time_end(ctx, cs);
