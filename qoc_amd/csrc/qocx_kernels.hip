@@ -1215,8 +1215,7 @@ template <int NB>
 struct KrylovLds {
     typedef Geo<NB> G;
     static constexpr int TAU_OFF = 0;                            // 13 tau vectors
-    static constexpr int RHO_OFF = TAU_OFF + 13 * G::NP * 16;    // 13 rho vectors
-    static constexpr int V_OFF = RHO_OFF + 13 * G::NP * 16;      // 2 chain vectors (sigma_j, delta_j)
+    static constexpr int V_OFF = TAU_OFF + 13 * G::NP * 16;      // 2 slots for the current rho
     static constexpr int BYTES = V_OFF + 2 * G::NP * 16;
 };
 
@@ -1235,7 +1234,6 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
     double2* vv = reinterpret_cast<double2*>(smem + L::V_OFF);
     double2* tau_l = reinterpret_cast<double2*>(smem + L::TAU_OFF);
-    double2* rho_l = reinterpret_cast<double2*>(smem + L::RHO_OFF);
     const int step = args.step0 + blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
     const int nsteps = args.nsteps, S = args.S, K = args.K;
@@ -1309,54 +1307,27 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
         }
     };
 
-    // the chains of one (sub-step, state): tau_0..12 into LDS, rho_0..12 into registers
+    // One (sub-step, state). Phase A: tau_i = (a^H)^i x, i = 0..12, all kept in LDS. Phase B: the
+    // rho_i by the Horner recurrence  rho_12 = b13 sigma,  rho_{i-1} = b_i w_i + a rho_i  with
+    // w_i = sigma (i odd) or delta (i even) - one matvec per rho instead of the two chains
+    // a^j sigma, a^j delta - and, as each rho_i appears, the rank-1 update abar += tau_i rho_i^H.
+    // The matvec a rho_i and the rank-1 update read the same LDS broadcast of rho_i.
     auto chains = [&](const double (&are)[CPL], const double (&aim)[CPL], const double (&hre)[HC],
                       const double (&him)[HC], double2 x, double2 p0, double2 p1,
-                      double (&rhr)[13], double (&rhi)[13]) __attribute__((always_inline)) {
-        double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
-        double dlr = p0.x - p1.x, dli = p0.y - p1.y;
+                      double (&abr)[CPL], double (&abi)[CPL]) __attribute__((always_inline)) {
+        const double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
+        const double dlr = p0.x - p1.x, dli = p0.y - p1.y;
         double tar = x.x, tai = x.y;
 #pragma unroll
-        for (int ii = 0; ii < 13; ++ii) {
-            rhr[ii] = 0;
-            rhi[ii] = 0;
-        }
-#pragma unroll
         for (int jj = 0; jj < 13; ++jj) {
-#pragma unroll
-            for (int ii = 0; ii + jj < 13; ++ii) {
-                const int mm = ii + jj + 1;
-                const double coef = PADE_B[mm];
-                if (mm & 1) {
-                    rhr[ii] += coef * sgr;
-                    rhi[ii] += coef * sgi;
-                } else {
-                    rhr[ii] += coef * dlr;
-                    rhi[ii] += coef * dli;
-                }
-            }
-            // tau_jj stays in LDS: it is the broadcast source of the next matvec and the
-            // left factor of the rank-1 update below
             // (every lane group holds the same sums: all of them store, no exec-mask branch)
             tau_l[jj * NP + i] = make_double2(tar, tai);
             if (jj < 12) {
-                vv[i] = make_double2(sgr, sgi);
-                vv[NP + i] = make_double2(dlr, dli);
-            }
-            if (jj < 12) {
                 wave_sync();
-                double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0;
+                double s2r = 0, s2i = 0;
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 v0 = vv[cc * H + h];
-                    const double2 v1 = vv[NP + cc * H + h];
                     const double2 v2 = tau_l[jj * NP + cc * H + h];
-                    // explicit FMA chains: two per complex component (the compiler may not
-                    // re-associate "s += x*y - z*w" into them; it costs a third more VALU)
-                    s0r = fma(-aim[cc], v0.y, fma(are[cc], v0.x, s0r));
-                    s0i = fma(aim[cc], v0.x, fma(are[cc], v0.y, s0i));
-                    s1r = fma(-aim[cc], v1.y, fma(are[cc], v1.x, s1r));
-                    s1i = fma(aim[cc], v1.x, fma(are[cc], v1.y, s1i));
                     if (SKEW) {  // a^H = -a
                         s2r = fma(aim[cc], v2.y, fma(-are[cc], v2.x, s2r));
                         s2i = fma(-aim[cc], v2.x, fma(-are[cc], v2.y, s2i));
@@ -1365,40 +1336,36 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                         s2i = fma(him[cc], v2.x, fma(hre[cc], v2.y, s2i));
                     }
                 }
-                sgr = sum_groups<NB>(s0r);
-                sgi = sum_groups<NB>(s0i);
-                dlr = sum_groups<NB>(s1r);
-                dli = sum_groups<NB>(s1i);
                 tar = sum_groups<NB>(s2r);
                 tai = sum_groups<NB>(s2i);
-                wave_sync();  // vv is rewritten by the next chain step
             }
         }
-    };
-    // abar += sum_t tau_t rho_t^H, the rho broadcast through LDS seven (six) at a time
-    auto rank1 = [&](const double (&rhr)[13], const double (&rhi)[13], double (&abr)[CPL],
-                     double (&abi)[CPL]) __attribute__((always_inline)) {
-        auto part = [&](auto T0, auto T1) __attribute__((always_inline)) {
-            constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value;
-            wave_sync();  // vv (first part) / the first seven rho (second part) are done with
+        double rr = PADE_B[13] * sgr, ri = PADE_B[13] * sgi;
 #pragma unroll
-            for (int tt = t0; tt < t1; ++tt)
-                rho_l[(tt - t0) * NP + i] = make_double2(rhr[tt], rhi[tt]);
+        for (int ii = 12; ii >= 0; --ii) {
+            double2* slot = vv + (ii & 1) * NP;  // two slots in turn: one sync per step
+            slot[i] = make_double2(rr, ri);
             wave_sync();
+            const double2 tv = tau_l[ii * NP + i];
+            double s0r = 0, s0i = 0;
 #pragma unroll
-            for (int tt = t0; tt < t1; ++tt) {
-                const double2 tv = tau_l[tt * NP + i];
-#pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) {
-                    const double2 r = rho_l[(tt - t0) * NP + cc * H + h];
-                    // tau * conj(rho)
-                    abr[cc] = fma(tv.y, r.y, fma(tv.x, r.x, abr[cc]));
-                    abi[cc] = fma(-tv.x, r.y, fma(tv.y, r.x, abi[cc]));
+            for (int cc = 0; cc < CPL; ++cc) {
+                const double2 r = slot[cc * H + h];
+                // tau * conj(rho)
+                abr[cc] = fma(tv.y, r.y, fma(tv.x, r.x, abr[cc]));
+                abi[cc] = fma(-tv.x, r.y, fma(tv.y, r.x, abi[cc]));
+                if (ii > 0) {
+                    s0r = fma(-aim[cc], r.y, fma(are[cc], r.x, s0r));
+                    s0i = fma(aim[cc], r.x, fma(are[cc], r.y, s0i));
                 }
             }
-        };
-        part(std::integral_constant<int, 0>(), std::integral_constant<int, 13>());
-        wave_sync();
+            if (ii > 0) {
+                const double coef = PADE_B[ii];
+                rr = fma(coef, (ii & 1) ? sgr : dlr, sum_groups<NB>(s0r));
+                ri = fma(coef, (ii & 1) ? sgi : dli, sum_groups<NB>(s0i));
+            }
+        }
+        wave_sync();  // tau_l and the slots are rewritten by the next (sub-step, state)
     };
 
     const size_t cap = args.slot_cap;
@@ -1419,10 +1386,8 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     for (int sub = 0; sub < nsub; ++sub)
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
-            double rhr[13], rhi[13];
             chains(are, aim, hre, him, xs_b[(t * S + s) * NP + i], states_b[(t * S + s) * NP + i],
-                   states_b[((t + 1) * S + s) * NP + i], rhr, rhi);
-            rank1(rhr, rhi, abr, abi);
+                   states_b[((t + 1) * S + s) * NP + i], abr, abi);
         }
     if constexpr (EXPLICIT) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
         double2* mb = args.mbar_rm + m * G::MAT;
