@@ -25,7 +25,7 @@ namespace pade2 {
 constexpr int PITCH = Geo<2>::PITCH, PLANE = Geo<2>::PLANE, MAT = Geo<2>::MAT;
 constexpr int SLOT_F64 = 2 * PLANE;             // re | im planes
 constexpr int MPITCH = 18, MTILE_F64 = 2 * 16 * MPITCH;
-constexpr int LDS_BYTES = (SLOT_F64 + MTILE_F64 + 2) * 8;
+constexpr int LDS_BYTES = (SLOT_F64 + MTILE_F64 + 6) * 8;  // + six norm words
 
 struct Col {  // tiles (0,w), (1,w) of a complex matrix, C-layout
     d4 re[2], im[2];
@@ -161,31 +161,61 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
     Col a;
     gen(a, W);
+    // The squaring count needs ||a||_1 only up to the interval (theta 2^(s-1), theta 2^s] it
+    // falls in. Two bounds without square roots, |z| <= |re| + |im| and |z| >= max(|re|, |im|),
+    // usually name the same interval (always when the norm is well below theta, the common
+    // case); only if they disagree is the exact norm formed (16 FP64 square roots per lane).
+    auto squarings = [](double v, bool& bad) {
+        double th = QOCX_THETA13;
+        int n = 0;
+        while (v > th && n < 30) {
+            th *= 2.0;
+            ++n;
+        }
+        bad = !(v <= th);  // inf / nan / absurd
+        return n;
+    };
+    auto column_max = [&](double v) {  // max over the wave's 16 columns of the column sums
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return wave_max(v);
+    };
     {
-        double s = 0;
+        double bu = 0, bl = 0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ar = fabs(a.re[ti][r]), ai = fabs(a.im[ti][r]);
+                bu += ar + ai;
+                bl += fmax(ar, ai);
+            }
+        bu = column_max(bu);
+        bl = column_max(bl);
+        if (lane == 0) {
+            nrm[W] = bu;
+            nrm[2 + W] = bl;
+        }
+    }
+    __syncthreads();  // 1
+    bool bad = false, bad_lower = false;
+    int sq = squarings(fmax(nrm[0], nrm[1]), bad);
+    const int sq_lower = squarings(fmax(nrm[2], nrm[3]), bad_lower);
+    if (!bad && sq != sq_lower) {  // the same decision in both waves: they read the same numbers
+        double e = 0;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                s += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        s = wave_max(s);
-        if (lane == 0) nrm[W] = s;
+                e += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
+        e = column_max(e);
+        if (lane == 0) nrm[4 + W] = e;
+        __syncthreads();
+        sq = squarings(fmax(nrm[4], nrm[5]), bad);
     }
-    __syncthreads();  // 1
-    const double norm1 = fmax(nrm[0], nrm[1]);
-    int sq = 0;
-    {
-        double th = QOCX_THETA13;
-        while (norm1 > th && sq < 30) {
-            th *= 2.0;
-            ++sq;
-        }
-        if (!(norm1 <= th)) {  // inf / nan / absurd
-            if (W == 0 && lane == 0) atomicOr(out.status, 2);
-            sq = 0;
-        }
+    if (bad) {
+        if (W == 0 && lane == 0) atomicOr(out.status, 2);
+        sq = 0;
     }
     if (sq > 0) {
         const double scale = ldexp(1.0, -sq);

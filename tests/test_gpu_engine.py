@@ -34,8 +34,14 @@ def test_wave_primitives(engine):
 def test_pade_factor_kernel(engine, n):
     rng = np.random.default_rng(100 + n)
     mats = []
+    theta = 5.371920351148152
+    # (norms on either side of the squaring thresholds: the two-wave kernel decides the squaring
+    # count from square-root-free bounds and forms the exact norm only when they disagree)
     for scale, skew in [(0.3, True), (2.0, True), (5.2, True), (5.5, True), (30.0, True),
-                        (1.0, False), (11.0, False), (300.0, False)]:
+                        (1.0, False), (11.0, False), (300.0, False),
+                        (theta * (1 - 1e-12), True), (theta * (1 + 1e-12), True),
+                        (4 * theta * (1 - 1e-12), False), (4 * theta * (1 + 1e-12), False),
+                        (theta / 1.3, True), (theta * 1.3, False)]:
         g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
         a = -1j * (g + g.conj().T) / 2 if skew else g
         mats.append(a * (scale / onp.one_norm(a)))
