@@ -6,11 +6,15 @@ lines differ from a script written for qoc.
     python examples/transmon_pi.py            # needs an MI355X and qoc_amd/libqocx.so
 """
 
+import os
+import sys
+
 import numpy as np
 
-from qoc_amd import grape_schroedinger_discrete
-from qoc_amd.standard import (SIGMA_Z, Adam, TargetStateInfidelity, get_annihilation_operator,
-                              get_creation_operator)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
+from qoc_amd import grape_schroedinger_discrete  # noqa: E402
+from qoc_amd.standard import (SIGMA_Z, Adam, TargetStateInfidelity,  # noqa: E402
+                              get_annihilation_operator, get_creation_operator)
 
 HILBERT_SIZE = 2
 A = get_annihilation_operator(HILBERT_SIZE)
