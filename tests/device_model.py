@@ -100,6 +100,30 @@ def krylov_abar(a_s, triples):
     return abar
 
 
+def krylov_abar_horner(a_s, triples):
+    """
+    The same abar in the order the device kernel (K3) works: tau chain first, then the rho_i by
+    the Horner recurrence rho_12 = b13 sigma, rho_{i-1} = b_i w_i + a rho_i (w_i = sigma for odd i,
+    delta for even i), each followed by its rank-1 update - 24 matrix-vector products instead
+    of 36.
+    """
+    n = a_s.shape[0]
+    ah = a_s.conj().T
+    b = [CU[m] + CV[m] for m in range(14)]  # b_m: odd m from CU, even m from CV
+    abar = np.zeros((n, n), dtype=np.complex128)
+    for x, psi, psi_next in triples:
+        sig, dlt = psi + psi_next, psi - psi_next
+        tau = [x]
+        for _ in range(12):
+            tau.append(ah @ tau[-1])
+        rho = b[13] * sig
+        for i in range(12, -1, -1):
+            abar = abar + tau[i] @ rho.conj().T
+            if i > 0:
+                rho = b[i] * (sig if i % 2 else dlt) + a_s @ rho
+    return abar
+
+
 def evaluate_with_grad(problem, controls):
     """Model of the whole device path for MagnusPolicy.M2. Returns (error, grads, final_states)."""
     assert problem.magnus_policy == "M2"

@@ -49,6 +49,10 @@ def test_krylov_adjoint_equals_dense_vjp():
         assert rel_err(lam_m, r.conj().T @ lam) < 1e-11
         abar = dm.krylov_abar(f["a"], triples) * (2 ** -f["s"])
         assert rel_err(abar, dense) < 1e-10
+        # the order the device kernel works in (Horner recurrence for the rho vectors)
+        abar_h = dm.krylov_abar_horner(f["a"], triples) * (2 ** -f["s"])
+        assert rel_err(abar_h, dense) < 1e-10
+        assert rel_err(abar_h, abar) < 1e-12
 
 
 @pytest.mark.parametrize("name", M2_GRAD_CASES)
