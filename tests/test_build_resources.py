@@ -1,0 +1,65 @@
+"""
+The pipeline of qocx_eval_resident relies on which kernels can share a SIMD (512 registers,
+DESIGN.md 4): the sweep must fit beside one two-wave K1a wave or one K3 wave, the two-wave K1a and
+the skew K3 must reach their waves per SIMD, and none of them may spill. This test compiles the
+device code for gfx950 with the resource remarks on (no GPU needed) and checks those budgets.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qoc_amd", "csrc")
+
+
+def resources(source):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = subprocess.run(
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c",
+         os.path.join(CSRC, source), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+        capture_output=True, text=True, check=True).stderr
+    table, name = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            table[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            table[name][m.group(1).strip()] = int(m.group(2))
+    return table
+
+
+def find(table, fragment):
+    hits = [v for k, v in table.items() if fragment in k]
+    assert len(hits) == 1, (fragment, [k for k in table if fragment in k])
+    return hits[0]
+
+
+def total_registers(entry):
+    return entry["VGPRs"] + entry.get("AGPRs", 0)
+
+
+def test_headline_kernels_share_a_simd():
+    kernels = resources("qocx_kernels.hip")
+    pade2 = resources("qocx_pade2.hip")
+    sweep = find(kernels, "sweep_kernelILi2ELi1E")
+    sweep4 = find(kernels, "sweep_kernelILi2ELi4E")
+    k1a = find(pade2, "pade_pq2_kernelILb1E")
+    k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0E")
+    lu = find(kernels, "lu_kernelILi2E")
+    for entry in (sweep, sweep4, k1a, k3, lu):
+        assert entry["VGPRs Spill"] == 0 and entry["ScratchSize"] == 0
+    granule = lambda r: (r + 7) // 8 * 8  # noqa: E731  (allocation granularity)
+    assert granule(total_registers(k1a)) * 2 <= 512          # two K1a waves per SIMD
+    assert granule(total_registers(k3)) * 3 <= 512           # three K3 waves per SIMD
+    assert granule(total_registers(lu)) * 3 <= 512           # three K1b waves per SIMD
+    # the sweep beside one wave of either throughput kernel
+    assert granule(total_registers(sweep)) + granule(total_registers(k1a)) <= 512
+    assert granule(total_registers(sweep)) + granule(total_registers(k3)) <= 512
+    assert granule(total_registers(sweep4)) + granule(total_registers(k3)) <= 512
