@@ -84,6 +84,8 @@ typedef struct qocx_cost_desc {
  * policy: nt = 1 (time independent) or nt = (system_eval_count-1) * nodes.
  */
 typedef struct qocx_schroedinger_problem {
+    int32_t struct_size;         /* sizeof(qocx_schroedinger_problem) of the CALLER's header: a
+                                    stale binding is rejected (QOCX_ERR_ARG) instead of over-read  */
     int32_t hilbert_size;        /* n, 1..32                                                       */
     int32_t state_count;         /* S >= 1                                                          */
     int32_t control_count;       /* K real controls, >= 0                                           */
@@ -104,10 +106,13 @@ typedef struct qocx_schroedinger_problem {
 /*
  * Static data of one Lindblad problem; mirrors the fields of GrapeLindbladDiscreteState
  * (qoc/models/lindbladmodels.py:125-203) that _evaluate_lindblad_discrete reads
- * (qoc/core/lindbladdiscrete.py:357-441). hamiltonian(u, t) = h0 + sum_k u_k g[k] and
- * lindblad_data(t) = (dissipators, operators) must not depend on time explicitly.
+ * (qoc/core/lindbladdiscrete.py:357-441). hamiltonian(u, t) = h0(t) + sum_k u_k g[k](t):
+ * time independent (h0, g; fixed_subdivision = 0) or sampled at the integrator's stage times
+ * (fixed_subdivision > 0, h0_stages, g_stages). lindblad_data(t) = (dissipators, operators) must
+ * not depend on time.
  */
 typedef struct qocx_lindblad_problem {
+    int32_t struct_size;          /* sizeof(qocx_lindblad_problem) of the CALLER's header         */
     int32_t hilbert_size;         /* n, 1..32 (n > 16: four tiles per matrix, HBM scratch)         */
     int32_t density_count;        /* S >= 1                                                        */
     int32_t control_count;        /* K real controls, 0..8                                         */

@@ -429,6 +429,9 @@ int qocx_synchronize(qocx_ctx* ctx) {
 
 int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem* p) {
     if (!ctx || !p) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (p->struct_size != (int32_t)sizeof(qocx_schroedinger_problem))
+        return fail(QOCX_ERR_ARG, "qocx_schroedinger_problem.struct_size does not match this "
+                                  "library's header (stale binding?)");
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count;
@@ -1122,6 +1125,9 @@ int upload_dumps(DevBuf<double2>& dst, const std::vector<cmat>& mats, int n, hip
 
 int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     if (!ctx || !p) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (p->struct_size != (int32_t)sizeof(qocx_lindblad_problem))
+        return fail(QOCX_ERR_ARG, "qocx_lindblad_problem.struct_size does not match this "
+                                  "library's header (stale binding?)");
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->density_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count, L = p->operator_count;

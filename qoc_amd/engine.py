@@ -42,7 +42,8 @@ class _CostDesc(ctypes.Structure):
 
 
 class _SchroedingerProblem(ctypes.Structure):
-    _fields_ = [("hilbert_size", ctypes.c_int32), ("state_count", ctypes.c_int32),
+    _fields_ = [("struct_size", ctypes.c_int32),
+                ("hilbert_size", ctypes.c_int32), ("state_count", ctypes.c_int32),
                 ("control_count", ctypes.c_int32), ("control_eval_count", ctypes.c_int32),
                 ("system_eval_count", ctypes.c_int32), ("cost_eval_step", ctypes.c_int32),
                 ("magnus_policy", ctypes.c_int32), ("nt", ctypes.c_int32),
@@ -52,7 +53,8 @@ class _SchroedingerProblem(ctypes.Structure):
 
 
 class _LindbladProblem(ctypes.Structure):
-    _fields_ = [("hilbert_size", ctypes.c_int32), ("density_count", ctypes.c_int32),
+    _fields_ = [("struct_size", ctypes.c_int32),
+                ("hilbert_size", ctypes.c_int32), ("density_count", ctypes.c_int32),
                 ("control_count", ctypes.c_int32), ("control_eval_count", ctypes.c_int32),
                 ("system_eval_count", ctypes.c_int32), ("cost_eval_step", ctypes.c_int32),
                 ("operator_count", ctypes.c_int32), ("evolution_time", ctypes.c_double),
@@ -207,6 +209,7 @@ class Engine(object):
                 keep.append(cnt)
                 descs[i].counts = cnt.ctypes.data_as(_c_int_p)
         p = _SchroedingerProblem()
+        p.struct_size = ctypes.sizeof(_SchroedingerProblem)
         p.hilbert_size, p.state_count, p.control_count = n, S, K
         p.control_eval_count, p.system_eval_count = int(control_eval_count), int(system_eval_count)
         p.cost_eval_step = int(cost_eval_step)
@@ -313,6 +316,7 @@ class Engine(object):
                 keep.append(cnt)
                 descs[i].counts = cnt.ctypes.data_as(_c_int_p)
         p = _LindbladProblem()
+        p.struct_size = ctypes.sizeof(_LindbladProblem)
         p.hilbert_size, p.density_count, p.control_count = n, S, K
         p.control_eval_count, p.system_eval_count = int(control_eval_count), int(system_eval_count)
         p.cost_eval_step = int(cost_eval_step)
