@@ -262,10 +262,16 @@ class LindbladEvaluator(object):
         self.final_system_eval_step = system_eval_count - 1
         self.cost_eval_step = cost_eval_step
         self.costs = list(costs)
+        self.backend = backend if backend is not None else make_backend()
+        self.kr = control_count * (2 if complex_controls else 1)
+        # time dependence is decided on the integrator's own grid: every stage time of the
+        # coarsest sub-division (12 per sub-interval), never on a handful of equispaced probes
+        self._coarse_times = self.backend.lindblad_stage_times(
+            evolution_time, system_eval_count, control_eval_count, self.kr, 1)
         h0, g, dissipators, operators, self.time_dependent = \
             structure.probe_static_lindblad_system(
                 hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
-                evolution_time)
+                evolution_time, probe_times=self._coarse_times)
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
         descriptors = []
         for cost in self.costs:
@@ -279,14 +285,13 @@ class LindbladEvaluator(object):
                 self.host_costs.append(cost)
             else:
                 self.opaque_costs.append(cost)
-        self.backend = backend if backend is not None else make_backend()
-        self.kr = control_count * (2 if complex_controls else 1)
         self._problem_args = (self.hilbert_size, self.density_count, self.kr, control_eval_count,
                               system_eval_count, evolution_time, h0, g, dissipators, operators,
                               initial_densities)
         self._problem_kw = dict(costs=descriptors, cost_eval_step=cost_eval_step)
         self._hamiltonian = hamiltonian
         self._table_bounds = None
+        self._coarse_samples = None
         if not self.time_dependent:
             self.backend.set_lindblad_problem(*self._problem_args, **self._problem_kw)
         elif control_bounds is not None:  # GRAPE: max_control_norms bound the controls for good
@@ -300,9 +305,11 @@ class LindbladEvaluator(object):
         (n, _, kr, nc, n_eval, evolution_time, h0, g, dissipators, operators, _) = \
             self._problem_args
         dt = evolution_time / (n_eval - 1)
-        probe_times = [evolution_time * q / 16 for q in range(17)]
-        h_probe, g_probe = structure.probe_hamiltonian(
-            self._hamiltonian, n, self.control_count, self.complex_controls, probe_times)
+        if self._coarse_samples is None:  # H on the coarsest stage grid: norms for the bound
+            self._coarse_samples = structure.probe_hamiltonian(
+                self._hamiltonian, n, self.control_count, self.complex_controls,
+                list(self._coarse_times))
+        h_probe, g_probe = self._coarse_samples
         h_norm = max(np.linalg.norm(m, 1) for m in h_probe)
         g_norms = [max(np.linalg.norm(g_probe[t, k], 1) for t in range(g_probe.shape[0]))
                    for k in range(kr)]

@@ -79,25 +79,55 @@ class TimeDependentSystemError(NotImplementedError):
     pass
 
 
+def decision_times(evolution_time, count=257):
+    """Fallback probe times for the time-dependence decision when the caller has no integrator
+    grid: `count` points of [0, T] displaced by a golden-ratio sequence, so that no drive whose
+    period divides T (or T / (count - 1)) aliases to a constant."""
+    phi = 0.6180339887498949
+    return [evolution_time * min(1.0, (q + (q * phi) % 1.0) / count) for q in range(count)]
+
+
 def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, control_count,
-                                 complex_controls, evolution_time, probe_count=7):
+                                 complex_controls, evolution_time, probe_times=None):
     """
     Structure of the Lindblad path's inputs (qoc/core/lindbladdiscrete.py:444-493):
     hamiltonian(controls, time) and lindblad_data(time) -> (dissipators, operators).
-    Returns (h0 (n, n), g (Kr, n, n), dissipators (L,) or None, operators (L, n, n) or None).
-    Returns (..., time_dependent): explicit time dependence of the Hamiltonian (probed at
-    `probe_count` times) is handled by sampling it at the integrator's stage times
-    (sample_lindblad_hamiltonian); a time-dependent lindblad_data is rejected loudly.
+    Returns (h0 (n, n), g (Kr, n, n), dissipators (L,) or None, operators (L, n, n) or None,
+    time_dependent). Explicit time dependence of the Hamiltonian is decided on `probe_times` -
+    the caller passes the integrator's own stage-time grid (every time the device would ever
+    read H at for the coarsest sub-division), so a periodic drive cannot alias to a constant - by
+    comparing H(0, t) and H(u_random, t) with their values at the first time, bit for bit. A
+    time-dependent Hamiltonian is then sampled at the stage times (sample_lindblad_hamiltonian);
+    a time-dependent lindblad_data is rejected loudly.
     """
     n = hilbert_size
-    times = [evolution_time * q / (probe_count - 1) for q in range(probe_count)]
+    times = list(decision_times(evolution_time) if probe_times is None else probe_times)
+    kr = control_count * (2 if complex_controls else 1)
+    time_dependent = False
     if hamiltonian is None:
         h0 = np.zeros((1, n, n), dtype=np.complex128)
-        kr = control_count * (2 if complex_controls else 1)
         g = np.zeros((1, kr, n, n), dtype=np.complex128)
     else:
-        h0, g = probe_hamiltonian(hamiltonian, n, control_count, complex_controls, times)
-    time_dependent = h0.shape[0] != 1
+        h0, g = probe_hamiltonian(hamiltonian, n, control_count, complex_controls, times[:1])
+        if control_count == 0:
+            trial = None
+        else:
+            rng = np.random.default_rng(54321)
+            trial = rng.standard_normal(control_count)
+            if complex_controls:
+                trial = trial + 1j * rng.standard_normal(control_count)
+            zero = np.zeros(control_count, dtype=trial.dtype)
+            at_trial = np.asarray(hamiltonian(trial, times[0]), dtype=np.complex128)
+        for t in times[1:]:
+            if control_count == 0:
+                same = np.array_equal(np.asarray(hamiltonian(None, t), dtype=np.complex128), h0[0])
+            else:
+                same = (np.array_equal(np.asarray(hamiltonian(zero, t), dtype=np.complex128), h0[0])
+                        and np.array_equal(np.asarray(hamiltonian(trial, t), dtype=np.complex128),
+                                           at_trial))
+            if not same:
+                time_dependent = True
+                break
     dissipators, operators = None, None
     if lindblad_data is not None:
         first = lindblad_data(times[0])

@@ -55,11 +55,85 @@ def _rendezvous_path():
     return os.path.join(base, "qocx_rdzv_" + key.replace("/", "_"))
 
 
+def _read(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError:
+        return b""
+
+
+def _write_atomic(path, data):
+    tmp = "{}.{}.tmp".format(path, os.getpid())
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def _remove(path):
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+
+
+_UID, _NONCE = 128, 16
+
+
+def exchange_unique_id(path, rank, world, make_uid, timeout=300.0, poll=0.02):
+    """
+    Hand rank 0's 128-byte id to the other ranks through files next to `path`, safe against a
+    file a crashed launch with the same key left behind: rank 0 publishes id + a fresh nonce;
+    every other rank acknowledges the nonce it read together with a random token of its own and
+    proceeds only once rank 0's "go" file carries that nonce AND that token - which a stale
+    file cannot. Returns the id (every rank) after which all ranks hold the same one.
+    """
+    go, deadline = path + ".go", time.time() + timeout
+    if rank == 0:
+        for stale in [path, go] + ["{}.ack.{}".format(path, r) for r in range(1, world)]:
+            _remove(stale)
+        uid, nonce = bytes(make_uid()), os.urandom(_NONCE)
+        assert len(uid) == _UID
+        _write_atomic(path, uid + nonce)
+        tokens = [None] * (world - 1)
+        while any(t is None for t in tokens):
+            if time.time() > deadline:
+                raise RuntimeError("qocx rendezvous: ranks {} never acknowledged {}".format(
+                    [r + 1 for r, t in enumerate(tokens) if t is None], path))
+            for r in range(1, world):
+                ack = _read("{}.ack.{}".format(path, r))
+                if len(ack) == 2 * _NONCE and ack[:_NONCE] == nonce:
+                    tokens[r - 1] = ack[_NONCE:]
+            time.sleep(poll)
+        _write_atomic(go, nonce + b"".join(tokens))
+        return uid
+    token, acked = os.urandom(_NONCE), None
+    while time.time() < deadline:
+        data = _read(path)
+        if len(data) == _UID + _NONCE:
+            nonce = data[_UID:]
+            if nonce != acked:
+                _write_atomic("{}.ack.{}".format(path, rank), nonce + token)
+                acked = nonce
+            ready = _read(go)
+            mine = ready[_NONCE * rank:_NONCE * (rank + 1)]
+            if ready[:_NONCE] == nonce and mine == token:
+                return data[:_UID]
+        time.sleep(poll)
+    raise RuntimeError("qocx rendezvous: no unique id at {}".format(path))
+
+
+def cleanup_rendezvous(path, world):
+    for name in [path, path + ".go"] + ["{}.ack.{}".format(path, r) for r in range(1, world)]:
+        _remove(name)
+
+
 class RcclComm(object):
     """
     RCCL communicator owned by an Engine context. The 128-byte ncclUniqueId of rank 0 reaches
-    the other ranks of the node through a file keyed by (MASTER_ADDR, MASTER_PORT, parent pid);
-    all ranks of one torchrun launch share that parent.
+    the other ranks of the node through files keyed by (MASTER_ADDR, MASTER_PORT, parent pid) -
+    all ranks of one torchrun launch share that parent - with the nonce / token handshake of
+    exchange_unique_id, so a file left by a crashed launch is never taken for the current one.
     """
 
     def __init__(self, engine, rank=None, world=None, timeout=300.0):
@@ -68,34 +142,11 @@ class RcclComm(object):
         self.world = env_world_size if world is None else world
         self.engine = engine
         path = _rendezvous_path()
-        if self.rank == 0:
-            uid = engine.comm_unique_id()
-            tmp = "{}.{}.tmp".format(path, os.getpid())
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)
-        else:
-            deadline = time.time() + timeout
-            uid = None
-            while time.time() < deadline:
-                try:
-                    with open(path, "rb") as f:
-                        data = f.read()
-                    if len(data) == 128:
-                        uid = data
-                        break
-                except OSError:
-                    pass
-                time.sleep(0.05)
-            if uid is None:
-                raise RuntimeError("qocx rendezvous: no unique id at {}".format(path))
+        uid = exchange_unique_id(path, self.rank, self.world, engine.comm_unique_id, timeout)
         engine.comm_init(uid, self.rank, self.world)
         self.barrier()
         if self.rank == 0:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+            cleanup_rendezvous(path, self.world)
 
     def allreduce_sum(self, array):
         return self.engine.comm_allreduce_sum(array)

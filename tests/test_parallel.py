@@ -116,3 +116,37 @@ def test_rendezvous_file_roundtrip(tmp_path, monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8")
     monkeypatch.setenv("LOCAL_RANK", "3")
     assert parallel.env_world() == (3, 8, 3)
+
+
+def test_rendezvous_ignores_files_of_a_crashed_launch(tmp_path):
+    """a stale id file (same key) left by a crashed launch must never reach
+    ncclCommInitRank; the nonce/token handshake makes every rank end with rank 0's fresh id."""
+    import threading
+    from qoc_amd import parallel
+
+    path = str(tmp_path / "qocx_rdzv_test")
+    world = 3
+    stale_uid, stale_nonce = b"\x01" * 128, b"\x02" * 16
+    with open(path, "wb") as f:                      # crashed launch: id published ...
+        f.write(stale_uid + stale_nonce)
+    with open(path + ".go", "wb") as f:              # ... and even released
+        f.write(stale_nonce + b"\x03" * 16 * (world - 1))
+    fresh = bytes(range(128))
+    got = {}
+
+    def run(rank, delay):
+        import time
+        time.sleep(delay)
+        got[rank] = parallel.exchange_unique_id(path, rank, world, lambda: fresh, timeout=20.0)
+
+    # the other ranks start BEFORE rank 0 and see the stale files first
+    threads = [threading.Thread(target=run, args=(1, 0.0)),
+               threading.Thread(target=run, args=(2, 0.05)),
+               threading.Thread(target=run, args=(0, 0.4))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(30)
+    assert got == {0: fresh, 1: fresh, 2: fresh}
+    parallel.cleanup_rendezvous(path, world)
+    assert not any(name.startswith("qocx_rdzv_test") for name in os.listdir(str(tmp_path)))
