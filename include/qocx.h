@@ -243,6 +243,16 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
                            double* q_out, double* lu_out, int32_t* perm_out,
                            double* dinv_out, int32_t* s_out);
 int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
+/* Force the variants of the Lindblad launch that large batches / little free HBM select:
+ *   stage_budget_seeds  seeds whose forward stage values may be kept for the adjoint (0: as many
+ *                       as fit 45 % of free HBM); a larger group is launched in pieces;
+ *   min_piece           below this many seeds per piece the adjoint recomputes the stage values
+ *                       from the checkpoints instead (default 256);
+ *   wave_mode           0 auto (several waves per seed while batch <= CU count), 1 one wave per
+ *                       seed, 2 several waves per seed whenever the problem was built for it.
+ * Results do not depend on any of them (tests/test_gpu_lindblad.py). */
+int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t min_piece,
+                              int32_t wave_mode);
 /* Sustained FP64 MFMA rate of the device: waves_per_simd x 4 x CUs waves issue `iters` rounds of
  * 8 independent v_mfma_f64_16x16x4_f64 from registers (no memory traffic). bench.py reports it
  * next to the spec peak. */

@@ -181,6 +181,10 @@ struct qocx_ctx {
         DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
+        // qocx_debug_lindblad_knobs (tests force the kernel variants large batches / little HBM use)
+        int64_t dbg_stage_seeds = 0;     // seeds whose stage values may be kept; 0: 45 % of free HBM
+        int dbg_min_piece = 256;         // below this many seeds per piece the adjoint recomputes
+        int dbg_wave_mode = 0;           // 0 auto, 1 one wave per seed, 2 several whenever built for
         DevBuf<double2> a0_tab, gp_tab;
     } lb;
     // ---- timing ----
@@ -1467,9 +1471,11 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         size_t want = 0;
         for (auto& kv : groups) {
             const size_t per_seed = (size_t)lb.grids[kv.first].nsub * S * md * 12;
-            const size_t piece = std::min<size_t>(kv.second.size(),
-                                                  std::max<size_t>(1, stage_budget / per_seed));
-            if (piece == kv.second.size() || piece >= 256) want = std::max(want, piece * per_seed);
+            const size_t fit = lb.dbg_stage_seeds > 0 ? (size_t)lb.dbg_stage_seeds
+                                                      : std::max<size_t>(1, stage_budget / per_seed);
+            const size_t piece = std::min<size_t>(kv.second.size(), fit);
+            if (piece == kv.second.size() || piece >= (size_t)lb.dbg_min_piece)
+                want = std::max(want, piece * per_seed);
         }
         if (want > 0 && lb.ystages.ensure(want)) return QOCX_ERR_HIP;
     }
@@ -1516,9 +1522,11 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         int piece = Bg;
         bool keep_stages = false;
         if (want_grad) {
-            const size_t fit = std::max<size_t>(1, stage_budget / per_seed_stage);
+            const size_t fit = lb.dbg_stage_seeds > 0
+                                   ? (size_t)lb.dbg_stage_seeds
+                                   : std::max<size_t>(1, stage_budget / per_seed_stage);
             if (fit >= (size_t)Bg) { keep_stages = true; }
-            else if (fit >= 256) { keep_stages = true; piece = (int)fit; }
+            else if (fit >= (size_t)lb.dbg_min_piece) { keep_stages = true; piece = (int)fit; }
         }
         for (int p0 = 0; p0 < Bg; p0 += piece) {
             const int Bp = std::min(piece, Bg - p0);
@@ -1539,6 +1547,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             // several waves per seed shorten a seed's serial chain by ~1.4x but hold one seed
             // per CU instead of two: worth it while the batch leaves CUs idle
             la.multi_wave = (lb.multi_wave && B <= ctx->cu_count) ? 1 : 0;
+            if (lb.dbg_wave_mode == 1) la.multi_wave = 0;
+            if (lb.dbg_wave_mode == 2) la.multi_wave = lb.multi_wave;
             la.cache_gen = (la.multi_wave && lb.cache_gen) ? 1 : 0;
             la.cost_out = lb.cost_out.p + pos0;
             la.final_out = lb.final_out.p + pos0 * S * md;
@@ -1590,6 +1600,17 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     lb.B = B;
     lb.have_results = true;
     lb.have_steps = ctx->keep_step_states != 0;
+    return 0;
+}
+
+int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t min_piece,
+                              int32_t wave_mode) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (stage_budget_seeds < 0 || min_piece < 1 || wave_mode < 0 || wave_mode > 2)
+        return fail(QOCX_ERR_ARG, "bad knob value");
+    ctx->lb.dbg_stage_seeds = stage_budget_seeds;
+    ctx->lb.dbg_min_piece = min_piece;
+    ctx->lb.dbg_wave_mode = wave_mode;
     return 0;
 }
 

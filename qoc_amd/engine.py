@@ -107,6 +107,7 @@ SIGNATURES = {
     "qocx_debug_pade_factor": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p, _c_double_p,
                                               _c_double_p, _c_int_p, _c_double_p, _c_int_p]),
     "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
+    "qocx_debug_lindblad_knobs": (ctypes.c_int, [_VP, _I64, _I32, _I32]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
 }
 
@@ -458,6 +459,12 @@ class Engine(object):
             self._ctx, count, n, _dp(a), _dp(q), _dp(lu), perm.ctypes.data_as(_c_int_p),
             _dp(dinv), s.ctypes.data_as(_c_int_p)))
         return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s)
+
+    def debug_lindblad_knobs(self, stage_budget_seeds=0, min_piece=256, wave_mode=0):
+        """Force the Lindblad launch variants (piece-wise, recompute, one / several waves per
+        seed); see include/qocx.h. Defaults restore the automatic choice."""
+        self._check(self._lib.qocx_debug_lindblad_knobs(
+            self._ctx, int(stage_budget_seeds), int(min_piece), int(wave_mode)))
 
     def mfma_peak(self, waves_per_simd=1, iters=20000):
         """Sustained FP64 MFMA TFLOP/s of a register-only MFMA loop (roofline calibration)."""
