@@ -243,6 +243,11 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
                            double* q_out, double* lu_out, int32_t* perm_out,
                            double* dinv_out, int32_t* s_out);
 int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
+/* Kernel-variant switches for A/B measurements in one process and for tests that pin a variant
+ * (results never depend on them beyond rounding). Known names:
+ *   "sweep_loader"  1 (default): a dedicated fetch wave per seed issues the sweep's LDS-DMA;
+ *                   0: the compute wave issues it from inside its triangular solves (round-1 form). */
+int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
 /* Force the variants of the Lindblad launch that large batches / little free HBM select:
  *   stage_budget_seeds  seeds whose forward stage values may be kept for the adjoint (0: as many
  *                       as fit 45 % of free HBM); a larger group is launched in pieces;

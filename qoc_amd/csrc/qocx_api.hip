@@ -187,6 +187,12 @@ struct qocx_ctx {
         int dbg_wave_mode = 0;           // 0 auto, 1 one wave per seed, 2 several whenever built for
         DevBuf<double2> a0_tab, gp_tab;
     } lb;
+    // ---- qocx_debug_set_knob: kernel-variant switches for A/B measurements and tests ----
+    std::map<std::string, int64_t> knobs;
+    int64_t knob(const char* name, int64_t dflt) const {
+        auto it = knobs.find(name);
+        return it == knobs.end() ? dflt : it->second;
+    }
     // ---- timing ----
     int timing = 0;
     std::vector<TimingRec> pending;
@@ -822,6 +828,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                              ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
         sa.status = ctx->status.p;
         sa.lam_buf = ctx->lam_buf.p;
+        sa.loader = (int)ctx->knob("sweep_loader", 1);
         sa.inj_count = ctx->inj_count;
         sa.inj_index = ctx->inj_count > 0 ? ctx->inj_index.p : nullptr;
         sa.inj_bars = ctx->inj_count > 0
@@ -1601,6 +1608,17 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     lb.have_results = true;
     lb.have_steps = ctx->keep_step_states != 0;
     return 0;
+}
+
+int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
+    static const char* known[] = {"sweep_loader"};
+    for (const char* k : known)
+        if (strcmp(k, name) == 0) {
+            ctx->knobs[name] = value;
+            return 0;
+        }
+    return fail(QOCX_ERR_ARG, std::string("unknown knob: ") + name);
 }
 
 int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t min_piece,

@@ -69,6 +69,7 @@ struct SweepArgs {
     // bit 0) and / or the adjoint sweep from j_end back to j_begin (phase bit 1); state is carried
     // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).
     int phase, j_begin, j_end;
+    int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA (default)
     double2* lam_buf;     // [B][S][NP]
     // Externally supplied state cotangents (user Cost plugins whose derivative the host
     // provides): inj_index[step] = row of inj_bars or -1; added to lambda at system step `step`

@@ -874,8 +874,14 @@ __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec
 // buffers all waves read; a workgroup barrier at every step start says "the operands have landed
 // and every wave has left the previous step". The costs couple the states, so wave 0 evaluates
 // them on all S states between two barriers. W = 1 is the single-state form: no barrier at all.
-template <int NB, int W>
-__global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
+//
+// LOADER: one more wave per seed does nothing but fetch: it issues the next step's 34 LDS-DMA
+// pieces back to back, waits for them and meets the compute waves at the step barrier. An LDS-DMA
+// costs its issuing wave 60-100 cycles of issue time each (MI355X_MICROARCH.md, 'LDS-DMA piece'),
+// i.e. 2 000 - 3 400 cycles per step when the compute wave issues them from inside its dependent
+// chains (the form without LOADER, kept for comparison: qocx_debug_set_knob "sweep_loader" 0).
+template <int NB, int W, bool LOADER>
+__global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
     typedef SweepLds<NB> L;
     constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
@@ -887,14 +893,19 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
     double2* dbuf = reinterpret_cast<double2*>(smem + L::D_OFF);
     int* pbuf = reinterpret_cast<int*>(smem + L::P_OFF);
-    const int w = W > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + w * NP;
+    constexpr bool MULTI = (W > 1) || LOADER;  // more than one wave in the workgroup
+    const int w = MULTI ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    // the wave that fetches: the extra one, or compute wave 0 from inside its solves
+    const bool fetcher = LOADER ? (w == W) : (w == 0);
+    const bool computes = !LOADER || (w < W);
+    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + (computes ? w : 0) * NP;
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
     auto block_sync = [&]() {
-        if constexpr (W > 1) __syncthreads();
+        if constexpr (MULTI) __syncthreads();
         else wave_sync();
     };
-    const int S = args.S;
+    // the loader wave runs the same control flow (every barrier) with empty state loops
+    const int S = args.S, s0 = computes ? w : args.S;
     double2* lam = vecs + S * NP;
     const int b = blockIdx.x;
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     bool overflow = false;
     if (do_fwd) {
         if (jb == 0) {
-            for (int s = w; s < S; s += W)
+            for (int s = s0; s < S; s += W)
                 if (g0) {
                     const double2 p = args.psi0[s * NP + i];
                     vecs[s * NP + i] = p;
@@ -925,7 +936,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
         } else {  // resume: states, slot counter and partial cost left by the previous segment
             slot = offs_b[jb];
             cost = args.cost_out[b];
-            for (int s = w; s < S; s += W)
+            for (int s = s0; s < S; s += W)
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
         }
         wave_sync();
@@ -988,22 +999,29 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
         for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
     };
     auto hook_a = [&](auto KK) __attribute__((always_inline)) {  // first solve: pieces 0 .. NP-2
-        if (pf_due) dma_one(KK);
+        if constexpr (!LOADER) {
+            if (pf_due) dma_one(KK);
+        }
     };
     auto hook_b = [&](auto KK) __attribute__((always_inline)) {  // second solve: the remaining pieces
         constexpr int piece = NP - 1 + decltype(KK)::value;
-        if constexpr (piece < PIECES) {
+        if constexpr (!LOADER && piece < PIECES) {
             if (pf_due) dma_one(std::integral_constant<int, piece>());
         }
     };
     auto finish_prefetch = [&]() {  // pieces that did not fit into the two solves (NP = 16)
         constexpr int DONE = 2 * (NP - 1), REST = PIECES > DONE ? PIECES - DONE : 0;
+        if constexpr (LOADER) return;
         if (pf_due)
             for_each_const(
                 [&](auto P) __attribute__((always_inline)) {
                     dma_one(std::integral_constant<int, DONE + decltype(P)::value>());
                 },
                 std::make_integer_sequence<int, REST>{});
+        pf_due = false;
+    };
+    auto issue_all_due = [&]() {  // LOADER: the whole step at once, from the wave that only fetches
+        if (pf_due) for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
         pf_due = false;
     };
     auto scalars = [&](int par, bool adjoint) {
@@ -1020,7 +1038,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
                 overflow = true;
                 break;
             }
-            for (int s = w; s < S; s += W) {
+            for (int s = s0; s < S; s += W) {
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
                 lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
@@ -1045,10 +1063,10 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     auto before_step = [&](int step) {  // called behind a barrier: every state of `step` is in vecs
         if (step != 0 && (step % args.cost_eval_step) == 0) {
             if (w == 0) cost += eval_costs<NB>(args, true, false, vecs, nullptr, h, i);
-            if constexpr (W > 1) __syncthreads();  // the other waves overwrite their states next
+            if constexpr (MULTI) __syncthreads();  // the other waves overwrite their states next
         }
         if (g0 && args.step_states != nullptr)
-            for (int s = w; s < S; s += W)
+            for (int s = s0; s < S; s += W)
                 args.step_states[(((size_t)b * (nsteps + 1) + step) * S + s) * NP + i] =
                     vecs[s * NP + i];
         if (w == 0 && lane == 0) offs_b[step] = slot;
@@ -1057,20 +1075,22 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     // ---- forward sweep: the next step's operands stream into LDS while the current step's
     // dependent chains run -------------------------------------------------------------------
     if (do_fwd) {
-        if (w == 0) issue_dma(m0 + jb, 0, false);
+        if (fetcher) issue_dma(m0 + jb, 0, false);
         int nsub_next = 1 << min(max(args.s_arr[m0 + jb], 0), 30);
         for (int step = jb; step < je; ++step) {
             const int par = (step - jb) & 1;
             const int nsub = nsub_next;
-            if (w == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             block_sync();
             const StepScalars sc = scalars(par, false);
-            lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
-                                   lane, i);
+            if (computes)
+                lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r,
+                                       sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = (w == 0) && (step + 1 < je);
+            pf_due = fetcher && (step + 1 < je);
             if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
+            if constexpr (LOADER) issue_all_due();
             if (step + 1 < je) nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             before_step(step);
             forward_step(sc, nsub);
@@ -1088,7 +1108,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
             before_step(nsteps);
             if (w == 0) cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
             if (g0)
-                for (int s = w; s < S; s += W)
+                for (int s = s0; s < S; s += W)
                     args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
         } else if (w == 0 && lane == 0) {
             offs_b[je] = slot;  // the next segment resumes from here
@@ -1103,7 +1123,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
         const int row = args.inj_index[step];
         if (row < 0) return;
         if (g0)
-            for (int s = w; s < S; s += W) {
+            for (int s = s0; s < S; s += W) {
                 const double2 e = args.inj_bars[(((size_t)b * args.inj_count + row) * S + s) * NP + i];
                 double2 l = lam[s * NP + i];
                 l.x += e.x;
@@ -1117,10 +1137,10 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     if (je == nsteps) {
         if (!do_fwd) {  // final states of the forward segments
             slot = offs_b[nsteps];
-            for (int s = w; s < S; s += W)
+            for (int s = s0; s < S; s += W)
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
         }
-        for (int s = w; s < S; s += W)
+        for (int s = s0; s < S; s += W)
             if (g0) lam[s * NP + i] = make_double2(0, 0);
         block_sync();
         // cotangent seeds on the final states: non-step costs, and step costs if the final step
@@ -1131,7 +1151,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
         inject(nsteps);
     } else {  // resume the adjoint sweep below step je
         slot = offs_b[je];
-        for (int s = w; s < S; s += W)
+        for (int s = s0; s < S; s += W)
             if (g0) lam[s * NP + i] = args.lam_buf[((size_t)b * S + s) * NP + i];
         wave_sync();
     }
@@ -1139,7 +1159,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     auto adjoint_step = [&](const StepScalars& sc, int nsub, int step) {
         for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
-            for (int s = w; s < S; s += W) {
+            for (int s = s0; s < S; s += W) {
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
@@ -1169,7 +1189,7 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
         if (step != 0 && (step % args.cost_eval_step) == 0 && args.has_step_costs) {
             // step costs were evaluated on the states *before* evolving from `step`
             if (g0)
-                for (int s = w; s < S; s += W)
+                for (int s = s0; s < S; s += W)
                     vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
             block_sync();
             if (w == 0) (void)eval_costs<NB>(args, true, false, vecs, lam, h, i);
@@ -1179,26 +1199,28 @@ __global__ __launch_bounds__(64 * W) void sweep_kernel(SweepArgs args) {
     };
     {
         const size_t ml = m0 + je - 1;
-        if (w == 0) issue_dma(ml, 0, true);
+        if (fetcher) issue_dma(ml, 0, true);
         int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
             const int par = it & 1;
             const int nsub = nsub_next;
-            if (w == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             block_sync();
             const StepScalars sc = scalars(par, true);
-            lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r, sc.pm,
-                                  lane, i);
+            if (computes)
+                lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r,
+                                      sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = (w == 0) && (step - 1 >= jb);
+            pf_due = fetcher && (step - 1 >= jb);
             if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
+            if constexpr (LOADER) issue_all_due();
             if (step - 1 >= jb) nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             adjoint_step(sc, nsub, step);
         }
     }
     if (jb > 0 && g0)
-        for (int s = w; s < S; s += W)
+        for (int s = s0; s < S; s += W)
             args.lam_buf[((size_t)b * S + s) * NP + i] = lam[s * NP + i];
 }
 
@@ -1496,13 +1518,19 @@ static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a
         hipLaunchKernelGGL((pade_pq_explicit_kernel<NB, false>), dim3(count), dim3(64),
                            PqLds<NB>::BYTES, st, a_in, n, a);
 }
-template <int NB, int W>
-static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
+template <int NB, int W, bool LOADER>
+static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
     const int bytes = SweepLds<NB>::bytes(a.S);
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W, LOADER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((sweep_kernel<NB, W>), dim3(batch), dim3(64 * W), bytes, st, a);
+    hipLaunchKernelGGL((sweep_kernel<NB, W, LOADER>), dim3(batch),
+                       dim3(64 * (W + (LOADER ? 1 : 0))), bytes, st, a);
+}
+template <int NB, int W>
+static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
+    if (a.loader) launch_sweep_wl<NB, W, true>(a, batch, st);
+    else launch_sweep_wl<NB, W, false>(a, batch, st);
 }
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {

@@ -108,6 +108,7 @@ SIGNATURES = {
                                               _c_double_p, _c_int_p, _c_double_p, _c_int_p]),
     "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
     "qocx_debug_lindblad_knobs": (ctypes.c_int, [_VP, _I64, _I32, _I32]),
+    "qocx_debug_set_knob": (ctypes.c_int, [_VP, ctypes.c_char_p, _I64]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
 }
 
@@ -459,6 +460,10 @@ class Engine(object):
             self._ctx, count, n, _dp(a), _dp(q), _dp(lu), perm.ctypes.data_as(_c_int_p),
             _dp(dinv), s.ctypes.data_as(_c_int_p)))
         return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s)
+
+    def set_knob(self, name, value):
+        """Kernel-variant switch (include/qocx.h: qocx_debug_set_knob)."""
+        self._check(self._lib.qocx_debug_set_knob(self._ctx, name.encode(), int(value)))
 
     def debug_lindblad_knobs(self, stage_budget_seeds=0, min_piece=256, wave_mode=0):
         """Force the Lindblad launch variants (piece-wise, recompute, one / several waves per

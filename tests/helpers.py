@@ -36,12 +36,21 @@ CASE_NAMES = [c.name for c in cases_mod.all_cases()]
 GRAD_CASE_NAMES = [c.name for c in cases_mod.all_cases() if c.controls is not None]
 
 
-def lindblad_grad_close(grads, ref):
+def lindblad_grad_close(grads, ref, case=None):
     """
-    Gradient gate of the Lindblad fixtures: 1e-6 of the largest entry, with an absolute floor of
-    5e-10. The floor is the reference's own noise: its adaptive integrator reproduces its forward
-    result only to ~4e-9 over the 500 steps of the full-length fixture (tools/
-    gen_golden_lindblad.py prints it), which shows up at ~1e-10 in a gradient of size 1e-5.
+    Gradient gate of the Lindblad fixtures.
+
+    * Fixtures with a well-conditioned gradient (`case.grad_rtol`, max |g| >= 1e-2:
+      lindblad_wc_*): **1e-8 of the largest entry**, no floor - north_star's bar.
+    * The round-1 fixtures aim at random densities (cost ~0.99, max |g| = 4e-6 .. 8e-3): 1e-6 of
+      the largest entry, with an absolute floor of 5e-10. The floor is the reference's own
+      noise: its adaptive integrator reproduces its forward result only to ~4e-9 over the 500
+      steps of the full-length fixture (tools/gen_golden_lindblad.py prints it), which shows up
+      at ~1e-10 in a gradient of size 1e-5.
     """
     import numpy as np
-    return np.max(np.abs(grads - ref)) < max(1e-6 * np.max(np.abs(ref)), 5e-10)
+    dev = np.max(np.abs(grads - ref))
+    rtol = getattr(case, "grad_rtol", None)
+    if rtol is not None:
+        return dev < rtol * np.max(np.abs(ref))
+    return dev < max(1e-6 * np.max(np.abs(ref)), 5e-10)

@@ -48,8 +48,8 @@ def total_registers(entry):
 def test_headline_kernels_share_a_simd():
     kernels = resources("qocx_kernels.hip")
     pade2 = resources("qocx_pade2.hip")
-    sweep = find(kernels, "sweep_kernelILi2ELi1E")
-    sweep4 = find(kernels, "sweep_kernelILi2ELi4E")
+    sweep = find(kernels, "sweep_kernelILi2ELi1ELb0E")
+    sweep4 = find(kernels, "sweep_kernelILi2ELi4ELb0E")
     k1a = find(pade2, "pade_pq2_kernelILb1E")
     k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0E")
     lu = find(kernels, "lu_kernelILi2E")

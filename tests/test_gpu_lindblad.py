@@ -61,7 +61,7 @@ def test_lindblad_engine_matches_golden_and_model(engine, name):
         assert abs(cost[b] - g["error"][b]) < 1e-9
         assert np.max(np.abs(final[b] - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
-        assert lindblad_grad_close(grads[b], ref)
+        assert lindblad_grad_close(grads[b], ref, case)
         m_err, m_grads, m_final = lm.evaluate_with_grad(
             system, controls[b], case.initial_densities, case.T, case.N, costs,
             case.cost_eval_step)
@@ -247,7 +247,7 @@ def test_lindblad_launch_variants_agree(engine, name):
             for c, gr, f in ((c_multi, g_multi, f_multi), (c_one, g_one, f_one)):
                 assert abs(c[b] - g["error"][b]) < 1e-9
                 assert np.max(np.abs(f[b] - g["final_densities"][b])) < 1e-8
-                assert lindblad_grad_close(gr[b], refs[b])
+                assert lindblad_grad_close(gr[b], refs[b], case)
         # the two kernels order their sums differently: round-off, not more
         assert np.max(np.abs(c_one - c_multi)) < 1e-13
         assert np.max(np.abs(f_one - f_multi)) < 1e-13
@@ -274,7 +274,7 @@ def test_lindblad_launch_variants_agree(engine, name):
         assert np.array_equal(c_r, c_ref) and np.array_equal(f_r, f_ref)
         assert np.max(np.abs(g_r - g_ref)) < 1e-13 * max(1.0, np.max(np.abs(g_ref)))
         for b in range(8):
-            assert lindblad_grad_close(g_r[b], refs[b % nb])
+            assert lindblad_grad_close(g_r[b], refs[b % nb], case)
         # the same two paths on the several-waves kernel
         engine.debug_lindblad_knobs(3, 2, 2)
         c_p2, g_p2, _ = engine.evaluate_lindblad(eight)

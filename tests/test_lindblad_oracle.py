@@ -144,7 +144,7 @@ def test_device_model_matches_fixtures(name):
         assert abs(err - g["error"][b]) < 1e-9
         assert np.max(np.abs(dens - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
-        assert lindblad_grad_close(grads, ref)
+        assert lindblad_grad_close(grads, ref, case)
 
 
 def test_device_model_gradient_vs_own_finite_differences():

@@ -38,11 +38,44 @@ def ref_forward(case, controls):
     return r.error, np.asarray(r.final_densities)
 
 
-def main():
+def richardson_fd(case, controls, index, h):
+    """d error / d(Re, Im) of controls.flat[index] from the REFERENCE's own forward
+    (qoc.evolve_lindblad_discrete(...).error), Richardson-extrapolated central differences: the
+    same cross-check tools/gen_golden.py applies to the Schroedinger fixtures."""
+    def f(c):
+        return ref_forward(case, c)[0]
+
+    def central(step, direction):
+        cp = controls.copy()
+        cm = controls.copy()
+        cp.flat[index] += step * direction
+        cm.flat[index] -= step * direction
+        return (f(cp) - f(cm)) / (2 * step)
+
+    def rich(direction):
+        return (4 * central(h / 2, direction) - central(h, direction)) / 3
+
+    g = rich(1.0)
+    if np.iscomplexobj(controls):
+        g = g + 1j * rich(1.0j)
+    return g
+
+
+# AD (mesh frozen) against finite differences of the reference forward. The forward is an
+# adaptive integration that reproduces itself to ~1e-10 (more over 500 steps), so a difference
+# quotient with step h carries noise ~1e-10 / h: the gate is 2e-7 relative where the gradient
+# is large (the well-conditioned fixtures), and the measured number is printed and stored.
+FD_COUNT = {"lindblad_c4_full": 2}
+FD_STEP = {"lindblad_wc_n4": 4e-2, "lindblad_wc_n16": 4e-2}
+
+
+def main(only=None):
     for case in cases_mod.lindblad_cases():
+        if only and case.name not in only:
+            continue
         t0 = time.time()
-        errors, finals, grads, traced = [], [], [], []
-        for controls in case.controls:
+        errors, finals, grads, traced, fd_index, grads_fd = [], [], [], [], [], []
+        for b, controls in enumerate(case.controls):
             err, final = ref_forward(case, controls)
             # AD with the mesh frozen (step sizes are constants of the tape): the gradient of the
             # discrete scheme on the mesh the reference chose
@@ -57,17 +90,33 @@ def main():
             assert dev < 1e-8, (case.name, dev)
             print("  forward reproducibility {:.1e}; traced-vs-frozen gradient {:.1e} rel".format(
                 dev, np.max(np.abs(g_traced - g_frozen)) / np.max(np.abs(g_frozen))))
+            rng = np.random.default_rng(9100 + b)
+            count = min(FD_COUNT.get(case.name, 4), controls.size)
+            idx = rng.choice(controls.size, size=count, replace=False)
+            g_fd = np.array([richardson_fd(case, controls, i, FD_STEP.get(case.name, 2e-2))
+                             for i in idx])
+            scale = np.max(np.abs(g_frozen))
+            fd_dev = np.max(np.abs(g_fd - g_frozen.flat[idx])) / scale
+            fd_gate = 2e-7 if getattr(case, "grad_rtol", None) else 1e-5
+            print("  AD(frozen mesh)-vs-FD(reference forward) {:.1e} rel of max|g| = {:.2e}".format(
+                fd_dev, scale))
+            # absolute floor: the noise of a difference quotient of the adaptive forward
+            # (~1e-10 reproducibility / h), which dominates where max|g| is 1e-5 .. 1e-4
+            assert fd_dev * scale < max(fd_gate * scale, 1e-9), (case.name, b, fd_dev)
             errors.append(err)
             finals.append(final)
             grads.append(g_frozen)
             traced.append(g_traced)
+            fd_index.append(idx)
+            grads_fd.append(g_fd)
         np.savez_compressed(os.path.join(GOLDEN, case.name + ".npz"), error=np.array(errors),
                             final_densities=np.stack(finals), grads_ad=np.stack(grads),
-                            grads_ad_traced_controller=np.stack(traced), controls=case.controls)
+                            grads_ad_traced_controller=np.stack(traced), controls=case.controls,
+                            fd_index=np.stack(fd_index), grads_fd=np.stack(grads_fd))
         print("{:24s} errors {} ({:.1f}s)".format(case.name, errors, time.time() - t0))
     # the reference's analytic known answers (tests/test_core.py:82-148) are asserted directly in
     # tests/test_lindblad_oracle.py; no fixture needed.
 
 
 if __name__ == "__main__":
-    main()
+    main(only=set(sys.argv[1:]))
