@@ -245,9 +245,24 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
 int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
 /* Kernel-variant switches for A/B measurements in one process and for tests that pin a variant
  * (results never depend on them beyond rounding). Known names:
- *   "sweep_loader"  1 (default): a dedicated fetch wave per seed issues the sweep's LDS-DMA;
- *                   0: the compute wave issues it from inside its triangular solves (round-1 form). */
+ *   "sweep_impl"    1 (default): column-chain sweep (one wavefront per seed; best inside the
+ *                   segmented pipeline of large batches); 3: blocked-inverse sweep (four wavefronts
+ *                   per seed: compute | inverter L | loader | inverter U'; qocx_sweep3.hip), 1.5x
+ *                   faster per step when the sweep has the chip to itself (<= 128 seeds). One
+ *                   implementation serves all batch sizes of a context, so results stay bit
+ *                   identical across batching. Environment QOCX_SWEEP_IMPL presets it.
+ *   "sweep3_phases" with the blocked sweep selected: bit 0 forward launches, bit 1 adjoint.
+ *   "sweep3_dbg"    timing diagnostics of the blocked sweep, results are garbage: bit 0 no block
+ *                   inversion, 1 no solves, 2 no LU fetch, 3 no Q fetch, 4 no Q touch.
+ *   "sweep3_stamps" 1: run the stamped diagnostic build (qocx_debug_read_stamps).
+ *   "sweep_loader"  column-chain sweep only. 0 (default): the compute wave issues the LDS-DMA from
+ *                   inside its triangular solves; 1: a dedicated fetch wave per seed does. */
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
+/* After evaluations with the knob "sweep3_stamps" = 1 (a diagnostic build of the sweep that
+ * executes in-kernel clock stamps; never the product kernel): per seed, per role (compute |
+ * inverter L | loader | inverter U'), 8 sums - shader-clock cycles per phase of the role's step loop, [7] = the
+ * 100 MHz real-time counter over the role's life. out: [batch][4][8]. */
+int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
 /* Force the variants of the Lindblad launch that large batches / little free HBM select:
  *   stage_budget_seeds  seeds whose forward stage values may be kept for the adjoint (0: as many
  *                       as fit 45 % of free HBM); a larger group is launched in pieces;

@@ -88,7 +88,14 @@ class SchroedingerEvaluator(object):
     def __init__(self, evolution_time, hamiltonian, initial_states, system_eval_count,
                  control_count=0, control_eval_count=0, complex_controls=False, costs=(),
                  cost_eval_step=1, interpolation_policy=InterpolationPolicy.LINEAR,
-                 magnus_policy=MagnusPolicy.M2, need_gradients=True, backend=None):
+                 magnus_policy=MagnusPolicy.M2, need_gradients=True, backend=None,
+                 latency_mode=False):
+        """
+        latency_mode: the evaluator will be asked for ONE control array at a time (the
+        reference's evolve_* / grape_* entry points). The engine then runs its blocked-inverse
+        sweep (four wavefronts per seed, 1.5x faster per step when the sweep has the chip to
+        itself: qocx_debug_set_knob "sweep_impl" = 3); batched evaluation keeps the default.
+        """
         if interpolation_policy != InterpolationPolicy.LINEAR:
             raise NotImplementedError("The interpolation policy {} is not yet supported for this "
                                       "method.".format(interpolation_policy))
@@ -122,6 +129,8 @@ class SchroedingerEvaluator(object):
             else:
                 self.opaque_costs.append(cost)
         self.backend = backend if backend is not None else make_backend()
+        if latency_mode and hasattr(self.backend, "set_knob"):
+            self.backend.set_knob("sweep_impl", 3)
         self.kr = control_count * (2 if complex_controls else 1)
         self.backend.set_schroedinger_problem(
             self.hilbert_size, self.state_count, self.kr, control_eval_count, system_eval_count,

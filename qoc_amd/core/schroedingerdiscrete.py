@@ -47,7 +47,7 @@ def evolve_schroedinger_discrete(evolution_time, hamiltonian, initial_states, sy
         control_count=control_count, control_eval_count=control_eval_count,
         complex_controls=controls is not None and np.iscomplexobj(controls), costs=costs,
         cost_eval_step=cost_eval_step, interpolation_policy=interpolation_policy,
-        magnus_policy=magnus_policy, need_gradients=False)
+        magnus_policy=magnus_policy, need_gradients=False, latency_mode=True)
     error, _, final_states, step_states = evaluator.evaluate(
         controls, want_grad=False, want_step_states=pstate.save_intermediate_states_)
     if pstate.save_intermediate_states_:
@@ -83,7 +83,7 @@ def grape_schroedinger_discrete(control_count, control_eval_count, costs, evolut
         control_count=control_count, control_eval_count=control_eval_count,
         complex_controls=complex_controls, costs=costs, cost_eval_step=cost_eval_step,
         interpolation_policy=interpolation_policy, magnus_policy=magnus_policy,
-        need_gradients=True)
+        need_gradients=True, latency_mode=True)
     pstate.log_and_save_initial()
     reporter = Dummy()
     reporter.iteration = 0

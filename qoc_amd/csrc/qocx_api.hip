@@ -189,6 +189,7 @@ struct qocx_ctx {
     } lb;
     // ---- qocx_debug_set_knob: kernel-variant switches for A/B measurements and tests ----
     std::map<std::string, int64_t> knobs;
+    DevBuf<unsigned long long> stamps;  // sweep3 diagnostic build
     int64_t knob(const char* name, int64_t dflt) const {
         auto it = knobs.find(name);
         return it == knobs.end() ? dflt : it->second;
@@ -369,6 +370,7 @@ int qocx_create(int device, qocx_ctx** out) {
         ctx->ev_factored.push_back(e1);
         ctx->ev_swept.push_back(e2);
     }
+    if (const char* env = getenv("QOCX_SWEEP_IMPL")) ctx->knobs["sweep_impl"] = atoi(env);  // test runs
     *out = ctx;
     return 0;
 }
@@ -828,7 +830,34 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                              ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
         sa.status = ctx->status.p;
         sa.lam_buf = ctx->lam_buf.p;
-        sa.loader = (int)ctx->knob("sweep_loader", 1);
+        sa.loader = (int)ctx->knob("sweep_loader", 0);
+        sa.dbg = (int)ctx->knob("sweep3_dbg", 0);
+        sa.stamps = nullptr;
+        if (ctx->knob("sweep3_stamps", 0)) {
+            if (ctx->stamps.ensure((size_t)B * 32)) return QOCX_ERR_HIP;
+            HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, (size_t)B * 32 * sizeof(unsigned long long), cs));
+            HIP_TRY(hipStreamSynchronize(cs));
+            sa.stamps = ctx->stamps.p + (size_t)b0 * 32;
+        }
+        // blocked-inverse sweep (three wavefronts per seed) unless switched off or the states do
+        // not fit beside its LDS ring
+        // "sweep_impl": 1 (default) column-chain sweep, 3 blocked sweep. ONE implementation serves
+        // every batch size, chunking and segmentation of a context, so that results stay bit
+        // identical across them (tests/test_gpu_engine.py::test_chunked_equals_unchunked,
+        // test_gpu_fullsize.py). Measured (profiles/r02_sweep_ab.jsonl): the blocked sweep takes
+        // 2.1 us per step against 3.2 us when it has the chip to itself - a single-seed evaluation
+        // (n = 32, 1000 steps) 4.2 ms against 6.4 ms, 64 seeds 5.8 against 8.1 ms - but inside
+        // the segmented pipeline at 256 seeds it loses (14.3 against 13.4 ms): its workgroup owns
+        // the CU's LDS, so K1a / K1b / K3 cannot run beside it. The host package selects it for
+        // the single-control-set entry points (latency mode), the batched evaluator keeps 1.
+        const bool sweep3 = ctx->knob("sweep_impl", 1) == 3 && S <= qocx::sweep3_max_states(ctx->nb);
+        // "sweep3_phases": bit 0 forward launches, bit 1 adjoint launches (and combined ones)
+        const int s3_phases = (int)ctx->knob("sweep3_phases", 3);
+        auto run_sweep = [&](const qocx::SweepArgs& a, int count, hipStream_t st) {
+            const bool use3 = sweep3 && ((a.phase & 2) ? (s3_phases & 2) : (s3_phases & 1));
+            if (use3) qocx::launch_sweep3(ctx->nb, a, count, st);
+            else qocx::launch_sweep(ctx->nb, a, count, st);
+        };
         sa.inj_count = ctx->inj_count;
         sa.inj_index = ctx->inj_count > 0 ? ctx->inj_index.p : nullptr;
         sa.inj_bars = ctx->inj_count > 0
@@ -867,7 +896,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             sa.j_begin = lo[i]; sa.j_end = lo[i + 1];
             sa.phase = (nseg == 1) ? (want_grad ? 3 : 1) : 1;
             time_begin(ctx, 1, ss);
-            qocx::launch_sweep(ctx->nb, sa, bc, ss);
+            run_sweep(sa, bc, ss);
             time_end(ctx, ss);
         }
         // ---- adjoint sweep walks back; K3 follows on the compute stream ----------------------
@@ -879,7 +908,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             for (int i = nseg - 1; i >= 0; --i) {
                 sa.j_begin = lo[i]; sa.j_end = lo[i + 1]; sa.phase = 2;
                 time_begin(ctx, 1, ss);
-                qocx::launch_sweep(ctx->nb, sa, bc, ss);
+                run_sweep(sa, bc, ss);
                 time_end(ctx, ss);
                 HIP_TRY(hipEventRecord(ctx->ev_swept[i], ss));
             }
@@ -1612,13 +1641,22 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
-    static const char* known[] = {"sweep_loader"};
+    static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
+                                  "sweep3_phases"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
             return 0;
         }
     return fail(QOCX_ERR_ARG, std::string("unknown knob: ") + name);
+}
+
+int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count) {
+    if (!ctx || !out) return fail(QOCX_ERR_ARG, "NULL argument");
+    if ((size_t)count > ctx->stamps.count) return fail(QOCX_ERR_ARG, "more stamps than were collected");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(out, ctx->stamps.p, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t min_piece,

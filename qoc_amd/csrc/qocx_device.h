@@ -69,7 +69,10 @@ struct SweepArgs {
     // bit 0) and / or the adjoint sweep from j_end back to j_begin (phase bit 1); state is carried
     // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).
     int phase, j_begin, j_end;
-    int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA (default)
+    int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
+    int dbg;              // sweep3 timing diagnostics (results are garbage): bit 0 no inversion,
+                          // bit 1 no solves, bit 2 no LU fetch, bit 3 no Q fetch, bit 4 no Q touch
+    unsigned long long* stamps;  // sweep3 diagnostic build: [B][4 roles][8] cycle sums, or nullptr
     double2* lam_buf;     // [B][S][NP]
     // Externally supplied state cotangents (user Cost plugins whose derivative the host
     // provides): inj_index[step] = row of inj_bars or -1; added to lambda at system step `step`
@@ -201,6 +204,9 @@ void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int co
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st);
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);
+// blocked-inverse sweep (qocx_sweep3.hip): three wavefronts per seed
+void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st);
+int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

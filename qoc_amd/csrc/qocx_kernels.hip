@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "qocx_wave.h"
+#include "qocx_sweep_common.h"
 
 namespace qocx {
 
@@ -665,94 +666,6 @@ __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
-// <t|psi> over lane group 0, result wave-uniform.
-__device__ __forceinline__ void inner(const double2 t, const double2 p, bool active, double& re,
-                                      double& im) {
-    double pr = active ? (t.x * p.x + t.y * p.y) : 0.0;  // conj(t) * p
-    double pi = active ? (t.x * p.y - t.y * p.x) : 0.0;
-    re = wave_sum(pr);
-    im = wave_sum(pi);
-}
-
-// Evaluate the selected costs on the S states in `vecs` (LDS, [S][NP]). If lam != nullptr also
-// adds dC/dRe + i dC/dIm into lam (LDS, [S][NP]). Formulas: qoc/standard/costs/
-// targetstateinfidelity.py:52-61, forbidstates.py:64-81; cotangents SURVEY.md Appendix A.
-template <int NB>
-__device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pass,
-                                             bool final_pass, const double2* vecs, double2* lam,
-                                             int h, int i) {
-    constexpr int NP = Geo<NB>::NP;
-    const int S = args.S;
-    const bool act = (h == 0);
-    double total = 0;
-    for (int ci = 0; ci < args.cost_count; ++ci) {
-        const DevCost c = args.costs[ci];
-        const bool on = c.step_cost ? step_pass : final_pass;
-        if (!on) continue;
-        const double2* pool = args.cost_vectors + (size_t)c.vec_offset * NP;
-        if (c.kind == QOCX_DEV_COST_COHERENT) {
-            double tre = 0, tim = 0;
-            for (int s = 0; s < S; ++s) {
-                double r, m;
-                inner(pool[s * NP + i], vecs[s * NP + i], act, r, m);
-                tre += r;
-                tim += m;
-            }
-            total += c.scale * (1.0 - (tre * tre + tim * tim) / ((double)S * S));
-            if (lam != nullptr && act) {
-                const double f = -2.0 * c.scale / ((double)S * S);
-                for (int s = 0; s < S; ++s) {
-                    const double2 t = pool[s * NP + i];
-                    double2 l = lam[s * NP + i];
-                    l.x += f * (tre * t.x - tim * t.y);
-                    l.y += f * (tre * t.y + tim * t.x);
-                    lam[s * NP + i] = l;
-                }
-            }
-        } else if (c.kind == QOCX_DEV_COST_INCOHERENT) {
-            double fid = 0;
-            const double f = -2.0 * c.scale / (double)S;
-            for (int s = 0; s < S; ++s) {
-                double r, m;
-                const double2 t = pool[s * NP + i];
-                inner(t, vecs[s * NP + i], act, r, m);
-                fid += r * r + m * m;
-                if (lam != nullptr && act) {
-                    double2 l = lam[s * NP + i];
-                    l.x += f * (r * t.x - m * t.y);
-                    l.y += f * (r * t.y + m * t.x);
-                    lam[s * NP + i] = l;
-                }
-            }
-            total += c.scale * (1.0 - fid / (double)S);
-        } else {  // QOCX_DEV_COST_FORBID
-            int base = 0;
-            double acc = 0;
-            for (int s = 0; s < S; ++s) {
-                const int fs = args.cost_counts[c.cnt_offset + s];
-                const double w = 1.0 / (double)fs;
-                for (int f = 0; f < fs; ++f) {
-                    double r, m;
-                    const double2 t = pool[(size_t)(base + f) * NP + i];
-                    inner(t, vecs[s * NP + i], act, r, m);
-                    acc += w * (r * r + m * m);
-                    if (lam != nullptr && act) {
-                        const double g = 2.0 * c.scale * w;
-                        double2 l = lam[s * NP + i];
-                        l.x += g * (r * t.x - m * t.y);
-                        l.y += g * (r * t.y + m * t.x);
-                        lam[s * NP + i] = l;
-                    }
-                }
-                base += fs;
-            }
-            total += c.scale * acc;
-        }
-    }
-    if (lam != nullptr) wave_sync();
-    return total;
-}
-
 template <int NB>
 struct SweepLds {
     typedef Geo<NB> G;
@@ -778,13 +691,6 @@ struct StepScalars {
     int pm;      // forward: perm[i] (row at position i); adjoint: iperm[i] (position of row i)
 };
 
-// One 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `g` land at lds_base + 16*l.
-__device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)g,
-        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-
 // The same with an instruction offset IMM (13 bits, signed): the 16 bytes at g + IMM land at
 // lds_dst + 16*l. The hardware adds the offset to the global AND to the LDS address, so M0 gets
 // lds_dst - IMM. One per-lane base address then serves many pieces of an image.
@@ -800,12 +706,6 @@ __device__ __forceinline__ void dma16_imm(const char* g, char* lds_dst) {
 template <class F, int... P>
 __device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, P...>) {
     (f(std::integral_constant<int, P>()), ...);
-}
-
-__device__ __forceinline__ void dma4(const int* g, int* lds_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)g,
-        (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 
 // LDS images -> registers. The LU image is stored in original row order, so the row at position
@@ -824,20 +724,6 @@ __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb
         r.lre[c] = e.x;
         r.lim[c] = e.y;
     }
-}
-
-// sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
-template <int NB>
-__device__ __forceinline__ double sum_groups(double v) {
-    if (Geo<NB>::H == 2) {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
-    }
-#pragma unroll
-    for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
-    return v;
 }
 
 // Partial row sums of a matvec whose matrix sits in LDS as an R-layout image (`qlane` = the image

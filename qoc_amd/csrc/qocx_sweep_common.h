@@ -1,0 +1,130 @@
+// qocx_sweep_common.h - pieces shared by the two sweep kernels (qocx_kernels.hip: the column-chain
+// sweep; qocx_sweep3.hip: the blocked-inverse sweep): state-cost evaluation, LDS-DMA helpers,
+// lane-group sums.
+#ifndef QOCX_SWEEP_COMMON_H
+#define QOCX_SWEEP_COMMON_H
+
+#include "qocx_wave.h"
+
+namespace qocx {
+
+// <t|psi> over lane group 0, result wave-uniform.
+__device__ __forceinline__ void inner(const double2 t, const double2 p, bool active, double& re,
+                                      double& im) {
+    double pr = active ? (t.x * p.x + t.y * p.y) : 0.0;  // conj(t) * p
+    double pi = active ? (t.x * p.y - t.y * p.x) : 0.0;
+    re = wave_sum(pr);
+    im = wave_sum(pi);
+}
+
+// Evaluate the selected costs on the S states in `vecs` (LDS, [S][NP]). If lam != nullptr also
+// adds dC/dRe + i dC/dIm into lam (LDS, [S][NP]). Formulas: qoc/standard/costs/
+// targetstateinfidelity.py:52-61, forbidstates.py:64-81; cotangents SURVEY.md Appendix A.
+template <int NB>
+__device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pass,
+                                             bool final_pass, const double2* vecs, double2* lam,
+                                             int h, int i) {
+    constexpr int NP = Geo<NB>::NP;
+    const int S = args.S;
+    const bool act = (h == 0);
+    double total = 0;
+    for (int ci = 0; ci < args.cost_count; ++ci) {
+        const DevCost c = args.costs[ci];
+        const bool on = c.step_cost ? step_pass : final_pass;
+        if (!on) continue;
+        const double2* pool = args.cost_vectors + (size_t)c.vec_offset * NP;
+        if (c.kind == QOCX_DEV_COST_COHERENT) {
+            double tre = 0, tim = 0;
+            for (int s = 0; s < S; ++s) {
+                double r, m;
+                inner(pool[s * NP + i], vecs[s * NP + i], act, r, m);
+                tre += r;
+                tim += m;
+            }
+            total += c.scale * (1.0 - (tre * tre + tim * tim) / ((double)S * S));
+            if (lam != nullptr && act) {
+                const double f = -2.0 * c.scale / ((double)S * S);
+                for (int s = 0; s < S; ++s) {
+                    const double2 t = pool[s * NP + i];
+                    double2 l = lam[s * NP + i];
+                    l.x += f * (tre * t.x - tim * t.y);
+                    l.y += f * (tre * t.y + tim * t.x);
+                    lam[s * NP + i] = l;
+                }
+            }
+        } else if (c.kind == QOCX_DEV_COST_INCOHERENT) {
+            double fid = 0;
+            const double f = -2.0 * c.scale / (double)S;
+            for (int s = 0; s < S; ++s) {
+                double r, m;
+                const double2 t = pool[s * NP + i];
+                inner(t, vecs[s * NP + i], act, r, m);
+                fid += r * r + m * m;
+                if (lam != nullptr && act) {
+                    double2 l = lam[s * NP + i];
+                    l.x += f * (r * t.x - m * t.y);
+                    l.y += f * (r * t.y + m * t.x);
+                    lam[s * NP + i] = l;
+                }
+            }
+            total += c.scale * (1.0 - fid / (double)S);
+        } else {  // QOCX_DEV_COST_FORBID
+            int base = 0;
+            double acc = 0;
+            for (int s = 0; s < S; ++s) {
+                const int fs = args.cost_counts[c.cnt_offset + s];
+                const double w = 1.0 / (double)fs;
+                for (int f = 0; f < fs; ++f) {
+                    double r, m;
+                    const double2 t = pool[(size_t)(base + f) * NP + i];
+                    inner(t, vecs[s * NP + i], act, r, m);
+                    acc += w * (r * r + m * m);
+                    if (lam != nullptr && act) {
+                        const double g = 2.0 * c.scale * w;
+                        double2 l = lam[s * NP + i];
+                        l.x += g * (r * t.x - m * t.y);
+                        l.y += g * (r * t.y + m * t.x);
+                        lam[s * NP + i] = l;
+                    }
+                }
+                base += fs;
+            }
+            total += c.scale * acc;
+        }
+    }
+    if (lam != nullptr) wave_sync();
+    return total;
+}
+
+// One 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `g` land at lds_base + 16*l.
+__device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void dma4(const int* g, int* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+
+
+// sum of a value over the H lane groups that share a row (lanes i, i + NP, ...)
+template <int NB>
+__device__ __forceinline__ double sum_groups(double v) {
+    if (Geo<NB>::H == 2) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
+    }
+#pragma unroll
+    for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+
+}  // namespace qocx
+
+#endif

@@ -109,6 +109,7 @@ SIGNATURES = {
     "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
     "qocx_debug_lindblad_knobs": (ctypes.c_int, [_VP, _I64, _I32, _I32]),
     "qocx_debug_set_knob": (ctypes.c_int, [_VP, ctypes.c_char_p, _I64]),
+    "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
 }
 
@@ -464,6 +465,13 @@ class Engine(object):
     def set_knob(self, name, value):
         """Kernel-variant switch (include/qocx.h: qocx_debug_set_knob)."""
         self._check(self._lib.qocx_debug_set_knob(self._ctx, name.encode(), int(value)))
+
+    def read_stamps(self, batch):
+        """[batch][4 roles][8] cycle sums of the stamped sweep build (knob sweep3_stamps)."""
+        out = np.zeros((batch, 4, 8), dtype=np.uint64)
+        self._check(self._lib.qocx_debug_read_stamps(
+            self._ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size))
+        return out
 
     def debug_lindblad_knobs(self, stage_budget_seeds=0, min_piece=256, wave_mode=0):
         """Force the Lindblad launch variants (piece-wise, recompute, one / several waves per
