@@ -7,9 +7,18 @@ TargetStateInfidelity cost; synthetic GUE-like H0 and G_k of unit 2-norm, dt = 0
 controls ~ N(0, 0.1^2), all seeded.
 
 One "step" = one evaluation (cost, d cost / d controls, final states) of every seed of every
-rank, controls resident in HBM when the clock starts. With --gpus N > 1 the driver launches
-one process per GPU (torchrun env); the seed axis is sharded and each step ends with the
-path's single RCCL all-reduce of [sum cost, sum gradient].
+rank, controls resident in HBM when the clock starts (`value`, as the bench contract defines it).
+With --gpus N > 1 the driver launches one process per GPU (torchrun env); the seed axis is
+sharded and each step ends with the path's single RCCL all-reduce of [sum cost, sum gradient].
+
+The line also carries, measured in the same run on rank 0:
+  host_to_host  the same evaluation through qocx_eval_schroedinger - FRESH controls from host
+                memory every step, costs + gradients + final states back in host memory (PCIe
+                inclusive; SURVEY.md 8d's "controls in, results out");
+  secondary     BASELINE.json configs[3]: dim=16 Lindblad, 500 steps, 64 seeds - ms per
+                evaluation, steps/s and the roofline of the Lindblad kernel;
+  cpu_baseline  the oracle on the host cores (all cores, and one core: the reference's execution
+                model).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
 """
@@ -54,6 +63,9 @@ def make_controls(first_seed, count):
     return out
 
 
+PMC_SUMMARY = "profiles/r01_v6_pmc_hbm.json"
+
+
 def pmc_traffic_bytes(kernel, units_per_launch):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
@@ -62,7 +74,7 @@ def pmc_traffic_bytes(kernel, units_per_launch):
     units per launch. PMC counters cannot be collected from inside the timed run; None if the
     summary is absent.
     """
-    path = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm.json")
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
         with open(path) as f:
             summary = json.load(f)
@@ -94,21 +106,89 @@ def _cpu_worker(seed_ids):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(seeds_per_worker=4):
-    """Oracle fwd+grad on a bounded sample: `cores` worker processes x seeds_per_worker seeds."""
+def cpu_baseline(seeds_per_worker=40):
+    """Oracle fwd+grad on a bounded sample: `cores` worker processes x seeds_per_worker seeds,
+    plus the single-core figure (one seed at a time, the reference's execution model)."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
     jobs = [[w * seeds_per_worker + i for i in range(seeds_per_worker)] for w in range(cores)]
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [[0]] * cores)  # process start, imports, BLAS warm-up: not timed
+        t0 = time.perf_counter()
         pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
+        single_seconds = pool.apply(_cpu_worker, (list(range(1000, 1024)),))  # others idle
     steps = cores * seeds_per_worker * (N_EVAL - 1)
     return dict(value=steps / wall, unit="propagator-steps/s", cores=cores, kind="port",
                 sample="{} seeds x {} steps (oracle/qoc_numpy.py fwd+grad, {} processes, "
-                       "1 BLAS thread each, {:.1f}s wall incl. process start)".format(
-                           cores * seeds_per_worker, N_EVAL - 1, cores, wall))
+                       "1 BLAS thread each, {:.1f}s wall, warm processes)".format(
+                           cores * seeds_per_worker, N_EVAL - 1, cores, wall),
+                single_core=dict(value=24 * (N_EVAL - 1) / single_seconds,
+                                 unit="propagator-steps/s", cores=1,
+                                 sample="24 seeds x {} steps, one process, 1 BLAS thread, "
+                                        "{:.1f}s".format(N_EVAL - 1, single_seconds)))
+
+
+# ---- secondary: BASELINE.json configs[3], the Lindblad path ------------------------------------
+
+LB_DIM, LB_EVAL, LB_SEEDS, LB_OPS = 16, 501, 64, 2
+
+
+def lindblad_problem():
+    rng = np.random.default_rng(2004)
+    h0 = gue(rng, LB_DIM)
+    g = [gue(rng, LB_DIM) for _ in range(K_CTRL)]
+    a = np.diag(np.sqrt(np.arange(1, LB_DIM)), 1).astype(np.complex128)
+    ops = np.stack([a, a.conj().T @ a])
+    gam = np.array([0.05, 0.02])
+    rho0 = np.zeros((1, LB_DIM, LB_DIM), dtype=np.complex128)
+    rho0[0, 0, 0] = 1
+    target = np.zeros((1, LB_DIM, LB_DIM), dtype=np.complex128)
+    target[0, 1, 1] = 1
+    return h0, g, gam, ops, rho0, target
+
+
+def lindblad_secondary(engine, reps=3):
+    """ms per fwd+grad evaluation of configs[3] and the roofline of the Lindblad kernel.
+    Algorithmic work per sub-interval (one 12-stage DOP853 step of one seed): the
+    right-hand side is (2 + 2 L) n^3 complex MACs (A_L rho, rho A_R, L_i rho, (.) L_i^H), 12
+    stages forward; the adjoint recomputes nothing (stage values are kept) but applies the
+    transposed right-hand side (the same count) and the control cotangent products
+    Y k^H - k^H Y (2 n^3): 12 x ((2 + 2 L) x 2 + 2) n^3 complex MACs x 8 flops."""
+    from qoc_amd.engine import COST_TARGET_DENSITY
+    h0, g, gam, ops, rho0, target = lindblad_problem()
+    engine.set_lindblad_problem(
+        LB_DIM, 1, K_CTRL, LB_EVAL, LB_EVAL, DT * (LB_EVAL - 1), h0, g, gam, ops, rho0,
+        costs=[dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=1.0, vectors=target)])
+    u = np.empty((LB_SEEDS, LB_EVAL, K_CTRL))
+    for b in range(LB_SEEDS):
+        u[b] = 0.1 * np.random.default_rng(1000 + b).standard_normal((LB_EVAL, K_CTRL))
+    engine.evaluate_lindblad(u)  # warm-up
+    engine.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cost, grads, final = engine.evaluate_lindblad(u)
+    wall = (time.perf_counter() - t0) / reps
+    launches, total_ms = engine.timing()["lindblad"]
+    subs = engine.lindblad_last_subintervals()
+    flops_per_sub = 8.0 * 12 * ((2 + 2 * LB_OPS) * 2 + 2) * LB_DIM ** 3
+    kernel_s = total_ms / max(launches, 1) * 1e-3
+    achieved = flops_per_sub * subs / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    return {
+        "config": {"workload": "configs[3]: dim=16 Lindblad, 500 system steps, 64 seeds, L=2 "
+                               "operators, K=2 real controls, S=1, fixed-step DOP853 + exact "
+                               "discrete adjoint"},
+        "metric": "propagator-steps/sec (fwd+grad), dim=16 Lindblad, 500 steps x 64 seeds",
+        "value": LB_SEEDS * (LB_EVAL - 1) / wall, "unit": "propagator-steps/s",
+        "ms_per_eval": wall * 1e3, "subintervals_per_step": subs / (LB_SEEDS * (LB_EVAL - 1.0)),
+        "roofline": {"bound": "mfma", "kernel": "qocx::lindblad_kernel", "achieved": achieved,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": kernel_s * 1e3,
+                     "flops_per_subinterval": flops_per_sub, "traffic": None},
+        "check": {"sum_cost": float(cost.sum()),
+                  "trace_defect": float(np.max(np.abs(np.trace(final[:, 0], axis1=-2, axis2=-1) - 1)))},
+    }
 
 
 def main():
@@ -118,6 +198,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seeds-per-gpu", type=int, default=SEEDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[3] Lindblad measurement")
     ap.add_argument("--time-segments", type=int, default=0,
                     help="tuning knob: time segments of the pipeline (0 = the engine's choice)")
     args = ap.parse_args()
@@ -169,6 +251,25 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
     timing = engine.timing()
+
+    # the same evaluation host buffer to host buffer (rank 0 of a single-GPU run): fresh controls
+    # from host memory every step, costs + gradients + final states back in host memory
+    host_to_host = None
+    if world == 1:
+        fresh = [make_controls(5000 + 300 * k, seeds) for k in range(3)]
+        engine.evaluate(fresh[0], want_grad=True)
+        engine.synchronize()
+        t_h = time.perf_counter()
+        for k in range(args.steps):
+            engine.evaluate(fresh[k % 3], want_grad=True)
+        h2h = (time.perf_counter() - t_h) / args.steps
+        host_to_host = dict(ms_per_step=h2h * 1e3, value=seeds * (N_EVAL - 1) / h2h,
+                            unit="propagator-steps/s",
+                            note="qocx_eval_schroedinger: H2D of fresh controls (4 MB), "
+                                 "evaluation, D2H of costs + gradients + final states, per step")
+    secondary = None
+    if world == 1 and not args.no_secondary:
+        secondary = lindblad_secondary(engine)
     engine.set_timing(False)
 
     units_per_step = world * seeds * (N_EVAL - 1)
@@ -188,6 +289,9 @@ def main():
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS,
                         peak_sustained_measured=engine.mfma_peak(2, 20000),
                         traffic=pmc_traffic_bytes("qocx::pade2::pade_pq2_kernel<true", units_per_launch),
+                        traffic_source="committed rocprofv3 --pmc passes of this command "
+                                       "({}; FETCH_SIZE x2 + WRITE_SIZE), not collected in "
+                                       "this run".format(PMC_SUMMARY),
                         avg_launch_ms=total_ms / launches)
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}
     path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
@@ -208,6 +312,10 @@ def main():
         "step_ms": step_ms,
         "path_algorithmic_tflops_per_gpu": path_tflops,
         "check": {"sum_cost": total_cost, "grad_l2": float(np.linalg.norm(total_grad))},
+        "value_definition": "controls resident in HBM when the clock starts (bench contract); "
+                            "the host-buffer-to-host-buffer rate is host_to_host",
+        "host_to_host": host_to_host,
+        "secondary": secondary,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -201,6 +201,9 @@ int qocx_lindblad_stage_times(double evolution_time, int32_t system_eval_count,
 int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int32_t want_grad,
                        double* cost_out, double* grad_out, double* final_out);
 int qocx_download_step_densities(qocx_ctx* ctx, double* densities_out);
+/* Sub-intervals (12-stage DOP853 steps) the last qocx_eval_lindblad integrated, summed over its
+ * seeds: the unit of the Lindblad kernel's work (bench.py prices its roofline with it). */
+int qocx_lindblad_last_subintervals(qocx_ctx* ctx, int64_t* total);
 /* The Lindblad twin of qocx_set_state_cotangents: bars [B][count][S][n][n] complex. */
 int qocx_set_density_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
                                 const double* bars);

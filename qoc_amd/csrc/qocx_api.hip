@@ -182,6 +182,7 @@ struct qocx_ctx {
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
         // qocx_debug_lindblad_knobs (tests force the kernel variants large batches / little HBM use)
+        int64_t last_subintervals = 0;   // sum over the seeds of the last evaluation
         int64_t dbg_stage_seeds = 0;     // seeds whose stage values may be kept; 0: 45 % of free HBM
         int dbg_min_piece = 256;         // below this many seeds per piece the adjoint recomputes
         int dbg_wave_mode = 0;           // 0 auto, 1 one wave per seed, 2 several whenever built for
@@ -1484,6 +1485,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     }
     size_t ckpt_total = 0, gsub_total = 0;
     lb.order.clear();
+    lb.last_subintervals = 0;
     for (auto& kv : groups) {
         auto it = lb.grids.find(kv.first);
         if (it == lb.grids.end()) {
@@ -1493,6 +1495,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         }
         ckpt_total += kv.second.size() * (size_t)it->second.nsub * S * md;
         gsub_total += kv.second.size() * (size_t)it->second.nsub * 2 * std::max(K, 1);
+        lb.last_subintervals += (int64_t)kv.second.size() * it->second.nsub;
         for (int b : kv.second) lb.order.push_back(b);
     }
     // The stage values of the forward pass are kept for the adjoint (12 x the checkpoints of the
@@ -1649,6 +1652,12 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
             return 0;
         }
     return fail(QOCX_ERR_ARG, std::string("unknown knob: ") + name);
+}
+
+int qocx_lindblad_last_subintervals(qocx_ctx* ctx, int64_t* total) {
+    if (!ctx || !total) return fail(QOCX_ERR_ARG, "NULL argument");
+    *total = ctx->lb.last_subintervals;
+    return 0;
 }
 
 int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count) {

@@ -947,7 +947,9 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         }
     };
     auto before_step = [&](int step) {  // called behind a barrier: every state of `step` is in vecs
-        if (step != 0 && (step % args.cost_eval_step) == 0) {
+        // (has_step_costs: without step costs eval_costs would still walk the cost table in HBM,
+        // a dependent trip to memory in front of every step when cost_eval_step = 1)
+        if (step != 0 && args.has_step_costs && (step % args.cost_eval_step) == 0) {
             if (w == 0) cost += eval_costs<NB>(args, true, false, vecs, nullptr, h, i);
             if constexpr (MULTI) __syncthreads();  // the other waves overwrite their states next
         }

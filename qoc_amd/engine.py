@@ -91,6 +91,7 @@ SIGNATURES = {
     "qocx_eval_lindblad": (ctypes.c_int, [_VP, _I32, _c_double_p, _I32, _c_double_p,
                                           _c_double_p, _c_double_p]),
     "qocx_download_step_densities": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_lindblad_last_subintervals": (ctypes.c_int, [_VP, ctypes.POINTER(_I64)]),
     "qocx_set_density_cotangents": (ctypes.c_int, [_VP, _I32, _I32, _c_int_p, _c_double_p]),
     "qocx_set_state_cotangents": (ctypes.c_int, [_VP, _I32, _I32, _c_int_p, _c_double_p]),
     "qocx_set_timing": (ctypes.c_int, [_VP, _I32]),
@@ -363,6 +364,12 @@ class Engine(object):
             _dp(cost), _dp(grads) if want_grad else None, _dp(final) if want_final else None))
         self._lindblad_batch = B
         return cost, grads, final
+
+    def lindblad_last_subintervals(self):
+        """DOP853 sub-intervals of the last evaluate_lindblad, summed over its seeds."""
+        total = _I64(0)
+        self._check(self._lib.qocx_lindblad_last_subintervals(self._ctx, ctypes.byref(total)))
+        return total.value
 
     def set_density_cotangents(self, steps, bars):
         """bars :: (B, len(steps), S, n, n) complex cotangents of the densities at `steps`."""
