@@ -7,7 +7,9 @@ SchusterLab/qoc (host: NumPy; device: hand-written gfx950 HIP through a ctypes C
 """
 
 from .core import (evolve_lindblad_discrete, evolve_schroedinger_discrete,
-                   grape_lindblad_discrete, grape_schroedinger_discrete)
+                   grape_lindblad_discrete, grape_schroedinger_discrete,
+                   grape_schroedinger_discrete_batch)
 
 __all__ = ["evolve_lindblad_discrete", "evolve_schroedinger_discrete",
-           "grape_lindblad_discrete", "grape_schroedinger_discrete"]
+           "grape_lindblad_discrete", "grape_schroedinger_discrete",
+           "grape_schroedinger_discrete_batch"]

@@ -148,3 +148,32 @@ def test_expm_and_example_on_gpu(capsys):
     result = module.main()
     assert result.best_error < 1e-2
     assert "best error" in capsys.readouterr().out
+
+
+def test_batch_grape_on_gpu_equals_eight_single_seed_runs():
+    """B = 8 trajectories of the multi-start driver equal eight B = 1 runs bit
+    for bit (one batched device evaluation per iteration; a seed's result does not depend on its
+    batch neighbours), and each agrees with grape_schroedinger_discrete from the same start."""
+    case = cases_mod.case_by_name("nc10_n101")
+    rng = np.random.default_rng(77)
+    u0 = 0.4 * rng.standard_normal((8, case.Nc, case.K))
+    args = (case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+            case.initial_states, case.N)
+    kw = dict(iteration_count=6, log_iteration_step=0, max_control_norms=np.full(case.K, 2.0))
+    batch = qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(),
+                                                      optimizer=Adam(learning_rate=2e-2), **kw)
+    for b in range(8):
+        one = qoc_amd.grape_schroedinger_discrete_batch(*args, u0[b:b + 1].copy(),
+                                                        optimizer=Adam(learning_rate=2e-2), **kw)
+        assert one.best_error[0] == batch.best_error[b]
+        assert one.best_iteration[0] == batch.best_iteration[b]
+        assert np.array_equal(one.best_controls[0], batch.best_controls[b])
+        assert np.array_equal(one.best_final_states[0], batch.best_final_states[b])
+        ref = qoc_amd.grape_schroedinger_discrete(*args, initial_controls=u0[b].copy(),
+                                                  optimizer=Adam(learning_rate=2e-2), **kw)
+        assert ref.best_iteration == batch.best_iteration[b]
+        assert abs(ref.best_error - batch.best_error[b]) < 1e-12
+        assert rel_err(ref.best_controls, batch.best_controls[b]) < 1e-10
+    assert np.all(batch.best_error < 1.0) and np.all(batch.iterations_run == 6)
+    # the optimisation does something
+    assert batch.best.best_error < np.max(batch.best_error) or np.ptp(batch.best_error) == 0

@@ -406,3 +406,77 @@ def test_expm_through_the_engine():
         assert rel_err(expm(a), scipy.linalg.expm(a)) < 1e-10
     with pytest.raises(ValueError):
         expm(np.zeros((2, 3)))
+
+
+# ---- multi-start GRAPE (grape_schroedinger_discrete_batch) ---------------------------------------
+
+def _batch_problem(case, seeds, sigma=0.3):
+    rng = np.random.default_rng(321)
+    shape = (seeds, case.Nc, case.K)
+    u = sigma * rng.standard_normal(shape)
+    if case.complex_controls:
+        u = u + 1j * sigma * rng.standard_normal(shape)
+    return u
+
+
+@pytest.mark.parametrize("name", ["ctrlcosts_r", "small_complex_M2"])
+def test_batch_grape_equals_independent_single_runs(name, capsys):
+    """Every seed of the batched driver walks the trajectory of grape_schroedinger_discrete
+    started from the same controls: same best error / iteration / controls (the oracle backend
+    evaluates a batch seed by seed, so the agreement is exact)."""
+    case = cases_mod.case_by_name(name)
+    u0 = _batch_problem(case, 3)
+    norms = np.full(case.K, 2.0)
+    kw = dict(complex_controls=case.complex_controls, cost_eval_step=case.cost_eval_step,
+              iteration_count=5, max_control_norms=norms,
+              magnus_policy=getattr(MagnusPolicy, case.magnus))
+    batch = qoc_amd.grape_schroedinger_discrete_batch(
+        case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+        case.initial_states, case.N, u0.copy(), optimizer=Adam(learning_rate=3e-2),
+        log_iteration_step=2, **kw)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("iter   |  summed error")
+    assert [line.split("|")[0].strip() for line in out[2:]] == ["0", "2", "4"]
+    for b in range(3):
+        single = qoc_amd.grape_schroedinger_discrete(
+            case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+            case.initial_states, case.N, initial_controls=u0[b].copy(),
+            optimizer=Adam(learning_rate=3e-2), log_iteration_step=0, **kw)
+        assert batch.best_error[b] == single.best_error
+        assert batch.best_iteration[b] == single.best_iteration
+        assert np.array_equal(batch.best_controls[b], single.best_controls)
+        assert np.array_equal(batch.best_final_states[b], single.best_final_states)
+    assert batch.best.best_error == np.min(batch.best_error)
+    assert batch.global_best_error == batch.best.best_error
+    assert np.all(batch.iterations_run == 5)
+
+
+def test_batch_grape_per_seed_termination_conditions_and_errors():
+    case = cases_mod.case_by_name("ctrlcosts_r")
+    u0 = _batch_problem(case, 4, sigma=0.2)
+
+    def conditions(controls):
+        controls[0, :] = 0
+        return controls
+
+    base = dict(cost_eval_step=case.cost_eval_step, max_control_norms=np.full(case.K, 1.0),
+                log_iteration_step=0, impose_control_conditions=conditions)
+    args = (case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+            case.initial_states, case.N)
+    ref = qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), iteration_count=3,
+                                                    optimizer=SGD(learning_rate=0.5), **base)
+    # a seed whose first error is below min_error stops at once, the others carry on untouched
+    threshold = float(np.sort(ref.best_error)[1]) + 1.0  # generous: at least two seeds stop early
+    early = qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), iteration_count=3,
+                                                      optimizer=SGD(learning_rate=0.5),
+                                                      min_error=threshold, **base)
+    assert np.all(early.iterations_run >= 1) and np.any(early.iterations_run == 1)
+    for b in range(4):
+        assert np.all(early.best_controls[b][0] == 0)
+        assert np.max(np.abs(early.best_controls[b])) <= 1.0 + 1e-12
+    with pytest.raises(ValueError):
+        qoc_amd.grape_schroedinger_discrete_batch(*args, u0[0], **base)
+    with pytest.raises(NotImplementedError):
+        qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), optimizer=LBFGSB(), **base)
+    with pytest.raises(ValueError):  # initial controls beyond max_control_norms
+        qoc_amd.grape_schroedinger_discrete_batch(*args, 10 * u0, **base)
