@@ -168,6 +168,22 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls);
 int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad);
 int qocx_download_results(qocx_ctx* ctx, double* cost_out, double* grad_out, double* final_out);
 
+/*
+ * Opaque Hamiltonians. The reference calls hamiltonian(controls, time) - arbitrary Python, not
+ * necessarily linear in the controls (schroedingerdiscrete.py:483-486) - at every step. For a
+ * callable the structured form above cannot represent, the host samples the step generators
+ * itself, M_j = -i dt H(u(t_j + dt/2), t_j + dt/2) (mathmethods.py:90-93, magnus_m2), and the
+ * engine takes them as they are (problem set with control_count = 0, magnus_policy M2):
+ *   generators  [B][N-1][n][n] complex, row-major
+ *   qocx_eval_resident / qocx_download_results as usual (cost_out, final_out);
+ *   cotangents  [B][N-1][n][n] complex: Mbar_j = d cost / d Re(M_j) + i d cost / d Im(M_j), from
+ *               which the host forms d cost / d u_k = Re sum_rc conj(Mbar_j[r][c]) (dM_j/du_k)[r][c]
+ *               (what autograd's tape does at :318-319 through the user's callable).
+ * qocx_upload_controls switches back to the structured form.
+ */
+int qocx_upload_generators(qocx_ctx* ctx, int32_t batch, const double* generators);
+int qocx_download_generator_cotangents(qocx_ctx* ctx, double* cotangents_out);
+
 /* Optional: all system-step states of the last evaluation, [B][N][S][n] complex
  * (what save_intermediate_states persists, schroedingerdiscrete.py:395-402). */
 int qocx_set_keep_step_states(qocx_ctx* ctx, int32_t keep); /* before the evaluation */

@@ -113,8 +113,26 @@ class SchroedingerEvaluator(object):
         dt = evolution_time / (system_eval_count - 1)
         times = [step * dt + dt * c for step in range(system_eval_count - 1)
                  for c in magnus_policy.nodes]
-        h0, g = structure.probe_hamiltonian(hamiltonian, self.hilbert_size, control_count,
-                                            complex_controls, times)
+        # A Hamiltonian that is real-linear in the controls goes to the device in structured form
+        # (H0, G_k; the engine builds every step generator itself). Anything else - the
+        # reference takes ANY callable, e.g. the epsilon^2 term of report.tex:22-32 - is sampled
+        # by the host at every step of every evaluation, as the reference does, and the engine
+        # takes the generators as they are (qocx_upload_generators).
+        self.opaque_hamiltonian = None
+        try:
+            h0, g = structure.probe_hamiltonian(hamiltonian, self.hilbert_size, control_count,
+                                                complex_controls, times)
+        except structure.NonLinearHamiltonianError:
+            if magnus_policy != MagnusPolicy.M2:
+                raise NotImplementedError(
+                    "a hamiltonian that is not linear in the controls is supported with "
+                    "MagnusPolicy.M2 only (got {}); there is no CPU fallback".format(magnus_policy))
+            self.opaque_hamiltonian = hamiltonian
+            self._dt = dt
+            self._mid_times = times
+            self._rows = structure.interpolation_rows(evolution_time, control_eval_count, times)
+            h0 = np.zeros((1, self.hilbert_size, self.hilbert_size), dtype=np.complex128)
+            g = None
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
         descriptors = []
         for cost in self.costs:
@@ -132,11 +150,37 @@ class SchroedingerEvaluator(object):
         if latency_mode and hasattr(self.backend, "set_knob"):
             self.backend.set_knob("sweep_impl", 3)
         self.kr = control_count * (2 if complex_controls else 1)
+        device_k = 0 if self.opaque_hamiltonian is not None else self.kr
         self.backend.set_schroedinger_problem(
-            self.hilbert_size, self.state_count, self.kr, control_eval_count, system_eval_count,
+            self.hilbert_size, self.state_count, device_k,
+            control_eval_count if device_k else 0, system_eval_count,
             evolution_time, h0, g, initial_states.reshape(self.state_count, self.hilbert_size),
             costs=descriptors, cost_eval_step=cost_eval_step, magnus_policy=magnus_policy.short)
         self.cost_eval_step = cost_eval_step
+
+    # -- device round trip: structured controls, or generators sampled from an opaque callable ----
+    def _upload(self, controls_batch, device_controls):
+        if self.opaque_hamiltonian is None:
+            self.backend.upload_controls(device_controls)
+            return
+        gens = [structure.sample_generators(self.opaque_hamiltonian, controls, self._rows,
+                                            self._mid_times, self._dt, self.hilbert_size)[0]
+                for controls in controls_batch]
+        self.backend.upload_generators(np.stack(gens))
+
+    def _download(self, controls_batch, want_grad):
+        if self.opaque_hamiltonian is None:
+            return self.backend.download_results(want_grad=want_grad)
+        cost, _, final = self.backend.download_results(want_grad=False)
+        grads = None
+        if want_grad:
+            bars = self.backend.download_generator_cotangents()
+            grads = np.stack([structure.generator_gradients(
+                self.opaque_hamiltonian, controls, self._rows, self._mid_times, self._dt,
+                bars[b], self.complex_controls) for b, controls in enumerate(controls_batch)])
+            grads = structure.to_real_controls(grads, self.complex_controls) \
+                if self.complex_controls else grads
+        return cost, grads, final
 
     def _host_terms(self, controls, want_grad):
         value, grad = 0.0, None
@@ -165,10 +209,10 @@ class SchroedingerEvaluator(object):
         need_steps = want_step_states or bool(self.opaque_costs)
         if need_steps:
             self.backend.set_keep_step_states(True)
-        self.backend.upload_controls(device_controls)
+        self._upload(controls_batch, device_controls)
         two_pass = want_grad and bool(self.opaque_costs)
         self.backend.eval_resident(want_grad and not two_pass)
-        cost, grads, final = self.backend.download_results(want_grad=want_grad and not two_pass)
+        cost, grads, final = self._download(controls_batch, want_grad and not two_pass)
         step_states = None
         if need_steps:
             step_states = self.backend.download_step_states()[..., None]
@@ -182,7 +226,7 @@ class SchroedingerEvaluator(object):
             self.backend.set_state_cotangents(steps, bars)
             try:
                 self.backend.eval_resident(True)
-                cost, grads, final = self.backend.download_results(want_grad=True)
+                cost, grads, final = self._download(controls_batch, True)
             finally:
                 self.backend.set_state_cotangents(None, None)
         errors = np.array(cost, dtype=np.float64)

@@ -79,6 +79,90 @@ class TimeDependentSystemError(NotImplementedError):
     pass
 
 
+# ---- opaque Hamiltonians: the host samples the step generators itself --------------------------
+
+def interpolation_rows(evolution_time, control_eval_count, times):
+    """
+    Linear interpolation of the controls at `times`, the reference's rule
+    (qoc/core/mathmethods.py:36-67: the two lowest / highest knots beyond the ends, else the
+    first knot >= t and its predecessor). Returns (i1, i2, x1, x2): index and abscissa arrays.
+    """
+    xs = np.linspace(0, evolution_time, control_eval_count)
+    i1 = np.empty(len(times), dtype=np.int64)
+    i2 = np.empty(len(times), dtype=np.int64)
+    for q, t in enumerate(times):
+        if t <= xs[0]:
+            i1[q], i2[q] = 0, 1
+        elif t >= xs[-1]:
+            i1[q], i2[q] = control_eval_count - 2, control_eval_count - 1
+        else:
+            index = int(np.argmax(t <= xs))
+            i1[q], i2[q] = index - 1, index
+    return i1, i2, xs[i1], xs[i2]
+
+
+def controls_at(controls, rows, times):
+    """(len(times), K) controls at `times`: y1 + ((y2 - y1) / (x2 - x1)) * (x3 - x1), the
+    reference's operation order (mathmethods.py:33)."""
+    i1, i2, x1, x2 = rows
+    y1, y2 = controls[i1], controls[i2]
+    return y1 + (((y2 - y1) / (x2 - x1)[:, None]) * (np.asarray(times) - x1)[:, None])
+
+
+def sample_generators(hamiltonian, controls, rows, times, dt, hilbert_size):
+    """M_j = dt * (-1j * hamiltonian(u(t_j), t_j)) for one control array (magnus_m2,
+    mathmethods.py:72-93 with a(t) = -1j H, schroedingerdiscrete.py:483-486)."""
+    u = controls_at(controls, rows, times)
+    out = np.empty((len(times), hilbert_size, hilbert_size), dtype=np.complex128)
+    for j, t in enumerate(times):
+        out[j] = dt * (-1j * np.asarray(hamiltonian(u[j], t), dtype=np.complex128))
+    return out, u
+
+
+_FD_H = 1e-4
+
+
+def hamiltonian_slopes(hamiltonian, u, t, complex_controls):
+    """
+    d H / d Re(u_k) (and d H / d Im(u_k) for complex controls) at (u, t) by 4th-order central
+    differences of the user's callable (the reference gets them from autograd's trace of it):
+    truncation ~h^4 |H^(5)|, round-off ~1e-16 |H| / h = 1e-12 |H| at h = 1e-4 max(1, |u_k|).
+    Returns [(k, direction, dH)] with direction 1 or 1j.
+    """
+    out = []
+    u = np.array(u)
+    for k in range(len(u)):
+        for direction in ((1.0, 1.0j) if complex_controls else (1.0,)):
+            h = _FD_H * max(1.0, abs(u[k]))
+
+            def at(step):
+                v = u.copy()
+                v[k] = v[k] + step * direction
+                return np.asarray(hamiltonian(v, t), dtype=np.complex128)
+            dh = (8.0 * (at(h) - at(-h)) - (at(2 * h) - at(-2 * h))) / (12.0 * h)
+            out.append((k, direction, dh))
+    return out
+
+
+def generator_gradients(hamiltonian, controls, rows, times, dt, gen_bars, complex_controls):
+    """
+    d cost / d controls from the generator cotangents Mbar_j (qocx_download_generator_cotangents):
+    d cost / d u_k(t_j) = Re sum conj(Mbar_j) * d M_j / d u_k with M_j = -1j dt H, carried to the
+    control grid by the transpose of the linear interpolation. Complex controls: qoc's
+    convention d/dRe + i d/dIm.
+    """
+    i1, i2, x1, x2 = rows
+    u = controls_at(controls, rows, times)
+    grads = np.zeros(controls.shape, dtype=np.complex128 if complex_controls else np.float64)
+    for j, t in enumerate(times):
+        w2 = (t - x1[j]) / (x2[j] - x1[j])
+        for k, direction, dh in hamiltonian_slopes(hamiltonian, u[j], t, complex_controls):
+            value = float(np.real(np.sum(np.conj(gen_bars[j]) * (-1j * dt * dh))))
+            grads[i1[j], k] += (1.0 - w2) * value * direction
+            grads[i2[j], k] += w2 * value * direction
+    return grads
+
+
 def decision_times(evolution_time, count=257):
     """Fallback probe times for the time-dependence decision when the caller has no integrator
     grid: `count` points of [0, T] displaced by a golden-ratio sequence, so that no drive whose

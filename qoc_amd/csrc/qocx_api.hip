@@ -146,6 +146,10 @@ struct qocx_ctx {
     int cu_count = 256;
     int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
+    // explicit-generator mode (qocx_upload_generators): opaque Hamiltonians sampled by the host
+    bool explicit_mode = false;
+    int explicit_hermitian = 0;
+    DevBuf<double2> gen_rm, genbar_rm;  // [B][nsteps] row-major padded generators / cotangents
     // ---- host-supplied state cotangents ----
     int inj_count = 0, inj_batch = 0;
     DevBuf<int> inj_index;
@@ -672,6 +676,72 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
     ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
     ctx->B = batch;
     ctx->have_results = false;
+    ctx->explicit_mode = false;
+    return 0;
+}
+
+int qocx_upload_generators(qocx_ctx* ctx, int32_t batch, const double* generators) {
+    if (!ctx || !generators) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->has_problem) return fail(QOCX_ERR_STATE, "no problem set");
+    if (batch < 1) return fail(QOCX_ERR_ARG, "batch must be >= 1");
+    if (ctx->K != 0 || ctx->nodes != 1)
+        return fail(QOCX_ERR_STATE, "explicit generators need a problem with control_count = 0 and "
+                                    "magnus_policy M2");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->n, np = ctx->np, nsteps = ctx->nsteps;
+    const size_t count = (size_t)batch * nsteps, mat = (size_t)np * np;
+    std::vector<double2> padded(count * mat, make_double2(0, 0));
+    double worst = 0;
+    bool skew = true;
+    for (size_t m = 0; m < count; ++m) {
+        const double* g = generators + m * (size_t)n * n * 2;
+        double norm1 = 0;
+        for (int c = 0; c < n; ++c) {
+            double col = 0;
+            for (int r = 0; r < n; ++r) {
+                const double re = g[2 * ((size_t)r * n + c)], im = g[2 * ((size_t)r * n + c) + 1];
+                col += std::hypot(re, im);
+                padded[m * mat + (size_t)r * np + c] = make_double2(re, im);
+                // skew-Hermitian bit for bit: a[r][c] == -conj(a[c][r])
+                if (re != -g[2 * ((size_t)c * n + r)] || im != g[2 * ((size_t)c * n + r) + 1])
+                    skew = false;
+            }
+            if (!(col <= norm1)) norm1 = col;
+        }
+        if (!(norm1 <= worst)) worst = norm1;
+    }
+    if (!(worst < 1e300)) return fail(QOCX_ERR_ARG, "non-finite generator");
+    ctx->sbound = pade_scale_count(worst);
+    if (ctx->sbound > 10)
+        return fail(QOCX_ERR_CAPACITY,
+                    "||dt H||_1 needs more than 2^10 squaring sub-steps per step; reduce dt");
+    ctx->slot_cap = ((size_t)nsteps << ctx->sbound) + 1;
+    if (ctx->gen_rm.upload(padded, ctx->stream)) return QOCX_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->B = batch;
+    ctx->have_results = false;
+    ctx->explicit_mode = true;
+    ctx->explicit_hermitian = skew ? 1 : 0;
+    return 0;
+}
+
+int qocx_download_generator_cotangents(qocx_ctx* ctx, double* out) {
+    if (!ctx || !out) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->have_results || !ctx->have_grads || !ctx->explicit_mode)
+        return fail(QOCX_ERR_STATE, "no generator cotangents (qocx_upload_generators + "
+                                    "qocx_eval_resident(want_grad = 1) first)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->n, np = ctx->np;
+    const size_t count = (size_t)ctx->B * ctx->nsteps, mat = (size_t)np * np;
+    std::vector<double2> padded(count * mat);
+    HIP_TRY(hipMemcpy(padded.data(), ctx->genbar_rm.p, padded.size() * sizeof(double2),
+                      hipMemcpyDeviceToHost));
+    for (size_t m = 0; m < count; ++m)
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                out[2 * ((m * n + r) * n + c)] = padded[m * mat + (size_t)r * np + c].x;
+                out[2 * ((m * n + r) * n + c) + 1] = padded[m * mat + (size_t)r * np + c].y;
+            }
     return 0;
 }
 
@@ -726,7 +796,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     if (!ctx->has_problem || ctx->B < 1) return fail(QOCX_ERR_STATE, "no problem / controls");
     HIP_TRY(hipSetDevice(ctx->device));
     const int B = ctx->B, np = ctx->np, mat = np * np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
-    want_grad = (want_grad && K > 0) ? 1 : 0;
+    const bool explicit_gen = ctx->explicit_mode;
+    want_grad = (want_grad && (K > 0 || explicit_gen)) ? 1 : 0;
+    if (explicit_gen && want_grad)
+        if (ctx->genbar_rm.ensure((size_t)B * nsteps * mat)) return QOCX_ERR_HIP;
     if (ctx->inj_count > 0 && ctx->inj_batch != B)
         return fail(QOCX_ERR_STATE, "state cotangents were set for a different batch size");
 
@@ -803,7 +876,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.h0_cimg = ctx->h0_cimg.p;
         fa.g_cimg = ctx->g_cimg.p;
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
-        fa.hermitian = ctx->hermitian;
+        fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         qocx::LuArgs la;
@@ -869,7 +942,12 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             const int len = lo[i + 1] - lo[i];
             fa.step0 = lo[i]; fa.seg_len = len;
             time_begin(ctx, 0, cs);
-            if (nodes > 1) {
+            if (explicit_gen) {
+                // generators sampled by the host (opaque Hamiltonian): [seed][step] row-major
+                qocx::FactorArgs fe = fa;
+                qocx::launch_pq_explicit(ctx->nb, ctx->gen_rm.p + (size_t)b0 * nsteps * mat, np, fe,
+                                         bc * len, cs);
+            } else if (nodes > 1) {
                 ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
                 qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
@@ -932,11 +1010,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             ka.gstep = ctx->gstep.p;
             ka.m_rm = nodes > 1 ? ctx->m_rm.p : nullptr;
             ka.mbar_rm = nodes > 1 ? ctx->mbar_rm.p : nullptr;
+            if (explicit_gen) {
+                ka.m_rm = ctx->gen_rm.p + (size_t)b0 * nsteps * mat;
+                ka.mbar_rm = ctx->genbar_rm.p + (size_t)b0 * nsteps * mat;
+            }
             for (int i = nseg - 1; i >= 0; --i) {
                 const int len = lo[i + 1] - lo[i];
                 if (nseg > 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[i], 0));
                     ka.step0 = lo[i];
-                ka.skew = ctx->hermitian;
+                ka.skew = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
                 time_begin(ctx, 2, cs);
                 qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
                 if (nodes > 1) {

@@ -83,6 +83,8 @@ SIGNATURES = {
     "qocx_upload_controls": (ctypes.c_int, [_VP, _I32, _c_double_p]),
     "qocx_eval_resident": (ctypes.c_int, [_VP, _I32]),
     "qocx_download_results": (ctypes.c_int, [_VP, _c_double_p, _c_double_p, _c_double_p]),
+    "qocx_upload_generators": (ctypes.c_int, [_VP, _I32, _c_double_p]),
+    "qocx_download_generator_cotangents": (ctypes.c_int, [_VP, _c_double_p]),
     "qocx_set_keep_step_states": (ctypes.c_int, [_VP, _I32]),
     "qocx_download_step_states": (ctypes.c_int, [_VP, _c_double_p]),
     "qocx_set_lindblad_problem": (ctypes.c_int, [_VP, ctypes.POINTER(_LindbladProblem)]),
@@ -239,6 +241,20 @@ class Engine(object):
             batch = 1 if controls is None else int(controls)
             self._check(self._lib.qocx_upload_controls(self._ctx, batch, None))
         self.batch = batch
+
+    def upload_generators(self, generators):
+        """generators :: (B, N-1, n, n) complex step generators M_j = -i dt H (opaque Hamiltonians);
+        the problem must have been set with control_count = 0 and magnus_policy M2."""
+        pr = self._problem
+        gens = _as_complex(generators).reshape(-1, pr["N"] - 1, pr["n"], pr["n"])
+        self._check(self._lib.qocx_upload_generators(self._ctx, gens.shape[0], _dp(gens)))
+        self.batch = gens.shape[0]
+
+    def download_generator_cotangents(self):
+        pr = self._problem
+        out = np.empty((self.batch, pr["N"] - 1, pr["n"], pr["n"]), dtype=np.complex128)
+        self._check(self._lib.qocx_download_generator_cotangents(self._ctx, _dp(out)))
+        return out
 
     def eval_resident(self, want_grad=True):
         self._check(self._lib.qocx_eval_resident(self._ctx, int(bool(want_grad))))

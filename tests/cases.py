@@ -39,6 +39,7 @@ class Case(object):
 
     def __init__(self, **kw):
         self.time_mod = None
+        self.quad = None  # [K x n x n] or None: + u_k^2 quad[k] (real) / |u_k|^2 quad[k] (complex)
         self.g_im = None
         self.magnus = "M2"
         self.cost_eval_step = 1
@@ -47,7 +48,7 @@ class Case(object):
 
     def hamiltonian(self):
         h0, g_re, g_im, omega = self.h0, self.g_re, self.g_im, self.time_mod
-        complex_controls = self.complex_controls
+        complex_controls, quad = self.complex_controls, self.quad
 
         def h(controls, time):
             base = h0 if omega is None else h0 * (1 + 0.3 * np.cos(omega * time))
@@ -59,6 +60,8 @@ class Case(object):
                     out = out + controls[k].real * g_re[k] + controls[k].imag * g_im[k]
                 else:
                     out = out + controls[k] * g_re[k]
+                if quad is not None:  # not linear in the controls: report.tex:22-32 (epsilon^2)
+                    out = out + (controls[k].real ** 2 + controls[k].imag ** 2) * quad[k]
             return out
         return h
 
@@ -228,8 +231,32 @@ def all_cases():
     return cases
 
 
+def opaque_cases():
+    """Hamiltonians that are NOT linear in the controls (the reference takes any callable,
+    schroedingerdiscrete.py:483-486; its design report names epsilon^2 terms, report.tex:22-32):
+    the engine's explicit-generator path. Real controls with u^2 terms (two states, Nc != N,
+    time-dependent drift) and a complex control with an |epsilon|^2 Stark shift, n = 20."""
+    real = case_random("opaque_eps2_real", n=6, N=31, seeds=2, h_seed=4401, S=2, K=2, Nc=9,
+                       dt=0.11, sigma=0.7, full_unitary=True)
+    rng = np.random.default_rng(4402)
+    real.quad = [0.8 * gue(rng, 6), -0.5 * gue(rng, 6)]
+    real.time_mod = 1.3
+    n = 20
+    rng = np.random.default_rng(4403)
+    a = annihilation(n)
+    ad = a.conj().T
+    cplx = Case(name="opaque_stark_complex", n=n, S=1, K=1, Nc=12, N=25, T=2.4,
+                h0=gue(rng, n) * 2.0, g_re=[(a + ad) / 4], g_im=[1j * (a - ad) / 4],
+                complex_controls=True, quad=[np.diag(np.linspace(-1.0, 1.0, n)).astype(complex)],
+                initial_states=column_states(np.eye(n)[:, :1]),
+                cost_specs=[("TargetStateInfidelity",
+                             dict(target_states=column_states(np.eye(n)[:, 1:2])))],
+                controls=_controls(4404, 2, 12, 1, True, 0.5))
+    return [real, cplx]
+
+
 def case_by_name(name):
-    for c in all_cases():
+    for c in all_cases() + opaque_cases():
         if c.name == name:
             return c
     raise KeyError(name)

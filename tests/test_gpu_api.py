@@ -177,3 +177,38 @@ def test_batch_grape_on_gpu_equals_eight_single_seed_runs():
     assert np.all(batch.best_error < 1.0) and np.all(batch.iterations_run == 6)
     # the optimisation does something
     assert batch.best.best_error < np.max(batch.best_error) or np.ptp(batch.best_error) == 0
+
+
+@pytest.mark.parametrize("name", ["opaque_eps2_real", "opaque_stark_complex"])
+def test_opaque_hamiltonian_on_gpu(name):
+    """a hamiltonian(controls, time) that is not linear in the controls (the
+    reference takes any callable; report.tex:22-32 names epsilon^2 terms). The host samples the
+    step generators, the engine takes them as they are (qocx_upload_generators) and returns their
+    cotangents. Gates: reference forward 1e-10, gradients 1e-8 vs AD of the same op sequence and
+    1e-7 vs finite differences of the reference forward (fixtures minted from the reference)."""
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    args = dict(cost_eval_step=case.cost_eval_step, costs=product_cost_list(case))
+    for b, u in enumerate(case.controls):
+        result = qoc_amd.evolve_schroedinger_discrete(
+            case.T, case.hamiltonian(), case.initial_states, case.N, controls=u, **args)
+        assert abs(result.error - g["error"][b]) < 1e-10
+        assert rel_err(result.final_states, g["final_states"][b]) < 1e-10
+    ev = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N, control_count=case.K,
+        control_eval_count=case.Nc, complex_controls=case.complex_controls,
+        costs=product_cost_list(case), cost_eval_step=case.cost_eval_step)
+    assert ev.opaque_hamiltonian is not None
+    errors, grads, finals, _ = ev.evaluate_batch(np.stack(case.controls), want_grad=True)
+    for b in range(len(case.controls)):
+        assert abs(errors[b] - g["error"][b]) < 1e-10
+        assert rel_err(grads[b], g["grads_ad"][b]) < 1e-8
+        scale = np.max(np.abs(g["grads_ad"][b]))
+        assert np.max(np.abs(np.asarray(grads[b]).flat[g["fd_index"][b]] - g["grads_fd"][b])) / scale < 1e-7
+    # and GRAPE runs on it: the error goes down, the controls respect their bounds
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(), case.initial_states,
+        case.N, complex_controls=case.complex_controls, initial_controls=case.controls[0].copy(),
+        iteration_count=8, log_iteration_step=0, optimizer=Adam(learning_rate=3e-2),
+        max_control_norms=np.full(case.K, 3.0))
+    assert result.best_error < g["error"][0] and result.best_iteration > 0

@@ -480,3 +480,50 @@ def test_batch_grape_per_seed_termination_conditions_and_errors():
         qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), optimizer=LBFGSB(), **base)
     with pytest.raises(ValueError):  # initial controls beyond max_control_norms
         qoc_amd.grape_schroedinger_discrete_batch(*args, 10 * u0, **base)
+
+
+# ---- opaque (non-linear) Hamiltonians: host-side sampling and gradient assembly -----------------
+
+def test_opaque_interpolation_matches_reference_rule():
+    g = golden("units")  # minted from the reference's interpolate_linear_set
+    xs, ys, xq = g["interp_xs"], g["interp_ys"], g["interp_xq"]
+    rows = structure.interpolation_rows(float(xs[-1]), len(xs), xq)
+    assert np.array_equal(structure.controls_at(ys, rows, xq), g["interp_out"])
+
+
+def test_opaque_generator_gradients_against_finite_differences():
+    """generator_gradients = the chain rule through M_j(u) = -i dt H(u(t_j), t_j): checked on a
+    cost that is an arbitrary smooth function of the generators, whose cotangents are known."""
+    case = cases_mod.case_by_name("opaque_stark_complex")
+    h = case.hamiltonian()
+    dt = case.T / (case.N - 1)
+    times = [j * dt + 0.5 * dt for j in range(case.N - 1)]
+    rows = structure.interpolation_rows(case.T, case.Nc, times)
+    rng = np.random.default_rng(8)
+    weights = rng.standard_normal((case.N - 1, case.n, case.n)) \
+        + 1j * rng.standard_normal((case.N - 1, case.n, case.n))
+
+    def cost(u):  # sum_j |<W_j, M_j>|^2 : cotangent 2 <W_j, M_j> W_j
+        gens, _ = structure.sample_generators(h, u, rows, times, dt, case.n)
+        ip = np.sum(np.conj(weights) * gens, axis=(1, 2))
+        return float(np.sum(np.abs(ip) ** 2)), 2 * ip[:, None, None] * weights
+    u0 = case.controls[0]
+    _, bars = cost(u0)
+    grads = structure.generator_gradients(h, u0, rows, times, dt, bars, True)
+    for index in [(0, 0), (5, 0), (case.Nc - 1, 0)]:
+        for direction in (1.0, 1.0j):
+            step = 1e-5
+            up, dn = u0.copy(), u0.copy()
+            up[index] += step * direction
+            dn[index] -= step * direction
+            fd = (cost(up)[0] - cost(dn)[0]) / (2 * step)
+            ref = grads[index].real if direction == 1.0 else grads[index].imag
+            assert abs(fd - ref) < 1e-7 * max(1.0, abs(ref))
+
+
+def test_opaque_hamiltonian_needs_m2():
+    case = cases_mod.case_by_name("opaque_eps2_real")
+    with pytest.raises(NotImplementedError):
+        qoc_amd.evolve_schroedinger_discrete(
+            case.T, case.hamiltonian(), case.initial_states, case.N, controls=case.controls[0],
+            magnus_policy=MagnusPolicy.M4)

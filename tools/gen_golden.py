@@ -182,7 +182,7 @@ def main():
     only = sys.argv[1:]
     if not only or "units" in only:
         do_units()
-    for case in cases_mod.all_cases():
+    for case in cases_mod.all_cases() + cases_mod.opaque_cases():
         if only and case.name not in only:
             continue
         big = case.n * case.N > 4000

@@ -159,6 +159,10 @@ def ad_eval(case, controls_np):
                 h = h + torch.real(u[k]) * g_re[k] + torch.imag(u[k]) * g_im[k]
             else:
                 h = h + u[k] * g_re[k]
+            if getattr(case, "quad", None) is not None:  # tests/cases.py Case.hamiltonian
+                mod2 = (torch.real(u[k]) ** 2 + torch.imag(u[k]) ** 2) if case.complex_controls \
+                    else u[k] ** 2
+                h = h + mod2 * torch.tensor(case.quad[k], dtype=C)
         return -1j * h
 
     states = torch.tensor(case.initial_states, dtype=C)
