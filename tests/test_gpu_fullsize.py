@@ -96,3 +96,48 @@ def test_rccl_single_rank(setup):
     total, grad = parallel.summed_cost_and_gradient(np.ones(3), np.ones((3, 5, 2)), comm)
     assert total == 3.0 and np.array_equal(grad, 3 * np.ones((5, 2)))
     engine.comm_destroy()
+
+
+def _device_count():
+    import ctypes
+    from qoc_amd import engine as eng
+    count = ctypes.c_int(0)
+    return count.value if eng.load_library().qocx_device_count(ctypes.byref(count)) == 0 else 0
+
+
+def test_two_gpu_bench_equals_two_single_gpu_runs(tmp_path):
+    """keep the N > 1 path launch ready. Runs bench.py --gpus 2 under
+    torch.distributed.run (one process per GPU, RCCL all-reduce of [sum cost, sum gradient]) and
+    checks its summed cost / gradient norm against the two single-GPU evaluations of the same
+    seed blocks. Skipped where fewer than two GPUs are visible (the driver's 8-GPU node runs it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QOCX_RDZV_DIR=str(tmp_path))
+    seeds = 16
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--seeds-per-gpu", str(seeds),
+           "--no-cpu-baseline", "--no-secondary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    # the same 2 x 16 seeds on one GPU: rank r evaluates seeds [16 r, 16 r + 16)
+    import bench
+    from qoc_amd.engine import Engine, COST_TARGET_COHERENT
+    engine = Engine(0)
+    h0, g, psi0, target = bench.make_problem()
+    engine.set_schroedinger_problem(
+        bench.DIM, 1, bench.K_CTRL, bench.N_EVAL, bench.N_EVAL, bench.DT * (bench.N_EVAL - 1),
+        h0[None], np.stack(g)[None], psi0,
+        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+    cost, grads, _ = engine.evaluate(bench.make_controls(0, 2 * seeds), True)
+    engine.close()
+    total_grad = (grads[:seeds].sum(axis=0) + grads[seeds:].sum(axis=0))
+    assert abs(line["check"]["sum_cost"] - cost.sum()) < 1e-9
+    assert abs(line["check"]["grad_l2"] - np.linalg.norm(total_grad)) < 1e-9
