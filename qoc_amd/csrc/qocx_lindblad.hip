@@ -53,7 +53,7 @@ struct Slot {
 // MW: several wavefronts work on one seed - wave 0 the generator terms A_L y + y A_R, wave 1 + i
 // the term of Lindblad operator i, the last wave the control cotangents of the adjoint - and
 // exchange their partial right-hand sides through LDS (two workgroup barriers per stage).
-template <int LNB, bool GS, bool MW>
+template <int LNB, bool GS, bool MW, bool RG = false>
 struct LB {
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                               // C-layout register tiles
@@ -61,6 +61,8 @@ static constexpr int MAT = 256 * LNB * LNB;          // complex elements of one 
 static constexpr int LPLANE = LG::PLANE;             // doubles per LDS plane
 static constexpr int SLOT_BYTES = 2 * LPLANE * 8;    // planar left-operand slot
 static constexpr int DUMP_BYTES = MAT * 16;          // C-layout dump of one matrix (lane-linear)
+// register-resident stage loops: one tile per matrix, densities in LDS
+static constexpr bool REG = RG && (LNB == 1) && !GS;
 
 static __device__ __forceinline__ Slot slot_at(char* base) {
     Slot s;
@@ -283,7 +285,7 @@ static __host__ __device__ int lds_bytes(int S, int nops, int cached_controls = 
     // cached_controls = K >= 0) copies of the constant generator dumps A0L A0R A0L^H A0R^H and
     // Gp Gp^H Gp^T per control
     const int slots = MW ? (2 + nops + 2) : 3;
-    return slots * SLOT_BYTES + nops * SLOT_BYTES + (MW ? waves(nops) * DUMP_BYTES : 0) +
+    return slots * SLOT_BYTES + nops * SLOT_BYTES + (MW ? 2 * waves(nops) * DUMP_BYTES : 0) +
            (GS ? 0 : (2 * S + STAGES) * DUMP_BYTES) +
            (cached_controls >= 0 ? (4 + 3 * cached_controls) * DUMP_BYTES : 0);
 }
@@ -388,6 +390,172 @@ struct Wave {
             }
         } else {
             out = acc;
+        }
+    }
+
+    // ---- register-resident stages (n <= 16, stage values kept in HBM, constant H0 / G_k) ------
+    // Inside one sub-interval the controls are linear in time, so the generators of its 12
+    // stages are A(c) = A_a + c dA: built ONCE per sub-interval (3 matrices = 48 registers) instead
+    // of 2 + K dump loads and axpys per stage.
+    // (kept as three LDS dumps in kdump[0..2], which the register-resident loops leave unused:
+    // 48 registers less per wave; only the first wave reads them)
+    struct GenLin {
+        double2* d;  // la | ld | ra : left(c) = la + c ld, right(c) = ra - c ld
+    };
+    __device__ __forceinline__ void build_linear(const SubStep& ss, bool adjoint, GenLin& out) const {
+        struct { Mat la, ld, ra; } g;
+        out.d = kdump;
+        dump_load(g.la, adjoint ? c_a0ld : c_a0l);
+        dump_load(g.ra, adjoint ? c_a0rd : c_a0r);
+        mat_zero(g.ld);
+        const int K = a.K;
+        for (int k = 0; k < K; ++k) {
+            const double ua = ss.wa1 * ctl_b[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl_b[(size_t)ss.ia2 * K + k];
+            const double ub = ss.wb1 * ctl_b[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl_b[(size_t)ss.ib2 * K + k];
+            Mat gk;
+            dump_load(gk, (adjoint ? c_gpd : c_gp) + (size_t)k * MAT);
+            mat_axpy(g.la, ua, gk);
+            mat_axpy(g.ra, -ua, gk);
+            mat_axpy(g.ld, ub - ua, gk);
+        }
+        wave_sync();
+        dump_store(g.la, out.d);
+        dump_store(g.ld, out.d + MAT);
+        dump_store(g.ra, out.d + 2 * (size_t)MAT);
+        wave_sync();
+    }
+
+    // rhs_split with the generator from `gen` and the partial sums in the `parity` set of `parts`
+    // (two sets: ONE workgroup barrier per stage instead of two)
+    template <bool ADJ>
+    __device__ __forceinline__ void rhs_lin(Mat& out, const Mat& y, const GenLin& gen, double c,
+                                            int parity) const {
+        Mat acc;
+        mat_zero(acc);
+        if (first()) {
+            Mat gl, gr, gd;
+            dump_load(gl, gen.d);
+            dump_load(gd, gen.d + MAT);
+            dump_load(gr, gen.d + 2 * (size_t)MAT);
+            mat_axpy(gl, c, gd);
+            mat_axpy(gr, -c, gd);
+            wave_sync();
+            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
+            cmat_to_lds<LNB>(y, slot_y.re, slot_y.im);
+            wave_sync();
+            gemm<false>(acc, slot_gen, y);
+            gemm<false>(acc, slot_y, gr);
+        }
+        for (int i = 0; i < a.nops; ++i) {
+            if (MW && wv != 1 + i) continue;
+            Mat t, opr;
+            mat_zero(t);
+            const Slot op = slot_at(op_planar + (size_t)i * SLOT_BYTES);
+            gemm<ADJ>(t, op, y);
+            cmat_scale<LNB>(t, a.gammas[i]);
+            wave_sync();
+            cmat_to_lds<LNB>(t, slot_tmp.re, slot_tmp.im);
+            wave_sync();
+            if (ADJ) load_plain(opr, op);
+            else load_adjoint(opr, op);
+            gemm<false>(acc, slot_tmp, opr);
+        }
+        wave_sync();
+        if (MW) {
+            double2* set = parts + (size_t)parity * nwaves * MAT;
+            if (wv < nwaves - 1) dump_store(acc, set + (size_t)wv * MAT);
+            __syncthreads();
+            mat_zero(out);
+            for (int w = 0; w < nwaves - 1; ++w) {
+                Mat p;
+                dump_load(p, set + (size_t)w * MAT);
+                mat_axpy(out, 1.0, p);
+            }
+        } else {
+            out = acc;
+        }
+    }
+
+    // forward sub-interval, the 12 stage derivatives in registers (192 of them at n <= 16); the
+    // stage loop is unrolled and the zeros of the tableau vanish at compile time
+    __device__ __forceinline__ void substep_reg(const SubStep& ss, Mat& y0, double2* ystore) const {
+        Mat k[STAGES];
+        GenLin gen{kdump};
+        if (first()) build_linear(ss, false, gen);
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            Mat y = y0;
+#pragma unroll
+            for (int j = 0; j < i; ++j)
+                if (QOCX_RK_A[i][j] != 0.0) mat_axpy(y, ss.h * QOCX_RK_A[i][j], k[j]);
+            if (ystore != nullptr && first()) dump_store(y, ystore + (size_t)i * MAT);
+            rhs_lin<false>(k[i], y, gen, QOCX_RK_C[i], i & 1);
+            __builtin_amdgcn_sched_barrier(0);  // one stage at a time (register pressure)
+        }
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i)
+            if (QOCX_RK_B[i] != 0.0) mat_axpy(y0, ss.h * QOCX_RK_B[i], k[i]);
+    }
+
+    // its discrete adjoint, the 12 Ybar_j in registers, the stage values Y_i from `ystore`
+    __device__ __forceinline__ void adjoint_substep_reg(const SubStep& ss, const Mat& lambda,
+                                                        Mat& lambda_new,
+                                                        double (&ga)[QOCX_LINDBLAD_MAX_K],
+                                                        double (&gb)[QOCX_LINDBLAD_MAX_K],
+                                                        const double2* ystore) const {
+        Mat yb[STAGES];
+        GenLin gen{kdump};
+        if (first()) build_linear(ss, true, gen);
+#pragma unroll
+        for (int ii = 0; ii < STAGES; ++ii) {
+            constexpr int LAST = STAGES - 1;
+            const int i = LAST - ii;
+            // kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j)
+            Mat kb;
+            mat_zero(kb);
+            if (QOCX_RK_B[LAST - ii] != 0.0) mat_axpy(kb, ss.h * QOCX_RK_B[LAST - ii], lambda);
+#pragma unroll
+            for (int jj = 0; jj < ii; ++jj)  // j = LAST - jj > i
+                if (QOCX_RK_A[LAST - jj][LAST - ii] != 0.0)
+                    mat_axpy(kb, ss.h * QOCX_RK_A[LAST - jj][LAST - ii], yb[LAST - jj]);
+            const double ci = QOCX_RK_C[LAST - ii];
+            rhs_lin<true>(yb[LAST - ii], kb, gen, ci, ii & 1);
+            mat_axpy(lambda_new, 1.0, yb[LAST - ii]);
+            if (z_wave()) {
+                // control cotangent of this stage: Re tr(Z Gp_k), Z = Y kbar^H - kbar^H Y
+                Mat y, kbd, z, z2;
+                dump_load(y, ystore + (size_t)i * MAT);
+                wave_sync();
+                if (MW) cmat_to_lds<LNB>(kb, slot_zk.re, slot_zk.im);  // (single wave: slot_y
+                wave_sync();                                          //  still holds kbar)
+                load_adjoint(kbd, slot_zk);
+                mat_zero(z2);
+                gemm<true>(z2, slot_zk, y);  // kbar^H Y
+                wave_sync();
+                cmat_to_lds<LNB>(y, slot_zy.re, slot_zy.im);
+                wave_sync();
+                mat_zero(z);
+                gemm<false>(z, slot_zy, kbd);  // Y kbar^H
+                mat_axpy(z, -1.0, z2);
+                const int K = a.K;
+                for (int k = 0; k < K; ++k) {
+                    Mat gt;
+                    dump_load(gt, c_gpt + (size_t)k * MAT);
+                    double pr = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                    const double g = wave_sum(pr);
+#pragma unroll
+                    for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                        if (kk == k) {
+                            ga[kk] += (1.0 - ci) * g;
+                            gb[kk] += ci * g;
+                        }
+                }
+                wave_sync();
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -529,8 +697,8 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         slot_zy = slot_tmp;
     }
     char* op_planar = p; p += (size_t)nops * SLOT_BYTES;     // L_i
-    double2* parts = reinterpret_cast<double2*>(p);
-    if (MW) p += (size_t)nwaves * DUMP_BYTES;
+    double2* parts = reinterpret_cast<double2*>(p);  // MW: two sets (stage parity)
+    if (MW) p += 2 * (size_t)nwaves * DUMP_BYTES;
     double2 *dens, *lam, *kdump;
     if (GS) {  // per-seed HBM scratch: S densities | S cotangents | STAGES stage derivatives
         dens = a.scratch + (size_t)b * (2 * S + STAGES) * MAT;
@@ -612,10 +780,13 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             Mat y0;
             dump_load(y0, dens + (size_t)s * MAT);
             if (lead) dump_store(y0, ckpt_b + ((size_t)q * S + s) * MAT);
-            w.substep(ss, q, y0, true,
-                      a.ystages != nullptr
-                          ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
-                          : nullptr);
+            double2* ys = a.ystages != nullptr
+                              ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
+                              : nullptr;
+            if (REG && a.a0_tab == nullptr && a.gp_tab == nullptr)
+                w.substep_reg(ss, y0, ys);  // (ys == nullptr: forward only, or the adjoint recomputes)
+            else
+                w.substep(ss, q, y0, true, ys);
             wave_sync();
             if (lead) dump_store(y0, dens + (size_t)s * MAT);
             block_sync();
@@ -679,7 +850,10 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
-            w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
+            if (REG && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
+                w.adjoint_substep_reg(ss, lambda, lambda_new, ga, gb, ys);
+            else
+                w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
             block_sync();  // every wave has read lambda
             if (lead) dump_store(lambda_new, lam + (size_t)s * MAT);
             block_sync();
@@ -709,20 +883,22 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 }
 };  // struct LB
 
-template <int LNB, bool GS, bool MW>
-__global__ __launch_bounds__(MW ? 384 : 64) void lindblad_kernel(LindbladArgs a) {
+// MW4: the multi-wave form with at most four wavefronts (nops <= 2): one per SIMD, so each may
+// use the whole register file (the register-resident stage loops need ~350)
+template <int LNB, bool GS, bool MW, bool MW4>
+__global__ __launch_bounds__(MW ? (MW4 ? 256 : 384) : 64) void lindblad_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LB<LNB, GS, MW>::run(a, smem);
+    LB<LNB, GS, MW, (LNB == 1 && !GS && (!MW || MW4))>::run(a, smem);
 }
 
-template <int LNB, bool GS, bool MW>
+template <int LNB, bool GS, bool MW, bool MW4 = false>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
     typedef LB<LNB, GS, MW> I;
     const int bytes = I::lds_bytes(a.S, a.nops, (MW && a.cache_gen) ? a.K : -1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW>), dim3(batch), dim3(64 * I::waves(a.nops)),
-                       bytes, st, a);
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4>), dim3(batch),
+                       dim3(64 * I::waves(a.nops)), bytes, st, a);
 }
 
 }  // namespace
@@ -730,6 +906,7 @@ void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
+    else if (a.multi_wave && a.nops <= 2) launch_t<1, false, true, true>(a, batch, st);
     else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
     else launch_t<1, false, false>(a, batch, st);
 }
