@@ -1675,6 +1675,13 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.final_out = lb.final_out.p + pos0 * S * md;
             la.step_densities = ctx->keep_step_states
                                     ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
+            la.stamps = nullptr;
+            if (ctx->knob("lindblad_stamps", 0)) {
+                if (ctx->stamps.ensure((size_t)B * 48)) return QOCX_ERR_HIP;
+                HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, (size_t)B * 48 * sizeof(unsigned long long),
+                                       ctx->stream));
+                la.stamps = ctx->stamps.p + pos0 * 48;
+            }
             la.inj_count = lb.inj_count;
             la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
             la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * md : nullptr;
@@ -1727,7 +1734,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
-                                  "sweep3_phases"};
+                                  "sweep3_phases", "lindblad_stamps"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

@@ -189,6 +189,7 @@ struct LindbladArgs {
     const int* inj_index;      // host-supplied density cotangents (see SweepArgs): [nsteps + 1]
     const double2* inj_bars;   // [B][inj_count][S] C-dumps
     int inj_count;
+    unsigned long long* stamps;  // diagnostic build: [B][6 waves][8] cycle sums, or nullptr
 };
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);

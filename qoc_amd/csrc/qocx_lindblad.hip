@@ -53,7 +53,7 @@ struct Slot {
 // MW: several wavefronts work on one seed - wave 0 the generator terms A_L y + y A_R, wave 1 + i
 // the term of Lindblad operator i, the last wave the control cotangents of the adjoint - and
 // exchange their partial right-hand sides through LDS (two workgroup barriers per stage).
-template <int LNB, bool GS, bool MW, bool RG = false>
+template <int LNB, bool GS, bool MW, bool RG = false, bool STAMP = false, bool QP = false>
 struct LB {
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                               // C-layout register tiles
@@ -63,6 +63,8 @@ static constexpr int SLOT_BYTES = 2 * LPLANE * 8;    // planar left-operand slot
 static constexpr int DUMP_BYTES = MAT * 16;          // C-layout dump of one matrix (lane-linear)
 // register-resident stage loops: one tile per matrix, densities in LDS
 static constexpr bool REG = RG && (LNB == 1) && !GS;
+// four waves with a quarter of every stage vector each (nops = 2)
+static constexpr bool QUARTER = QP && MW && (LNB == 1) && !GS;
 
 static __device__ __forceinline__ Slot slot_at(char* base) {
     Slot s;
@@ -308,6 +310,7 @@ struct Wave {
     const double* ctl_b;
     // constant generator dumps: the HBM images, or their copies in LDS (MW with room to spare)
     const double2 *c_a0l, *c_a0r, *c_a0ld, *c_a0rd, *c_gp, *c_gpd, *c_gpt;
+    StampClock<STAMP>* clk;  // diagnostic build: cycles per phase of a stage (this wave)
 
     __device__ __forceinline__ bool first() const { return !MW || wv == 0; }
     __device__ __forceinline__ bool z_wave() const { return !MW || wv == nwaves - 1; }
@@ -427,11 +430,14 @@ struct Wave {
 
     // rhs_split with the generator from `gen` and the partial sums in the `parity` set of `parts`
     // (two sets: ONE workgroup barrier per stage instead of two)
+    // `opr` (multi-wave form): the right-operand image of THIS wave's operator (L^H forward, L
+    // adjoint), loaded once per sub-interval instead of once per stage
     template <bool ADJ>
     __device__ __forceinline__ void rhs_lin(Mat& out, const Mat& y, const GenLin& gen, double c,
-                                            int parity) const {
+                                            int parity, const Mat& opr_mw) const {
         Mat acc;
         mat_zero(acc);
+        clk->lap(0);  // stage value (axpys), kbar
         if (first()) {
             Mat gl, gr, gd;
             dump_load(gl, gen.d);
@@ -443,8 +449,10 @@ struct Wave {
             cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
             cmat_to_lds<LNB>(y, slot_y.re, slot_y.im);
             wave_sync();
+            clk->lap(1);  // generator of the stage, operands to LDS
             gemm<false>(acc, slot_gen, y);
             gemm<false>(acc, slot_y, gr);
+            clk->lap(2);  // products
         }
         for (int i = 0; i < a.nops; ++i) {
             if (MW && wv != 1 + i) continue;
@@ -456,24 +464,237 @@ struct Wave {
             wave_sync();
             cmat_to_lds<LNB>(t, slot_tmp.re, slot_tmp.im);
             wave_sync();
-            if (ADJ) load_plain(opr, op);
-            else load_adjoint(opr, op);
-            gemm<false>(acc, slot_tmp, opr);
+            clk->lap(1);
+            if (MW) {
+                gemm<false>(acc, slot_tmp, opr_mw);
+                clk->lap(2);
+            } else {
+                if (ADJ) load_plain(opr, op);
+                else load_adjoint(opr, op);
+                gemm<false>(acc, slot_tmp, opr);
+            }
         }
         wave_sync();
         if (MW) {
             double2* set = parts + (size_t)parity * nwaves * MAT;
             if (wv < nwaves - 1) dump_store(acc, set + (size_t)wv * MAT);
+            clk->lap(3);  // partial result to LDS
             __syncthreads();
+            clk->lap(4);  // barrier
             mat_zero(out);
             for (int w = 0; w < nwaves - 1; ++w) {
                 Mat p;
                 dump_load(p, set + (size_t)w * MAT);
                 mat_axpy(out, 1.0, p);
             }
+            clk->lap(5);  // sum of the partial results
         } else {
             out = acc;
         }
+    }
+
+    // ---- four waves, each a QUARTER of every stage vector -----------------------------------
+    // (nops = 2: waves = generator | operator 1 | operator 2 | control cotangents.) The stamps of
+    // the register-resident loops (tools/lindblad_stamps.py, profiles/r02_lindblad_stamps_*.json)
+    // show a third of a stage going into the Runge-Kutta combinations y_i = y0 + h sum a_ij k_j:
+    // every wave formed all of them, from 192 registers of k_j that only fit as AGPRs (16 copies
+    // per use). Here wave w keeps component w of the C-layout registers of every k_j (one complex
+    // per lane: 48 registers for the 12 of them), forms its quarter of y_i, and the four quarters
+    // meet in one LDS dump that every wave reads back whole: two workgroup barriers per stage.
+    __device__ __forceinline__ static void quarter_of(const Mat& m, int w, double& re, double& im) {
+        re = w == 0 ? m.re[0][0][0] : w == 1 ? m.re[0][0][1] : w == 2 ? m.re[0][0][2] : m.re[0][0][3];
+        im = w == 0 ? m.im[0][0][0] : w == 1 ? m.im[0][0][1] : w == 2 ? m.im[0][0][2] : m.im[0][0][3];
+    }
+    // the products of one right-hand side that belong to this wave -> acc
+    template <bool ADJ>
+    __device__ __forceinline__ void rhs_products(Mat& acc, const Mat& y, const GenLin& gen, double c,
+                                                 const Mat& opr_mw) const {
+        mat_zero(acc);
+        if (wv == 0) {
+            Mat gl, gr, gd;
+            dump_load(gl, gen.d);
+            dump_load(gd, gen.d + MAT);
+            dump_load(gr, gen.d + 2 * (size_t)MAT);
+            mat_axpy(gl, c, gd);
+            mat_axpy(gr, -c, gd);
+            wave_sync();
+            cmat_to_lds<LNB>(gl, slot_gen.re, slot_gen.im);
+            cmat_to_lds<LNB>(y, slot_y.re, slot_y.im);
+            wave_sync();
+            clk->lap(1);
+            gemm<false>(acc, slot_gen, y);
+            gemm<false>(acc, slot_y, gr);
+            clk->lap(2);
+        } else if (wv <= a.nops) {
+            Mat t;
+            mat_zero(t);
+            const Slot op = slot_at(op_planar + (size_t)(wv - 1) * SLOT_BYTES);
+            gemm<ADJ>(t, op, y);
+            cmat_scale<LNB>(t, a.gammas[wv - 1]);
+            wave_sync();
+            cmat_to_lds<LNB>(t, slot_tmp.re, slot_tmp.im);
+            wave_sync();
+            clk->lap(1);
+            gemm<false>(acc, slot_tmp, opr_mw);
+            clk->lap(2);
+        }
+    }
+    // this wave's component of sum_w parts[w] (the three waves that own products)
+    __device__ __forceinline__ void sum_quarter(double& re, double& im) const {
+        const int lane = lane_id();
+        re = 0;
+        im = 0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const double2 e = parts[(size_t)w * MAT + wv * 64 + lane];
+            re += e.x;
+            im += e.y;
+        }
+    }
+
+    __device__ __forceinline__ void substep_q(const SubStep& ss, Mat& y0, double2* ystore) const {
+        const int lane = lane_id();
+        double2* ybuf = kdump + 3 * (size_t)MAT;  // kdump[0..2]: the linear generator
+        double kr[STAGES], ki[STAGES];
+        GenLin gen{kdump};
+        if (wv == 0) build_linear(ss, false, gen);
+        Mat opr;
+        mat_zero(opr);
+        if (wv >= 1 && wv <= a.nops)
+            load_adjoint(opr, slot_at(op_planar + (size_t)(wv - 1) * SLOT_BYTES));
+        double y0r, y0i;
+        quarter_of(y0, wv, y0r, y0i);
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            double yr = y0r, yi = y0i;
+#pragma unroll
+            for (int j = 0; j < i; ++j)  // kr / ki hold h k_j: the tableau entries stay literals
+                if (QOCX_RK_A[i][j] != 0.0) {
+                    yr = fma(QOCX_RK_A[i][j], kr[j], yr);
+                    yi = fma(QOCX_RK_A[i][j], ki[j], yi);
+                }
+            ybuf[wv * 64 + lane] = make_double2(yr, yi);
+            clk->lap(0);
+            __syncthreads();
+            clk->lap(4);
+            Mat y, acc;
+            dump_load(y, ybuf);
+            if (ystore != nullptr && wv == 3) dump_store(y, ystore + (size_t)i * MAT);
+            rhs_products<false>(acc, y, gen, QOCX_RK_C[i], opr);
+            if (wv < 3) dump_store(acc, parts + (size_t)wv * MAT);
+            clk->lap(3);
+            __syncthreads();
+            clk->lap(4);
+            sum_quarter(kr[i], ki[i]);
+            kr[i] *= ss.h;
+            ki[i] *= ss.h;
+            clk->lap(5);
+        }
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i)
+            if (QOCX_RK_B[i] != 0.0) {
+                y0r = fma(QOCX_RK_B[i], kr[i], y0r);
+                y0i = fma(QOCX_RK_B[i], ki[i], y0i);
+            }
+        ybuf[wv * 64 + lane] = make_double2(y0r, y0i);
+        __syncthreads();
+        dump_load(y0, ybuf);
+        __syncthreads();  // ybuf is free again
+    }
+
+    __device__ __forceinline__ void adjoint_substep_q(const SubStep& ss, const Mat& lambda,
+                                                      Mat& lambda_new,
+                                                      double (&ga)[QOCX_LINDBLAD_MAX_K],
+                                                      double (&gb)[QOCX_LINDBLAD_MAX_K],
+                                                      const double2* ystore) const {
+        const int lane = lane_id();
+        double2* ybuf = kdump + 3 * (size_t)MAT;
+        double br[STAGES], bi[STAGES];  // this wave's component of every Ybar_j
+        GenLin gen{kdump};
+        if (wv == 0) build_linear(ss, true, gen);
+        Mat opr;
+        mat_zero(opr);
+        if (wv >= 1 && wv <= a.nops)
+            load_plain(opr, slot_at(op_planar + (size_t)(wv - 1) * SLOT_BYTES));
+        double lr, li;
+        quarter_of(lambda, wv, lr, li);
+        double nr = lr, ni = li;  // lambda_new = lambda + sum_i Ybar_i
+        const double hlr = ss.h * lr, hli = ss.h * li;  // br / bi hold h Ybar_j
+#pragma unroll
+        for (int ii = 0; ii < STAGES; ++ii) {
+            constexpr int LAST = STAGES - 1;
+            const int i = LAST - ii;
+            // kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j)
+            double kbr = 0, kbi = 0;
+            if (QOCX_RK_B[LAST - ii] != 0.0) {
+                kbr = QOCX_RK_B[LAST - ii] * hlr;
+                kbi = QOCX_RK_B[LAST - ii] * hli;
+            }
+#pragma unroll
+            for (int jj = 0; jj < ii; ++jj)
+                if (QOCX_RK_A[LAST - jj][LAST - ii] != 0.0) {
+                    kbr = fma(QOCX_RK_A[LAST - jj][LAST - ii], br[LAST - jj], kbr);
+                    kbi = fma(QOCX_RK_A[LAST - jj][LAST - ii], bi[LAST - jj], kbi);
+                }
+            ybuf[wv * 64 + lane] = make_double2(kbr, kbi);
+            clk->lap(0);
+            __syncthreads();
+            clk->lap(4);
+            Mat kb, acc;
+            dump_load(kb, ybuf);
+            const double ci = QOCX_RK_C[LAST - ii];
+            if (wv < 3) {
+                rhs_products<true>(acc, kb, gen, ci, opr);
+                dump_store(acc, parts + (size_t)wv * MAT);
+                clk->lap(3);
+            } else {
+                // control cotangent of this stage, beside the other waves' products:
+                // Re tr(Z Gp_k), Z = Y kbar^H - kbar^H Y
+                Mat y, kbd, z, z2;
+                dump_load(y, ystore + (size_t)i * MAT);
+                wave_sync();
+                cmat_to_lds<LNB>(kb, slot_zk.re, slot_zk.im);
+                wave_sync();
+                load_adjoint(kbd, slot_zk);
+                mat_zero(z2);
+                gemm<true>(z2, slot_zk, y);  // kbar^H Y
+                wave_sync();
+                cmat_to_lds<LNB>(y, slot_zy.re, slot_zy.im);
+                wave_sync();
+                mat_zero(z);
+                gemm<false>(z, slot_zy, kbd);  // Y kbar^H
+                mat_axpy(z, -1.0, z2);
+                const int K = a.K;
+                for (int k = 0; k < K; ++k) {
+                    Mat gt;
+                    dump_load(gt, c_gpt + (size_t)k * MAT);
+                    double pr = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                    const double g = wave_sum(pr);
+#pragma unroll
+                    for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                        if (kk == k) {
+                            ga[kk] += (1.0 - ci) * g;
+                            gb[kk] += ci * g;
+                        }
+                }
+                clk->lap(6);
+            }
+            __syncthreads();
+            clk->lap(4);
+            sum_quarter(br[LAST - ii], bi[LAST - ii]);
+            nr += br[LAST - ii];
+            ni += bi[LAST - ii];
+            br[LAST - ii] *= ss.h;
+            bi[LAST - ii] *= ss.h;
+            clk->lap(5);
+        }
+        ybuf[wv * 64 + lane] = make_double2(nr, ni);
+        __syncthreads();
+        dump_load(lambda_new, ybuf);
+        __syncthreads();
     }
 
     // forward sub-interval, the 12 stage derivatives in registers (192 of them at n <= 16); the
@@ -482,6 +703,10 @@ struct Wave {
         Mat k[STAGES];
         GenLin gen{kdump};
         if (first()) build_linear(ss, false, gen);
+        Mat opr;
+        mat_zero(opr);
+        if (MW && wv >= 1 && wv <= a.nops)
+            load_adjoint(opr, slot_at(op_planar + (size_t)(wv - 1) * SLOT_BYTES));
 #pragma unroll
         for (int i = 0; i < STAGES; ++i) {
             Mat y = y0;
@@ -489,7 +714,7 @@ struct Wave {
             for (int j = 0; j < i; ++j)
                 if (QOCX_RK_A[i][j] != 0.0) mat_axpy(y, ss.h * QOCX_RK_A[i][j], k[j]);
             if (ystore != nullptr && first()) dump_store(y, ystore + (size_t)i * MAT);
-            rhs_lin<false>(k[i], y, gen, QOCX_RK_C[i], i & 1);
+            rhs_lin<false>(k[i], y, gen, QOCX_RK_C[i], i & 1, opr);
             __builtin_amdgcn_sched_barrier(0);  // one stage at a time (register pressure)
         }
 #pragma unroll
@@ -506,6 +731,10 @@ struct Wave {
         Mat yb[STAGES];
         GenLin gen{kdump};
         if (first()) build_linear(ss, true, gen);
+        Mat opr;
+        mat_zero(opr);
+        if (MW && wv >= 1 && wv <= a.nops)
+            load_plain(opr, slot_at(op_planar + (size_t)(wv - 1) * SLOT_BYTES));
 #pragma unroll
         for (int ii = 0; ii < STAGES; ++ii) {
             constexpr int LAST = STAGES - 1;
@@ -519,7 +748,7 @@ struct Wave {
                 if (QOCX_RK_A[LAST - jj][LAST - ii] != 0.0)
                     mat_axpy(kb, ss.h * QOCX_RK_A[LAST - jj][LAST - ii], yb[LAST - jj]);
             const double ci = QOCX_RK_C[LAST - ii];
-            rhs_lin<true>(yb[LAST - ii], kb, gen, ci, ii & 1);
+            rhs_lin<true>(yb[LAST - ii], kb, gen, ci, ii & 1, opr);
             mat_axpy(lambda_new, 1.0, yb[LAST - ii]);
             if (z_wave()) {
                 // control cotangent of this stage: Re tr(Z Gp_k), Z = Y kbar^H - kbar^H Y
@@ -554,6 +783,7 @@ struct Wave {
                         }
                 }
                 wave_sync();
+                clk->lap(6);  // control cotangents of the stage
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -756,9 +986,11 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         c_gp = cache + 4 * (size_t)MAT; c_gpd = c_gp + (size_t)K * MAT; c_gpt = c_gpd + (size_t)K * MAT;
         block_sync();
     }
+    StampClock<STAMP> clock;
+    clock.start();
     const Wave w{a, wv, nwaves, slot_gen, slot_y, slot_tmp, slot_zk, slot_zy, op_planar, parts,
                  kdump, a.controls + (size_t)b * a.nc * K,
-                 c_a0l, c_a0r, c_a0ld, c_a0rd, c_gp, c_gpd, c_gpt};
+                 c_a0l, c_a0r, c_a0ld, c_a0rd, c_gp, c_gpd, c_gpt, &clock};
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
 
     // ---- forward ------------------------------------------------------------------------
@@ -783,7 +1015,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             double2* ys = a.ystages != nullptr
                               ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                               : nullptr;
-            if (REG && a.a0_tab == nullptr && a.gp_tab == nullptr)
+            if (QUARTER && a.a0_tab == nullptr && a.gp_tab == nullptr)
+                w.substep_q(ss, y0, ys);
+            else if (REG && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.substep_reg(ss, y0, ys);  // (ys == nullptr: forward only, or the adjoint recomputes)
             else
                 w.substep(ss, q, y0, true, ys);
@@ -805,7 +1039,10 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
                                     (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
         }
     }
-    if (!a.want_grad) return;
+    if (!a.want_grad) {
+        clock.finish(a.stamps, 6, wv);
+        return;
+    }
 
     // ---- discrete adjoint ----------------------------------------------------------------
     // lambda += host-supplied cotangent of the densities at system step `step`, if there is one
@@ -850,7 +1087,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
-            if (REG && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
+            if (QUARTER && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
+                w.adjoint_substep_q(ss, lambda, lambda_new, ga, gb, ys);
+            else if (REG && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.adjoint_substep_reg(ss, lambda, lambda_new, ga, gb, ys);
             else
                 w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
@@ -880,24 +1119,25 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             block_sync();
         }
     }
+    clock.finish(a.stamps, 6, wv);
 }
 };  // struct LB
 
-// MW4: the multi-wave form with at most four wavefronts (nops <= 2): one per SIMD, so each may
-// use the whole register file (the register-resident stage loops need ~350)
-template <int LNB, bool GS, bool MW, bool MW4>
+// MW4: the multi-wave form with exactly four wavefronts (nops = 2), one per SIMD: the
+// quarter-split stage loops
+template <int LNB, bool GS, bool MW, bool MW4, bool STAMP = false>
 __global__ __launch_bounds__(MW ? (MW4 ? 256 : 384) : 64) void lindblad_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LB<LNB, GS, MW, (LNB == 1 && !GS && (!MW || MW4))>::run(a, smem);
+    LB<LNB, GS, MW, (LNB == 1 && !GS && !MW), STAMP, MW4>::run(a, smem);
 }
 
-template <int LNB, bool GS, bool MW, bool MW4 = false>
+template <int LNB, bool GS, bool MW, bool MW4 = false, bool STAMP = false>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
     typedef LB<LNB, GS, MW> I;
     const int bytes = I::lds_bytes(a.S, a.nops, (MW && a.cache_gen) ? a.K : -1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4, STAMP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4>), dim3(batch),
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4, STAMP>), dim3(batch),
                        dim3(64 * I::waves(a.nops)), bytes, st, a);
 }
 
@@ -906,7 +1146,9 @@ void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
-    else if (a.multi_wave && a.nops <= 2) launch_t<1, false, true, true>(a, batch, st);
+    else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr)
+        launch_t<1, false, true, true, true>(a, batch, st);  // diagnostic build (in-kernel stamps)
+    else if (a.multi_wave && a.nops == 2) launch_t<1, false, true, true>(a, batch, st);
     else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
     else launch_t<1, false, false>(a, batch, st);
 }

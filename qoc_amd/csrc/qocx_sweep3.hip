@@ -201,44 +201,6 @@ __device__ __forceinline__ void invert_blocks(const char* slot, char* inv, int l
         *reinterpret_cast<double2*>(dst + (UPPER ? -i : i) * (17 * 16)) = make_double2(xre[i], xim[i]);
 }
 
-// In-kernel stamps (diagnostic build of the kernel only: STAMP = true, knob "sweep3_stamps"; the
-// product kernel executes none). Each role accumulates shader-clock cycles per phase of its loop
-// in scalar registers and stores the sums once at the end: args.stamps[seed][role][8] (+ the
-// 100 MHz real-time counter in slot 7, which gives the clock). cdna_hip_programming.md section 7.
-template <bool STAMP>
-struct S3Clock {
-    unsigned long long last, acc[8];
-    __device__ __forceinline__ void start() {
-        if constexpr (STAMP) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0;
-            __builtin_amdgcn_sched_barrier(0);
-            last = __builtin_amdgcn_s_memtime();
-            acc[7] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __device__ __forceinline__ void lap(int k) {  // k is a literal at every call site
-        if constexpr (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long now;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            acc[k] += now - last;
-            last = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __device__ __forceinline__ void finish(const SweepArgs& args, int role) {
-        if constexpr (STAMP) {
-            acc[7] = __builtin_amdgcn_s_memrealtime() - acc[7];
-            if (lane_id() == 0 && args.stamps != nullptr)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    atomicAdd(args.stamps + ((size_t)blockIdx.x * 4 + role) * 8 + k, acc[k]);
-        }
-    }
-};
-
 // What every role needs to walk the steps of a launch in lock step.
 struct S3Walk {
     size_t m0;      // first matrix of the seed
@@ -285,7 +247,7 @@ struct S3Subs {
 template <int NB, bool STAMP>
 __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w, char* smem,
                                           int slot) {
-    S3Clock<STAMP> clk;
+    StampClock<STAMP> clk;
     clk.start();
     typedef Geo<NB> G;
     typedef S3<NB> L;
@@ -367,7 +329,7 @@ __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w
         s3_barrier();  // A0
         (void)pass(true);
     }
-    clk.finish(args, 2);
+    clk.finish(args.stamps, 4, 2);
 }
 
 // ---- wave 1: inverter -----------------------------------------------------------------------
@@ -375,7 +337,7 @@ template <int NB, bool STAMP, bool UPPER>
 __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk& w, char* smem,
                                             int slot) {
     const int lane = lane_id();
-    S3Clock<STAMP> clk;
+    StampClock<STAMP> clk;
     clk.start();
     auto pass = [&](bool adjoint) {
         s3_barrier();  // P0
@@ -401,14 +363,14 @@ __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk&
         s3_barrier();  // A0
         (void)pass(true);
     }
-    clk.finish(args, UPPER ? 3 : 1);
+    clk.finish(args.stamps, 4, UPPER ? 3 : 1);
 }
 
 // ---- wave 0: compute ------------------------------------------------------------------------
 template <int NB, bool STAMP>
 __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& w, char* smem,
                                            int slot) {
-    S3Clock<STAMP> clk;
+    StampClock<STAMP> clk;
     clk.start();
     typedef Geo<NB> G;
     typedef S3<NB> L;
@@ -628,7 +590,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
         if (lane == 0) args.cost_out[b] = cost;
     }
     if (!w.do_bwd) {
-        clk.finish(args, 0);
+        clk.finish(args.stamps, 4, 0);
         return;
     }
 
@@ -733,7 +695,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
     if (jb > 0 && g0)
         for (int s = 0; s < S; ++s)
             args.lam_buf[((size_t)b * S + s) * NP + i] = lam[s * NP + i];
-    clk.finish(args, 0);
+    clk.finish(args.stamps, 4, 0);
 }
 
 template <int NB, bool STAMP>

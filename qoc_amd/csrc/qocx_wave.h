@@ -205,6 +205,46 @@ __device__ __forceinline__ double control_at(const double* ctl_b, const StepInte
 }
 
 
+// In-kernel stamps (diagnostic builds of a kernel only: STAMP = true, knobs "sweep3_stamps" /
+// "lindblad_stamps"; the product kernels execute none). Each role (wave) accumulates shader-clock cycles per phase of its loop
+// in scalar registers and stores the sums once at the end: args.stamps[seed][role][8] (+ the
+// 100 MHz real-time counter in slot 7, which gives the clock). cdna_hip_programming.md section 7.
+template <bool STAMP>
+struct StampClock {
+    unsigned long long last, acc[8];
+    __device__ __forceinline__ void start() {
+        if constexpr (STAMP) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0;
+            __builtin_amdgcn_sched_barrier(0);
+            last = __builtin_amdgcn_s_memtime();
+            acc[7] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __device__ __forceinline__ void lap(int k) {  // k is a literal at every call site
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long now;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            acc[k] += now - last;
+            last = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // stamps[workgroup][roles][8] += this wave's sums
+    __device__ __forceinline__ void finish(unsigned long long* stamps, int roles, int role) {
+        if constexpr (STAMP) {
+            acc[7] = __builtin_amdgcn_s_memrealtime() - acc[7];
+            if (lane_id() == 0 && stamps != nullptr)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    atomicAdd(stamps + ((size_t)blockIdx.x * roles + role) * 8 + k, acc[k]);
+        }
+    }
+};
+
+
 }  // namespace qocx
 
 #endif

@@ -489,9 +489,10 @@ class Engine(object):
         """Kernel-variant switch (include/qocx.h: qocx_debug_set_knob)."""
         self._check(self._lib.qocx_debug_set_knob(self._ctx, name.encode(), int(value)))
 
-    def read_stamps(self, batch):
-        """[batch][4 roles][8] cycle sums of the stamped sweep build (knob sweep3_stamps)."""
-        out = np.zeros((batch, 4, 8), dtype=np.uint64)
+    def read_stamps(self, batch, roles=4):
+        """[batch][roles][8] cycle sums of a stamped diagnostic kernel build (knobs sweep3_stamps:
+        4 roles; lindblad_stamps: 6 wavefronts)."""
+        out = np.zeros((batch, roles, 8), dtype=np.uint64)
         self._check(self._lib.qocx_debug_read_stamps(
             self._ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size))
         return out
