@@ -510,16 +510,30 @@ __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
         const unsigned long long bits =
             mine ? ((unsigned long long)__double_as_longlong(mag) + 1ull) : 0ull;
         const unsigned khi = (unsigned)(bits >> 32), klo = (unsigned)bits;
-        const unsigned mh = wave_max_u32(khi);
-        unsigned ml = 2u;  // only compared against 1 below unless the low words were needed
-        unsigned long long ball = __ballot(khi == mh);
-        if (__popcll(ball) > 1 || mh == 0u) {  // wave-uniform; rare: the high words tie
-            ml = wave_max_u32(khi == mh ? klo : 0u);
-            ball = __ballot(khi == mh && klo == ml);
+        // Fast path: row k itself is the pivot row whenever it is still unpivoted and no other
+        // candidate has a STRICTLY larger |re|+|im| (izamax takes the first maximum, and k is the
+        // smallest unpivoted index then). One broadcast, one compare, one ballot instead of the
+        // max-reduction; for the Pade denominators of well-scaled generators (P ~ b0 (I - a/2))
+        // that is every step. Same pivot, same arithmetic: bit-identical factors.
+        const int diag_lane = hk * NP + k;
+        const unsigned long long dbits =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, diag_lane) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)klo, diag_lane);
+        int lp;
+        if (dbits > 1ull && __ballot(bits > dbits) == 0ull) {  // wave-uniform
+            lp = diag_lane;
+        } else {
+            const unsigned mh = wave_max_u32(khi);
+            unsigned ml = 2u;  // only compared against 1 below unless the low words were needed
+            unsigned long long ball = __ballot(khi == mh);
+            if (__popcll(ball) > 1 || mh == 0u) {  // wave-uniform; rare: the high words tie
+                ml = wave_max_u32(khi == mh ? klo : 0u);
+                ball = __ballot(khi == mh && klo == ml);
+            }
+            lp = __ffsll((long long)ball) - 1;  // a lane of group hk, never -1
+            singular = singular || (mh == 0u && ml <= 1u);
         }
-        const int lp = __ffsll((long long)ball) - 1;  // a lane of group hk, never -1
         const int p = lp % NP;
-        singular = singular || (mh == 0u && ml <= 1u);
         // ---- reciprocal pivot, multipliers
         const double pr = readlane_f64(pre[ck], lp), pi = readlane_f64(pim[ck], lp);
         const double rden = fast_rcp(pr * pr + pi * pi);

@@ -150,15 +150,24 @@ static __device__ __forceinline__ void gemm(Mat& acc, const Slot& left, const Ma
     const int q = lane_id() >> 4, c = lane_id() & 15;
     if constexpr (LNB == 1) {
         d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+        // all eight operand reads first, then twelve MFMAs back to back (three independent chains)
+        double are[4], aim[4], asum[4], bsum[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int off = LEFT_ADJ ? ((4 * kk + q) * LG::PITCH + c) : (c * LG::PITCH + 4 * kk + q);
-            const double are = left.re[off];
-            const double aim = LEFT_ADJ ? -left.im[off] : left.im[off];
-            const double bre = right.re[0][0][kk], bim = right.im[0][0][kk];
-            t1 = mfma_f64(are, bre, t1);
-            t2 = mfma_f64(aim, bim, t2);
-            t3 = mfma_f64(are + aim, bre + bim, t3);
+            are[kk] = left.re[off];
+            aim[kk] = LEFT_ADJ ? -left.im[off] : left.im[off];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            asum[kk] = are[kk] + aim[kk];
+            bsum[kk] = right.re[0][0][kk] + right.im[0][0][kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            t1 = mfma_f64(are[kk], right.re[0][0][kk], t1);
+            t2 = mfma_f64(aim[kk], right.im[0][0][kk], t2);
+            t3 = mfma_f64(asum[kk], bsum[kk], t3);
         }
         acc.re[0][0] += t1 - t2;
         acc.im[0][0] += t3 - t1 - t2;
