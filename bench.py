@@ -63,15 +63,15 @@ def make_controls(first_seed, count):
     return out
 
 
-PMC_SUMMARY = "profiles/r01_v6_pmc_hbm.json"
+PMC_SUMMARY = "profiles/r02_pmc_hbm.json"
 
 
 def pmc_traffic_bytes(kernel, units_per_launch):
     """
-    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/r01_v6_pmc_hbm.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this
-    bench command, gfx950 correction applied; tools/pmc_summary.py), rescaled to this run's
-    units per launch. PMC counters cannot be collected from inside the timed run; None if the
+    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (PMC_SUMMARY:
+    FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this bench command, gfx950 correction
+    applied; tools/profile_round.sh + tools/pmc_summary.py), rescaled to this run's units per
+    launch. PMC counters cannot be collected from inside the timed run; None if the
     summary is absent.
     """
     path = os.path.join(ROOT, PMC_SUMMARY)
@@ -185,7 +185,10 @@ def lindblad_secondary(engine, reps=3):
         "roofline": {"bound": "mfma", "kernel": "qocx::lindblad_kernel", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": kernel_s * 1e3,
-                     "flops_per_subinterval": flops_per_sub, "traffic": None},
+                     "flops_per_subinterval": flops_per_sub,
+                     "traffic": pmc_traffic_bytes("qocx::lindblad_kernel", 32000),
+                     "traffic_source": "committed rocprofv3 --pmc passes ({}), per launch of this "
+                                       "workload".format(PMC_SUMMARY)},
         "check": {"sum_cost": float(cost.sum()),
                   "trace_defect": float(np.max(np.abs(np.trace(final[:, 0], axis1=-2, axis2=-1) - 1)))},
     }

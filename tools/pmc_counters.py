@@ -18,7 +18,7 @@ def main():
         for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                     if not name.startswith("qocx::"):
                         continue
                     slot = out.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0])

@@ -23,7 +23,7 @@ def collect(directory, counter):
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 sums[name] = sums.get(name, 0.0) + float(row["Counter_Value"])
                 counts[name] = counts.get(name, 0) + 1
     return sums, counts
