@@ -108,8 +108,9 @@ typedef struct qocx_schroedinger_problem {
  * (qoc/models/lindbladmodels.py:125-203) that _evaluate_lindblad_discrete reads
  * (qoc/core/lindbladdiscrete.py:357-441). hamiltonian(u, t) = h0(t) + sum_k u_k g[k](t):
  * time independent (h0, g; fixed_subdivision = 0) or sampled at the integrator's stage times
- * (fixed_subdivision > 0, h0_stages, g_stages). lindblad_data(t) = (dissipators, operators) must
- * not depend on time.
+ * (fixed_subdivision > 0, h0_stages, g_stages). lindblad_data(t) = (dissipators, operators) is
+ * constant (dissipators, operators) or sampled the same way (diss_stages, op_stages; the reference
+ * calls it at every right-hand side, lindbladdiscrete.py:486-492).
  */
 typedef struct qocx_lindblad_problem {
     int32_t struct_size;          /* sizeof(qocx_lindblad_problem) of the CALLER's header         */
@@ -134,6 +135,9 @@ typedef struct qocx_lindblad_problem {
     int32_t fixed_subdivision;
     const double* h0_stages;      /* [count][n][n] complex                                         */
     const double* g_stages;       /* [count][K][n][n] complex, or NULL when g is constant          */
+    /* time-dependent lindblad_data (needs fixed_subdivision > 0 and h0_stages): both or neither   */
+    const double* diss_stages;    /* [count][L] float64 gamma_i(t), or NULL                        */
+    const double* op_stages;      /* [count][L][n][n] complex L_i(t), or NULL                      */
 } qocx_lindblad_problem;
 
 const char* qocx_last_error(void);

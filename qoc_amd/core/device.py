@@ -325,6 +325,8 @@ class LindbladEvaluator(object):
             structure.probe_static_lindblad_system(
                 hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
                 evolution_time, probe_times=self._coarse_times)
+        self._lindblad_data = lindblad_data if getattr(
+            structure.probe_static_lindblad_system, "lindblad_time_dependent", False) else None
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
         descriptors = []
         for cost in self.costs:
@@ -345,6 +347,7 @@ class LindbladEvaluator(object):
         self._hamiltonian = hamiltonian
         self._table_bounds = None
         self._coarse_samples = None
+        self._coarse_lindblad = None
         if not self.time_dependent:
             self.backend.set_lindblad_problem(*self._problem_args, **self._problem_kw)
         elif control_bounds is not None:  # GRAPE: max_control_norms bound the controls for good
@@ -358,6 +361,9 @@ class LindbladEvaluator(object):
         (n, _, kr, nc, n_eval, evolution_time, h0, g, dissipators, operators, _) = \
             self._problem_args
         dt = evolution_time / (n_eval - 1)
+        if self._coarse_samples is None and self._hamiltonian is None:
+            self._coarse_samples = (np.asarray(h0, dtype=np.complex128)[None],
+                                    np.zeros((1, kr, n, n), dtype=np.complex128))
         if self._coarse_samples is None:  # H on the coarsest stage grid: norms for the bound
             self._coarse_samples = structure.probe_hamiltonian(
                 self._hamiltonian, n, self.control_count, self.complex_controls,
@@ -367,11 +373,25 @@ class LindbladEvaluator(object):
         g_norms = [max(np.linalg.norm(g_probe[t, k], 1) for t in range(g_probe.shape[0]))
                    for k in range(kr)]
         ksub = structure.lindblad_subdivision(h_norm, g_norms, bounds, dissipators, operators, dt)
+        if self._lindblad_data is not None:  # the largest dissipative norm over the coarse grid
+            if self._coarse_lindblad is None:
+                self._coarse_lindblad = structure.sample_lindblad_data(
+                    self._lindblad_data, n, list(self._coarse_times))
+            ksub = max(structure.lindblad_subdivision(h_norm, g_norms, bounds, d, o, dt)
+                       for d, o in zip(*self._coarse_lindblad))
         times = self.backend.lindblad_stage_times(evolution_time, n_eval, nc, kr, ksub)
-        h0_stages, g_stages = structure.sample_lindblad_hamiltonian(
-            self._hamiltonian, n, self.control_count, self.complex_controls, times)
+        if self._hamiltonian is None:
+            h0_stages = np.repeat(np.asarray(h0, dtype=np.complex128)[None], len(times), axis=0)
+            g_stages = None
+        else:
+            h0_stages, g_stages = structure.sample_lindblad_hamiltonian(
+                self._hamiltonian, n, self.control_count, self.complex_controls, times)
+        extra = {}
+        if self._lindblad_data is not None:
+            diss_stages, op_stages = structure.sample_lindblad_data(self._lindblad_data, n, times)
+            extra = dict(diss_stages=diss_stages, op_stages=op_stages)
         self.backend.set_lindblad_problem(*self._problem_args, fixed_subdivision=ksub,
-                                          h0_stages=h0_stages, g_stages=g_stages,
+                                          h0_stages=h0_stages, g_stages=g_stages, **extra,
                                           **self._problem_kw)
         self._table_bounds = np.asarray(bounds, dtype=np.float64)
 

@@ -181,8 +181,10 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
     the caller passes the integrator's own stage-time grid (every time the device would ever
     read H at for the coarsest sub-division), so a periodic drive cannot alias to a constant - by
     comparing H(0, t) and H(u_random, t) with their values at the first time, bit for bit. A
-    time-dependent Hamiltonian is then sampled at the stage times (sample_lindblad_hamiltonian);
-    a time-dependent lindblad_data is rejected loudly.
+    time-dependent Hamiltonian is then sampled at the stage times (sample_lindblad_hamiltonian),
+    and so is a time-dependent lindblad_data (sample_lindblad_data; the reference calls both at
+    every right-hand side, lindbladdiscrete.py:483-492). `time_dependent` covers either; the
+    function attribute `lindblad_time_dependent` says whether lindblad_data was the (or a) cause.
     """
     n = hilbert_size
     times = list(decision_times(evolution_time) if probe_times is None else probe_times)
@@ -213,6 +215,7 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
                 time_dependent = True
                 break
     dissipators, operators = None, None
+    lindblad_time_dependent = False
     if lindblad_data is not None:
         first = lindblad_data(times[0])
         if first[0] is not None and first[1] is not None:
@@ -230,9 +233,15 @@ def probe_static_lindblad_system(hamiltonian, lindblad_data, hilbert_size, contr
                 or (np.array_equal(np.asarray(d, dtype=np.float64), dissipators)
                     and np.array_equal(np.asarray(o, dtype=np.complex128), operators)))
             if not same:
-                raise TimeDependentSystemError(
-                    "lindblad_data(time) depends on time: the MI355X Lindblad engine needs "
-                    "constant dissipators and operators. There is no CPU fallback.")
+                if dissipators is None or d is None:
+                    raise ValueError("lindblad_data(time) returns data at some times and None at "
+                                     "others")
+                # explicit time dependence: sampled at the integrator's stage times, like the
+                # Hamiltonian (sample_lindblad_data)
+                time_dependent = True
+                lindblad_time_dependent = True
+                break
+    probe_static_lindblad_system.lindblad_time_dependent = lindblad_time_dependent
     return h0[0], g[0], dissipators, operators, time_dependent
 
 
@@ -246,6 +255,19 @@ def sample_lindblad_hamiltonian(hamiltonian, hilbert_size, control_count, comple
         g = np.repeat(g, nt, axis=0)
     g_constant = bool(np.all(g == g[:1]))
     return h0, (None if g_constant else g)
+
+
+def sample_lindblad_data(lindblad_data, hilbert_size, times):
+    """(dissipators (nt, L), operators (nt, L, n, n)) at the given stage times."""
+    diss, ops = [], []
+    for t in times:
+        d, o = lindblad_data(t)
+        diss.append(np.asarray(d, dtype=np.float64))
+        ops.append(np.asarray(o, dtype=np.complex128))
+    diss, ops = np.stack(diss), np.stack(ops)
+    if ops.shape[1:] != (diss.shape[1], hilbert_size, hilbert_size):
+        raise ValueError("lindblad_data returned operators of shape {}".format(ops.shape[1:]))
+    return diss, ops
 
 
 def lindblad_subdivision(h0_norm, g_norms, control_bounds, dissipators, operators, dt,

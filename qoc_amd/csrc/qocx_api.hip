@@ -190,7 +190,8 @@ struct qocx_ctx {
         int64_t dbg_stage_seeds = 0;     // seeds whose stage values may be kept; 0: 45 % of free HBM
         int dbg_min_piece = 256;         // below this many seeds per piece the adjoint recomputes
         int dbg_wave_mode = 0;           // 0 auto, 1 one wave per seed, 2 several whenever built for
-        DevBuf<double2> a0_tab, gp_tab;
+        DevBuf<double2> a0_tab, gp_tab, op_tab;
+        DevBuf<double> gamma_tab;
     } lb;
     // ---- qocx_debug_set_knob: kernel-variant switches for A/B measurements and tests ----
     std::map<std::string, int64_t> knobs;
@@ -1318,6 +1319,13 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     lb.fixed_ksub = 0;
     lb.a0_tab.release();
     lb.gp_tab.release();
+    lb.op_tab.release();
+    lb.gamma_tab.release();
+    const bool td_ops = p->op_stages != nullptr && L > 0;
+    if ((p->op_stages != nullptr) != (p->diss_stages != nullptr))
+        return fail(QOCX_ERR_ARG, "diss_stages and op_stages go together");
+    if (td_ops && p->fixed_subdivision <= 0)
+        return fail(QOCX_ERR_ARG, "time-dependent lindblad_data needs fixed_subdivision > 0");
     if (p->fixed_subdivision > 0) {
         if (!p->h0_stages) return fail(QOCX_ERR_ARG, "h0_stages missing");
         int64_t count = 0;
@@ -1327,18 +1335,37 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         const size_t md = dump_elems(n);
         std::vector<double2> tab((size_t)count * 4 * md);
         lb.h0_norm = 0;
+        std::vector<double2> otab(td_ops ? (size_t)count * L * md : 0);
+        std::vector<double> gtab_d(td_ops ? (size_t)count * L : 0);
+        if (td_ops) lb.diss_norm = 0;
         for (int64_t st = 0; st < count; ++st) {
             const cmat h = cm_from(p->h0_stages + (size_t)st * n * n * 2, n);
             lb.h0_norm = std::max(lb.h0_norm, one_norm(h.data(), n));
             cmat l = cm_scale(h, 0.0, -1.0), r = cm_scale(h, 0.0, 1.0);
-            cm_axpy(l, -0.5, decay);
-            cm_axpy(r, -0.5, decay);
+            cmat decay_st = decay;
+            if (td_ops) {  // -1/2 sum_i gamma_i(t) L_i(t)^H L_i(t) of THIS stage time
+                decay_st = cm_zero(n);
+                double dn = 0;
+                for (int i = 0; i < L; ++i) {
+                    const cmat li = cm_from(p->op_stages + ((size_t)st * L + i) * n * n * 2, n);
+                    const double gi = p->diss_stages[(size_t)st * L + i];
+                    cm_axpy(decay_st, gi, cm_mul(cm_adjoint(li, n), li, n));
+                    c_dump(li, n, otab.data() + ((size_t)st * L + i) * md);
+                    gtab_d[(size_t)st * L + i] = gi;
+                    dn += fabs(gi) * one_norm(li.data(), n) * cm_norm_inf(li, n);
+                }
+                lb.diss_norm = std::max(lb.diss_norm, dn);
+            }
+            cm_axpy(l, -0.5, decay_st);
+            cm_axpy(r, -0.5, decay_st);
             c_dump(l, n, tab.data() + ((size_t)st * 4 + 0) * md);
             c_dump(r, n, tab.data() + ((size_t)st * 4 + 1) * md);
             c_dump(cm_adjoint(l, n), n, tab.data() + ((size_t)st * 4 + 2) * md);
             c_dump(cm_adjoint(r, n), n, tab.data() + ((size_t)st * 4 + 3) * md);
         }
         if (lb.a0_tab.upload(tab, ctx->stream)) return QOCX_ERR_HIP;
+        if (td_ops && (lb.op_tab.upload(otab, ctx->stream) || lb.gamma_tab.upload(gtab_d, ctx->stream)))
+            return QOCX_ERR_HIP;
         if (p->g_stages && K > 0) {
             std::vector<double2> gtab((size_t)count * K * 3 * md);
             lb.g_norm.assign(K, 0.0);
@@ -1658,6 +1685,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.gammas = lb.gammas.p; la.rho0_cimg = lb.rho0.p;
             la.a0_tab = lb.fixed_ksub > 0 ? lb.a0_tab.p : nullptr;
             la.gp_tab = (lb.fixed_ksub > 0 && lb.gp_tab.p) ? lb.gp_tab.p : nullptr;
+            la.op_tab = (lb.fixed_ksub > 0 && lb.op_tab.p) ? lb.op_tab.p : nullptr;
+            la.gamma_tab = la.op_tab ? lb.gamma_tab.p : nullptr;
             la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
             la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
             la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;

@@ -167,6 +167,9 @@ struct LindbladArgs {
     const double2* a0_tab;     // time-dependent H: [nsub * 12][4] dumps A0L, A0R, A0L^H, A0R^H at the
                                // stage times, or nullptr
     const double2* gp_tab;     // time-dependent G: [nsub * 12][K][3] dumps Gp, Gp^H, Gp^T, or nullptr
+    const double2* op_tab;     // time-dependent lindblad_data: [nsub * 12][nops] dumps of L_i at the
+                               // stage times (+ gamma_tab [nsub * 12][nops]), or nullptr
+    const double* gamma_tab;
     const double2* op_cimg;    // [nops] L_i
     const double* gammas;      // [nops]
     const double2* rho0_cimg;  // [S]

@@ -380,8 +380,19 @@ struct Wave {
             Mat t, opr;
             mat_zero(t);
             const Slot op = slot_at(op_planar + (size_t)i * SLOT_BYTES);
+            double gamma = a.gammas[i];
+            if (a.op_tab != nullptr) {
+                // time-dependent lindblad_data: this stage's L_i(t) replaces the image in LDS
+                // (the slot of operator i is read by the wave that owns the operator only)
+                Mat opm;
+                dump_load(opm, a.op_tab + (stage * a.nops + i) * MAT);
+                gamma = a.gamma_tab[stage * a.nops + i];
+                wave_sync();
+                cmat_to_lds<LNB>(opm, op.re, op.im);
+                wave_sync();
+            }
             gemm<ADJ>(t, op, y);
-            cmat_scale<LNB>(t, a.gammas[i]);
+            cmat_scale<LNB>(t, gamma);
             wave_sync();
             cmat_to_lds<LNB>(t, slot_tmp.re, slot_tmp.im);
             wave_sync();

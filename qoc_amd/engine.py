@@ -62,7 +62,8 @@ class _LindbladProblem(ctypes.Structure):
                 ("operators", _c_double_p), ("initial_densities", _c_double_p),
                 ("cost_count", ctypes.c_int32), ("costs", ctypes.POINTER(_CostDesc)),
                 ("fixed_subdivision", ctypes.c_int32), ("h0_stages", _c_double_p),
-                ("g_stages", _c_double_p)]
+                ("g_stages", _c_double_p), ("diss_stages", _c_double_p),
+                ("op_stages", _c_double_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/qocx.h
@@ -308,7 +309,7 @@ class Engine(object):
                              control_eval_count, system_eval_count, evolution_time,
                              h0, g, dissipators, operators, initial_densities, costs=(),
                              cost_eval_step=1, fixed_subdivision=0, h0_stages=None,
-                             g_stages=None):
+                             g_stages=None, diss_stages=None, op_stages=None):
         """
         h0 :: (n, n), g :: (K, n, n), dissipators :: (L,), operators :: (L, n, n),
         initial_densities :: (S, n, n); costs :: dicts {kind (3|4), step_cost, scale,
@@ -355,6 +356,11 @@ class Engine(object):
                 gs = _as_complex(g_stages).reshape(-1, K, n, n)
                 keep.append(gs)
                 p.g_stages = _dp(gs)
+            if op_stages is not None and L > 0:  # time-dependent lindblad_data
+                ds = np.ascontiguousarray(diss_stages, dtype=np.float64).reshape(-1, L)
+                os_ = _as_complex(op_stages).reshape(-1, L, n, n)
+                keep.extend([ds, os_])
+                p.diss_stages, p.op_stages = _dp(ds), _dp(os_)
         self._check(self._lib.qocx_set_lindblad_problem(self._ctx, ctypes.byref(p)))
         self._lindblad = dict(n=n, S=S, K=K, Nc=int(control_eval_count),
                               N=int(system_eval_count))

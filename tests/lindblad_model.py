@@ -57,9 +57,12 @@ def substep_grid(evolution_time, system_eval_count, control_eval_count, norm_bou
 class StructuredLindblad(object):
     """h0, g (real controls: list of K matrices), gammas (L,), ops (L x n x n). A Hamiltonian
     with explicit time dependence is given by the callables h0_of_t(t) -> (n x n) and
-    g_of_t(t) -> list of K matrices; h0 / g then only provide shapes and norm bounds."""
+    g_of_t(t) -> list of K matrices; h0 / g then only provide shapes and norm bounds. Likewise
+    data_of_t(t) -> (gammas, ops) for a time-dependent lindblad_data (gammas / ops then provide
+    the norm bound only)."""
 
-    def __init__(self, h0, g, gammas, ops, h0_of_t=None, g_of_t=None):
+    def __init__(self, h0, g, gammas, ops, h0_of_t=None, g_of_t=None, data_of_t=None):
+        self.data_of_t = data_of_t
         self.h0 = np.asarray(h0, dtype=np.complex128)
         self.g = [np.asarray(x, dtype=np.complex128) for x in g]
         self.h0_of_t, self.g_of_t = h0_of_t, g_of_t
@@ -73,20 +76,27 @@ class StructuredLindblad(object):
         return self.g if self.g_of_t is None else self.g_of_t(t)
 
     def generator(self, u, t=None):
+        """(A, gammas, ops) of one stage: A = -i H(u, t) - 1/2 sum gamma_i L_i^H L_i."""
         h0 = self.h0 if self.h0_of_t is None else self.h0_of_t(t)
         ham = h0 + sum((uk * gk for uk, gk in zip(u, self.g_at(t))), np.zeros_like(self.h0))
-        return -1j * ham - 0.5 * self.decay
+        if self.data_of_t is None:
+            return -1j * ham - 0.5 * self.decay, self.gammas, self.ops
+        gammas, ops = self.data_of_t(t)
+        decay = sum((gm * (h(op) @ op) for gm, op in zip(gammas, ops)), np.zeros_like(self.h0))
+        return -1j * ham - 0.5 * decay, gammas, ops
 
-    def rhs(self, a, rho):
+    def rhs(self, gen, rho):
+        a, gammas, ops = gen
         out = a @ rho + rho @ h(a)
-        for gm, op in zip(self.gammas, self.ops):
+        for gm, op in zip(gammas, ops):
             out = out + gm * (op @ rho @ h(op))
         return out
 
-    def rhs_adjoint(self, a, x):
-        """adjoint of rho -> rhs(a, rho) w.r.t. Re tr(X^H Y)."""
+    def rhs_adjoint(self, gen, x):
+        """adjoint of rho -> rhs(gen, rho) w.r.t. Re tr(X^H Y)."""
+        a, gammas, ops = gen
         out = h(a) @ x + x @ a
-        for gm, op in zip(self.gammas, self.ops):
+        for gm, op in zip(gammas, ops):
             out = out + gm * (h(op) @ x @ op)
         return out
 

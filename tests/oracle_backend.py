@@ -218,10 +218,10 @@ class OracleBackend(object):
 
     def set_lindblad_problem(self, n, S, K, Nc, N, T, h0, g, dissipators, operators,
                              initial_densities, costs=(), cost_eval_step=1, fixed_subdivision=0,
-                             h0_stages=None, g_stages=None):
+                             h0_stages=None, g_stages=None, diss_stages=None, op_stages=None):
         from tests import lindblad_model as lm
         g = np.asarray(g if K > 0 else np.zeros((0, n, n)), dtype=np.complex128).reshape(K, n, n)
-        h0_of_t = g_of_t = None
+        h0_of_t = g_of_t = data_of_t = None
         self.lb_subdivision = None
         if fixed_subdivision:
             times = self.lindblad_stage_times(T, N, Nc, K, fixed_subdivision)
@@ -233,9 +233,17 @@ class OracleBackend(object):
                 g = np.max(np.abs(gs), axis=0) * 0 + gs[np.argmax(
                     [np.linalg.norm(x.reshape(K * n, n), 1) for x in gs])]
             h0 = hs[int(np.argmax([np.linalg.norm(x, 1) for x in hs]))]
+            if op_stages is not None:
+                ds = np.asarray(diss_stages, dtype=np.float64).reshape(len(times), -1)
+                os_ = np.asarray(op_stages, dtype=np.complex128).reshape(len(times), -1, n, n)
+                data_of_t = lambda t: (ds[int(np.argmin(np.abs(times - t)))],
+                                       os_[int(np.argmin(np.abs(times - t)))])
+                worst = int(np.argmax([sum(g_ * np.linalg.norm(o, 1) * np.linalg.norm(o, np.inf)
+                                           for g_, o in zip(d, o_)) for d, o_ in zip(ds, os_)]))
+                dissipators, operators = ds[worst], os_[worst]
             self.lb_subdivision = int(fixed_subdivision)
         self.lb_system = lm.StructuredLindblad(np.asarray(h0).reshape(n, n), list(g),
-                                               dissipators, operators, h0_of_t, g_of_t)
+                                               dissipators, operators, h0_of_t, g_of_t, data_of_t)
         self.lb_costs = [_DensityDescriptorCost(c, S, n) for c in costs]
         self.lb = dict(n=n, S=S, K=K, Nc=Nc, N=N, T=T, ces=cost_eval_step,
                        rho0=np.asarray(initial_densities, dtype=np.complex128).reshape(S, n, n))

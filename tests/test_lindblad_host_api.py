@@ -109,12 +109,20 @@ def test_structure_rejects_time_dependence_and_size():
         case.T, case.initial_densities, case.N, controls=case.controls[0],
         hamiltonian=lambda u, t: h(u, t) * (1 + 0.1 * t), lindblad_data=case.lindblad_data())
     assert abs(np.trace(r.final_densities[0]) - 1) < 1e-10
-    # ... of the dissipators / operators it is not
+    # ... and so is explicit time dependence of the dissipators / operators (the reference calls
+    # lindblad_data(t) at every right-hand side, lindbladdiscrete.py:486-492): the same
+    # evolution against the reference integrator
     gam, ops = case.dissipators, case.operators
-    with pytest.raises(structure.TimeDependentSystemError):
-        qoc_amd.evolve_lindblad_discrete(
-            case.T, case.initial_densities, case.N, controls=case.controls[0],
-            hamiltonian=h, lindblad_data=lambda t: (gam * (1 + t), ops))
+    data = lambda t: (gam * (1 + 0.5 * np.sin(2.0 * t)), ops * (1 + 0.2 * np.cos(1.3 * t)))
+    r = qoc_amd.evolve_lindblad_discrete(
+        case.T, case.initial_densities, case.N, controls=case.controls[0],
+        hamiltonian=h, lindblad_data=data)
+    from oracle import qoc_lindblad_numpy as ol
+    problem = ol.LindbladProblem(case.T, case.initial_densities, case.N, hamiltonian=h,
+                                 lindblad_data=data, control_eval_count=case.Nc,
+                                 control_count=case.K)
+    _, dens = ol.evaluate(problem, case.controls[0])
+    assert np.max(np.abs(r.final_densities - dens)) < 1e-8
     with pytest.raises(structure.NonLinearHamiltonianError):
         qoc_amd.evolve_lindblad_discrete(
             case.T, case.initial_densities, case.N, controls=case.controls[0],
