@@ -16,8 +16,18 @@ _backend_factory = None
 
 
 def set_backend_factory(factory):
-    """Test hook: replace the engine constructor (tests inject the CPU oracle here)."""
+    """
+    TEST HOOK, inert in production: replaces the engine constructor so that the host logic can be
+    exercised on a machine without a GPU (tests/conftest.py arms it with QOC_AMD_TEST_HOOKS=1 and
+    injects a NumPy model of the device; nothing in the product sets that variable or calls
+    this). Without the variable any attempt to install a factory is refused - the product has no
+    CPU fallback.
+    """
+    import os
     global _backend_factory
+    if factory is not None and os.environ.get("QOC_AMD_TEST_HOOKS") != "1":
+        raise RuntimeError("qoc_amd has no CPU fallback: set_backend_factory is a test hook "
+                           "(QOC_AMD_TEST_HOOKS=1)")
     _backend_factory = factory
 
 

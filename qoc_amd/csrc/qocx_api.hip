@@ -888,6 +888,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
         ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
         ma.dt = ctx->dt; ma.scratch = ctx->magnus_scratch.p;
+        ma.skew = (ctx->hermitian && !ctx->knob("magnus_general", 0)) ? 1 : 0;
         qocx::SweepArgs sa;
         sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;
         sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
@@ -1763,7 +1764,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
-                                  "sweep3_phases", "lindblad_stamps"};
+                                  "sweep3_phases", "lindblad_stamps", "magnus_general"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

@@ -127,6 +127,7 @@ struct MagnusArgs {
     const double2* g_cimg;     // [nt][K]
     int K, nc, nsteps, nt, nodes;
     int step0, seg_len;        // work item w -> (seed w / seg_len, step step0 + w % seg_len)
+    int skew;                  // every H0(t), G_k(t) Hermitian: one product per commutator
     double dt;
     double2* m_rm;             // fwd out: [B][nsteps] row-major padded generators
     const double2* mbar_rm;    // vjp in : cotangents of the generators

@@ -40,6 +40,15 @@ struct Ctx {
     double* aim;
     double* bre;  // slot B
     double* bim;
+    // Every node generator is skew-Hermitian (Hermitian H0(t), G_k(t): checked on the host). Then
+    // so are b1, b2, b3, every commutator and M itself, and [X, Y] = XY - (XY)^H: ONE product per
+    // commutator instead of two. In the reverse pass only the skew-Hermitian part of a cotangent
+    // can reach the controls (the contraction is with -i G_k, skew-Hermitian, and Hermitian is
+    // orthogonal to skew-Hermitian under Re tr(A^H B)); the forward maps send skew perturbations
+    // to skew ones, so their adjoints may project: with Zs = (Zbar - Zbar^H) / 2,
+    //   Xbar = [Y, Zs] = V - V^H, V = Y Zs ;  Ybar = [Zs, X] = W - W^H, W = Zs X :
+    // two products instead of four.
+    bool skew;
 
     __device__ __forceinline__ void dump_store(const Mat& m, double2* d) const {
         const int lane = lane_id();
@@ -126,13 +135,27 @@ struct Ctx {
         });
     }
     // out = X Y - Y X   (convenience.py:16-29)
+    // out -= out^H (through slot B)
+    __device__ __forceinline__ void minus_own_adjoint(Mat& out) const {
+        wave_sync();
+        cmat_to_lds<NB>(out, bre, bim);
+        wave_sync();
+        Mat t;
+        load_adjoint(t, bre, bim);
+        axpy(out, -1.0, t);
+        wave_sync();
+    }
     __device__ __forceinline__ void commutator(Mat& out, const Mat& x, const Mat& y) const {
         wave_sync();
         cmat_to_lds<NB>(x, are, aim);
-        cmat_to_lds<NB>(y, bre, bim);
+        if (!skew) cmat_to_lds<NB>(y, bre, bim);
         wave_sync();
         cmat_zero<NB>(out);
         gemm(out, are, aim, y, 1.0);
+        if (skew) {
+            minus_own_adjoint(out);  // Y X = (X Y)^H
+            return;
+        }
         gemm(out, bre, bim, x, -1.0);
         wave_sync();
     }
@@ -140,6 +163,32 @@ struct Ctx {
     // X and Y are given as scratch dumps and loaded only while needed (register pressure).
     __device__ __forceinline__ void commutator_vjp(Mat& xbar, Mat& ybar, const double2* x_dump,
                                                    const double2* y_dump, const Mat& zbar) const {
+        if (skew) {
+            Mat zs = zbar;  // Zs = (Zbar - Zbar^H) / 2
+            minus_own_adjoint(zs);
+            cmat_scale<NB>(zs, 0.5);
+            {
+                Mat y;
+                dump_load(y, y_dump);
+                wave_sync();
+                cmat_to_lds<NB>(y, are, aim);
+                wave_sync();
+            }
+            cmat_zero<NB>(xbar);
+            gemm(xbar, are, aim, zs, 1.0);  // V = Y Zs
+            minus_own_adjoint(xbar);
+            wave_sync();
+            cmat_to_lds<NB>(zs, are, aim);
+            wave_sync();
+            {
+                Mat x;
+                dump_load(x, x_dump);
+                cmat_zero<NB>(ybar);
+                gemm(ybar, are, aim, x, 1.0);  // W = Zs X
+            }
+            minus_own_adjoint(ybar);
+            return;
+        }
         wave_sync();
         cmat_to_lds<NB>(zbar, are, aim);
         {
@@ -380,6 +429,7 @@ __global__ __launch_bounds__(64) void magnus_fwd_kernel(MagnusArgs args) {
     cx.aim = cx.are + G::PLANE;
     cx.bre = cx.aim + G::PLANE;
     cx.bim = cx.bre + G::PLANE;
+    cx.skew = args.skew != 0;
     double2* scr = args.scratch + (size_t)blockIdx.x * S_COUNT * G::MAT;
     for (size_t w = blockIdx.x; w < args.total; w += gridDim.x) {
         const int step = args.step0 + (int)(w % args.seg_len);
@@ -413,6 +463,7 @@ __global__ __launch_bounds__(64) void magnus_vjp_kernel(MagnusArgs args) {
     cx.aim = cx.are + G::PLANE;
     cx.bre = cx.aim + G::PLANE;
     cx.bim = cx.bre + G::PLANE;
+    cx.skew = args.skew != 0;
     double2* scr = args.scratch + (size_t)blockIdx.x * S_COUNT * G::MAT;
     const double dt = args.dt;
     for (size_t w = blockIdx.x; w < args.total; w += gridDim.x) {

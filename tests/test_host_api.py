@@ -527,3 +527,14 @@ def test_opaque_hamiltonian_needs_m2():
         qoc_amd.evolve_schroedinger_discrete(
             case.T, case.hamiltonian(), case.initial_states, case.N, controls=case.controls[0],
             magnus_policy=MagnusPolicy.M4)
+
+
+def test_backend_hook_is_inert_outside_the_tests(monkeypatch):
+    """The product has no CPU fallback: without QOC_AMD_TEST_HOOKS=1 (set by tests/conftest.py
+    only) a backend factory cannot be installed."""
+    monkeypatch.delenv("QOC_AMD_TEST_HOOKS")
+    with pytest.raises(RuntimeError):
+        device.set_backend_factory(OracleBackend)
+    device.set_backend_factory(None)  # clearing is always allowed
+    monkeypatch.setenv("QOC_AMD_TEST_HOOKS", "1")
+    device.set_backend_factory(OracleBackend)
