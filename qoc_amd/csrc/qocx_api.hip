@@ -377,6 +377,7 @@ int qocx_create(int device, qocx_ctx** out) {
         ctx->ev_swept.push_back(e2);
     }
     if (const char* env = getenv("QOCX_SWEEP_IMPL")) ctx->knobs["sweep_impl"] = atoi(env);  // test runs
+    if (const char* env = getenv("QOCX_SWEEP_LOADER")) ctx->knobs["sweep_loader"] = atoi(env);
     *out = ctx;
     return 0;
 }

@@ -680,16 +680,16 @@ __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
-template <int NB>
+template <int NB, int NBUF = 2>
 struct SweepLds {
     typedef Geo<NB> G;
     static constexpr int BUF_BYTES = G::MAT * 16;              // one matrix image
-    static constexpr int Q_OFF = 0;                            // 2 x Q image (double buffer)
-    static constexpr int L_OFF = Q_OFF + 2 * BUF_BYTES;         // 2 x LU image
-    static constexpr int D_OFF = L_OFF + 2 * BUF_BYTES;         // 2 x 64 complex: 1/U_kk
-    static constexpr int P_OFF = D_OFF + 2 * 64 * 16;           // 2 x 64 int: perm | iperm
+    static constexpr int Q_OFF = 0;                            // NBUF x Q image (ring)
+    static constexpr int L_OFF = Q_OFF + NBUF * BUF_BYTES;      // NBUF x LU image
+    static constexpr int D_OFF = L_OFF + NBUF * BUF_BYTES;      // NBUF x 64 complex: 1/U_kk
+    static constexpr int P_OFF = D_OFF + NBUF * 64 * 16;        // NBUF x 64 int: perm | iperm
     static constexpr int MAX_WAVES = 4;                        // waves per seed (multi-state)
-    static constexpr int TMP_OFF = P_OFF + 2 * 64 * 4;          // NP complex scratch per wave
+    static constexpr int TMP_OFF = P_OFF + NBUF * 64 * 4;       // NP complex scratch per wave
     static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * G::NP * 16;  // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
@@ -783,7 +783,10 @@ __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec
 template <int NB, int W, bool LOADER>
 __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
-    typedef SweepLds<NB> L;
+    // With a loader wave the operands of TWO steps travel at once (ring of three buffers): the
+    // fetch of step t+2 is issued while step t computes and has until the start of step t+2 to land.
+    constexpr int NBUF = LOADER ? 3 : 2;
+    typedef SweepLds<NB, NBUF> L;
     constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the sweep is the serial chain of the evaluation: where it shares a SIMD with a wave of the
@@ -801,8 +804,22 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + (computes ? w : 0) * NP;
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
     auto block_sync = [&]() {
-        if constexpr (MULTI) __syncthreads();
-        else wave_sync();
+        if constexpr (LOADER) {
+            // LDS hand-off only: a __syncthreads() also waits for vmcnt(0), i.e. for the fetch the
+            // loader has just issued - which is what made the first loader variant slower
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if constexpr (MULTI) {
+            __syncthreads();
+        } else {
+            wave_sync();
+        }
+    };
+    // the loader's wait at the top of a step: everything but the fetch that is one step ahead
+    auto wait_landed = [&](bool younger_in_flight) {
+        if (LOADER && younger_in_flight)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (G::MAT / 64) + 2) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // the loader wave runs the same control flow (every barrier) with empty state loops
     const int S = args.S, s0 = computes ? w : args.S;
@@ -978,11 +995,12 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     // dependent chains run -------------------------------------------------------------------
     if (do_fwd) {
         if (fetcher) issue_dma(m0 + jb, 0, false);
+        if (LOADER && fetcher && jb + 1 < je) issue_dma(m0 + jb + 1, 1, false);
         int nsub_next = 1 << min(max(args.s_arr[m0 + jb], 0), 30);
         for (int step = jb; step < je; ++step) {
-            const int par = (step - jb) & 1;
+            const int par = (step - jb) % NBUF;
             const int nsub = nsub_next;
-            if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fetcher) wait_landed(step + 1 < je);
             block_sync();
             const StepScalars sc = scalars(par, false);
             if (computes)
@@ -990,9 +1008,14 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                                        sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = fetcher && (step + 1 < je);
-            if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
-            if constexpr (LOADER) issue_all_due();
+            if constexpr (LOADER) {
+                pf_due = fetcher && (step + 2 < je);
+                if (pf_due) set_prefetch(m0 + step + 2, (par + 2) % NBUF, false);
+                issue_all_due();
+            } else {
+                pf_due = fetcher && (step + 1 < je);
+                if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
+            }
             if (step + 1 < je) nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             before_step(step);
             forward_step(sc, nsub);
@@ -1102,11 +1125,12 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     {
         const size_t ml = m0 + je - 1;
         if (fetcher) issue_dma(ml, 0, true);
+        if (LOADER && fetcher && je - 2 >= jb) issue_dma(ml - 1, 1, true);
         int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
-            const int par = it & 1;
+            const int par = it % NBUF;
             const int nsub = nsub_next;
-            if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fetcher) wait_landed(step - 1 >= jb);
             block_sync();
             const StepScalars sc = scalars(par, true);
             if (computes)
@@ -1114,9 +1138,14 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                                       sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
-            pf_due = fetcher && (step - 1 >= jb);
-            if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
-            if constexpr (LOADER) issue_all_due();
+            if constexpr (LOADER) {
+                pf_due = fetcher && (step - 2 >= jb);
+                if (pf_due) set_prefetch(m0 + step - 2, (par + 2) % NBUF, true);
+                issue_all_due();
+            } else {
+                pf_due = fetcher && (step - 1 >= jb);
+                if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
+            }
             if (step - 1 >= jb) nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             adjoint_step(sc, nsub, step);
         }
@@ -1422,7 +1451,7 @@ static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a
 }
 template <int NB, int W, bool LOADER>
 static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
-    const int bytes = SweepLds<NB>::bytes(a.S);
+    const int bytes = SweepLds<NB, LOADER ? 3 : 2>::bytes(a.S);
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W, LOADER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1431,7 +1460,8 @@ static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
 }
 template <int NB, int W>
 static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
-    if (a.loader) launch_sweep_wl<NB, W, true>(a, batch, st);
+    // (the loader variant's ring of three must fit the CU's LDS beside the state vectors)
+    if (a.loader && SweepLds<NB, 3>::bytes(a.S) <= 160 * 1024) launch_sweep_wl<NB, W, true>(a, batch, st);
     else launch_sweep_wl<NB, W, false>(a, batch, st);
 }
 template <int NB>
