@@ -454,8 +454,8 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count;
-    if (n < 1 || n > 32)
-        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..32 for the wavefront engine");
+    if (n < 1 || n > 64)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..64 for the wavefront engine");
     if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "state_count must be in 1..64");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
@@ -473,7 +473,11 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (p->cost_count < 0 || (p->cost_count > 0 && !p->costs))
         return fail(QOCX_ERR_ARG, "costs missing");
 
-    const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np, nt = p->nt;
+    // matrices are padded to 16, 32 or 64: one, four or sixteen MFMA tiles (33 <= n <= 64 runs on
+    // the four-wave K1a of qocx_pade4.hip and the NB = 4 forms of K1b / K2 / K3)
+    const int nb = (n <= 16) ? 1 : (n <= 32 ? 2 : 4), np = 16 * nb, mat = np * np, nt = p->nt;
+    if (nb == 4 && nodes > 1)
+        return fail(QOCX_ERR_ARG, "magnus_policy M4 / M6 needs hilbert_size <= 32");
     ctx->has_problem = false;
     ctx->n = n; ctx->nb = nb; ctx->np = np; ctx->S = S; ctx->K = K; ctx->nc = nc; ctx->N = N;
     ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt; ctx->nodes = nodes;
@@ -927,7 +931,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         // the segmented pipeline at 256 seeds it loses (14.3 against 13.4 ms): its workgroup owns
         // the CU's LDS, so K1a / K1b / K3 cannot run beside it. The host package selects it for
         // the single-control-set entry points (latency mode), the batched evaluator keeps 1.
-        const bool sweep3 = ctx->knob("sweep_impl", 1) == 3 && S <= qocx::sweep3_max_states(ctx->nb);
+        const bool sweep3 = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 &&
+                            S <= qocx::sweep3_max_states(ctx->nb);
         // "sweep3_phases": bit 0 forward launches, bit 1 adjoint launches (and combined ones)
         const int s3_phases = (int)ctx->knob("sweep3_phases", 3);
         auto run_sweep = [&](const qocx::SweepArgs& a, int count, hipStream_t st) {
@@ -1913,9 +1918,9 @@ int qocx_comm_destroy(qocx_ctx* ctx) {
 int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double* a, double* q_out,
                            double* lu_out, int32_t* perm_out, double* dinv_out, int32_t* s_out) {
     if (!ctx || !a || count < 1) return fail(QOCX_ERR_ARG, "bad argument");
-    if (n < 1 || n > 32) return fail(QOCX_ERR_ARG, "n must be in 1..32");
+    if (n < 1 || n > 64) return fail(QOCX_ERR_ARG, "n must be in 1..64");
     HIP_TRY(hipSetDevice(ctx->device));
-    const int nb = (n <= 16) ? 1 : 2, np = 16 * nb, mat = np * np;
+    const int nb = (n <= 16) ? 1 : (n <= 32 ? 2 : 4), np = 16 * nb, mat = np * np;
     DevBuf<double2> a_d, q_d, lu_d, dinv_d;
     DevBuf<int> perm_d, iperm_d, s_d;
     int rc = a_d.ensure((size_t)count * n * n) | q_d.ensure((size_t)count * mat) |

@@ -206,6 +206,9 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
 // two-wave K1a for nb == 2 (qocx_pade2.hip)
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
+// 33 <= n <= 64: four-wave workgroups (qocx_pade4.hip)
+void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st);
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);

@@ -680,16 +680,22 @@ __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
-template <int NB, int NBUF = 2>
+template <int NB>
+struct SweepPrefetch {
+    static constexpr bool value = NB < 4;
+};
+
+template <int NB, int NBUF = (SweepPrefetch<NB>::value ? 2 : 1)>
 struct SweepLds {
     typedef Geo<NB> G;
     static constexpr int BUF_BYTES = G::MAT * 16;              // one matrix image
     static constexpr int Q_OFF = 0;                            // NBUF x Q image (ring)
     static constexpr int L_OFF = Q_OFF + NBUF * BUF_BYTES;      // NBUF x LU image
     static constexpr int D_OFF = L_OFF + NBUF * BUF_BYTES;      // NBUF x 64 complex: 1/U_kk
-    static constexpr int P_OFF = D_OFF + NBUF * 64 * 16;        // NBUF x 64 int: perm | iperm
+    static constexpr int P_OFF = D_OFF + NBUF * 64 * 16;        // NBUF x PINTS int: perm | iperm
+    static constexpr int PINTS = G::NP > 32 ? 128 : 64;        // iperm starts at PINTS / 2
     static constexpr int MAX_WAVES = 4;                        // waves per seed (multi-state)
-    static constexpr int TMP_OFF = P_OFF + NBUF * 64 * 4;       // NP complex scratch per wave
+    static constexpr int TMP_OFF = P_OFF + NBUF * PINTS * 4;    // NP complex scratch per wave
     static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * G::NP * 16;  // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
@@ -785,7 +791,11 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     typedef Geo<NB> G;
     // With a loader wave the operands of TWO steps travel at once (ring of three buffers): the
     // fetch of step t+2 is issued while step t computes and has until the start of step t+2 to land.
-    constexpr int NBUF = LOADER ? 3 : 2;
+    // NB = 4 (33 <= n <= 64): one Q and one LU image are 64 KiB each, so there is room for ONE
+    // set of operands only - the step's fetch is issued at its start and waited for (PREFETCH off).
+    constexpr bool PREFETCH = SweepPrefetch<NB>::value;
+    static_assert(PREFETCH || !LOADER, "the loader variant needs a ring of buffers");
+    constexpr int NBUF = LOADER ? 3 : (PREFETCH ? 2 : 1);
     typedef SweepLds<NB, NBUF> L;
     constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -816,10 +826,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     };
     // the loader's wait at the top of a step: everything but the fetch that is one step ahead
     auto wait_landed = [&](bool younger_in_flight) {
-        if (LOADER && younger_in_flight)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (G::MAT / 64) + 2) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LOADER) {
+            if (younger_in_flight) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (G::MAT / 64) + 2) : "memory");
+                return;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // the loader wave runs the same control flow (every barrier) with empty state loops
     const int S = args.S, s0 = computes ? w : args.S;
@@ -866,7 +879,8 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     // gathers the transposed images), 1/U_kk, perm | iperm: 2*MAT/64 + 2 pieces. They are issued
     // one per column of the current step's triangular solves, into the bubbles of the
     // dependent readlane -> fma chain (an in-order wave cannot fill them otherwise).
-    constexpr int IMG_PIECES = MAT / 64, PIECES = 2 * IMG_PIECES + 2;
+    constexpr int IMG_PIECES = MAT / 64, PIECES = 2 * IMG_PIECES + 2 + (NP > 32 ? 1 : 0);
+    constexpr int PINTS = L::PINTS;
     // Per-lane global base addresses of the step being fetched; the pieces of an image are
     // reached through the instruction offset (dma16_imm), so a step needs six addresses, not one
     // per piece. Plain image: piece j is the KiB at j * 1024, two bases per image, each in the
@@ -878,9 +892,10 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     const char* pf_l[NGROUP];
     const double2* pf_d = nullptr;
     const int* pf_p = nullptr;
+    const int* pf_p2 = nullptr;  // NP = 64: perm and iperm are a piece each
     int pf_par = 0;
     bool pf_adjoint = false, pf_due = false;
-    auto set_prefetch = [&](size_t m, int par, bool adjoint) {
+    auto set_prefetch = [&](size_t m, int par, bool adjoint) __attribute__((always_inline)) {
         pf_par = par;
         pf_adjoint = adjoint;
         const size_t el = adjoint ? (size_t)(lane % NP) * NP + lane / NP : (size_t)lane;
@@ -891,7 +906,12 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             pf_l[g] = reinterpret_cast<const char*>(args.lu_img + m * MAT + el + mid);
         }
         pf_d = args.dinv + m * NP + i;
-        pf_p = (lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP;
+        if constexpr (NP > 32) {
+            pf_p = args.perm + m * NP + lane;
+            pf_p2 = args.iperm + m * NP + lane;
+        } else {
+            pf_p = (lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP;
+        }
     };
     auto dma_image = [&](auto J, const char* const (&base)[NGROUP], double2* buf) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
@@ -908,27 +928,31 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         } else if constexpr (piece == 2 * IMG_PIECES) {
             dma16(pf_d, dbuf + pf_par * 64);
         } else if constexpr (piece == 2 * IMG_PIECES + 1) {
-            dma4(pf_p, pbuf + pf_par * 64);
-        }
+            dma4(pf_p, pbuf + pf_par * PINTS);
+        } else if constexpr (piece == 2 * IMG_PIECES + 2 && NP > 32) {
+            dma4(pf_p2, pbuf + pf_par * PINTS + PINTS / 2);
+        }  // (NP = 16: hook_a also passes piece numbers >= PIECES, which fetch nothing)
     };
-    auto issue_dma = [&](size_t m, int par, bool adjoint) {
+    // (always_inline: as a real call - what NB = 4 with its 131 pieces otherwise becomes - the closure
+    // lives in scratch and the LDS-DMA destinations are no longer compile-time address-space known)
+    auto issue_dma = [&](size_t m, int par, bool adjoint) __attribute__((always_inline)) {
         set_prefetch(m, par, adjoint);
         for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
     };
     auto hook_a = [&](auto KK) __attribute__((always_inline)) {  // first solve: pieces 0 .. NP-2
-        if constexpr (!LOADER) {
+        if constexpr (!LOADER && PREFETCH) {
             if (pf_due) dma_one(KK);
         }
     };
     auto hook_b = [&](auto KK) __attribute__((always_inline)) {  // second solve: the remaining pieces
         constexpr int piece = NP - 1 + decltype(KK)::value;
-        if constexpr (!LOADER && piece < PIECES) {
+        if constexpr (!LOADER && PREFETCH && piece < PIECES) {
             if (pf_due) dma_one(std::integral_constant<int, piece>());
         }
     };
     auto finish_prefetch = [&]() {  // pieces that did not fit into the two solves (NP = 16)
         constexpr int DONE = 2 * (NP - 1), REST = PIECES > DONE ? PIECES - DONE : 0;
-        if constexpr (LOADER) return;
+        if constexpr (LOADER || !PREFETCH) return;
         if (pf_due)
             for_each_const(
                 [&](auto P) __attribute__((always_inline)) {
@@ -944,7 +968,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     auto scalars = [&](int par, bool adjoint) {
         StepScalars sc;
         sc.dv = dbuf[par * 64 + i];
-        sc.pm = min(max(pbuf[par * 64 + (adjoint ? 32 : 0) + i], 0), NP - 1);
+        sc.pm = min(max(pbuf[par * PINTS + (adjoint ? PINTS / 2 : 0) + i], 0), NP - 1);
         return sc;
     };
 
@@ -1000,11 +1024,17 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         for (int step = jb; step < je; ++step) {
             const int par = (step - jb) % NBUF;
             const int nsub = nsub_next;
+            if constexpr (!PREFETCH) {
+                if (step > jb) {
+                    if constexpr (MULTI) __syncthreads();  // every wave has left the previous operands
+                    if (fetcher) issue_dma(m0 + step, 0, false);
+                }
+            }
             if (fetcher) wait_landed(step + 1 < je);
             block_sync();
             const StepScalars sc = scalars(par, false);
             if (computes)
-                lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r,
+                lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
                                        sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
@@ -1012,7 +1042,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 pf_due = fetcher && (step + 2 < je);
                 if (pf_due) set_prefetch(m0 + step + 2, (par + 2) % NBUF, false);
                 issue_all_due();
-            } else {
+            } else if constexpr (PREFETCH) {
                 pf_due = fetcher && (step + 1 < je);
                 if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
             }
@@ -1130,11 +1160,17 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
             const int par = it % NBUF;
             const int nsub = nsub_next;
+            if constexpr (!PREFETCH) {
+                if (it > 0) {
+                    if constexpr (MULTI) __syncthreads();
+                    if (fetcher) issue_dma(m0 + step, 0, true);
+                }
+            }
             if (fetcher) wait_landed(step - 1 >= jb);
             block_sync();
             const StepScalars sc = scalars(par, true);
             if (computes)
-                lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * 64, r,
+                lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
                                       sc.pm, lane, i);
             qcur = qbuf + par * MAT;
             wave_sync();
@@ -1142,7 +1178,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 pf_due = fetcher && (step - 2 >= jb);
                 if (pf_due) set_prefetch(m0 + step - 2, (par + 2) % NBUF, true);
                 issue_all_due();
-            } else {
+            } else if constexpr (PREFETCH) {
                 pf_due = fetcher && (step - 1 >= jb);
                 if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
             }
@@ -1371,7 +1407,7 @@ __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
 
 // Hermitian-generator variant: half the generator registers, so two waves share a SIMD.
 template <int NB, bool EXPLICIT>
-__global__ __launch_bounds__(64, 2) void krylov_grad_skew_kernel(KrylovArgs args) {
+__global__ __launch_bounds__(64, NB < 4 ? 2 : 1) void krylov_grad_skew_kernel(KrylovArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     krylov_grad_body<NB, EXPLICIT, true>(args, smem);
 }
@@ -1451,7 +1487,7 @@ static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a
 }
 template <int NB, int W, bool LOADER>
 static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
-    const int bytes = SweepLds<NB, LOADER ? 3 : 2>::bytes(a.S);
+    const int bytes = LOADER ? SweepLds<NB, 3>::bytes(a.S) : SweepLds<NB>::bytes(a.S);
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W, LOADER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1461,8 +1497,13 @@ static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
 template <int NB, int W>
 static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
     // (the loader variant's ring of three must fit the CU's LDS beside the state vectors)
-    if (a.loader && SweepLds<NB, 3>::bytes(a.S) <= 160 * 1024) launch_sweep_wl<NB, W, true>(a, batch, st);
-    else launch_sweep_wl<NB, W, false>(a, batch, st);
+    if constexpr (SweepPrefetch<NB>::value) {
+        if (a.loader && SweepLds<NB, 3>::bytes(a.S) <= 160 * 1024) {
+            launch_sweep_wl<NB, W, true>(a, batch, st);
+            return;
+        }
+    }
+    launch_sweep_wl<NB, W, false>(a, batch, st);
 }
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
@@ -1496,27 +1537,34 @@ static bool one_wave_pq() {
 }
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
+    else if (nb == 4) launch_pq4(a, nsteps, batch, st);
     else if (one_wave_pq()) launch_pq_t<2>(a, nsteps, batch, st);
     else launch_pq2(a, nsteps, batch, st);
 }
 void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
                         hipStream_t st) {
     if (nb == 1) launch_pq_explicit_t<1>(a_in, n, a, count, st);
+    else if (nb == 4) launch_pq4_explicit(a_in, n, a, count, st);
     else if (one_wave_pq()) launch_pq_explicit_t<2>(a_in, n, a, count, st);
     else launch_pq2_explicit(a_in, n, a, count, st);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
+    else if (nb == 2) hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(lu_kernel<4>, dim3((unsigned)count), dim3(64), 0, st, a);
 }
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st) {
     if (nb == 1) launch_sweep_t<1>(a, batch, st);
-    else launch_sweep_t<2>(a, batch, st);
+    else if (nb == 2) launch_sweep_t<2>(a, batch, st);
+    else launch_sweep_t<4>(a, batch, st);
 }
-int sweep_lds_bytes(int nb, int S) { return nb == 1 ? SweepLds<1>::bytes(S) : SweepLds<2>::bytes(S); }
+int sweep_lds_bytes(int nb, int S) {
+    return nb == 1 ? SweepLds<1>::bytes(S) : (nb == 2 ? SweepLds<2>::bytes(S) : SweepLds<4>::bytes(S));
+}
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
     if (nb == 1) launch_krylov_t<1>(a, nsteps, batch, st);
-    else launch_krylov_t<2>(a, nsteps, batch, st);
+    else if (nb == 2) launch_krylov_t<2>(a, nsteps, batch, st);
+    else launch_krylov_t<4>(a, nsteps, batch, st);
 }
 void launch_scatter(const ScatterArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.B * a.nc * a.K;

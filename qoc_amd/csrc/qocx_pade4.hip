@@ -1,0 +1,353 @@
+// qocx_pade4.hip - K1a for 33 <= n <= 64 (padded to 64): a FOUR-wave workgroup per propagator step.
+//
+// Same construction as the two-wave kernel of qocx_pade2.hip, one size up: wave w of the
+// workgroup owns COLUMN BLOCK w (tiles (0..3, w) of every 64 x 64 matrix, C-layout, 64 registers
+// per matrix). A product C = A B needs all of A - from the planar LDS slot, staged by the four
+// waves together - and only B(:, w), which is the wave's own column block of an earlier product;
+// the C-layout tile is the B operand of v_mfma_f64_16x16x4_f64 as it stands. Complex products by
+// the 3M scheme (three real MFMA chains, qocx_kernels.hip). One workgroup per CU-quarter is not the
+// aim here: a wave holds ~450 registers, i.e. one wave per SIMD, and the 67 KiB slot allows two
+// workgroups per CU.
+//
+// Reference: expm_pade (qoc/core/expm.py:153-252), always order 13, s from ||a||_1 and theta13;
+// the LU solve of expm.py:246-249 is K1b + the sweep (qocx_kernels.hip).
+#include "qocx_wave.h"
+
+namespace qocx {
+
+namespace pade4 {
+
+constexpr int NT = 4;                         // row tiles of a column block = waves per workgroup
+constexpr int NP = Geo<4>::NP, PITCH = Geo<4>::PITCH, PLANE = Geo<4>::PLANE, MAT = Geo<4>::MAT;
+constexpr int SLOT_F64 = 2 * PLANE;           // re | im planes
+constexpr int LDS_BYTES = (SLOT_F64 + 8) * 8;  // + two norm words per wave
+
+struct Col {  // tiles (0..3, w) of a complex matrix, C-layout
+    d4 re[NT], im[NT];
+};
+struct Acc3 {
+    d4 t1[NT], t2[NT], t3[NT];
+};
+
+__device__ __forceinline__ void stage_col(double* slot, int w, const Col& m) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int off = (16 * ti + 4 * r + q) * PITCH + 16 * w + c;
+            slot[off] = m.re[ti][r];
+            slot[PLANE + off] = m.im[ti][r];
+        }
+}
+
+// acc(ti) += A(ti, :) B(:, w), 3M scheme; A from the slot, B fragment from `bf`
+template <class BFrag>
+__device__ __forceinline__ void gemm3(Acc3& acc, const double* slot, BFrag bf) {
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int kk = 0; kk < 4 * NT; ++kk) {
+        double are[NT], aim[NT], asum[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int off = (16 * ti + c) * PITCH + 4 * kk + q;
+            are[ti] = slot[off];
+            aim[ti] = slot[PLANE + off];
+            asum[ti] = are[ti] + aim[ti];
+        }
+        double bre, bim;
+        bf(kk, bre, bim);
+        const double bsum = bre + bim;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            acc.t1[ti] = mfma_f64(are[ti], bre, acc.t1[ti]);
+            acc.t2[ti] = mfma_f64(aim[ti], bim, acc.t2[ti]);
+            acc.t3[ti] = mfma_f64(asum[ti], bsum, acc.t3[ti]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart (register pressure)
+    }
+}
+__device__ __forceinline__ void acc_zero(Acc3& a) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        a.t1[ti] = d4{0, 0, 0, 0};
+        a.t2[ti] = d4{0, 0, 0, 0};
+        a.t3[ti] = d4{0, 0, 0, 0};
+    }
+}
+__device__ __forceinline__ void acc_init(Acc3& a, const Col& c) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        a.t1[ti] = c.re[ti];
+        a.t2[ti] = d4{0, 0, 0, 0};
+        a.t3[ti] = c.re[ti] + c.im[ti];
+    }
+}
+__device__ __forceinline__ void acc_finish(Col& c, const Acc3& a) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        c.re[ti] = a.t1[ti] - a.t2[ti];
+        c.im[ti] = a.t3[ti] - a.t1[ti] - a.t2[ti];
+    }
+}
+
+struct Out {
+    double2* q_img;
+    double2* p_img;
+    int* s_out;
+    int* status;
+};
+
+// Every wave executes the same barriers; w = the wave's column block (wave-uniform).
+template <class Gen>
+__device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
+    double* sl = smem;
+    double* nrm = sl + SLOT_F64;
+    const int lane = lane_id();
+    const int q = lane >> 4, c = lane & 15;
+
+    // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
+    Col a;
+    gen(a, w);
+    {
+        double e = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                e += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
+        e += __shfl_xor(e, 16);
+        e += __shfl_xor(e, 32);
+        e = wave_max(e);  // the largest column sum of this column block
+        if (lane == 0) nrm[w] = e;
+    }
+    __syncthreads();  // 1
+    const double norm1 = fmax(fmax(nrm[0], nrm[1]), fmax(nrm[2], nrm[3]));
+    int sq = 0;
+    {
+        double th = QOCX_THETA13;
+        while (norm1 > th && sq < 30) {
+            th *= 2.0;
+            ++sq;
+        }
+        if (!(norm1 <= th)) {  // inf / nan / absurd
+            if (w == 0 && lane == 0) atomicOr(out.status, 2);
+            sq = 0;
+        }
+    }
+    const double scale = ldexp(1.0, -sq);
+    if (sq > 0) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    if (w == 0 && lane == 0) *out.s_out = sq;
+    stage_col(sl, w, a);
+    __syncthreads();  // 2
+
+    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
+    Col x2, x4, x6;
+    Acc3 acc;
+    acc_zero(acc);
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    acc_finish(x2, acc);
+    __syncthreads();  // 3: every read of a is done
+    stage_col(sl, w, x2);
+    __syncthreads();  // 4
+    acc_zero(acc);
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = x2.re[kk >> 2][kk & 3];
+        bim = x2.im[kk >> 2][kk & 3];
+    });
+    acc_finish(x4, acc);
+    acc_zero(acc);
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = x4.re[kk >> 2][kk & 3];
+        bim = x4.im[kk >> 2][kk & 3];
+    });
+    acc_finish(x6, acc);
+    __syncthreads();  // 5: every read of a2 is done
+    stage_col(sl, w, x6);
+    __syncthreads();  // 6
+
+    // ---- w2 = a6 (b13 a6 + b11 a4 + b9 a2) + b7 a6 + b5 a4 + b3 a2 (expm.py:157) ---------
+    // ---- v  = a6 (b12 a6 + b10 a4 + b8 a2) + b6 a6 + b4 a4 + b2 a2 + b0 I (expm.py:158) --
+    const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
+                 b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
+                 b10 = PADE_B[10], b11 = PADE_B[11], b12 = PADE_B[12], b13 = PADE_B[13];
+    Col w2, v;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        w2.re[ti] = b7 * x6.re[ti] + b5 * x4.re[ti] + b3 * x2.re[ti];
+        w2.im[ti] = b7 * x6.im[ti] + b5 * x4.im[ti] + b3 * x2.im[ti];
+    }
+    acc_init(acc, w2);
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        const int tb = kk >> 2, r = kk & 3;
+        bre = b13 * x6.re[tb][r] + b11 * x4.re[tb][r] + b9 * x2.re[tb][r];
+        bim = b13 * x6.im[tb][r] + b11 * x4.im[tb][r] + b9 * x2.im[tb][r];
+    });
+    acc_finish(w2, acc);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        v.re[ti] = b6 * x6.re[ti] + b4 * x4.re[ti] + b2 * x2.re[ti];
+        v.im[ti] = b6 * x6.im[ti] + b4 * x4.im[ti] + b2 * x2.im[ti];
+        if (ti == w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + q == c) v.re[ti][r] += b0;
+        }
+    }
+    acc_init(acc, v);
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        const int tb = kk >> 2, r = kk & 3;
+        bre = b12 * x6.re[tb][r] + b10 * x4.re[tb][r] + b8 * x2.re[tb][r];
+        bim = b12 * x6.im[tb][r] + b10 * x4.im[tb][r] + b8 * x2.im[tb][r];
+    });
+    acc_finish(v, acc);
+    __syncthreads();  // 7: every read of a6 is done
+    stage_col(sl, w, w2);
+
+    // ---- u = a w2 + b1 a (expm.py:157), evaluated as w2 a + b1 a: w2 is a polynomial in a, the
+    // two commute, and this way the A operand is the product just finished while B is the
+    // wave's own column block of the generator (rebuilt rather than kept in 64 registers).
+    gen(a, w);
+    if (sq > 0) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    Col u;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        u.re[ti] = b1 * a.re[ti];
+        u.im[ti] = b1 * a.im[ti];
+    }
+    acc_init(acc, u);
+    __syncthreads();  // 8
+    gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    acc_finish(u, acc);
+
+    // ---- P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers: for a
+    // fixed r the four q-lanes of a column hold rows 4r..4r+3 of one tile, i.e. one 64-byte run
+    // of the column-major image.
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = (16 * w + c) * NP + 16 * ti + 4 * r + q;
+            out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
+            out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
+        }
+}
+
+__global__ __launch_bounds__(256) void pade_pq4_kernel(FactorArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const int step = args.step0 + blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t m = (size_t)b * args.nsteps + step;
+    Out out;
+    out.q_img = args.q_img + m * MAT;
+    out.p_img = args.lu_img + m * MAT;
+    out.s_out = args.s_arr + m;
+    out.status = args.status;
+    const StepInterp si = args.interp[step];
+    const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
+    const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
+    const double2* h0 = args.h0_cimg + tsel * MAT;
+    const double2* g = args.g_cimg + tsel * args.K * MAT;
+    const double dt = args.dt;
+    const int K = args.K;
+    auto gen = [&](Col& a, int wcol) {
+        // H = h0 + sum_k u_k g_k ; a = dt * (-i H)  (schroedingerdiscrete.py:485-486,
+        // mathmethods.py:90-93); C-layout image index ((ti * 4 + tj) * 4 + r) * 64 + lane
+        d4 hre[NT], him[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = h0[((ti * NT + wcol) * 4 + r) * 64 + lane];
+                hre[ti][r] = e.x;
+                him[ti][r] = e.y;
+            }
+        for (int k = 0; k < K; ++k) {
+            const double uk = control_at(ctl_b, si, K, k);
+            const double2* gk = g + (size_t)k * MAT;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 e = gk[((ti * NT + wcol) * 4 + r) * 64 + lane];
+                    hre[ti][r] += uk * e.x;
+                    him[ti][r] += uk * e.y;
+                }
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            a.re[ti] = dt * him[ti];
+            a.im[ti] = -dt * hre[ti];
+        }
+    };
+    body(gen, out, smem, w);
+}
+
+// Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
+__global__ __launch_bounds__(256) void pade_pq4_explicit_kernel(const double2* a_in, int n,
+                                                                FactorArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
+                     blockIdx.x % args.seg_len;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, c = lane & 15;
+    Out out;
+    out.q_img = args.q_img + m * MAT;
+    out.p_img = args.lu_img + m * MAT;
+    out.s_out = args.s_arr + m;
+    out.status = args.status;
+    const double2* am = a_in + m * (size_t)n * n;
+    auto gen = [&](Col& a, int wcol) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + q, col = 16 * wcol + c;
+                double2 e = make_double2(0, 0);
+                if (row < n && col < n) e = am[(size_t)row * n + col];
+                a.re[ti][r] = e.x;
+                a.im[ti][r] = e.y;
+            }
+    };
+    body(gen, out, smem, w);
+}
+
+}  // namespace pade4
+
+static void pade4_lds_attr(const void* fn) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pade4::LDS_BYTES);
+}
+
+void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    pade4_lds_attr(reinterpret_cast<const void*>(pade4::pade_pq4_kernel));
+    hipLaunchKernelGGL(pade4::pade_pq4_kernel, dim3(nsteps, batch), dim3(256), pade4::LDS_BYTES, st, a);
+}
+void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {
+    pade4_lds_attr(reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel));
+    hipLaunchKernelGGL(pade4::pade_pq4_explicit_kernel, dim3(count), dim3(256), pade4::LDS_BYTES, st,
+                       a_in, n, a);
+}
+
+}  // namespace qocx

@@ -30,7 +30,7 @@ def test_wave_primitives(engine):
     assert failures == 0, report
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 17, 32])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 17, 32, 33, 48, 64])
 def test_pade_factor_kernel(engine, n):
     rng = np.random.default_rng(100 + n)
     mats = []
@@ -171,6 +171,10 @@ EDGE_CASES = [
     dict(n=31, N=5, Nc=9, K=8, S=2, dt=0.05, ces=1, sigma=0.1),   # Nc > N, many controls
     dict(n=20, N=14, Nc=5, K=2, S=6, dt=0.3, ces=2, sigma=1.5),   # 6 states on 4 sweep waves (2,2,1,1)
     dict(n=9, N=10, Nc=10, K=2, S=5, dt=0.9, ces=3, sigma=3.0),   # multi-wave sweep with squarings
+    # 33 <= n <= 64: sixteen tiles (four-wave K1a, NB = 4 forms of K1b / K2 / K3)
+    dict(n=33, N=6, Nc=4, K=2, S=1, dt=0.05, ces=1, sigma=0.5),   # 31 padded rows
+    dict(n=64, N=5, Nc=5, K=3, S=3, dt=0.02, ces=2, sigma=0.3),   # full size, two sweep waves
+    dict(n=40, N=7, Nc=3, K=2, S=5, dt=0.2, ces=3, sigma=1.0),    # four sweep waves, squarings
 ]
 
 

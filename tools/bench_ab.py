@@ -30,15 +30,24 @@ def main():
     ap.add_argument("--evals", type=int, default=4)
     ap.add_argument("--seeds", type=int, default=bench.SEEDS_PER_GPU)
     ap.add_argument("--time-segments", type=int, default=0)
+    ap.add_argument("--magnus", default="M2", choices=["M2", "M4", "M6"])
+    ap.add_argument("--states", type=int, default=1,
+                    help="S > 1: orthonormal random initial states and targets")
     args = ap.parse_args()
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 
     engine = Engine(0)
     h0, g, psi0, target = bench.make_problem()
+    if args.states > 1:
+        rng = np.random.default_rng(7)
+        q = lambda: np.linalg.qr(rng.standard_normal((bench.DIM, bench.DIM))  # noqa: E731
+                                 + 1j * rng.standard_normal((bench.DIM, bench.DIM)))[0]
+        psi0, target = q()[:args.states], q()[:args.states]
     engine.set_schroedinger_problem(
-        bench.DIM, 1, bench.K_CTRL, bench.N_EVAL, bench.N_EVAL, bench.DT * (bench.N_EVAL - 1),
-        h0[None], np.stack(g)[None], psi0,
-        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+        bench.DIM, args.states, bench.K_CTRL, bench.N_EVAL, bench.N_EVAL,
+        bench.DT * (bench.N_EVAL - 1), h0[None], np.stack(g)[None], psi0,
+        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)],
+        magnus_policy=args.magnus)
     engine.upload_controls(bench.make_controls(0, args.seeds))
     if args.time_segments:
         engine.set_pipeline(args.time_segments)
