@@ -209,6 +209,9 @@ void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int co
 // 33 <= n <= 64: four-wave workgroups (qocx_pade4.hip)
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
+// ... and the four-wave K1b / K3 of qocx_big.hip
+void launch_lu4(const LuArgs& a, size_t count, hipStream_t st);
+void launch_krylov4(const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st);
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);

@@ -457,18 +457,6 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
 // is final, which frees its registers); perm/iperm give the row order. Pivot choice = first
 // maximum of |re|+|im| (LAPACK izamax). Only the pivot row goes through LDS; the pivot element
 // comes from a dynamic v_readlane, the multipliers cross lane groups by ds_bpermute.
-// wave-wide max of a u32: four symmetric DPP exchanges inside each 16-lane row, then
-// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row results into lane 63
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // value of lane group `g` (static) of a double, replicated to every lane group
 template <int NB, int g>
 __device__ __forceinline__ double from_group(double v, int i) {
@@ -1216,6 +1204,16 @@ struct KrylovLds {
 // (<= 168 registers, 10 KiB LDS): no faster than two waves per SIMD of this form. What did pay
 // (16 %) was removing the exec-mask branches around the LDS stores: after sum_groups every lane
 // group holds the same values, so all of them store.
+// NB = 4: a lane walks 64 columns per matvec. Without a fence the compiler hoists all 64 LDS reads
+// of an unrolled loop above its FMAs (256 registers of operands on top of the 256 - 384 the
+// generator and abar occupy) and spills; eight columns in flight are plenty.
+template <int NB>
+__device__ __forceinline__ void column_fence(int cc) {
+    if constexpr (NB >= 4) {
+        if ((cc & 7) == 7) asm volatile("" ::: "memory");
+    }
+}
+
 template <int NB, bool EXPLICIT, bool SKEW>
 __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* smem) {
     typedef Geo<NB> G;
@@ -1269,6 +1267,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                     tr_[cc] = f.x;
                     ti_[cc] = f.y;
                 }
+                column_fence<NB>(cc);
             }
             for (int k = 0; k < K; ++k) {
                 const double uk = control_at(ctl_b, si, K, k);
@@ -1282,6 +1281,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                         tr_[cc] += uk * f.x;
                         ti_[cc] += uk * f.y;
                     }
+                    column_fence<NB>(cc);
                 }
             }
 #pragma unroll
@@ -1324,6 +1324,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                         s2r = fma(-him[cc], v2.y, fma(hre[cc], v2.x, s2r));
                         s2i = fma(him[cc], v2.x, fma(hre[cc], v2.y, s2i));
                     }
+                    column_fence<NB>(cc);
                 }
                 tar = sum_groups<NB>(s2r);
                 tai = sum_groups<NB>(s2i);
@@ -1347,6 +1348,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                     s0r = fma(-aim[cc], r.y, fma(are[cc], r.x, s0r));
                     s0i = fma(aim[cc], r.x, fma(are[cc], r.y, s0i));
                 }
+                column_fence<NB>(cc);
             }
             if (ii > 0) {
                 const double coef = PADE_B[ii];
@@ -1392,6 +1394,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
             for (int cc = 0; cc < CPL; ++cc) {
                 const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
                 acc = fma(abi[cc], -dts * e.x, fma(abr[cc], dts * e.y, acc));
+                column_fence<NB>(cc);
             }
             acc = wave_sum(acc);
             if (lane == 0) args.gstep[m * K + k] = acc;
@@ -1551,7 +1554,7 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 2) hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(lu_kernel<4>, dim3((unsigned)count), dim3(64), 0, st, a);
+    else launch_lu4(a, count, st);  // qocx_big.hip
 }
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st) {
     if (nb == 1) launch_sweep_t<1>(a, batch, st);
@@ -1564,7 +1567,7 @@ int sweep_lds_bytes(int nb, int S) {
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
     if (nb == 1) launch_krylov_t<1>(a, nsteps, batch, st);
     else if (nb == 2) launch_krylov_t<2>(a, nsteps, batch, st);
-    else launch_krylov_t<4>(a, nsteps, batch, st);
+    else launch_krylov4(a, nsteps, batch, st);  // qocx_big.hip
 }
 void launch_scatter(const ScatterArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.B * a.nc * a.K;

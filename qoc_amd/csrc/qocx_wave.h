@@ -68,6 +68,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// wave-wide max of a u32: four symmetric DPP exchanges inside each 16-lane row, then
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row results into lane 63
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }

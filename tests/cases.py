@@ -214,6 +214,21 @@ def case_non_hermitian():
     return c
 
 
+def big_cases():
+    """33 <= n <= 64 (sixteen MFMA tiles; the reference has no size limit and its report quotes
+    n = 64 rows, report.tex:58): a Hermitian n = 48 problem, the full n = 64 with three states and
+    Nc != N, and a non-Hermitian n = 40 one whose steps need squarings."""
+    a = case_random("big_n48", n=48, N=41, seeds=2, h_seed=5101, dt=0.05, sigma=0.3)
+    b = case_random("big_n64_fullU", n=64, N=17, seeds=2, h_seed=5102, S=3, K=2, Nc=9, dt=0.1,
+                    sigma=0.5, full_unitary=True)
+    c = case_random("big_nonherm_n40", n=40, N=13, seeds=2, h_seed=5103, S=2, K=2, dt=0.3,
+                    sigma=0.8, full_unitary=True)
+    rng = np.random.default_rng(5104)
+    c.h0 = c.h0 * 12.0 - 0.2j * np.diag(rng.uniform(0, 1, 40))
+    c.g_re = [c.g_re[0], c.g_re[1] + 0.2j * gue(rng, 40)]
+    return [a, b, c]
+
+
 def all_cases():
     cases = [case_iswap(m) for m in ("M2", "M4", "M6")]
     cases.append(case_non_hermitian())
@@ -228,6 +243,7 @@ def all_cases():
     cases.append(case_nc_ne_n())
     cases.append(case_control_costs(False))
     cases.append(case_control_costs(True))
+    cases.extend(big_cases())
     return cases
 
 
@@ -252,7 +268,12 @@ def opaque_cases():
                 cost_specs=[("TargetStateInfidelity",
                              dict(target_states=column_states(np.eye(n)[:, 1:2])))],
                 controls=_controls(4404, 2, 12, 1, True, 0.5))
-    return [real, cplx]
+    # the same through the sixteen-tile kernels (explicit generators into the four-wave Pade kernel)
+    big = case_random("opaque_eps2_n36", n=36, N=9, seeds=2, h_seed=4411, S=1, K=2, Nc=5, dt=0.15,
+                      sigma=0.6)
+    rng = np.random.default_rng(4412)
+    big.quad = [0.8 * gue(rng, 36), -0.5 * gue(rng, 36)]
+    return [real, cplx, big]
 
 
 def case_by_name(name):

@@ -63,3 +63,23 @@ def test_headline_kernels_share_a_simd():
     assert granule(total_registers(sweep)) + granule(total_registers(k1a)) <= 512
     assert granule(total_registers(sweep)) + granule(total_registers(k3)) <= 512
     assert granule(total_registers(sweep4)) + granule(total_registers(k3)) <= 512
+
+
+def test_sixteen_tile_kernels_do_not_spill():
+    """33 <= n <= 64 (qocx_pade4.hip, qocx_big.hip): a 64 x 64 complex matrix is 256 registers per
+    lane of one wave, so K1a / K1b / K3 are four-wave workgroups with a quarter of the columns per
+    wave. Their budgets: no scratch in K1b and K3 (the one-wave forms spilled 1000-2000 registers and
+    ran 3x slower), at most a few spilled registers in K1a."""
+    big = resources("qocx_big.hip")
+    pade4 = resources("qocx_pade4.hip")
+    lu = find(big, "lu4_kernel")
+    assert lu["ScratchSize"] == 0 and lu["VGPRs Spill"] == 0
+    assert (total_registers(lu) + 7) // 8 * 8 * 4 <= 512          # four K1b waves per SIMD
+    for frag in ("krylov4_kernelILb0ELb1E", "krylov4_kernelILb0ELb0E", "krylov4_kernelILb1ELb1E",
+                 "krylov4_kernelILb1ELb0E"):
+        k3 = find(big, frag)
+        assert k3["ScratchSize"] == 0, frag
+    assert total_registers(find(big, "krylov4_kernelILb0ELb1E")) <= 256   # two per SIMD (Hermitian H)
+    for frag in ("pade_pq4_kernel", "pade_pq4_explicit_kernel"):
+        k1a = find(pade4, frag)
+        assert k1a["ScratchSize"] <= 128, (frag, k1a)

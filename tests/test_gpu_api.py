@@ -179,7 +179,7 @@ def test_batch_grape_on_gpu_equals_eight_single_seed_runs():
     assert batch.best.best_error < np.max(batch.best_error) or np.ptp(batch.best_error) == 0
 
 
-@pytest.mark.parametrize("name", ["opaque_eps2_real", "opaque_stark_complex"])
+@pytest.mark.parametrize("name", ["opaque_eps2_real", "opaque_stark_complex", "opaque_eps2_n36"])
 def test_opaque_hamiltonian_on_gpu(name):
     """a hamiltonian(controls, time) that is not linear in the controls (the
     reference takes any callable; report.tex:22-32 names epsilon^2 terms). The host samples the

@@ -294,3 +294,17 @@ def test_random_shapes_fuzz(engine):
         checked += 1
         assert worst < 1.0, tag
     assert checked > 60
+
+
+def test_random_shapes_fuzz_big(engine):
+    """The same for 33 <= n <= 64 (M2): 24 random problems against the oracle."""
+    from tools import fuzz_parity
+    rng = np.random.default_rng(6464)
+    checked = 0
+    for index in range(24):
+        worst, tag = fuzz_parity.one(engine, rng, index, nmin=33, nmax=64)
+        if worst is None:
+            continue
+        checked += 1
+        assert worst < 1.0, tag
+    assert checked > 15

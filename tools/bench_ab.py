@@ -31,12 +31,14 @@ def main():
     ap.add_argument("--seeds", type=int, default=bench.SEEDS_PER_GPU)
     ap.add_argument("--time-segments", type=int, default=0)
     ap.add_argument("--magnus", default="M2", choices=["M2", "M4", "M6"])
+    ap.add_argument("--dim", type=int, default=bench.DIM, help="Hilbert size (GUE problem of bench.py)")
     ap.add_argument("--states", type=int, default=1,
                     help="S > 1: orthonormal random initial states and targets")
     args = ap.parse_args()
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 
     engine = Engine(0)
+    bench.DIM = args.dim
     h0, g, psi0, target = bench.make_problem()
     if args.states > 1:
         rng = np.random.default_rng(7)

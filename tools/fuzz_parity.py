@@ -22,14 +22,16 @@ NODES = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
          "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}
 
 
-def one(engine, rng, index):
-    n = int(rng.integers(1, 33))
+def one(engine, rng, index, nmin=1, nmax=32):
+    n = int(rng.integers(nmin, nmax + 1))
     N = int(rng.integers(2, 14))
     K = int(rng.integers(1, 4))
     Nc = int(rng.integers(2, 16))
     S = int(rng.integers(1, 5))
     ces = int(rng.integers(1, 4))
     policy = ("M2", "M2", "M4", "M6")[int(rng.integers(0, 4))]
+    if n > 32:
+        policy = "M2"  # the Magnus kernels stop at two tiles per side
     hermitian = rng.random() < 0.7
     time_dep = rng.random() < 0.3
     dt = float(10 ** rng.uniform(-2, 0.3))
@@ -96,12 +98,14 @@ def one(engine, rng, index):
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     rng = np.random.default_rng(seed)
     engine = Engine(0)
     bad = skipped = 0
     overall = 0.0
     for index in range(count):
-        worst, tag = one(engine, rng, index)
+        worst, tag = one(engine, rng, index, nmin, nmax)
         if worst is None:
             skipped += 1
             continue
