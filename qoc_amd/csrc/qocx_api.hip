@@ -476,8 +476,6 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     // matrices are padded to 16, 32 or 64: one, four or sixteen MFMA tiles (33 <= n <= 64 runs on
     // the four-wave K1a of qocx_pade4.hip and the NB = 4 forms of K1b / K2 / K3)
     const int nb = (n <= 16) ? 1 : (n <= 32 ? 2 : 4), np = 16 * nb, mat = np * np, nt = p->nt;
-    if (nb == 4 && nodes > 1)
-        return fail(QOCX_ERR_ARG, "magnus_policy M4 / M6 needs hilbert_size <= 32");
     ctx->has_problem = false;
     ctx->n = n; ctx->nb = nb; ctx->np = np; ctx->S = S; ctx->K = K; ctx->nc = nc; ctx->N = N;
     ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt; ctx->nodes = nodes;

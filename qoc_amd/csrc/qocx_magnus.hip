@@ -574,8 +574,20 @@ size_t magnus_scratch_elems(int nb, int blocks) {
     return (size_t)blocks * S_COUNT * (size_t)(256 * nb * nb);
 }
 
+// NB = 4 (33 <= n <= 64): the two operand slots are 135 KiB, and a C-layout matrix is 256 registers
+// of the one wave, so these instantiations live on scratch (6-13 KB per lane). They exist so that M4 /
+// M6 work at those sizes at all; the fast path there is M2.
+template <class Kernel>
+static void magnus_lds_attr(Kernel kernel, int bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 template <int NB>
 static void launch_fwd_t(const MagnusArgs& a, int blocks, hipStream_t st) {
+    magnus_lds_attr(magnus_fwd_kernel<NB, 2>, MagnusLds<NB>::BYTES);
+    magnus_lds_attr(magnus_fwd_kernel<NB, 3>, MagnusLds<NB>::BYTES);
     if (a.nodes == 2)
         hipLaunchKernelGGL((magnus_fwd_kernel<NB, 2>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
                            st, a);
@@ -585,6 +597,8 @@ static void launch_fwd_t(const MagnusArgs& a, int blocks, hipStream_t st) {
 }
 template <int NB>
 static void launch_vjp_t(const MagnusArgs& a, int blocks, hipStream_t st) {
+    magnus_lds_attr(magnus_vjp_kernel<NB, 2>, MagnusLds<NB>::BYTES);
+    magnus_lds_attr(magnus_vjp_kernel<NB, 3>, MagnusLds<NB>::BYTES);
     if (a.nodes == 2)
         hipLaunchKernelGGL((magnus_vjp_kernel<NB, 2>), dim3(blocks), dim3(64), MagnusLds<NB>::BYTES,
                            st, a);
@@ -595,12 +609,14 @@ static void launch_vjp_t(const MagnusArgs& a, int blocks, hipStream_t st) {
 
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
     if (nb == 1) launch_fwd_t<1>(a, blocks, st);
-    else launch_fwd_t<2>(a, blocks, st);
+    else if (nb == 2) launch_fwd_t<2>(a, blocks, st);
+    else launch_fwd_t<4>(a, blocks, st);
 }
 
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
     if (nb == 1) launch_vjp_t<1>(a, blocks, st);
-    else launch_vjp_t<2>(a, blocks, st);
+    else if (nb == 2) launch_vjp_t<2>(a, blocks, st);
+    else launch_vjp_t<4>(a, blocks, st);
 }
 
 }  // namespace qocx

@@ -226,7 +226,16 @@ def big_cases():
     rng = np.random.default_rng(5104)
     c.h0 = c.h0 * 12.0 - 0.2j * np.diag(rng.uniform(0, 1, 40))
     c.g_re = [c.g_re[0], c.g_re[1] + 0.2j * gue(rng, 40)]
-    return [a, b, c]
+    out = [a, b, c]
+    # M4 / M6 at sixteen tiles (slow one-wave Magnus kernels, see qocx_magnus.hip): large steps so
+    # that the commutators matter, explicit time dependence, Nc != N
+    for magnus in ("M4", "M6"):
+        d = case_random("big_n40_" + magnus, n=40, N=6, seeds=2, h_seed=5105, S=1, K=2, Nc=4,
+                        dt=0.4, magnus=magnus, sigma=1.0)
+        d.h0 = d.h0 * 4.0
+        d.time_mod = 2.3
+        out.append(d)
+    return out
 
 
 def all_cases():

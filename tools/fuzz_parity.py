@@ -30,8 +30,6 @@ def one(engine, rng, index, nmin=1, nmax=32):
     S = int(rng.integers(1, 5))
     ces = int(rng.integers(1, 4))
     policy = ("M2", "M2", "M4", "M6")[int(rng.integers(0, 4))]
-    if n > 32:
-        policy = "M2"  # the Magnus kernels stop at two tiles per side
     hermitian = rng.random() < 0.7
     time_dep = rng.random() < 0.3
     dt = float(10 ** rng.uniform(-2, 0.3))
