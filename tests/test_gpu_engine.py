@@ -132,7 +132,7 @@ def test_error_paths(engine):
             fresh.eval_resident(True)
         assert err.value.code == -3
         with pytest.raises(QocxError) as err:  # unsupported size
-            fresh.set_schroedinger_problem(33, 1, 0, 0, 5, 1.0, np.eye(33), None, np.eye(33)[:1])
+            fresh.set_schroedinger_problem(65, 1, 0, 0, 5, 1.0, np.eye(65), None, np.eye(65)[:1])
         assert err.value.code == -1 and "hilbert_size" in err.value.message
         with pytest.raises(QocxError):  # nt neither 1 nor (N-1) * nodes
             fresh.set_schroedinger_problem(4, 1, 0, 0, 5, 1.0, np.stack([np.eye(4)] * 3), None,
