@@ -307,10 +307,35 @@ class LindbladEvaluator(object):
                  lindblad_data=None, control_count=0, control_eval_count=0,
                  complex_controls=False, costs=(), cost_eval_step=1,
                  interpolation_policy=InterpolationPolicy.LINEAR, need_gradients=True,
-                 backend=None, control_bounds=None):
+                 backend=None, control_bounds=None, frozen_controls=None):
+        """
+        frozen_controls :: (Nc x K) or None. Forward-only evaluation of ONE control array under a
+        hamiltonian(controls, time) that is not linear in the controls (the reference calls any
+        callable per RHS evaluation, lindbladdiscrete.py:479-483): the controls are folded into a
+        control-free, time-dependent Hamiltonian t -> hamiltonian(u(t), t), which the engine takes
+        as per-stage samples like any other time dependence. Costs still see the controls.
+        """
         if interpolation_policy != InterpolationPolicy.LINEAR:
             raise NotImplementedError("This operation does not yet support the interpolation "
                                       "policy {}.".format(interpolation_policy))
+        self._cost_controls = None
+        if frozen_controls is not None:
+            if need_gradients:
+                raise structure.NonLinearHamiltonianError(
+                    "gradients through a hamiltonian(controls, time) that is not linear in the "
+                    "controls are available on the Schroedinger path only")
+            frozen_controls = np.asarray(frozen_controls)
+            self._cost_controls = frozen_controls
+            user_hamiltonian, frozen_nc = hamiltonian, frozen_controls.shape[0]
+
+            def hamiltonian(_, time):
+                rows = structure.interpolation_rows(evolution_time, frozen_nc, [time])
+                return user_hamiltonian(structure.controls_at(frozen_controls, rows, [time])[0],
+                                        time)
+            # one dummy control with a zero coupling keeps the control knots in the integrator's
+            # grid: u(t) has kinks there, and a sub-interval that straddled one would lose the
+            # integrator's order (the engine cuts sub-intervals at knots only when it has controls)
+            control_count, control_eval_count, complex_controls = 1, frozen_nc, False
         initial_densities = np.asarray(initial_densities)
         self.density_count = initial_densities.shape[0]
         self.hilbert_size = initial_densities.shape[1]
@@ -460,6 +485,8 @@ class LindbladEvaluator(object):
                                  else np.real(opaque_grads))
         for b in range(batch):
             controls = None if self.control_count == 0 else controls_batch[b]
+            if self._cost_controls is not None:
+                controls = self._cost_controls
             for cost_ in self.host_costs:
                 errors[b] += cost_.cost(controls, None, self.final_system_eval_step)
                 if want_grad:
@@ -494,6 +521,8 @@ class LindbladEvaluator(object):
 
     def evaluate(self, controls, want_grad=True, want_step_densities=False):
         batch = None if controls is None else np.asarray(controls)[None]
+        if self._cost_controls is not None:  # frozen controls: the device's dummy control is zero
+            batch = np.zeros((1, self.control_eval_count, 1))
         errors, grads, final, steps = self.evaluate_batch(batch, want_grad, want_step_densities)
         return (float(errors[0]), None if grads is None else grads[0], final[0],
                 None if steps is None else steps[0])

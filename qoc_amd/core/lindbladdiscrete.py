@@ -14,6 +14,7 @@ import numpy as np
 from qoc_amd.core.common import (clip_control_norms, initialize_controls, slap_controls,
                                  strip_controls)
 from qoc_amd.core.device import LindbladEvaluator
+from qoc_amd.core.structure import NonLinearHamiltonianError
 from qoc_amd.models import (Dummy, EvolveLindbladDiscreteState, EvolveLindbladResult,
                             GrapeLindbladDiscreteState, GrapeLindbladResult,
                             InterpolationPolicy)
@@ -41,15 +42,23 @@ def evolve_lindblad_discrete(evolution_time, initial_densities, system_eval_coun
                                          interpolation_policy, lindblad_data, save_file_path,
                                          save_intermediate_densities, system_eval_count)
     pstate.save_initial(controls)
-    evaluator = LindbladEvaluator(
-        evolution_time, initial_densities, system_eval_count, hamiltonian=hamiltonian,
-        lindblad_data=lindblad_data, control_count=control_count,
-        control_eval_count=control_eval_count,
-        complex_controls=controls is not None and np.iscomplexobj(controls), costs=costs,
-        cost_eval_step=cost_eval_step, interpolation_policy=interpolation_policy,
-        need_gradients=False)
+    common = dict(hamiltonian=hamiltonian, lindblad_data=lindblad_data, costs=costs,
+                  cost_eval_step=cost_eval_step, interpolation_policy=interpolation_policy,
+                  need_gradients=False)
+    try:
+        evaluator = LindbladEvaluator(
+            evolution_time, initial_densities, system_eval_count, control_count=control_count,
+            control_eval_count=control_eval_count,
+            complex_controls=controls is not None and np.iscomplexobj(controls), **common)
+        device_controls = controls
+    except NonLinearHamiltonianError:
+        # not linear in the controls: fold this control array into a time-dependent Hamiltonian
+        evaluator = LindbladEvaluator(evolution_time, initial_densities, system_eval_count,
+                                      frozen_controls=controls, **common)
+        device_controls = None
     error, _, final_densities, step_densities = evaluator.evaluate(
-        controls, want_grad=False, want_step_densities=pstate.save_intermediate_densities_)
+        device_controls, want_grad=False,
+        want_step_densities=pstate.save_intermediate_densities_)
     if pstate.save_intermediate_densities_:
         pstate.save_all_intermediate_densities(0, step_densities)
     return EvolveLindbladResult(error=error, final_densities=final_densities)

@@ -400,8 +400,19 @@ def lindblad_cases():
     ]
 
 
+def lindblad_opaque_cases():
+    """A Hamiltonian that is not linear in the controls on the Lindblad path (forward only: the
+    host folds the control array into a time-dependent Hamiltonian)."""
+    c = lindblad_case("lindblad_opaque_n6", n=6, N=21, S=2, K=2, seeds=2, h_seed=7701, Nc=7,
+                      sigma=0.6, with_forbid=True, cost_eval_step=2)
+    rng = np.random.default_rng(7702)
+    c.quad = [0.7 * gue(rng, 6), -0.4 * gue(rng, 6)]
+    c.time_mod = 1.7
+    return [c]
+
+
 def lindblad_case_by_name(name):
-    for c in lindblad_cases():
+    for c in lindblad_cases() + lindblad_opaque_cases():
         if c.name == name:
             return c
     raise KeyError(name)

@@ -27,7 +27,7 @@ def real_engine():
     device.set_backend_factory(None)
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + [c.name for c in cases_mod.lindblad_opaque_cases()])
 def test_evolve_lindblad_on_gpu(name):
     case = cases_mod.lindblad_case_by_name(name)
     g = golden(name)

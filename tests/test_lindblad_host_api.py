@@ -123,10 +123,30 @@ def test_structure_rejects_time_dependence_and_size():
                                  control_count=case.K)
     _, dens = ol.evaluate(problem, case.controls[0])
     assert np.max(np.abs(r.final_densities - dens)) < 1e-8
+    # a Hamiltonian that is NOT linear in the controls (the reference calls any callable at every
+    # right-hand side, lindbladdiscrete.py:479-483): evolve folds the control array into a
+    # time-dependent Hamiltonian; against the reference integrator, with a control cost on top
+    from qoc_amd.standard import ControlNorm
+    quad = lambda u, t: case.h0 + u[0] * case.g_re[0] + u[1] ** 2 * case.g_re[1] * (1 + 0.2 * t)
+    coarse = case.controls[0][:4] * 2.0  # Nc = 4 knots that do not fall on system steps (N = 11)
+    r = qoc_amd.evolve_lindblad_discrete(
+        case.T, case.initial_densities, case.N, controls=coarse, hamiltonian=quad,
+        lindblad_data=case.lindblad_data(),
+        costs=[ControlNorm(4, case.K, cost_multiplier=0.3,
+                           max_control_norms=np.full(case.K, 2.0))])
+    problem = ol.LindbladProblem(case.T, case.initial_densities, case.N, hamiltonian=quad,
+                                 lindblad_data=case.lindblad_data(), control_eval_count=4,
+                                 control_count=case.K)
+    _, dens = ol.evaluate(problem, coarse)
+    assert np.max(np.abs(r.final_densities - dens)) < 1e-8
+    expected = ControlNorm(4, case.K, cost_multiplier=0.3,
+                           max_control_norms=np.full(case.K, 2.0)).cost(coarse, None, 0)
+    assert abs(r.error - expected) < 1e-12 and expected > 0
+    # (gradients through such a callable exist on the Schroedinger path only)
     with pytest.raises(structure.NonLinearHamiltonianError):
-        qoc_amd.evolve_lindblad_discrete(
-            case.T, case.initial_densities, case.N, controls=case.controls[0],
-            hamiltonian=lambda u, t: case.h0 + u[0] ** 2 * case.g_re[0])
+        qoc_amd.grape_lindblad_discrete(
+            case.K, case.Nc, [], case.T, case.initial_densities, case.N, hamiltonian=quad,
+            lindblad_data=case.lindblad_data(), iteration_count=1, log_iteration_step=0)
     with pytest.raises(NotImplementedError):
         qoc_amd.evolve_lindblad_discrete(1.0, np.eye(33)[None] / 33, 2,
                                          hamiltonian=lambda u, t: np.eye(33))

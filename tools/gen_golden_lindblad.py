@@ -114,6 +114,15 @@ def main(only=None):
                             grads_ad_traced_controller=np.stack(traced), controls=case.controls,
                             fd_index=np.stack(fd_index), grads_fd=np.stack(grads_fd))
         print("{:24s} errors {} ({:.1f}s)".format(case.name, errors, time.time() - t0))
+    # Hamiltonians that are not linear in the controls: forward only (errors, final densities)
+    for case in cases_mod.lindblad_opaque_cases():
+        if only and case.name not in only:
+            continue
+        out = [ref_forward(case, controls) for controls in case.controls]
+        np.savez_compressed(os.path.join(GOLDEN, case.name + ".npz"),
+                            error=np.array([o[0] for o in out]),
+                            final_densities=np.stack([o[1] for o in out]), controls=case.controls)
+        print("{:24s} errors {}".format(case.name, [o[0] for o in out]))
     # the reference's analytic known answers (tests/test_core.py:82-148) are asserted directly in
     # tests/test_lindblad_oracle.py; no fixture needed.
 
