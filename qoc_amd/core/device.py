@@ -404,8 +404,8 @@ class LindbladEvaluator(object):
                 self._hamiltonian, n, self.control_count, self.complex_controls,
                 list(self._coarse_times))
         h_probe, g_probe = self._coarse_samples
-        h_norm = max(np.linalg.norm(m, 1) for m in h_probe)
-        g_norms = [max(np.linalg.norm(g_probe[t, k], 1) for t in range(g_probe.shape[0]))
+        h_norm = max(np.linalg.norm(m, 2) for m in h_probe)
+        g_norms = [max(np.linalg.norm(g_probe[t, k], 2) for t in range(g_probe.shape[0]))
                    for k in range(kr)]
         ksub = structure.lindblad_subdivision(h_norm, g_norms, bounds, dissipators, operators, dt)
         if self._lindblad_data is not None:  # the largest dissipative norm over the coarse grid

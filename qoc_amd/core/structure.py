@@ -273,13 +273,14 @@ def sample_lindblad_data(lindblad_data, hilbert_size, times):
 def lindblad_subdivision(h0_norm, g_norms, control_bounds, dissipators, operators, dt,
                          margin=1.25, max_phase=0.4):
     """Sub-division count for a time-dependent Hamiltonian: the engine's per-seed rule
-    (||Liouvillian|| * piece <= max_phase) evaluated for the largest controls, with a margin for
-    the norm of H between the probe times."""
+    (||Liouvillian||_2 * piece <= max_phase, with ||.||_2 bounded by 2 ||H||_2 + 2 sum gamma
+    ||L||_2^2) evaluated for the largest controls, with a margin for the norm of H between the
+    probe times. h0_norm / g_norms are spectral norms."""
     bound = h0_norm + sum(b * g for b, g in zip(control_bounds, g_norms))
     diss = 0.0
     if dissipators is not None:
         for gm, op in zip(dissipators, operators):
-            diss += abs(gm) * np.linalg.norm(op, 1) * np.linalg.norm(op, np.inf)
+            diss += abs(gm) * np.linalg.norm(op, 2) ** 2
     return max(1, int(np.ceil(margin * (2 * bound + 2 * diss) * abs(dt) / max_phase)))
 
 

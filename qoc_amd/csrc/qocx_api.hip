@@ -91,6 +91,65 @@ double one_norm(const double* m, int n) {  // complex row-major
     return best;
 }
 
+// Largest singular value of a complex n x n matrix (row-major, interleaved), for the step-size
+// rule of the Lindblad integrator: power iteration on A^H A from a fixed start vector, stopped at
+// 1e-4 relative change; the estimate comes from below, so 2 % are added, and it never exceeds the
+// rigorous bound sqrt(||A||_1 ||A||_inf). (The 1-norm used before over-estimates the 2-norm of a
+// dense Hermitian matrix by 2-3x, i.e. made the integrator take 2-3x more sub-intervals than the
+// same threshold on the operator norm asks for.)
+double two_norm(const double* m, int n) {
+    double n1 = one_norm(m, n), ninf = 0;
+    for (int r = 0; r < n; ++r) {
+        double sum = 0;
+        for (int c = 0; c < n; ++c) sum += hypot(m[2 * ((size_t)r * n + c)], m[2 * ((size_t)r * n + c) + 1]);
+        ninf = std::max(ninf, sum);
+    }
+    const double upper = std::sqrt(n1 * ninf);
+    if (!(upper > 0) || !(upper < 1e300)) return upper;
+    std::vector<double> v(2 * n), w(2 * n);
+    double nv = 0;
+    for (int i = 0; i < n; ++i) {
+        v[2 * i] = 1.0 + 0.37 * i / n;
+        v[2 * i + 1] = 0.11 * ((i * 7) % 5);
+        nv += v[2 * i] * v[2 * i] + v[2 * i + 1] * v[2 * i + 1];
+    }
+    nv = std::sqrt(nv);
+    for (auto& e : v) e /= nv;
+    double sigma = 0, prev = -1;
+    for (int it = 0; it < 200; ++it) {
+        double nw = 0;
+        for (int r = 0; r < n; ++r) {  // w = A v
+            double re = 0, im = 0;
+            for (int c = 0; c < n; ++c) {
+                const double ar = m[2 * ((size_t)r * n + c)], ai = m[2 * ((size_t)r * n + c) + 1];
+                re += ar * v[2 * c] - ai * v[2 * c + 1];
+                im += ar * v[2 * c + 1] + ai * v[2 * c];
+            }
+            w[2 * r] = re; w[2 * r + 1] = im;
+            nw += re * re + im * im;
+        }
+        sigma = std::sqrt(nw);  // ||A v||, ||v|| = 1
+        if (!(sigma > 0)) break;
+        if (it >= 6 && std::fabs(sigma - prev) <= 1e-4 * sigma) break;
+        prev = sigma;
+        double nn = 0;
+        for (int c = 0; c < n; ++c) {  // v = A^H w, normalised
+            double re = 0, im = 0;
+            for (int r = 0; r < n; ++r) {
+                const double ar = m[2 * ((size_t)r * n + c)], ai = m[2 * ((size_t)r * n + c) + 1];
+                re += ar * w[2 * r] + ai * w[2 * r + 1];
+                im += ar * w[2 * r + 1] - ai * w[2 * r];
+            }
+            v[2 * c] = re; v[2 * c + 1] = im;
+            nn += re * re + im * im;
+        }
+        nn = std::sqrt(nn);
+        if (!(nn > 0)) break;
+        for (auto& e : v) e /= nn;
+    }
+    return std::min(1.02 * sigma, upper);
+}
+
 struct TimingRec {
     int which;
     hipEvent_t a, b;
@@ -157,7 +216,7 @@ struct qocx_ctx {
     struct Lindblad {
         bool has_problem = false, have_results = false, have_grads = false, have_steps = false;
         int n = 0, S = 0, K = 0, nc = 0, N = 0, nsteps = 0, ces = 1, nops = 0;
-        double T = 0, dt = 0, h0_norm = 0, diss_norm = 0;
+        double T = 0, dt = 0, h0_norm = 0, diss_norm = 0, l0_norm = 0;
         std::vector<double> g_norm;
         int has_step_costs = 0, cost_count = 0;
         DevBuf<double2> a0l, a0r, a0ld, a0rd, gp, gpd, gpt, ops, rho0, cost_matrices;
@@ -1242,6 +1301,53 @@ double cm_norm_inf(const cmat& m, int n) {
     return best;
 }
 
+// Spectral norm of the control-free Liouvillian X -> A_L X + X A_R + sum_i gamma_i L_i X L_i^H as
+// an operator on C^(n x n) (Frobenius inner product): matrix-free power iteration on its
+// adjoint-times-itself, stopped at 1e-4 relative change, + 2 % (the estimate comes from below).
+// The sum of the parts' bounds (2 ||H0||_2 + 2 sum gamma ||L||_2^2) over-estimates it 2-3x when
+// the dissipators are stiff in a few levels only (a^H a of a 16-level oscillator), and the
+// integrator's sub-division count is proportional to this number.
+double liouvillian_norm(const cmat& al, const cmat& ar, const std::vector<cmat>& ops,
+                        const std::vector<double>& gammas, int n) {
+    const cmat alh = cm_adjoint(al, n), arh = cm_adjoint(ar, n);
+    std::vector<cmat> opsh;
+    for (const auto& o : ops) opsh.push_back(cm_adjoint(o, n));
+    auto apply = [&](const cmat& x, bool adjoint) {
+        cmat y = cm_mul(adjoint ? alh : al, x, n);
+        cm_axpy(y, 1.0, cm_mul(x, adjoint ? arh : ar, n));
+        for (size_t i = 0; i < ops.size(); ++i)
+            cm_axpy(y, gammas[i], adjoint ? cm_mul(cm_mul(opsh[i], x, n), ops[i], n)
+                                          : cm_mul(cm_mul(ops[i], x, n), opsh[i], n));
+        return y;
+    };
+    auto fro = [](const cmat& x) {
+        double s = 0;
+        for (double e : x) s += e * e;
+        return std::sqrt(s);
+    };
+    cmat x((size_t)2 * n * n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            x[2 * ((size_t)r * n + c)] = 1.0 / (1.0 + r + c) + (r == c ? 1.0 : 0.0);
+            x[2 * ((size_t)r * n + c) + 1] = 0.3 * ((3 * r + c) % 4) - 0.4;
+        }
+    double nx = fro(x);
+    for (auto& e : x) e /= nx;
+    double sigma = 0, prev = -1;
+    for (int it = 0; it < 400; ++it) {
+        const cmat y = apply(x, false);
+        sigma = fro(y);
+        if (!(sigma > 0) || !(sigma < 1e300)) break;
+        if (it >= 8 && std::fabs(sigma - prev) <= 1e-4 * sigma) break;
+        prev = sigma;
+        x = apply(y, true);
+        nx = fro(x);
+        if (!(nx > 0)) break;
+        for (auto& e : x) e /= nx;
+    }
+    return 1.02 * sigma;
+}
+
 int upload_dumps(DevBuf<double2>& dst, const std::vector<cmat>& mats, int n, hipStream_t st) {
     const size_t md = dump_elems(n);
     std::vector<double2> img(mats.size() * md);
@@ -1296,18 +1402,25 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         ops.push_back(cm_from(p->operators + (size_t)i * n * n * 2, n));
         gammas[i] = p->dissipators[i];
         cm_axpy(decay, gammas[i], cm_mul(cm_adjoint(ops[i], n), ops[i], n));
-        lb.diss_norm += fabs(gammas[i]) * one_norm(ops[i].data(), n) * cm_norm_inf(ops[i], n);
+        // || rho -> gamma (L rho L^H - {L^H L, rho} / 2) || <= 2 gamma ||L||_2^2 (the factor 2 is
+        // applied where the bound is formed)
+        const double opn = two_norm(ops[i].data(), n);
+        lb.diss_norm += fabs(gammas[i]) * opn * opn;
     }
     // A0L = -i H0 - decay/2 ; A0R = +i H0 - decay/2   (mathmethods.py:188, :200-203)
     cmat a0l = cm_scale(h0, 0.0, -1.0), a0r = cm_scale(h0, 0.0, 1.0);
     cm_axpy(a0l, -0.5, decay);
     cm_axpy(a0r, -0.5, decay);
-    lb.h0_norm = one_norm(h0.data(), n);
+    lb.h0_norm = two_norm(h0.data(), n);
+    // static problem: the control-free Liouvillian as a whole (never above the sum of the parts)
+    lb.l0_norm = std::min(liouvillian_norm(a0l, a0r, ops, gammas, n),
+                          2 * lb.h0_norm + 2 * lb.diss_norm);
+    if (!(lb.l0_norm < 1e300)) lb.l0_norm = 2 * lb.h0_norm + 2 * lb.diss_norm;
     std::vector<cmat> gp, gpd, gpt;
     lb.g_norm.assign(K, 0.0);
     for (int k = 0; k < K; ++k) {
         const cmat gk = cm_from(p->g + (size_t)k * n * n * 2, n);
-        lb.g_norm[k] = one_norm(gk.data(), n);
+        lb.g_norm[k] = two_norm(gk.data(), n);
         gp.push_back(cm_scale(gk, 0.0, -1.0));  // Gp = -i G
         gpd.push_back(cm_adjoint(gp.back(), n));
         gpt.push_back(cm_transpose(gp.back(), n));
@@ -1345,7 +1458,11 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         if (td_ops) lb.diss_norm = 0;
         for (int64_t st = 0; st < count; ++st) {
             const cmat h = cm_from(p->h0_stages + (size_t)st * n * n * 2, n);
-            lb.h0_norm = std::max(lb.h0_norm, one_norm(h.data(), n));
+            // (norms on every fourth stage sample: they vary smoothly in time, the host picked
+            // the sub-division with a 25 % margin, and a power iteration per sample is what made
+            // this loop slow)
+            const bool norm_sample = (st % 4 == 0) || st == count - 1;
+            if (norm_sample) lb.h0_norm = std::max(lb.h0_norm, two_norm(h.data(), n));
             cmat l = cm_scale(h, 0.0, -1.0), r = cm_scale(h, 0.0, 1.0);
             cmat decay_st = decay;
             if (td_ops) {  // -1/2 sum_i gamma_i(t) L_i(t)^H L_i(t) of THIS stage time
@@ -1357,7 +1474,10 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
                     cm_axpy(decay_st, gi, cm_mul(cm_adjoint(li, n), li, n));
                     c_dump(li, n, otab.data() + ((size_t)st * L + i) * md);
                     gtab_d[(size_t)st * L + i] = gi;
-                    dn += fabs(gi) * one_norm(li.data(), n) * cm_norm_inf(li, n);
+                    if (norm_sample) {
+                        const double opn = two_norm(li.data(), n);
+                        dn += fabs(gi) * opn * opn;
+                    }
                 }
                 lb.diss_norm = std::max(lb.diss_norm, dn);
             }
@@ -1377,7 +1497,8 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
             for (int64_t st = 0; st < count; ++st)
                 for (int k = 0; k < K; ++k) {
                     const cmat gk = cm_from(p->g_stages + ((size_t)st * K + k) * n * n * 2, n);
-                    lb.g_norm[k] = std::max(lb.g_norm[k], one_norm(gk.data(), n));
+                    if (st % 4 == 0 || st == count - 1)
+                        lb.g_norm[k] = std::max(lb.g_norm[k], two_norm(gk.data(), n));
                     const cmat gpk = cm_scale(gk, 0.0, -1.0);
                     double2* dst = gtab.data() + (((size_t)st * K + k) * 3) * md;
                     c_dump(gpk, n, dst);
@@ -1565,16 +1686,20 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     // with equal counts are evaluated together: `order` lists the seeds group by group.
     std::vector<int> ksub_of(B);
     for (int b = 0; b < B; ++b) {
-        double bound = lb.h0_norm;
+        // || Liouvillian ||_2 <= || control-free part ||_2 + sum_k |u_k| 2 ||G_k||_2; with a
+        // time-dependent Hamiltonian / lindblad_data (tables) the control-free part is bounded by
+        // the sum of its parts' bounds over the samples
+        double ctl = 0;
         for (int k = 0; k < K; ++k) {
             double um = 0;
             for (int i = 0; i < nc; ++i) {
                 const double a = fabs(controls[((size_t)b * nc + i) * K + k]);
                 if (!(a <= um)) um = a;
             }
-            bound += um * lb.g_norm[k];
+            ctl += um * lb.g_norm[k];
         }
-        bound = 2 * bound + 2 * lb.diss_norm;
+        const double base = lb.fixed_ksub > 0 ? 2 * lb.h0_norm + 2 * lb.diss_norm : lb.l0_norm;
+        const double bound = base + 2 * ctl;
         if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or operators");
         const double pieces = ceil(bound * fabs(lb.dt) / 0.4);
         if (pieces * nsteps > (double)(1 << 24))
