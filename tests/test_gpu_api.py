@@ -99,13 +99,14 @@ def test_transmon_pi_pulse_example():
     assert np.all(np.abs(result.best_controls) <= 0.5 + 1e-12)
 
 
-@pytest.mark.parametrize("with_hook", [True, False])
-def test_user_cost_in_grape_on_gpu(with_hook):
-    """Host-supplied state cotangents (qocx_set_state_cotangents) against the built-in cost."""
+@pytest.mark.parametrize("with_hook,name,ces", [(True, "nc10_n101", 10), (False, "nc10_n101", 10),
+                                                (True, "big_n48", 8)])
+def test_user_cost_in_grape_on_gpu(with_hook, name, ces):
+    """Host-supplied state cotangents (qocx_set_state_cotangents) against the built-in cost; also
+    through the sixteen-tile sweep (n = 48): step states kept, cotangents injected per cost step."""
     from qoc_amd.standard import ForbidStates
     from tests.test_host_api import _UserOccupation
-    case = cases_mod.case_by_name("nc10_n101")
-    ces = 10
+    case = cases_mod.case_by_name(name)
     count = (case.N - 1) // ces
     forb = np.zeros((1, 1, case.n, 1), dtype=np.complex128)
     forb[0, 0, 1, 0] = 1

@@ -260,7 +260,8 @@ def test_multi_state_sweep_segments(engine):
     assert np.all(np.isfinite(ref[0])) and np.all(np.isfinite(ref[1]))
 
 
-@pytest.mark.parametrize("name", ["magnus_n20_M6", "small_complex_M4", "nonhermitian_n24"])
+@pytest.mark.parametrize("name", ["magnus_n20_M6", "small_complex_M4", "nonhermitian_n24",
+                                  "big_nonherm_n40", "big_n64_fullU"])
 def test_segments_and_chunks_with_other_kernel_variants(engine, name):
     """Time segments / memory chunks through the Magnus kernels, the explicit-generator K3 and
     the general (non-Hermitian) kernels give bit-identical results."""
