@@ -291,8 +291,9 @@ int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
  *                       as fit 45 % of free HBM); a larger group is launched in pieces;
  *   min_piece           below this many seeds per piece the adjoint recomputes the stage values
  *                       from the checkpoints instead (default 256);
- *   wave_mode           0 auto (several waves per seed while batch <= CU count), 1 one wave per
- *                       seed, 2 several waves per seed whenever the problem was built for it.
+ *   wave_mode           0 auto (several waves per seed, batches beyond the CU count in rounds of
+ *                       one seed per CU), 1 one wave per seed, 2 several waves per seed in ONE
+ *                       launch whatever the batch size.
  * Results do not depend on any of them (tests/test_gpu_lindblad.py). */
 int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t min_piece,
                               int32_t wave_mode);

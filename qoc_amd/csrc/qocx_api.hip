@@ -1806,6 +1806,13 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             if (fit >= (size_t)Bg) { keep_stages = true; }
             else if (fit >= (size_t)lb.dbg_min_piece) { keep_stages = true; piece = (int)fit; }
         }
+        // Several waves per seed (one seed per CU) whenever the kernel is built for this problem;
+        // batches beyond the CU count go in rounds of one seed per CU. (Round 1 switched to one wave
+        // per seed, two seeds per CU, beyond 256 seeds; measured on configs[3] at 300 / 512 / 768 /
+        // 1024 seeds: 73.7 / 80.7 / 126.6 / 123.7 ms against 74.4 / 76.6 / 82.7 / 104.8 ms in rounds.)
+        bool multi = lb.multi_wave != 0;
+        if (lb.dbg_wave_mode == 1) multi = false;
+        if (multi && lb.dbg_wave_mode != 2) piece = std::min(piece, ctx->cu_count);
         for (int p0 = 0; p0 < Bg; p0 += piece) {
             const int Bp = std::min(piece, Bg - p0);
             qocx::LindbladArgs la;
@@ -1826,9 +1833,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.scratch = lb.global_scratch ? lb.scratch.p : nullptr;  // likewise
             // several waves per seed shorten a seed's serial chain by ~1.4x but hold one seed
             // per CU instead of two: worth it while the batch leaves CUs idle
-            la.multi_wave = (lb.multi_wave && B <= ctx->cu_count) ? 1 : 0;
-            if (lb.dbg_wave_mode == 1) la.multi_wave = 0;
-            if (lb.dbg_wave_mode == 2) la.multi_wave = lb.multi_wave;
+            la.multi_wave = multi ? 1 : 0;
             la.cache_gen = (la.multi_wave && lb.cache_gen) ? 1 : 0;
             la.cost_out = lb.cost_out.p + pos0;
             la.final_out = lb.final_out.p + pos0 * S * md;

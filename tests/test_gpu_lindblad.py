@@ -252,9 +252,16 @@ def test_lindblad_launch_variants_agree(engine, name):
         assert np.max(np.abs(c_one - c_multi)) < 1e-13
         assert np.max(np.abs(f_one - f_multi)) < 1e-13
         assert np.max(np.abs(g_one - g_multi)) < 1e-12 * max(1.0, np.max(np.abs(g_multi)))
-        # B > CU count selects the one-wave kernel by itself: bit-identical to the forced one
-        engine.debug_lindblad_knobs(0, 256, 0)
+        # B > CU count: the automatic choice runs the several-wave kernel in rounds of one seed per
+        # CU (256 + 44 here) - bit-identical to the small batch; forced into one launch of the
+        # one-wave kernel (two seeds per CU) it is bit-identical to that kernel's small batch
         big = np.concatenate([u] * 150)                   # 300 seeds > 256 CUs
+        engine.debug_lindblad_knobs(0, 256, 0)
+        c_big, g_big, f_big = engine.evaluate_lindblad(big)
+        assert np.array_equal(c_big.reshape(150, nb), np.broadcast_to(c_multi, (150, nb)))
+        assert np.array_equal(g_big[:nb], g_multi) and np.array_equal(g_big[-nb:], g_multi)
+        assert np.array_equal(f_big[-nb:], f_multi)
+        engine.debug_lindblad_knobs(0, 256, 1)
         c_big, g_big, f_big = engine.evaluate_lindblad(big)
         assert np.array_equal(c_big.reshape(150, nb), np.broadcast_to(c_one, (150, nb)))
         assert np.array_equal(g_big[:nb], g_one) and np.array_equal(g_big[-nb:], g_one)
