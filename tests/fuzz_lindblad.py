@@ -1,9 +1,9 @@
 """
-fuzz_lindblad.py - BUILD TOOLING: random Lindblad problem shapes, engine (through the C ABI)
+fuzz_lindblad.py - TEST TOOLING (parity checker; lives under tests/ because it drives the oracle): random Lindblad problem shapes, engine (through the C ABI)
 against the NumPy model of the device algorithm (tests/lindblad_model.py), which the CPU suite
 holds against the reference fixtures.
 
-    python tools/fuzz_lindblad.py [count] [seed]
+    python -m tests.fuzz_lindblad [count] [seed]
 """
 import os
 import sys

@@ -1,10 +1,10 @@
 """
-fuzz_parity.py - BUILD TOOLING: random problem shapes, engine (through the C ABI) against the
+fuzz_parity.py - TEST TOOLING (parity checker; lives under tests/ because it drives the oracle): random problem shapes, engine (through the C ABI) against the
 oracle. Complements the fixed fixtures: sizes 1..32, random step counts / control grids / state
 counts / time steps (so that 0..4 squarings occur), all three Magnus policies, Hermitian and
 non-Hermitian generators, all state-cost kinds at once.
 
-    python tools/fuzz_parity.py [count] [seed]
+    python -m tests.fuzz_parity [count] [seed]
 """
 import os
 import sys

@@ -283,9 +283,9 @@ def test_segments_and_chunks_with_other_kernel_variants(engine, name):
 
 
 def test_random_shapes_fuzz(engine):
-    """tools/fuzz_parity.py: 80 random problems (sizes, grids, Magnus policies, Hermitian or not,
+    """tests/fuzz_parity.py: 80 random problems (sizes, grids, Magnus policies, Hermitian or not,
     time dependent or not, 0..4 squarings) against the oracle at the parity tolerances."""
-    from tools import fuzz_parity
+    from tests import fuzz_parity
     rng = np.random.default_rng(2024)
     checked = 0
     for index in range(80):
@@ -299,7 +299,7 @@ def test_random_shapes_fuzz(engine):
 
 def test_random_shapes_fuzz_big(engine):
     """The same for 33 <= n <= 64 (M2): 24 random problems against the oracle."""
-    from tools import fuzz_parity
+    from tests import fuzz_parity
     rng = np.random.default_rng(6464)
     checked = 0
     for index in range(24):

@@ -214,9 +214,9 @@ def test_lindblad_edge_shapes_against_model(engine, spec):
 
 
 def test_lindblad_random_shapes_fuzz(engine):
-    """tools/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
+    """tests/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
     several densities, batches that mix sub-division counts) against the device model."""
-    from tools import fuzz_lindblad
+    from tests import fuzz_lindblad
     rng = np.random.default_rng(2025)
     for index in range(40):
         worst, tag = fuzz_lindblad.one(engine, rng, index)

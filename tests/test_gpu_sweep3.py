@@ -107,9 +107,9 @@ def test_blocked_sweep_batch_independence_and_state_cotangents(engine):
 
 
 def test_blocked_sweep_random_shapes_fuzz(engine):
-    """tools/fuzz_parity.py on the blocked sweep: random sizes, grids, Magnus policies, Hermitian
+    """tests/fuzz_parity.py on the blocked sweep: random sizes, grids, Magnus policies, Hermitian
     or not, time dependent or not, 0..4 squarings, every cost kind, against the oracle."""
-    from tools import fuzz_parity
+    from tests import fuzz_parity
     rng = np.random.default_rng(4048)
     checked = 0
     for index in range(60):

@@ -2,8 +2,8 @@
 bench_lindblad.py - secondary measurement (not the driver's bench contract): the Lindblad
 engine on BASELINE.json configs[3] (SURVEY.md 8d "C4": n=16, N=501, L=2 operators a and a^dag a
 with gamma=(0.05, 0.02), K=2 real controls, S=1, dt=0.05), fwd+grad, for several batch sizes.
-Prints one JSON line per batch size; `cpu` times the oracle (the reference's adaptive RKDP5,
-forward only - the reference's gradient needs autograd) on one seed.
+Prints one JSON line per batch size. (The CPU restatement is timed by bench.py's cpu_baseline
+only: nothing under tools/ touches oracle/.)
 
     python tools/bench_lindblad.py --batches 64,1024 --reps 3
 """
@@ -53,7 +53,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="64,1024")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--cpu", action="store_true")
     args = ap.parse_args()
     from qoc_amd.engine import Engine, COST_TARGET_DENSITY
     h0, g, gam, ops, rho0, target = problem()
@@ -77,18 +76,6 @@ def main():
             steps_per_s=batch * (N_EVAL - 1) / wall, trace_defect=float(
                 np.max(np.abs(np.trace(final[:, 0], axis1=-2, axis2=-1) - 1))),
             cost0=float(cost[0]))), flush=True)
-    if args.cpu:
-        from oracle import qoc_lindblad_numpy as ol
-        p = ol.LindbladProblem(DT * (N_EVAL - 1), rho0, N_EVAL,
-                               hamiltonian=lambda uu, t: h0 + uu[0] * g[0] + uu[1] * g[1],
-                               lindblad_data=lambda t: (gam, ops), control_eval_count=N_EVAL,
-                               costs=[ol.TargetDensityInfidelity(target)], control_count=K_CTRL)
-        t0 = time.perf_counter()
-        err, _ = ol.evaluate(p, controls(1)[0])
-        wall = time.perf_counter() - t0
-        print(json.dumps(dict(cpu="oracle adaptive RKDP5 forward only, 1 seed, 1 core",
-                              steps_per_s=(N_EVAL - 1) / wall, seconds=wall,
-                              cost0=float(err))), flush=True)
 
 
 if __name__ == "__main__":

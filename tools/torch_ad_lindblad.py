@@ -8,10 +8,18 @@ only the accept/reject comparisons are decisions. HIPS autograd is not installed
 reference pins no gradient value, so this plays the role of its AD for the golden vectors.
 """
 
+import os
+
 import numpy as np
 import torch
 
-from oracle import qoc_lindblad_numpy as ol
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refstubs"))
+sys.path.insert(0, "/root/reference")
+from qoc.core import mathmethods as ol  # noqa: E402  the REFERENCE's own RKDP5(4) tableau
+
+ol.P_ORDER = ol.P  # (the name this file uses for the order)
 
 C = torch.complex128
 
