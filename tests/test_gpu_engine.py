@@ -134,6 +134,9 @@ def test_error_paths(engine):
         with pytest.raises(QocxError) as err:  # unsupported size
             fresh.set_schroedinger_problem(65, 1, 0, 0, 5, 1.0, np.eye(65), None, np.eye(65)[:1])
         assert err.value.code == -1 and "hilbert_size" in err.value.message
+        with pytest.raises(QocxError) as err:  # sixteen tiles: 14 states do not fit the sweep's LDS
+            fresh.set_schroedinger_problem(40, 14, 0, 0, 5, 1.0, np.eye(40), None, np.eye(40)[:14])
+        assert "state_count" in err.value.message
         with pytest.raises(QocxError):  # nt neither 1 nor (N-1) * nodes
             fresh.set_schroedinger_problem(4, 1, 0, 0, 5, 1.0, np.stack([np.eye(4)] * 3), None,
                                            np.eye(4)[:1])
@@ -175,6 +178,7 @@ EDGE_CASES = [
     dict(n=33, N=6, Nc=4, K=2, S=1, dt=0.05, ces=1, sigma=0.5),   # 31 padded rows
     dict(n=64, N=5, Nc=5, K=3, S=3, dt=0.02, ces=2, sigma=0.3),   # full size, two sweep waves
     dict(n=40, N=7, Nc=3, K=2, S=5, dt=0.2, ces=3, sigma=1.0),    # four sweep waves, squarings
+    dict(n=64, N=4, Nc=4, K=1, S=13, dt=0.1, ces=1, sigma=0.5),   # the most states that fit the LDS
 ]
 
 
