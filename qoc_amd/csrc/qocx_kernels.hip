@@ -668,6 +668,59 @@ __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
+// The same solves with the coefficients fetched from the LDS image stage by stage (NB = 4: a lane's
+// row of the LU image would be 256 registers; held there, the sweep wave owns a whole SIMD and only
+// one four-wave K3 workgroup fits on the other three). The coefficient of stage KK + 8 is requested
+// while stage KK runs (a ring of eight in registers); the asm statements of the chain carry memory
+// clobbers, so the requests stay where they are written. Forward: the lane at position i takes row
+// pm = perm[i], element (col k, row pm). Adjoint (the image in LDS is the transposed one): column
+// perm[k], element (col perm[k], row i), perm[k] by v_readlane from `permv` (lane l holds perm[l]).
+template <int NB, bool ADJ>
+__device__ __forceinline__ double2 lds_coef(const double2* lb, int pm, int i, int permv, int k) {
+    constexpr int NP = Geo<NB>::NP;
+    if constexpr (ADJ) {
+        const int pc = min(max(__builtin_amdgcn_readlane(permv, k), 0), NP - 1);
+        return lb[pc * NP + i];
+    } else {
+        return lb[k * NP + pm];
+    }
+}
+
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK>
+__device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, int permv,
+                                             double2 (&ring)[8], double& zre, double& zim) {
+    constexpr int NP = Geo<NB>::NP, D = 8;
+    constexpr int k = LOWER ? KK : (NP - 1 - KK);
+    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
+    const double2 c = ring[KK % D];
+    if constexpr (KK + D < NP - 1) {
+        constexpr int kn = LOWER ? (KK + D) : (NP - 1 - (KK + D));
+        ring[KK % D] = lds_coef<NB, ADJ>(lb, pm, i, permv, kn);
+    }
+    const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
+    masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
+        zre, zim, c.x, c.y, kre, kim);
+}
+
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int... KK>
+__device__ __forceinline__ void tri_solve_lds_seq(const double2* lb, int pm, int i, int permv,
+                                                  double2 (&ring)[8], double& zre, double& zim,
+                                                  std::integer_sequence<int, KK...>) {
+    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK>(lb, pm, i, permv, ring, zre, zim), ...);
+}
+
+template <int NB, bool LOWER, bool CONJ, bool ADJ>
+__device__ __forceinline__ void tri_solve_lds(const double2* lb, int pm, int i, int permv,
+                                              double& zre, double& zim) {
+    constexpr int NP = Geo<NB>::NP, D = 8;
+    double2 ring[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        ring[j] = lds_coef<NB, ADJ>(lb, pm, i, permv, LOWER ? j : (NP - 1 - j));
+    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ>(lb, pm, i, permv, ring, zre, zim,
+                                            std::make_integer_sequence<int, NP - 1>{});
+}
+
 template <int NB>
 struct SweepPrefetch {
     static constexpr bool value = NB < 4;
@@ -861,6 +914,8 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     }
     StepRegs<NB> r;
     const double2* qcur = qbuf;  // Q image of the step being computed
+    const double2* lcur = lbuf;  // LU image of the step (read stage by stage when !PREFETCH)
+    int permv = 0;               // perm[lane] of the step (adjoint, !PREFETCH)
     constexpr int MVB = Geo<NB>::CPL < 4 ? Geo<NB>::CPL : 4;  // (matrix, vector) LDS read pairs in flight
 
     // Everything a step needs arrives by LDS-DMA one step ahead: Q and LU images (the adjoint
@@ -971,11 +1026,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
                 lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
-                tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
+                if constexpr (PREFETCH) tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, false, false>(lcur, sc.pm, i, permv, zre, zim);
                 const double t = zre * sc.dv.x - zim * sc.dv.y;
                 zim = zre * sc.dv.y + zim * sc.dv.x;
                 zre = t;
-                tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
+                if constexpr (PREFETCH) tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, false, false>(lcur, sc.pm, i, permv, zre, zim);
                 finish_prefetch();
                 wave_sync();
                 {   // every lane group holds the same z: all of them store (no exec-mask branch
@@ -1021,9 +1078,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             if (fetcher) wait_landed(step + 1 < je);
             block_sync();
             const StepScalars sc = scalars(par, false);
-            if (computes)
-                lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
-                                       sc.pm, lane, i);
+            if constexpr (PREFETCH) {
+                if (computes)
+                    lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
+                                           sc.pm, lane, i);
+            } else {
+                lcur = lbuf + par * MAT;
+            }
             qcur = qbuf + par * MAT;
             wave_sync();
             if constexpr (LOADER) {
@@ -1106,11 +1167,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
-                tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
+                if constexpr (PREFETCH) tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, true, true>(lcur, sc.pm, i, permv, zre, zim);
                 const double t = zre * sc.dv.x + zim * sc.dv.y;
                 zim = zim * sc.dv.x - zre * sc.dv.y;
                 zre = t;
-                tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
+                if constexpr (PREFETCH) tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, true, true>(lcur, sc.pm, i, permv, zre, zim);
                 finish_prefetch();
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
@@ -1157,9 +1220,14 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             if (fetcher) wait_landed(step - 1 >= jb);
             block_sync();
             const StepScalars sc = scalars(par, true);
-            if (computes)
-                lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
-                                      sc.pm, lane, i);
+            if constexpr (PREFETCH) {
+                if (computes)
+                    lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
+                                          sc.pm, lane, i);
+            } else {
+                lcur = lbuf + par * MAT;
+                permv = pbuf[par * PINTS + lane];
+            }
             qcur = qbuf + par * MAT;
             wave_sync();
             if constexpr (LOADER) {
