@@ -686,9 +686,10 @@ __device__ __forceinline__ double2 lds_coef(const double2* lb, int pm, int i, in
     }
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK>
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK, class Hook>
 __device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, int permv,
-                                             double2 (&ring)[8], double& zre, double& zim) {
+                                             double2 (&ring)[8], double& zre, double& zim,
+                                             Hook& hook) {
     constexpr int NP = Geo<NB>::NP, D = 8;
     constexpr int k = LOWER ? KK : (NP - 1 - KK);
     constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
@@ -698,32 +699,45 @@ __device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, i
         ring[KK % D] = lds_coef<NB, ADJ>(lb, pm, i, permv, kn);
     }
     const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
+    hook(std::integral_constant<int, KK>());  // independent work for the chain's bubbles
     masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
         zre, zim, c.x, c.y, kre, kim);
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int... KK>
+template <int NB, bool LOWER, bool CONJ, bool ADJ, class Hook, int... KK>
 __device__ __forceinline__ void tri_solve_lds_seq(const double2* lb, int pm, int i, int permv,
                                                   double2 (&ring)[8], double& zre, double& zim,
-                                                  std::integer_sequence<int, KK...>) {
-    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK>(lb, pm, i, permv, ring, zre, zim), ...);
+                                                  Hook& hook, std::integer_sequence<int, KK...>) {
+    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK>(lb, pm, i, permv, ring, zre, zim, hook), ...);
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ>
+template <int NB, bool LOWER, bool CONJ, bool ADJ, class Hook>
 __device__ __forceinline__ void tri_solve_lds(const double2* lb, int pm, int i, int permv,
-                                              double& zre, double& zim) {
+                                              double& zre, double& zim, Hook& hook) {
     constexpr int NP = Geo<NB>::NP, D = 8;
     double2 ring[D];
 #pragma unroll
     for (int j = 0; j < D; ++j)
         ring[j] = lds_coef<NB, ADJ>(lb, pm, i, permv, LOWER ? j : (NP - 1 - j));
-    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ>(lb, pm, i, permv, ring, zre, zim,
+    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ>(lb, pm, i, permv, ring, zre, zim, hook,
                                             std::make_integer_sequence<int, NP - 1>{});
 }
 
 template <int NB>
 struct SweepPrefetch {
     static constexpr bool value = NB < 4;
+};
+// L / U coefficients from the LDS image stage by stage (tri_solve_lds) instead of a register row:
+// for sixteen tiles only. Measured at n = 32 and n = 16 (-DQOCX_LDSCOEF_MIN_NB=1, bit-identical
+// results): the sweep takes 1.57 instead of 0.525 ms per 125-step segment (0.54 instead of 0.27 at
+// n = 16) - the extra LDS round trip sits on the dependent chain there, while at NB = 4 the register
+// row costs a whole SIMD and scratch.
+#ifndef QOCX_LDSCOEF_MIN_NB
+#define QOCX_LDSCOEF_MIN_NB 4
+#endif
+template <int NB>
+struct SweepLdsCoef {
+    static constexpr bool value = NB >= QOCX_LDSCOEF_MIN_NB;
 };
 
 template <int NB, int NBUF = (SweepPrefetch<NB>::value ? 2 : 1)>
@@ -835,6 +849,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     // NB = 4 (33 <= n <= 64): one Q and one LU image are 64 KiB each, so there is room for ONE
     // set of operands only - the step's fetch is issued at its start and waited for (PREFETCH off).
     constexpr bool PREFETCH = SweepPrefetch<NB>::value;
+    constexpr bool LDSCOEF = SweepLdsCoef<NB>::value;
     static_assert(PREFETCH || !LOADER, "the loader variant needs a ring of buffers");
     constexpr int NBUF = LOADER ? 3 : (PREFETCH ? 2 : 1);
     typedef SweepLds<NB, NBUF> L;
@@ -1026,13 +1041,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
                 lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
-                if constexpr (PREFETCH) tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
-                else tri_solve_lds<NB, true, false, false>(lcur, sc.pm, i, permv, zre, zim);
+                if constexpr (!LDSCOEF) tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, false, false>(lcur, sc.pm, i, permv, zre, zim, hook_a);
                 const double t = zre * sc.dv.x - zim * sc.dv.y;
                 zim = zre * sc.dv.y + zim * sc.dv.x;
                 zre = t;
-                if constexpr (PREFETCH) tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
-                else tri_solve_lds<NB, false, false, false>(lcur, sc.pm, i, permv, zre, zim);
+                if constexpr (!LDSCOEF) tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, false, false>(lcur, sc.pm, i, permv, zre, zim, hook_b);
                 finish_prefetch();
                 wave_sync();
                 {   // every lane group holds the same z: all of them store (no exec-mask branch
@@ -1078,7 +1093,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             if (fetcher) wait_landed(step + 1 < je);
             block_sync();
             const StepScalars sc = scalars(par, false);
-            if constexpr (PREFETCH) {
+            if constexpr (!LDSCOEF) {
                 if (computes)
                     lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
                                            sc.pm, lane, i);
@@ -1167,13 +1182,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
-                if constexpr (PREFETCH) tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
-                else tri_solve_lds<NB, true, true, true>(lcur, sc.pm, i, permv, zre, zim);
+                if constexpr (!LDSCOEF) tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, true, true>(lcur, sc.pm, i, permv, zre, zim, hook_a);
                 const double t = zre * sc.dv.x + zim * sc.dv.y;
                 zim = zim * sc.dv.x - zre * sc.dv.y;
                 zre = t;
-                if constexpr (PREFETCH) tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
-                else tri_solve_lds<NB, false, true, true>(lcur, sc.pm, i, permv, zre, zim);
+                if constexpr (!LDSCOEF) tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, true, true>(lcur, sc.pm, i, permv, zre, zim, hook_b);
                 finish_prefetch();
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
@@ -1220,13 +1235,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             if (fetcher) wait_landed(step - 1 >= jb);
             block_sync();
             const StepScalars sc = scalars(par, true);
-            if constexpr (PREFETCH) {
+            if constexpr (!LDSCOEF) {
                 if (computes)
                     lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
                                           sc.pm, lane, i);
             } else {
                 lcur = lbuf + par * MAT;
-                permv = pbuf[par * PINTS + lane];
+                permv = pbuf[par * PINTS + lane % NP];
             }
             qcur = qbuf + par * MAT;
             wave_sync();
