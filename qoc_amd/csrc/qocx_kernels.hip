@@ -1595,8 +1595,10 @@ template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
     // waves per seed: the states are independent chains, up to four of them run side by side
     // (eight were measured at S = 32: no faster, the adjoint phase is K3 bound by then)
-    if (a.S >= 4) launch_sweep_w<NB, 4>(a, batch, st);
-    else if (a.S >= 2) launch_sweep_w<NB, 2>(a, batch, st);
+    static const int forced = getenv("QOCX_SWEEP_W") ? atoi(getenv("QOCX_SWEEP_W")) : 0;  // experiments
+    const int w = forced > 0 ? forced : (a.S >= 4 ? 4 : (a.S >= 2 ? 2 : 1));
+    if (w >= 4) launch_sweep_w<NB, 4>(a, batch, st);
+    else if (w >= 2) launch_sweep_w<NB, 2>(a, batch, st);
     else launch_sweep_w<NB, 1>(a, batch, st);
 }
 template <int NB>
