@@ -875,6 +875,8 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             // loader has just issued - which is what made the first loader variant slower
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else if constexpr (MULTI) {
+            // (measured: a raw s_barrier without the vmcnt drain changes nothing here - at S > 1
+            // the evaluation is bound by K3 and K1b on the compute stream, not by the sweep)
             __syncthreads();
         } else {
             wave_sync();
