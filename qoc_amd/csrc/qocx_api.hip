@@ -963,11 +963,12 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.g_cimg = ctx->g_cimg.p;
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
         fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
+        fa.n = ctx->n;
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
-        la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps;
+        la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
@@ -2084,12 +2085,12 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     qocx::FactorArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
-    fa.nsteps = count; fa.step0 = 0; fa.seg_len = count;
+    fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
     la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
     la.status = ctx->status.p;
-    la.nsteps = count; la.step0 = 0; la.seg_len = count;
+    la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
     qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
         pre[c] = fma(mu.y, vi, fma(-mu.x, vr, pre[c]));
         pim[c] = fma(-mu.y, vr, fma(-mu.x, vi, pim[c]));
     };
+    // n <= 48 (the nine-tile K1a wrote the pad block b0 I): rows and columns 48..63 need no
+    // elimination step - the pad rows are zero left of the diagonal, so they are never pivots and
+    // their multipliers vanish; their columns in HBM are final as they stand.
+    const int kmax = (args.n > 0 && args.n <= 48) ? 48 : NP;
     if (w == 0) factor_column(std::integral_constant<int, 0>());
     // Step k: one barrier, then every wave applies the step to its columns. LOOKAHEAD: the owner of
     // column k + 1 updates that column first, factors it and publishes step k + 1 (the other LDS
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
     for_each_step([&](auto KC) __attribute__((always_inline)) {
         constexpr int k = decltype(KC)::value;
         constexpr int par = k & 1;
+        if (k >= kmax) return;  // workgroup-uniform
         __syncthreads();
         const int p = __builtin_amdgcn_readfirstlane(lds.prow[par]);
         {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
         }
         const double2 mu = lds.mult[par][lane];
         if constexpr (k + 1 < NP) {
-            if (w == ((k + 1) >> 4)) {
+            if (k + 1 < kmax && w == ((k + 1) >> 4)) {
                 update_column((k + 1) & 15, p, mu);
                 factor_column(std::integral_constant<int, k + 1>());
             }
@@ -157,6 +162,12 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the unrolled steps from interleaving
     });
+    if (kmax < NP) {  // the pad rows stay where they are: position = row, 1 / U_kk = 1 / b0
+        if (lane >= kmax) {
+            mypos = lane;
+            if (w == 0) args.dinv[m * NP + lane] = make_double2(1.0 / PADE_B[0], 0.0);
+        }
+    }
     if (singular && lane == 0) atomicOr(args.status, 1);
     if (mypos < 0 || mypos >= NP) {  // only reachable with non-finite input
         mypos = lane;

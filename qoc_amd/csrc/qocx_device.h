@@ -39,6 +39,7 @@ struct FactorArgs {
     int K, nc, nsteps, nt;
     int step0, seg_len;        // this launch covers steps [step0, step0 + seg_len) of every seed
     int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
+    int n;                     // Hilbert size (used by the sixteen-tile K1a: <= 48 -> nine tiles); 0: unknown
     double dt;
     // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
@@ -54,6 +55,7 @@ struct LuArgs {
     int* iperm;       // [NP] iperm[row] = pos
     int* status;
     int nsteps, step0, seg_len;  // work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len
+    int n;                       // Hilbert size (sixteen-tile K1b: <= 48 -> 48 elimination steps); 0: unknown
 };
 
 struct SweepArgs {

@@ -10,6 +10,10 @@
 // one wave and a CU one workgroup: the kernel runs at 79 % of the sustained MFMA rate of its
 // 4 608 instructions per matrix.
 //
+// NT = 3 (n <= 48): the same with three waves and three row tiles per column block - 9 of the 16
+// tiles, 0.56 of the MFMA work; the images stay 64 x 64 (K1b, the sweep and K3 see the padded
+// matrix), so the waves also write the pad block b0 I of P and Q.
+//
 // Reference: expm_pade (qoc/standard/functions/expm.py:153-252), always order 13, s from ||a||_1
 // and theta13; the LU solve of expm.py:246-249 is K1b + the sweep (qocx_big.hip, qocx_kernels.hip).
 #include "qocx_wave.h"
@@ -18,19 +22,29 @@ namespace qocx {
 
 namespace pade4 {
 
-constexpr int NT = 4;                         // row tiles of a column block = waves per workgroup
-constexpr int NP = Geo<4>::NP, PITCH = Geo<4>::PITCH, PLANE = Geo<4>::PLANE, MAT = Geo<4>::MAT;
-constexpr int SLOT_F64 = 2 * PLANE;           // re | im planes
-constexpr int LDS_BYTES = (SLOT_F64 + 8) * 8;  // + two norm words per wave
+constexpr int NP = Geo<4>::NP, MAT = Geo<4>::MAT;  // the images are always 64 x 64
 
-struct Col {  // tiles (0..3, w) of a complex matrix, C-layout
+template <int NT>  // row tiles of a column block = column blocks = waves per workgroup
+struct Cfg {
+    static constexpr int NA = 16 * NT;          // active size
+    static constexpr int PITCH = NA + 2;        // LDS row pitch (f64) of the planar A-operand slot
+    static constexpr int PLANE = NA * PITCH;
+    static constexpr int SLOT_F64 = 2 * PLANE;  // re | im planes
+    static constexpr int LDS_BYTES = (SLOT_F64 + 8) * 8;  // + a norm word per wave
+};
+
+template <int NT>
+struct Col {  // tiles (0..NT-1, w) of a complex matrix, C-layout
     d4 re[NT], im[NT];
 };
+template <int NT>
 struct Acc3 {
     d4 t1[NT], t2[NT], t3[NT];
 };
 
-__device__ __forceinline__ void stage_col(double* slot, int w, const Col& m) {
+template <int NT>
+__device__ __forceinline__ void stage_col(double* slot, int w, const Col<NT>& m) {
+    constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE;
     const int q = lane_id() >> 4, c = lane_id() & 15;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -43,8 +57,9 @@ __device__ __forceinline__ void stage_col(double* slot, int w, const Col& m) {
 }
 
 // acc(ti) += A(ti, :) B(:, w), 3M scheme; A from the slot, B fragment from `bf`
-template <class BFrag>
-__device__ __forceinline__ void gemm3(Acc3& acc, const double* slot, BFrag bf) {
+template <int NT, class BFrag>
+__device__ __forceinline__ void gemm3(Acc3<NT>& acc, const double* slot, BFrag bf) {
+    constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE;
     const int q = lane_id() >> 4, c = lane_id() & 15;
 #pragma unroll
     for (int kk = 0; kk < 4 * NT; ++kk) {
@@ -68,7 +83,8 @@ __device__ __forceinline__ void gemm3(Acc3& acc, const double* slot, BFrag bf) {
         __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart (register pressure)
     }
 }
-__device__ __forceinline__ void acc_zero(Acc3& a) {
+template <int NT>
+__device__ __forceinline__ void acc_zero(Acc3<NT>& a) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         a.t1[ti] = d4{0, 0, 0, 0};
@@ -76,7 +92,8 @@ __device__ __forceinline__ void acc_zero(Acc3& a) {
         a.t3[ti] = d4{0, 0, 0, 0};
     }
 }
-__device__ __forceinline__ void acc_init(Acc3& a, const Col& c) {
+template <int NT>
+__device__ __forceinline__ void acc_init(Acc3<NT>& a, const Col<NT>& c) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         a.t1[ti] = c.re[ti];
@@ -84,7 +101,8 @@ __device__ __forceinline__ void acc_init(Acc3& a, const Col& c) {
         a.t3[ti] = c.re[ti] + c.im[ti];
     }
 }
-__device__ __forceinline__ void acc_finish(Col& c, const Acc3& a) {
+template <int NT>
+__device__ __forceinline__ void acc_finish(Col<NT>& c, const Acc3<NT>& a) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         c.re[ti] = a.t1[ti] - a.t2[ti];
@@ -100,10 +118,12 @@ struct Out {
 };
 
 // Every wave executes the same barriers; w = the wave's column block (wave-uniform).
-template <class Gen>
+template <int NT, class Gen>
 __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
+    typedef Col<NT> Col;
+    typedef Acc3<NT> Acc3;
     double* sl = smem;
-    double* nrm = sl + SLOT_F64;
+    double* nrm = sl + Cfg<NT>::SLOT_F64;
     const int lane = lane_id();
     const int q = lane >> 4, c = lane & 15;
 
@@ -123,7 +143,8 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
         if (lane == 0) nrm[w] = e;
     }
     __syncthreads();  // 1
-    const double norm1 = fmax(fmax(nrm[0], nrm[1]), fmax(nrm[2], nrm[3]));
+    double norm1 = fmax(fmax(nrm[0], nrm[1]), nrm[2]);
+    if constexpr (NT == 4) norm1 = fmax(norm1, nrm[3]);
     int sq = 0;
     {
         double th = QOCX_THETA13;
@@ -250,9 +271,27 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
             out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
             out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
         }
+    if constexpr (NT < 4) {
+        // the pad block of the 64 x 64 images: v = b0 I and u = 0 there, so P = Q = b0 I
+        constexpr int NA = Cfg<NT>::NA;
+#pragma unroll
+        for (int r = 0; r < (NP - NA) / 4; ++r) {  // rows NA..63 of this wave's columns
+            const int idx = (16 * w + c) * NP + NA + 4 * r + q;
+            out.q_img[idx] = make_double2(0, 0);
+            out.p_img[idx] = make_double2(0, 0);
+        }
+        for (int e = w * 64 + lane; e < (NP - NA) * NP; e += 64 * NT) {  // columns NA..63
+            const int col = NA + e / NP, row = e % NP;
+            const double2 val = make_double2(row == col ? b0 : 0.0, 0.0);
+            out.q_img[col * NP + row] = val;
+            out.p_img[col * NP + row] = val;
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void pade_pq4_kernel(FactorArgs args) {
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
+    typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
     const int step = args.step0 + blockIdx.x, b = blockIdx.y;
@@ -273,13 +312,14 @@ __global__ __launch_bounds__(256) void pade_pq4_kernel(FactorArgs args) {
     const int K = args.K;
     auto gen = [&](Col& a, int wcol) {
         // H = h0 + sum_k u_k g_k ; a = dt * (-i H)  (schroedingerdiscrete.py:485-486,
-        // mathmethods.py:90-93); C-layout image index ((ti * 4 + tj) * 4 + r) * 64 + lane
+        // mathmethods.py:90-93); C-layout image index ((ti * 4 + tj) * 4 + r) * 64 + lane (the
+        // C-images always have four tiles per side)
         d4 hre[NT], him[NT];
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 e = h0[((ti * NT + wcol) * 4 + r) * 64 + lane];
+                const double2 e = h0[((ti * 4 + wcol) * 4 + r) * 64 + lane];
                 hre[ti][r] = e.x;
                 him[ti][r] = e.y;
             }
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(256) void pade_pq4_kernel(FactorArgs args) {
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double2 e = gk[((ti * NT + wcol) * 4 + r) * 64 + lane];
+                    const double2 e = gk[((ti * 4 + wcol) * 4 + r) * 64 + lane];
                     hre[ti][r] += uk * e.x;
                     him[ti][r] += uk * e.y;
                 }
@@ -301,12 +341,14 @@ __global__ __launch_bounds__(256) void pade_pq4_kernel(FactorArgs args) {
             a.im[ti] = -dt * hre[ti];
         }
     };
-    body(gen, out, smem, w);
+    body<NT>(gen, out, smem, w);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
-__global__ __launch_bounds__(256) void pade_pq4_explicit_kernel(const double2* a_in, int n,
-                                                                FactorArgs args) {
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void pade_pq4_explicit_kernel(const double2* a_in, int n,
+                                                                    FactorArgs args) {
+    typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
     const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
@@ -332,23 +374,38 @@ __global__ __launch_bounds__(256) void pade_pq4_explicit_kernel(const double2* a
                 a.im[ti][r] = e.y;
             }
     };
-    body(gen, out, smem, w);
+    body<NT>(gen, out, smem, w);
 }
 
 }  // namespace pade4
 
-static void pade4_lds_attr(const void* fn) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pade4::LDS_BYTES);
+template <int NT>
+static void launch_pq4_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL(pade4::pade_pq4_kernel<NT>, dim3(nsteps, batch), dim3(64 * NT), bytes, st, a);
+}
+template <int NT>
+static void launch_pq4_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
+                                  hipStream_t st) {
+    constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL(pade4::pade_pq4_explicit_kernel<NT>, dim3(count), dim3(64 * NT), bytes, st,
+                       a_in, n, a);
 }
 
+// a.n: the Hilbert size (33..64). Up to 48 the three-wave form computes 9 of the 16 tiles.
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    pade4_lds_attr(reinterpret_cast<const void*>(pade4::pade_pq4_kernel));
-    hipLaunchKernelGGL(pade4::pade_pq4_kernel, dim3(nsteps, batch), dim3(256), pade4::LDS_BYTES, st, a);
+    if (a.n > 0 && a.n <= 48) launch_pq4_t<3>(a, nsteps, batch, st);
+    else launch_pq4_t<4>(a, nsteps, batch, st);
 }
 void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {
-    pade4_lds_attr(reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel));
-    hipLaunchKernelGGL(pade4::pade_pq4_explicit_kernel, dim3(count), dim3(256), pade4::LDS_BYTES, st,
-                       a_in, n, a);
+    if (a.n > 0 && a.n <= 48) launch_pq4_explicit_t<3>(a_in, n, a, count, st);
+    else launch_pq4_explicit_t<4>(a_in, n, a, count, st);
 }
 
 }  // namespace qocx

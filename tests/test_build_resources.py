@@ -80,6 +80,7 @@ def test_sixteen_tile_kernels_do_not_spill():
         k3 = find(big, frag)
         assert k3["ScratchSize"] == 0, frag
     assert total_registers(find(big, "krylov4_kernelILb0ELb1E")) <= 256   # two per SIMD (Hermitian H)
-    for frag in ("pade_pq4_kernel", "pade_pq4_explicit_kernel"):
+    for frag in ("pade_pq4_kernelILi4E", "pade_pq4_explicit_kernelILi4E", "pade_pq4_kernelILi3E",
+                 "pade_pq4_explicit_kernelILi3E"):
         k1a = find(pade4, frag)
         assert k1a["ScratchSize"] <= 128, (frag, k1a)
