@@ -102,9 +102,12 @@ class SchroedingerEvaluator(object):
                  latency_mode=False):
         """
         latency_mode: the evaluator will be asked for ONE control array at a time (the
-        reference's evolve_* / grape_* entry points). The engine then runs its blocked-inverse
-        sweep (four wavefronts per seed, 1.5x faster per step when the sweep has the chip to
-        itself: qocx_debug_set_knob "sweep_impl" = 3); batched evaluation keeps the default.
+        reference's evolve_* / grape_* entry points). For 17 <= n <= 32 the engine then runs its
+        blocked-inverse sweep (four wavefronts per seed, 1.5x faster per step when the sweep has
+        the chip to itself: qocx_debug_set_knob "sweep_impl" = 3); batched evaluation keeps the
+        default, and so do n <= 16 (one seed, 1000 steps: 3.3 ms with the column-chain sweep
+        against 4.1 ms with the blocked one - a single 16 x 16 block leaves nothing to overlap)
+        and n > 32 (not built there).
         """
         if interpolation_policy != InterpolationPolicy.LINEAR:
             raise NotImplementedError("The interpolation policy {} is not yet supported for this "
@@ -157,8 +160,9 @@ class SchroedingerEvaluator(object):
             else:
                 self.opaque_costs.append(cost)
         self.backend = backend if backend is not None else make_backend()
-        if latency_mode and hasattr(self.backend, "set_knob"):
-            self.backend.set_knob("sweep_impl", 3)
+        if hasattr(self.backend, "set_knob"):
+            self.backend.set_knob(
+                "sweep_impl", 3 if (latency_mode and 16 < self.hilbert_size <= 32) else 1)
         self.kr = control_count * (2 if complex_controls else 1)
         device_k = 0 if self.opaque_hamiltonian is not None else self.kr
         self.backend.set_schroedinger_problem(
