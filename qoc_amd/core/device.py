@@ -12,29 +12,10 @@ import numpy as np
 from qoc_amd.core import structure
 from qoc_amd.models.policies import InterpolationPolicy, MagnusPolicy
 
-_backend_factory = None
-
-
-def set_backend_factory(factory):
-    """
-    TEST HOOK, inert in production: replaces the engine constructor so that the host logic can be
-    exercised on a machine without a GPU (tests/conftest.py arms it with QOC_AMD_TEST_HOOKS=1 and
-    injects a NumPy model of the device; nothing in the product sets that variable or calls
-    this). Without the variable any attempt to install a factory is refused - the product has no
-    CPU fallback.
-    """
-    import os
-    global _backend_factory
-    if factory is not None and os.environ.get("QOC_AMD_TEST_HOOKS") != "1":
-        raise RuntimeError("qoc_amd has no CPU fallback: set_backend_factory is a test hook "
-                           "(QOC_AMD_TEST_HOOKS=1)")
-    _backend_factory = factory
-
-
 def make_backend(device=-1):
-    if _backend_factory is not None:
-        return _backend_factory()
-    from qoc_amd.engine import Engine  # raises loudly when libqocx.so / the GPU is missing
+    """The HIP engine. There is no CPU fallback: this raises when libqocx.so or the GPU is
+    missing."""
+    from qoc_amd.engine import Engine
     return Engine(device)
 
 

@@ -1016,7 +1016,12 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                             S <= qocx::sweep3_max_states(ctx->nb);
         // "sweep3_phases": bit 0 forward launches, bit 1 adjoint launches (and combined ones)
         const int s3_phases = (int)ctx->knob("sweep3_phases", 3);
+        // "dbg_skip" (timing experiments only, results are garbage): bit 0 no forward sweep,
+        // bit 1 no adjoint sweep, bit 2 no K3
+        const int dbg_skip = (int)ctx->knob("dbg_skip", 0);
         auto run_sweep = [&](const qocx::SweepArgs& a, int count, hipStream_t st) {
+            if ((dbg_skip & 1) && (a.phase & 1)) return;
+            if ((dbg_skip & 2) && (a.phase & 2)) return;
             const bool use3 = sweep3 && ((a.phase & 2) ? (s3_phases & 2) : (s3_phases & 1));
             if (use3) qocx::launch_sweep3(ctx->nb, a, count, st);
             else qocx::launch_sweep(ctx->nb, a, count, st);
@@ -1109,7 +1114,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                     ka.step0 = lo[i];
                 ka.skew = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
                 time_begin(ctx, 2, cs);
-                qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
+                if (!(dbg_skip & 4)) qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
                 if (nodes > 1) {
                     ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
                     ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
@@ -1922,7 +1927,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
-                                  "sweep3_phases", "lindblad_stamps", "magnus_general"};
+                                  "sweep3_phases", "lindblad_stamps", "magnus_general",
+                                  "dbg_skip", "bidir", "unit_adjoint"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

@@ -3,8 +3,6 @@
 import os
 import sys
 
-os.environ.setdefault("QOC_AMD_TEST_HOOKS", "1")  # arms qoc_amd.core.device.set_backend_factory
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -54,3 +54,20 @@ def lindblad_grad_close(grads, ref, case=None):
     if rtol is not None:
         return dev < rtol * np.max(np.abs(ref))
     return dev < max(1e-6 * np.max(np.abs(ref)), 5e-10)
+
+
+_REAL_MAKE_BACKEND = None
+
+
+def set_backend_factory(factory):
+    """
+    Tests only: run the product's HOST logic (entry points, structure probing, optimizers, save
+    files) on a machine without a GPU by swapping qoc_amd.core.device.make_backend for a NumPy
+    model of the device (tests/oracle_backend.py). The product itself has no hook and no CPU
+    fallback; this patches the module attribute from outside. None restores the real engine.
+    """
+    global _REAL_MAKE_BACKEND
+    from qoc_amd.core import device
+    if _REAL_MAKE_BACKEND is None:
+        _REAL_MAKE_BACKEND = device.make_backend
+    device.make_backend = (lambda device=-1: factory()) if factory is not None else _REAL_MAKE_BACKEND

@@ -1,6 +1,6 @@
 """
 oracle_backend.py - TEST INFRASTRUCTURE: an object with the Engine's method surface whose
-arithmetic is the CPU oracle. Injected through qoc_amd.core.device.set_backend_factory so that
+arithmetic is the CPU oracle. Injected through tests.helpers.set_backend_factory so that
 the host logic (entry points, structure extraction, control layouts, optimizers, bookkeeping)
 can be tested without a GPU. Never shipped, never selected by the product.
 """

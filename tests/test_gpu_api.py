@@ -13,6 +13,7 @@ from qoc_amd.core import device
 from qoc_amd.models import MagnusPolicy
 from qoc_amd.standard import SGD, Adam
 from tests import cases as cases_mod
+from tests import helpers
 from tests.helpers import golden, rel_err
 from tests.oracle_backend import OracleBackend
 
@@ -67,12 +68,12 @@ def test_grape_trajectory_matches_oracle_backend(name, complex_norm):
     case = cases_mod.case_by_name(name)
     norms = np.full(case.K, 5.0 if complex_norm is None else complex_norm)
     gpu_result, gpu_trace = run_grape(case, Adam(learning_rate=2e-2), 6, max_control_norms=norms)
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     try:
         cpu_result, cpu_trace = run_grape(case, Adam(learning_rate=2e-2), 6,
                                           max_control_norms=norms)
     finally:
-        device.set_backend_factory(None)
+        helpers.set_backend_factory(None)
     assert len(gpu_trace) == len(cpu_trace) == 6
     for (ge, gg), (ce, cg) in zip(gpu_trace, cpu_trace):
         assert abs(ge - ce) < 1e-9 * max(1, abs(ce))

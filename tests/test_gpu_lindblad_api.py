@@ -11,6 +11,7 @@ import qoc_amd
 from qoc_amd.core import device
 from qoc_amd.standard import Adam
 from tests import cases as cases_mod
+from tests import helpers
 from tests.helpers import golden
 from tests.oracle_backend import OracleBackend
 from tests.test_lindblad_host_api import product_cost_list, run_grape
@@ -22,9 +23,9 @@ NAMES = [c.name for c in cases_mod.lindblad_cases()]
 
 @pytest.fixture(autouse=True)
 def real_engine():
-    device.set_backend_factory(None)
+    helpers.set_backend_factory(None)
     yield
-    device.set_backend_factory(None)
+    helpers.set_backend_factory(None)
 
 
 @pytest.mark.parametrize("name", NAMES + [c.name for c in cases_mod.lindblad_opaque_cases()])
@@ -46,12 +47,12 @@ def test_grape_lindblad_trajectory_matches_model_backend(name):
     norms = np.full(case.K, 5.0)
     gpu_result, gpu_trace = run_grape(case, Adam(learning_rate=2e-2), 5, log_iteration_step=0,
                                       max_control_norms=norms)
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     try:
         cpu_result, cpu_trace = run_grape(case, Adam(learning_rate=2e-2), 5,
                                           log_iteration_step=0, max_control_norms=norms)
     finally:
-        device.set_backend_factory(None)
+        helpers.set_backend_factory(None)
     assert len(gpu_trace) == len(cpu_trace) == 5
     for (ge, gg), (ce, cg) in zip(gpu_trace, cpu_trace):
         assert abs(ge - ce) < 1e-10
@@ -76,11 +77,11 @@ def test_user_density_cost_forward_on_gpu():
     args = dict(controls=case.controls[0], cost_eval_step=5, costs=[Purity()],
                 hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
     gpu = qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N, **args)
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     try:
         cpu = qoc_amd.evolve_lindblad_discrete(case.T, case.initial_densities, case.N, **args)
     finally:
-        device.set_backend_factory(None)
+        helpers.set_backend_factory(None)
     assert abs(gpu.error - cpu.error) < 1e-12
 
 
@@ -153,11 +154,11 @@ def test_time_dependent_lindblad_data_on_gpu():
             max_control_norms=np.full(case.K, 5.0))
         return res, trace
     gpu_result, gpu_trace = run(4)
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     try:
         cpu_result, cpu_trace = run(4)
     finally:
-        device.set_backend_factory(None)
+        helpers.set_backend_factory(None)
     for (ge, gg), (ce, cg) in zip(gpu_trace, cpu_trace):
         assert abs(ge - ce) < 1e-10
         assert np.max(np.abs(gg - cg)) / np.max(np.abs(cg)) < 1e-8

@@ -1,7 +1,7 @@
 """
 CPU tests of the host-side mirror of the reference interface: entry points, Cost / Optimizer
 plugins, control plumbing, Hamiltonian structure extraction. The GPU engine is replaced by the
-oracle through the test hook qoc_amd.core.device.set_backend_factory (tests/oracle_backend.py);
+oracle through the test hook tests.helpers.set_backend_factory (tests/oracle_backend.py);
 the same entry points run on the real engine in tests/test_gpu_api.py.
 """
 
@@ -18,15 +18,16 @@ from qoc_amd.standard import (SIGMA_X, SIGMA_Y, Adam, LBFGSB, SGD, ControlNorm, 
 import qoc_amd.standard.costs as product_costs
 from oracle import qoc_numpy as onp
 from tests import cases as cases_mod
+from tests import helpers
 from tests.helpers import golden, rel_err
 from tests.oracle_backend import OracleBackend
 
 
 @pytest.fixture(autouse=True)
 def oracle_engine():
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     yield
-    device.set_backend_factory(None)
+    helpers.set_backend_factory(None)
 
 
 def product_cost_list(case):
@@ -529,12 +530,20 @@ def test_opaque_hamiltonian_needs_m2():
             magnus_policy=MagnusPolicy.M4)
 
 
-def test_backend_hook_is_inert_outside_the_tests(monkeypatch):
-    """The product has no CPU fallback: without QOC_AMD_TEST_HOOKS=1 (set by tests/conftest.py
-    only) a backend factory cannot be installed."""
-    monkeypatch.delenv("QOC_AMD_TEST_HOOKS")
-    with pytest.raises(RuntimeError):
-        device.set_backend_factory(OracleBackend)
-    device.set_backend_factory(None)  # clearing is always allowed
-    monkeypatch.setenv("QOC_AMD_TEST_HOOKS", "1")
-    device.set_backend_factory(OracleBackend)
+def test_product_has_no_backend_hook_and_no_cpu_fallback():
+    """The product carries no test hook (the tests patch qoc_amd.core.device.make_backend from
+    outside, tests/helpers.py) and no CPU fallback: without a GPU the engine refuses to start."""
+    from qoc_amd import engine
+    assert not hasattr(device, "set_backend_factory")
+    helpers.set_backend_factory(None)
+    try:
+        lib = engine.load_library()
+        import ctypes
+        count = ctypes.c_int(0)
+        has_gpu = lib.qocx_device_count(ctypes.byref(count)) == 0 and count.value > 0
+        if has_gpu:
+            pytest.skip("a GPU is visible: the engine starts")
+        with pytest.raises(Exception):
+            device.make_backend()
+    finally:
+        helpers.set_backend_factory(OracleBackend)

@@ -1,7 +1,7 @@
 """
 CPU tests of the host-side mirror of the reference's Lindblad interface
 (evolve_lindblad_discrete / grape_lindblad_discrete, density Cost plugins, program states).
-The GPU engine is replaced through qoc_amd.core.device.set_backend_factory by the NumPy model
+The GPU engine is replaced through tests.helpers.set_backend_factory by the NumPy model
 of the device algorithm (tests/oracle_backend.py -> tests/lindblad_model.py); the same entry
 points run on the real engine in tests/test_gpu_lindblad_api.py.
 """
@@ -18,6 +18,7 @@ from qoc_amd.standard import (Adam, SGD, ForbidDensities, TargetDensityInfidelit
                               TargetDensityInfidelityTime, get_annihilation_operator,
                               get_creation_operator)
 from tests import cases as cases_mod
+from tests import helpers
 from tests.helpers import golden
 from tests.oracle_backend import OracleBackend
 from tests.test_lindblad_oracle import density_cost_known_answers
@@ -27,9 +28,9 @@ NAMES = [c.name for c in cases_mod.lindblad_cases()]
 
 @pytest.fixture(autouse=True)
 def oracle_engine():
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     yield
-    device.set_backend_factory(None)
+    helpers.set_backend_factory(None)
 
 
 def product_cost_list(case):

@@ -15,6 +15,7 @@ import qoc_amd.standard.costs as product_costs
 from qoc_amd.core import device
 from qoc_amd.standard import Adam
 from tests import cases as cases_mod
+from tests import helpers
 from tests import fake_h5py
 from tests.oracle_backend import OracleBackend
 
@@ -23,9 +24,9 @@ from tests.oracle_backend import OracleBackend
 def environment(monkeypatch):
     monkeypatch.setitem(sys.modules, "h5py", fake_h5py)
     fake_h5py.STORE.clear()
-    device.set_backend_factory(OracleBackend)
+    helpers.set_backend_factory(OracleBackend)
     yield
-    device.set_backend_factory(None)
+    helpers.set_backend_factory(None)
 
 
 def costs_of(case):
