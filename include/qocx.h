@@ -286,6 +286,11 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
  * inverter L | loader | inverter U'), 8 sums - shader-clock cycles per phase of the role's step loop, [7] = the
  * 100 MHz real-time counter over the role's life. out: [batch][4][8]. */
 int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
+/* With qocx_set_timing on: the kernel launches of the LAST evaluation as (which, start_ms, end_ms)
+ * triples relative to its first launch (HIP events on the launch streams; which = the index of
+ * qocx_get_timing: 0 K1a, 1 sweep, 2 K3, 3 scatter, 4 K1b, 5 Lindblad). out holds up to `capacity`
+ * triples, *count receives how many there were. A view of how the pipeline overlaps. */
+int qocx_debug_timeline(qocx_ctx* ctx, double* out, int64_t capacity, int64_t* count);
 /* Force the variants of the Lindblad launch that large batches / little free HBM select:
  *   stage_budget_seeds  seeds whose forward stage values may be kept for the adjoint (0: as many
  *                       as fit 45 % of free HBM); a larger group is launched in pieces;

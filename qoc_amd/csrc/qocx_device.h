@@ -71,6 +71,12 @@ struct SweepArgs {
     // bit 0) and / or the adjoint sweep from j_end back to j_begin (phase bit 1); state is carried
     // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).
     int phase, j_begin, j_end;
+    int unit_adjoint = 0; // separable final cost: the adjoint runs on lam = targets (qocx_sweep_common.h)
+    double2* lam_scale = nullptr;   // [B][S] scalars c_s, written at the end of the forward sweep, read by K3
+    int* offs_x = nullptr;  // unit adjoint: [B][nsteps+1] first xs slot of each step, written by the ADJOINT
+                          // sweep (it may run before the forward sweep has numbered the sub-steps)
+    int batch = 0;        // seeds of the launch (set by the launcher of the two-seeds-per-workgroup form)
+    int onebuf = 0;       // one state: one operand set in LDS; 1: one seed per workgroup, 2: two
     int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
     int dbg;              // sweep3 timing diagnostics (results are garbage): bit 0 no inversion,
                           // bit 1 no solves, bit 2 no LU fetch, bit 3 no Q fetch, bit 4 no Q touch
@@ -115,6 +121,11 @@ struct KrylovArgs {
     const double2* xs;
     size_t slot_cap;
     double* gstep;  // [B][nsteps][K]
+    // unit adjoint (qocx_sweep_common.h): x sits at slots of its own (offs_x: first xs slot of each
+    // step) and is the back-propagated TARGET; gstep then receives the complex number
+    // gamma = sum conj(abar_1) E_k per (step, k) - [B][nsteps][K][2] - and the scatter kernel forms
+    // Re(conj(c) gamma) with the cost's scalar c. nullptr: x is the true cotangent, gstep is real.
+    const int* offs_x = nullptr;
     // Magnus M4/M6: the generator is read from m_rm (row-major padded NP x NP, unscaled) and the
     // cotangent of M is written to mbar_rm instead of the contraction with G_k. nullptr for M2.
     const double2* m_rm;
@@ -145,6 +156,8 @@ struct ScatterArgs {
     const double* weight; // [nnz]
     double* grads;        // [B][nc][K]
     int B, nc, K, nsteps;
+    const double2* lam_scale = nullptr;  // unit adjoint: [B][S] (entry of state 0 is used), gstep holds
+    int S = 1;                           // complex numbers (see KrylovArgs); nullptr: gstep is real
 };
 
 // One sub-interval of the fixed-step Lindblad integrator: [t_a, t_b] inside system step `step`,

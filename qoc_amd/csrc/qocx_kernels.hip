@@ -753,6 +753,7 @@ struct SweepLds {
     static constexpr int TMP_OFF = P_OFF + NBUF * PINTS * 4;    // NP complex scratch per wave
     static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * G::NP * 16;  // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
+    __host__ __device__ static constexpr int bytes_static(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
 
 // Per-step operands of the sweep, in registers: Q in R-layout (matvec), LU in F-layout (solves).
@@ -841,9 +842,21 @@ __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec
 // costs its issuing wave 60-100 cycles of issue time each (MI355X_MICROARCH.md, 'LDS-DMA piece'),
 // i.e. 2 000 - 3 400 cycles per step when the compute wave issues them from inside its dependent
 // chains (the form without LOADER, kept for comparison: qocx_debug_set_knob "sweep_loader" 0).
-template <int NB, int W, bool LOADER>
-__global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(SweepArgs args) {
+//
+// ONEBUF (one state, one wave per seed): ONE set of operand buffers instead of two, and TWO seeds
+// per workgroup (two independent waves, no barrier between them). A step's LU image is copied to
+// registers at the top of the step and its Q image is last read by the matvec of the last
+// squaring sub-step (forward) - so the next step's operands can land in the SAME buffers while
+// the solves run. The adjoint reads Q at the END of a sub-step (lambda = Q^H x): there the fetch
+// of a step brings the step's OWN Q image (first solve, waited for with a counted vmcnt in front
+// of the matvec) and the NEXT step's LU image. 35 KiB of LDS per seed instead of 68: two seeds
+// share a CU, which halves the CUs on which the sweep displaces a K1a workgroup (a 221-register
+// sweep wave leaves room for three two-wave K1a workgroups instead of four - whether the CU hosts
+// one sweep wave or two).
+template <int NB, int W, bool LOADER, bool ONEBUF = false>
+__global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
+    static_assert(!ONEBUF || (W == 1 && !LOADER && SweepPrefetch<NB>::value), "ONEBUF: one wave per seed");
     // With a loader wave the operands of TWO steps travel at once (ring of three buffers): the
     // fetch of step t+2 is issued while step t computes and has until the start of step t+2 to land.
     // NB = 4 (33 <= n <= 64): one Q and one LU image are 64 KiB each, so there is room for ONE
@@ -851,10 +864,13 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     constexpr bool PREFETCH = SweepPrefetch<NB>::value;
     constexpr bool LDSCOEF = SweepLdsCoef<NB>::value;
     static_assert(PREFETCH || !LOADER, "the loader variant needs a ring of buffers");
-    constexpr int NBUF = LOADER ? 3 : (PREFETCH ? 2 : 1);
+    constexpr int NBUF = LOADER ? 3 : ((PREFETCH && !ONEBUF) ? 2 : 1);
     typedef SweepLds<NB, NBUF> L;
     constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // ONEBUF: wave v of the workgroup is seed 2 * blockIdx.x + v, with LDS of its own
+    const int pack_wave = ONEBUF ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    char* smem = smem_raw + (ONEBUF ? pack_wave * L::bytes_static(1) : 0);
     // the sweep is the serial chain of the evaluation: where it shares a SIMD with a wave of the
     // throughput kernels (two-wave K1a, K3) its instructions go first
     __builtin_amdgcn_s_setprio(3);
@@ -895,7 +911,8 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     // the loader wave runs the same control flow (every barrier) with empty state loops
     const int S = args.S, s0 = computes ? w : args.S;
     double2* lam = vecs + S * NP;
-    const int b = blockIdx.x;
+    const int b = ONEBUF ? (int)(blockDim.x >> 6) * blockIdx.x + pack_wave : blockIdx.x;
+    if (ONEBUF && b >= args.batch) return;  // odd batch: the last workgroup has one seed
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
     const int nsteps = args.nsteps;
     const size_t cap = args.slot_cap;
@@ -955,14 +972,19 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     const int* pf_p2 = nullptr;  // NP = 64: perm and iperm are a piece each
     int pf_par = 0;
     bool pf_adjoint = false, pf_due = false;
-    auto set_prefetch = [&](size_t m, int par, bool adjoint) __attribute__((always_inline)) {
+    // what the hooks of the running (sub-step, state) issue: the Q pieces / everything else.
+    // Two buffers: both follow pf_due in the first (sub-step, state) of a step. ONEBUF: see there.
+    bool pf_fire_q = false, pf_fire_l = false;
+    bool pf_qdue = false;  // ONEBUF adjoint: the step's own Q image is to be fetched
+    // m: step whose LU image, 1/U_kk and permutation are fetched; mq: step of the Q image
+    auto set_prefetch = [&](size_t m, int par, bool adjoint, size_t mq) __attribute__((always_inline)) {
         pf_par = par;
         pf_adjoint = adjoint;
         const size_t el = adjoint ? (size_t)(lane % NP) * NP + lane / NP : (size_t)lane;
 #pragma unroll
         for (int g = 0; g < NGROUP; ++g) {
             const size_t mid = adjoint ? 0 : (size_t)(g * GROUP + CENTER) * 64;
-            pf_q[g] = reinterpret_cast<const char*>(args.q_img + m * MAT + el + mid);
+            pf_q[g] = reinterpret_cast<const char*>(args.q_img + mq * MAT + el + mid);
             pf_l[g] = reinterpret_cast<const char*>(args.lu_img + m * MAT + el + mid);
         }
         pf_d = args.dinv + m * NP + i;
@@ -996,30 +1018,46 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     // (always_inline: as a real call - what NB = 4 with its 131 pieces otherwise becomes - the closure
     // lives in scratch and the LDS-DMA destinations are no longer compile-time address-space known)
     auto issue_dma = [&](size_t m, int par, bool adjoint) __attribute__((always_inline)) {
-        set_prefetch(m, par, adjoint);
+        set_prefetch(m, par, adjoint, m);
         for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
     };
-    auto hook_a = [&](auto KK) __attribute__((always_inline)) {  // first solve: pieces 0 .. NP-2
-        if constexpr (!LOADER && PREFETCH) {
-            if (pf_due) dma_one(KK);
+    // a piece under the flags of the running (sub-step, state)
+    auto dma_fire = [&](auto PIECE) __attribute__((always_inline)) {
+        if constexpr (decltype(PIECE)::value < IMG_PIECES) {
+            if (pf_fire_q) dma_one(PIECE);
+        } else {
+            if (pf_fire_l) dma_one(PIECE);
         }
+    };
+    auto issue_lu_only = [&](size_t m, bool adjoint) __attribute__((always_inline)) {  // ONEBUF adjoint
+        set_prefetch(m, 0, adjoint, m);
+        pf_fire_q = false;
+        pf_fire_l = true;
+        for_each_const(dma_fire, std::make_integer_sequence<int, PIECES>{});
+        pf_fire_l = false;
+    };
+    auto hook_a = [&](auto KK) __attribute__((always_inline)) {  // first solve: pieces 0 .. NP-2
+        if constexpr (!LOADER && PREFETCH) dma_fire(KK);
     };
     auto hook_b = [&](auto KK) __attribute__((always_inline)) {  // second solve: the remaining pieces
         constexpr int piece = NP - 1 + decltype(KK)::value;
-        if constexpr (!LOADER && PREFETCH && piece < PIECES) {
-            if (pf_due) dma_one(std::integral_constant<int, piece>());
-        }
+        if constexpr (!LOADER && PREFETCH && piece < PIECES)
+            dma_fire(std::integral_constant<int, piece>());
     };
     auto finish_prefetch = [&]() {  // pieces that did not fit into the two solves (NP = 16)
         constexpr int DONE = 2 * (NP - 1), REST = PIECES > DONE ? PIECES - DONE : 0;
         if constexpr (LOADER || !PREFETCH) return;
-        if (pf_due)
-            for_each_const(
-                [&](auto P) __attribute__((always_inline)) {
-                    dma_one(std::integral_constant<int, DONE + decltype(P)::value>());
-                },
-                std::make_integer_sequence<int, REST>{});
-        pf_due = false;
+        for_each_const(
+            [&](auto P) __attribute__((always_inline)) {
+                dma_fire(std::integral_constant<int, DONE + decltype(P)::value>());
+            },
+            std::make_integer_sequence<int, REST>{});
+        if (pf_fire_l || pf_fire_q) {
+            pf_due = false;
+            pf_qdue = false;
+        }
+        pf_fire_q = false;
+        pf_fire_l = false;
     };
     auto issue_all_due = [&]() {  // LOADER: the whole step at once, from the wave that only fetches
         if (pf_due) for_each_const(dma_one, std::make_integer_sequence<int, PIECES>{});
@@ -1040,6 +1078,9 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                 break;
             }
             for (int s = s0; s < S; s += W) {
+                // the next step's operands: ONEBUF into the buffers of this step, once its last
+                // matvec has read Q; else into the other set during the first (sub-step, state)
+                pf_fire_q = pf_fire_l = pf_due && (!ONEBUF || sub == nsub - 1);
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
                 lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
@@ -1106,11 +1147,11 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             wave_sync();
             if constexpr (LOADER) {
                 pf_due = fetcher && (step + 2 < je);
-                if (pf_due) set_prefetch(m0 + step + 2, (par + 2) % NBUF, false);
+                if (pf_due) set_prefetch(m0 + step + 2, (par + 2) % NBUF, false, m0 + step + 2);
                 issue_all_due();
             } else if constexpr (PREFETCH) {
-                pf_due = fetcher && (step + 1 < je);
-                if (pf_due) set_prefetch(m0 + step + 1, par ^ 1, false);
+                pf_due = fetcher && (step + 1 < je) && !(args.dbg & 256);  // (dbg: timing experiment)
+                if (pf_due) set_prefetch(m0 + step + 1, (par + 1) % NBUF, false, m0 + step + 1);
             }
             if (step + 1 < je) nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
             before_step(step);
@@ -1128,6 +1169,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         if (je == nsteps) {
             before_step(nsteps);
             if (w == 0) cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
+            if (w == 0 && args.unit_adjoint && args.want_grad) unit_adjoint_scales<NB>(args, vecs, b, h, i);
             if (g0)
                 for (int s = s0; s < S; s += W)
                     args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
@@ -1155,7 +1197,15 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
     };
 
     // ---- adjoint sweep ---------------------------------------------------------------------
-    if (je == nsteps) {
+    const bool unit = args.unit_adjoint != 0;
+    int* offs_x = unit ? args.offs_x + (size_t)b * (nsteps + 1) : nullptr;
+    if (je == nsteps && unit) {
+        // lam = the targets. The forward sweep may not have numbered the sub-steps yet: the xs
+        // slots are counted down from the capacity and recorded per step in offs_x
+        unit_adjoint_seed<NB>(args, lam, s0, W, h, i);
+        slot = (int)cap;
+        block_sync();
+    } else if (je == nsteps) {
         if (!do_fwd) {  // final states of the forward segments
             slot = offs_b[nsteps];
             for (int s = s0; s < S; s += W)
@@ -1171,7 +1221,7 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
         block_sync();
         inject(nsteps);
     } else {  // resume the adjoint sweep below step je
-        slot = offs_b[je];
+        slot = unit ? offs_x[je] : offs_b[je];
         for (int s = s0; s < S; s += W)
             if (g0) lam[s * NP + i] = args.lam_buf[((size_t)b * S + s) * NP + i];
         wave_sync();
@@ -1179,8 +1229,17 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
 
     auto adjoint_step = [&](const StepScalars& sc, int nsub, int step) {
         for (int sub = nsub - 1; sub >= 0; --sub) {
+            if (slot <= 0) {  // (unit adjoint: nobody has checked the capacity before)
+                overflow = true;
+                break;
+            }
             --slot;
             for (int s = s0; s < S; s += W) {
+                // (ONEBUF: the first sub-step processed fetches the step's own Q and the next
+                // step's LU image; pf_due / pf_qdue are cleared by finish_prefetch)
+                pf_fire_l = pf_due;
+                pf_fire_q = ONEBUF ? pf_qdue : pf_due;
+                const bool q_in_flight = ONEBUF && pf_fire_q, l_in_flight = pf_fire_l;
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
@@ -1201,6 +1260,14 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
                     xs_b[((size_t)slot * S + s) * NP + i] = x;
                 }
                 wave_sync();
+                if constexpr (ONEBUF) {
+                    // the Q pieces went out first (hook_a); younger than them: the LU image, 1/U_kk
+                    // and the permutation of the next step, and the store of x just above
+                    if (q_in_flight) {
+                        if (l_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IMG_PIECES + 3) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    }
+                }
                 // lambda = Q^H x ; the LDS image is that of Q^T (lane (h,i): Q[cc*H+h][i])
                 double yre, yim;
                 lds_matvec<NB, true, MVB>(qcur, tmp, lane, h, yre, yim);
@@ -1219,10 +1286,12 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             block_sync();
         }
         if (step != 0) inject(step);
+        if (unit && w == 0 && lane == 0) offs_x[step] = slot;
     };
     {
         const size_t ml = m0 + je - 1;
-        if (fetcher) issue_dma(ml, 0, true);
+        if constexpr (ONEBUF) issue_lu_only(ml, true);
+        else if (fetcher) issue_dma(ml, 0, true);
         if (LOADER && fetcher && je - 2 >= jb) issue_dma(ml - 1, 1, true);
         int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
@@ -1249,15 +1318,25 @@ __global__ __launch_bounds__(64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(Swee
             wave_sync();
             if constexpr (LOADER) {
                 pf_due = fetcher && (step - 2 >= jb);
-                if (pf_due) set_prefetch(m0 + step - 2, (par + 2) % NBUF, true);
+                if (pf_due) set_prefetch(m0 + step - 2, (par + 2) % NBUF, true, m0 + step - 2);
                 issue_all_due();
+            } else if constexpr (ONEBUF) {
+                pf_due = (step - 1 >= jb) && !(args.dbg & 512);
+                pf_qdue = !(args.dbg & 512);
+                set_prefetch(pf_due ? m0 + step - 1 : m0 + step, 0, true, m0 + step);
             } else if constexpr (PREFETCH) {
                 pf_due = fetcher && (step - 1 >= jb);
-                if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true);
+                if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true, m0 + step - 1);
             }
             if (step - 1 >= jb) nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
             adjoint_step(sc, nsub, step);
+            if (overflow) break;
         }
+    }
+    if (overflow) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (w == 0 && lane == 0) atomicOr(args.status, 4);
+        return;
     }
     if (jb > 0 && g0)
         for (int s = s0; s < S; s += W)
@@ -1450,6 +1529,9 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     const int t0 = args.offs[(size_t)b * (nsteps + 1) + step];
     const int nsub = 1 << sq;
     if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) return;  // sweep overflowed (status bit 2)
+    // unit adjoint: x sits at slots of its own and is scaled by the cost's scalar here
+    const int tx = args.offs_x ? args.offs_x[(size_t)b * (nsteps + 1) + step] : t0;
+    if (tx < 0 || (size_t)tx + (size_t)nsub > cap) return;
 
     double are[CPL], aim[CPL], hre[HC], him[HC];
     build(are, aim, hre, him);
@@ -1462,7 +1544,8 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     for (int sub = 0; sub < nsub; ++sub)
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
-            chains(are, aim, hre, him, xs_b[(t * S + s) * NP + i], states_b[(t * S + s) * NP + i],
+            const double2 x = xs_b[(((size_t)tx + sub) * S + s) * NP + i];
+            chains(are, aim, hre, him, x, states_b[(t * S + s) * NP + i],
                    states_b[((t + 1) * S + s) * NP + i], abr, abi);
         }
     if constexpr (EXPLICIT) {  // Mbar = 2^-s abar; the Magnus reverse kernel finishes the chain
@@ -1473,16 +1556,28 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
             mb[(size_t)i * NP + cc * H + h] = make_double2(sc * abr[cc], sc * abi[cc]);
     } else {
         // g_k = Re <abar, E_k>, E_k = d a / d u_k = -i dts G_k  (H-bar = i dt M-bar, Appendix A)
+        // unit adjoint: abar is that of the back-propagated target, abar = c abar_1 with the cost's
+        // scalar c: g_k = Re(conj(c) gamma_k), gamma_k = sum conj(abar_1) E_k (real part as above)
+        const bool unit = args.offs_x != nullptr;
         for (int k = 0; k < K; ++k) {
-            double acc = 0;
+            double acc = 0, acc_im = 0;
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 const double2 e = gr[(size_t)k * G::MAT + cc * 64 + lane];
                 acc = fma(abi[cc], -dts * e.x, fma(abr[cc], dts * e.y, acc));
+                acc_im = fma(abi[cc], -dts * e.y, fma(abr[cc], -dts * e.x, acc_im));
                 column_fence<NB>(cc);
             }
             acc = wave_sum(acc);
-            if (lane == 0) args.gstep[m * K + k] = acc;
+            if (unit) {
+                acc_im = wave_sum(acc_im);
+                if (lane == 0) {
+                    args.gstep[(m * K + k) * 2] = acc;
+                    args.gstep[(m * K + k) * 2 + 1] = acc_im;
+                }
+            } else if (lane == 0) {
+                args.gstep[m * K + k] = acc;
+            }
         }
     }
 }
@@ -1509,8 +1604,16 @@ __global__ void scatter_kernel(ScatterArgs args) {
     const int ic = (int)((idx / args.K) % args.nc);
     const size_t b = idx / ((size_t)args.K * args.nc);
     double acc = 0;
-    for (int e = args.row_ptr[ic]; e < args.row_ptr[ic + 1]; ++e)
-        acc += args.weight[e] * args.gstep[(b * args.nsteps + args.col_step[e]) * args.K + k];
+    if (args.lam_scale != nullptr) {  // unit adjoint: Re(conj(c) gamma)
+        const double2 c = args.lam_scale[b * args.S];
+        for (int e = args.row_ptr[ic]; e < args.row_ptr[ic + 1]; ++e) {
+            const double* g = args.gstep + ((b * args.nsteps + args.col_step[e]) * args.K + k) * 2;
+            acc += args.weight[e] * fma(c.y, g[1], c.x * g[0]);
+        }
+    } else {
+        for (int e = args.row_ptr[ic]; e < args.row_ptr[ic + 1]; ++e)
+            acc += args.weight[e] * args.gstep[(b * args.nsteps + args.col_step[e]) * args.K + k];
+    }
     args.grads[idx] = acc;
 }
 
@@ -1593,8 +1696,31 @@ static void launch_sweep_w(const SweepArgs& a, int batch, hipStream_t st) {
     }
     launch_sweep_wl<NB, W, false>(a, batch, st);
 }
+// one state, one wave per seed: one operand set in LDS, two seeds per workgroup
+template <int NB>
+static void launch_sweep_onebuf(const SweepArgs& a, int batch, hipStream_t st) {
+    if constexpr (SweepPrefetch<NB>::value) {
+        const int bytes = 2 * SweepLds<NB, 1>::bytes_static(1);
+        static bool attr_set = false;
+        if (bytes > 48 * 1024 && !attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, 1, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            attr_set = true;
+        }
+        SweepArgs b = a;
+        b.batch = batch;
+        const int pack = a.onebuf >= 2 ? 2 : 1;  // seeds (waves) per workgroup
+        hipLaunchKernelGGL((sweep_kernel<NB, 1, false, true>), dim3((batch + pack - 1) / pack),
+                           dim3(64 * pack), bytes / 2 * pack, st, b);
+    }
+}
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
+    if (SweepPrefetch<NB>::value && a.onebuf && a.S == 1 && !a.loader &&
+        getenv("QOCX_SWEEP_W") == nullptr) {
+        launch_sweep_onebuf<NB>(a, batch, st);
+        return;
+    }
     // waves per seed: the states are independent chains, up to four of them run side by side
     // (eight were measured at S = 32: no faster, the adjoint phase is K3 bound by then)
     static const int forced = getenv("QOCX_SWEEP_W") ? atoi(getenv("QOCX_SWEEP_W")) : 0;  // experiments

@@ -96,6 +96,54 @@ __device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pa
     return total;
 }
 
+// ---- separable final cost ("unit adjoint") ---------------------------------------------------
+// When the ONLY cost is one TargetStateInfidelity (coherent or incoherent) on the final states, the
+// cotangent of the final states is lam_s = c_s t_s: the target vectors times scalars that depend
+// on the final states (eval_costs above: c = f (tre + i tim), resp. c_s = f (r_s + i m_s)). The
+// adjoint recursion is linear in lam, so it can run on lam_s = t_s WITHOUT knowing the forward
+// result - the classic GRAPE back-propagation of the target - and K3 applies c_s to x = P^-H lam'
+// when it forms the gradient. The forward and the adjoint sweep then only meet in K3, and the
+// pipeline runs them side by side (qocx_api.hip). args.unit_adjoint selects it; args.lam_scale
+// [B][S] carries the scalars from the end of the forward sweep to K3.
+template <int NB>
+__device__ __forceinline__ void unit_adjoint_scales(const SweepArgs& args, const double2* vecs, int b,
+                                                    int h, int i) {
+    constexpr int NP = Geo<NB>::NP;
+    const int S = args.S;
+    const DevCost c = args.costs[0];
+    const double2* pool = args.cost_vectors + (size_t)c.vec_offset * NP;
+    const bool act = (h == 0);
+    if (c.kind == QOCX_DEV_COST_COHERENT) {
+        double tre = 0, tim = 0;
+        for (int s = 0; s < S; ++s) {
+            double r, m;
+            inner(pool[s * NP + i], vecs[s * NP + i], act, r, m);
+            tre += r;
+            tim += m;
+        }
+        const double f = -2.0 * c.scale / ((double)S * S);
+        if (lane_id() == 0)
+            for (int s = 0; s < S; ++s) args.lam_scale[(size_t)b * S + s] = make_double2(f * tre, f * tim);
+    } else {  // QOCX_DEV_COST_INCOHERENT
+        const double f = -2.0 * c.scale / (double)S;
+        for (int s = 0; s < S; ++s) {
+            double r, m;
+            inner(pool[s * NP + i], vecs[s * NP + i], act, r, m);
+            if (lane_id() == 0) args.lam_scale[(size_t)b * S + s] = make_double2(f * r, f * m);
+        }
+    }
+}
+
+// lam_s = t_s for the states s0, s0 + W, ... (lane group 0 writes)
+template <int NB>
+__device__ __forceinline__ void unit_adjoint_seed(const SweepArgs& args, double2* lam, int s0, int W,
+                                                  int h, int i) {
+    constexpr int NP = Geo<NB>::NP;
+    const double2* pool = args.cost_vectors + (size_t)args.costs[0].vec_offset * NP;
+    if (h == 0)
+        for (int s = s0; s < args.S; s += W) lam[s * NP + i] = pool[s * NP + i];
+}
+
 // One 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `g` land at lds_base + 16*l.
 __device__ __forceinline__ void dma16(const double2* g, double2* lds_base) {
     __builtin_amdgcn_global_load_lds(

@@ -114,6 +114,7 @@ SIGNATURES = {
     "qocx_debug_lindblad_knobs": (ctypes.c_int, [_VP, _I64, _I32, _I32]),
     "qocx_debug_set_knob": (ctypes.c_int, [_VP, ctypes.c_char_p, _I64]),
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
+    "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
 }
 
@@ -428,6 +429,14 @@ class Engine(object):
     def set_pipeline(self, time_segments):
         """Number of time segments the evaluation pipeline is cut into (0 = automatic)."""
         self._check(self._lib.qocx_set_pipeline(self._ctx, int(time_segments)))
+
+    def timeline(self, capacity=4096):
+        """(which, start_ms, end_ms) of the last evaluation's kernel launches (timing on)."""
+        out = np.zeros((capacity, 3))
+        count = _I64(0)
+        self._check(self._lib.qocx_debug_timeline(
+            self._ctx, out.ctypes.data_as(_c_double_p), capacity, ctypes.byref(count)))
+        return out[:min(capacity, count.value)]
 
     # -- timing --------------------------------------------------------------------------------
     def set_timing(self, enable):

@@ -297,10 +297,15 @@ def case_by_name(name):
 class LindbladCase(Case):
     """Adds: dissipators (L,), operators (L x n x n), initial_densities (S x n x n)."""
 
+    data_mod = None  # (w_gamma, w_ops): gamma_i (1 + 0.5 sin(w_gamma t)), L_i (1 + 0.2 cos(w_ops t))
+
     def lindblad_data(self):
         gam, ops = self.dissipators, self.operators
         if gam is None:
             return None
+        if self.data_mod is not None:
+            wg, wo = self.data_mod
+            return lambda time: (gam * (1 + 0.5 * np.sin(wg * time)), ops * (1 + 0.2 * np.cos(wo * time)))
         return lambda time: (gam, ops)
 
 
@@ -400,6 +405,48 @@ def lindblad_cases():
     ]
 
 
+def lindblad_bench_case():
+    """
+    BASELINE.json configs[3] EXACTLY as bench.py times it: bench.lindblad_problem()
+    - GUE H0 and G_k of unit 2-norm, un-normalised ladder operators a and a^H a, |0><0| -> |1><1|,
+    n = 16, 501 system evaluations - with the controls of bench seeds 0 and 1. The GPU test evaluates
+    the whole 64-seed bench batch and compares seeds 0 and 1 with this fixture: cost 1e-9, densities
+    1e-8, gradient by tests/helpers.py::lindblad_grad_close. With these controls (sigma = 0.1 on a
+    random H0) the cost stays at 0.995 and max |g| = 1.5e-5, so the gradient gate is the one of the
+    other tiny-gradient fixtures (1e-6 relative, 5e-10 floor = the reference's own noise: its
+    adaptive forward reproduces itself to 3e-10 here, tools/gen_golden_lindblad.py prints it); a 1e-8
+    relative gate would be 1.5e-13 absolute, far below what the reference itself defines.
+    """
+    import bench
+    h0, g, gam, ops, rho0, target = bench.lindblad_problem()
+    controls = np.stack([0.1 * np.random.default_rng(1000 + b).standard_normal((bench.LB_EVAL, bench.K_CTRL))
+                         for b in range(2)])
+    c = LindbladCase(name="lindblad_bench_c4", n=bench.LB_DIM, S=1, K=bench.K_CTRL, Nc=bench.LB_EVAL,
+                     N=bench.LB_EVAL, T=bench.DT * (bench.LB_EVAL - 1), h0=h0, g_re=list(g), g_im=None,
+                     complex_controls=False, initial_states=None, cost_eval_step=1,
+                     cost_specs=[("TargetDensityInfidelity", dict(target_densities=target))],
+                     controls=controls)
+    c.initial_densities = rho0
+    c.dissipators = gam
+    c.operators = ops
+    return c
+
+
+def lindblad_timedep_data_case():
+    """lindblad_data(t) with explicit time dependence (the reference calls it at every right-hand
+    side, lindbladdiscrete.py:486-492): dissipation rates and operators both modulated; a
+    well-conditioned problem (reachable target, few knots) so the gradient gate is 1e-8."""
+    c = lindblad_wellconditioned_case("lindblad_timedep_data", n=5, N=15, Nc=5, T=3.0, sigma=0.7,
+                                      drive=0.4)
+    c.data_mod = (2.0, 1.3)
+    return c
+
+
+def lindblad_extra_cases():
+    """Fixtures with gradients that the generic per-case tests do not iterate over."""
+    return [lindblad_bench_case(), lindblad_timedep_data_case()]
+
+
 def lindblad_opaque_cases():
     """A Hamiltonian that is not linear in the controls on the Lindblad path (forward only: the
     host folds the control array into a time-dependent Hamiltonian)."""
@@ -412,7 +459,7 @@ def lindblad_opaque_cases():
 
 
 def lindblad_case_by_name(name):
-    for c in lindblad_cases() + lindblad_opaque_cases():
+    for c in lindblad_cases() + lindblad_opaque_cases() + lindblad_extra_cases():
         if c.name == name:
             return c
     raise KeyError(name)

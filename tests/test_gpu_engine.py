@@ -122,6 +122,42 @@ def test_chunked_equals_unchunked(engine):
     engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("name", ["nc10_n101", "scaled_n8", "c3_fullU_short"])
+def test_unit_adjoint_and_two_sided_pipeline(engine, name):
+    """
+    A single final TargetStateInfidelity makes the cotangent of the final states a scalar times the
+    targets: the adjoint sweep then back-propagates the TARGETS (no dependence on the forward
+    sweep), K3 emits complex numbers and the scatter kernel applies the scalar
+    (qocx_sweep_common.h; knob "unit_adjoint"). Same derivative as the classic order - forward,
+    cost, adjoint - to rounding; and the two-sided schedule built on it (knob "bidir": both sweeps
+    at once, factorisation from both ends) is pure scheduling: bit-identical.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_by_name(name)
+    gh.setup_engine(engine, case)
+    u = gh.real_controls(case, case.controls)
+    u = np.concatenate([u, 0.5 * u, -u])
+    try:
+        engine.set_knob("unit_adjoint", 0)
+        classic = engine.evaluate(u, True)
+        engine.set_knob("unit_adjoint", 1)
+        unit = engine.evaluate(u, True)
+        assert np.array_equal(classic[0], unit[0]) and np.array_equal(classic[2], unit[2])
+        assert np.max(np.abs(classic[1] - unit[1])) <= 1e-12 * np.max(np.abs(classic[1]))
+        for pipe in (4, 8):
+            engine.set_pipeline(pipe)
+            engine.set_knob("bidir", 1)
+            two_sided = engine.evaluate(u, True)
+            engine.set_knob("bidir", 0)
+            one_sided = engine.evaluate(u, True)
+            for a, b, c in zip(unit, two_sided, one_sided):
+                assert np.array_equal(a, b) and np.array_equal(a, c)
+    finally:
+        engine.set_knob("unit_adjoint", 1)
+        engine.set_knob("bidir", 1)
+        engine.set_pipeline(0)
+
+
 def test_error_paths(engine):
     """The C ABI reports misuse and numerical trouble loudly (include/qocx.h error codes)."""
     from qoc_amd.engine import Engine, QocxError

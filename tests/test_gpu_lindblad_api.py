@@ -163,3 +163,27 @@ def test_time_dependent_lindblad_data_on_gpu():
         assert abs(ge - ce) < 1e-10
         assert np.max(np.abs(gg - cg)) / np.max(np.abs(cg)) < 1e-8
     assert gpu_result.best_iteration == cpu_result.best_iteration
+
+
+def test_time_dependent_lindblad_data_fixture():
+    """lindblad_data(t) with explicit time dependence against a fixture minted from the REFERENCE
+    (forward: its evolve_lindblad_discrete; gradient: frozen-mesh AD cross-checked with finite
+    differences of the reference forward, tools/gen_golden_lindblad.py) - forward 1e-9 / 1e-8,
+    gradient 1e-8 relative."""
+    case = cases_mod.lindblad_case_by_name("lindblad_timedep_data")
+    g = golden("lindblad_timedep_data")
+    costs = product_cost_list(case)
+    for b, u in enumerate(case.controls):
+        result = qoc_amd.evolve_lindblad_discrete(
+            case.T, case.initial_densities, case.N, controls=u, costs=costs,
+            hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data())
+        assert abs(result.error - g["error"][b]) < 1e-9
+        assert np.max(np.abs(result.final_densities - g["final_densities"][b])) < 1e-8
+    ev = device.LindbladEvaluator(case.T, case.initial_densities, case.N, costs=costs,
+                                  hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data(),
+                                  control_count=case.K, control_eval_count=case.Nc)
+    errors, grads, finals, _ = ev.evaluate_batch(np.stack(case.controls))
+    for b in range(len(case.controls)):
+        assert abs(errors[b] - g["error"][b]) < 1e-9
+        ref = g["grads_ad"][b]
+        assert np.max(np.abs(grads[b] - ref)) < 1e-8 * np.max(np.abs(ref))

@@ -25,6 +25,9 @@ from tests import lindblad_model as lm
 from tests.helpers import golden, lindblad_grad_close
 
 NAMES = [c.name for c in cases_mod.lindblad_cases()]
+# fixtures with gradients outside the generic list: bench.py's own configs[3] problem (two of its
+# 64 seeds) and a time-dependent lindblad_data
+EXTRA_NAMES = [c.name for c in cases_mod.lindblad_extra_cases()]
 
 
 def oracle_problem(case):
@@ -46,6 +49,9 @@ def structured(case):
     g = list(case.g_re)
     if case.complex_controls:
         g = [case.g_re[0], case.g_im[0]]
+    if getattr(case, "data_mod", None) is not None:  # tests/cases.py LindbladCase.lindblad_data
+        bound = (1.5 * case.dissipators, 1.2 * case.operators)  # norm bounds over all times
+        return lm.StructuredLindblad(case.h0, g, bound[0], bound[1], data_of_t=case.lindblad_data())
     if getattr(case, "time_mod", None) is None:
         return lm.StructuredLindblad(case.h0, g, case.dissipators, case.operators)
     omega = case.time_mod  # tests/cases.py Case.hamiltonian: h0 (1 + 0.3 cos(omega t))
@@ -119,7 +125,7 @@ def test_density_cost_known_answers():
     density_cost_known_answers(ol)
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + EXTRA_NAMES)
 def test_oracle_forward_matches_reference(name):
     case = cases_mod.lindblad_case_by_name(name)
     g = golden(name)
@@ -131,7 +137,7 @@ def test_oracle_forward_matches_reference(name):
         assert abs(np.trace(dens[0]) - 1) < 1e-11
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + EXTRA_NAMES)
 def test_device_model_matches_fixtures(name):
     case = cases_mod.lindblad_case_by_name(name)
     g = golden(name)

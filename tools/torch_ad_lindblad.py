@@ -67,10 +67,17 @@ def ad_eval(case, controls_np, freeze_mesh=False):
             else:
                 h = h + u[k] * g_re[k]
         out = -1j * (torch.matmul(h, rho) - torch.matmul(rho, h))
+        gs, os_, osd, osp = gam, ops, ops_d, ops_p
+        if getattr(case, "data_mod", None) is not None:  # tests/cases.py LindbladCase.lindblad_data
+            wg, wo = case.data_mod
+            tt = torch.as_tensor(t)
+            gs = gam * (1 + 0.5 * torch.sin(wg * tt))
+            fo = 1 + 0.2 * torch.cos(wo * tt)
+            os_, osd, osp = ops * fo, ops_d * fo, ops_p * (fo * fo)
         for i in range(ops.shape[0]):
-            out = out + gam[i] * (torch.matmul(torch.matmul(ops[i], rho), ops_d[i])
-                                  - 0.5 * torch.matmul(ops_p[i], rho)
-                                  - 0.5 * torch.matmul(rho, ops_p[i]))
+            out = out + gs[i] * (torch.matmul(torch.matmul(os_[i], rho), osd[i])
+                                 - 0.5 * torch.matmul(osp[i], rho)
+                                 - 0.5 * torch.matmul(rho, osp[i]))
         return out
 
     def rk_step(h, x0, y0, k1):
