@@ -307,6 +307,29 @@ int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t
  * next to the spec peak. */
 int qocx_debug_mfma_peak(qocx_ctx* ctx, int32_t waves_per_simd, int32_t iters, double* tflops);
 
+/* ---- host-side helpers of the multi-start GRAPE driver (no GPU work, no context) --------------
+ * The reference's driver loop clips the controls and applies its optimizer plugin to ONE control
+ * set per process (qoc/core/common.py:8-30, qoc/standard/optimizers/adam.py:110-165, sgd.py). The
+ * batched driver holds B optimizer states as [B][P] arrays; these two functions are that loop's
+ * arithmetic over the rows `rows[0..row_count)` on a few host threads - IEEE double operations in
+ * the reference's order (no contraction), so every seed walks its single-seed trajectory bit for
+ * bit. */
+/* controls [B][Nc][K] real, in place: an entry whose modulus exceeds max_norms[k] becomes
+ * (entry / modulus) * max_norms[k] (clip_control_norms). */
+int qocx_host_clip_controls(double* controls, int64_t batch, int64_t nc, int32_t k,
+                            const double* max_norms);
+/* Adam.update on rows of params / grads / moment / square_moment (all [B][P]):
+ *   g' = clip(g, -clip_grads, clip_grads) if apply_clip_grads
+ *   m = beta_1 m + (1 - beta_1) g' ; v = beta_2 v + (1 - beta_2) g'^2
+ *   params -= learning_rate * ((m / corr_1) / (sqrt(v / corr_2) + epsilon))
+ * corr_i = 1 - beta_i^step and the (possibly decayed) learning rate are the caller's scalars.
+ * kind 0 = SGD (params -= learning_rate * g; the other arguments are ignored). */
+int qocx_host_optimizer_update(int32_t kind, double* params, const double* grads, double* moment,
+                               double* square_moment, int64_t p, const int64_t* rows,
+                               int64_t row_count, double learning_rate, double beta_1,
+                               double beta_2, double epsilon, double corr_1, double corr_2,
+                               int32_t apply_clip_grads, double clip_grads);
+
 #ifdef __cplusplus
 }
 #endif

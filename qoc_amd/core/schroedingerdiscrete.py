@@ -15,7 +15,7 @@ from qoc_amd.core.device import SchroedingerEvaluator
 from qoc_amd.models import (Dummy, EvolveSchroedingerDiscreteState, EvolveSchroedingerResult,
                             GrapeSchroedingerDiscreteState, GrapeSchroedingerResult,
                             InterpolationPolicy, MagnusPolicy)
-from qoc_amd.standard.optimizers import Adam
+from qoc_amd.standard.optimizers import SGD, Adam
 
 
 def evolve_schroedinger_discrete(evolution_time, hamiltonian, initial_states, system_eval_count,
@@ -170,6 +170,172 @@ def _optimizer_clone(optimizer, flat_controls):
     return clone
 
 
+# ---- the B optimizer states as [B, P] arrays ------------------------------------------------------
+# The per-seed loop (one plugin object per seed: slap / clip / strip / update = ~60 small NumPy
+# calls per seed and iteration) costs 13 ms of host time per iteration at B = 256, Nc = 1001,
+# K = 2 - as long as the device evaluation it wraps. For the built-in Adam and
+# SGD the same arithmetic runs on [rows, P] blocks: every operation is elementwise and in the
+# reference's order (adam.py:110-165, sgd.py), so seed b still walks exactly its single-seed
+# trajectory, bit for bit. Row blocks keep the temporaries cache resident.
+_ROW_BLOCK = 16
+_POOL = None
+
+
+def _row_blocks(rows):
+    """rows (sorted index array) as a list of slices where they are consecutive, index arrays
+    otherwise, at most _ROW_BLOCK rows each."""
+    out = []
+    for lo in range(0, len(rows), _ROW_BLOCK):
+        r = rows[lo:lo + _ROW_BLOCK]
+        out.append(slice(int(r[0]), int(r[-1]) + 1) if r[-1] - r[0] + 1 == len(r) else r)
+    return out
+
+
+def _for_blocks(work, blocks):
+    """work(block) for every block, on a small thread pool (NumPy releases the GIL inside its
+    loops; the blocks are disjoint rows)."""
+    global _POOL
+    if len(blocks) < 4:
+        for blk in blocks:
+            work(blk)
+        return
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+    list(_POOL.map(work, blocks))
+
+
+def _native_ok(*arrays):
+    return all(a.dtype == np.float64 and a.flags.c_contiguous for a in arrays)
+
+
+class _BatchedSGD(object):
+    def __init__(self, optimizer, params):
+        self.learning_rate = optimizer.learning_rate
+
+    def update(self, grads, params, rows):
+        """params[rows] <- SGD.update(grads[rows], params[rows]), in place."""
+        if _native_ok(grads, params):
+            from qoc_amd import engine
+            engine.host_optimizer_update(0, params, grads, None, None, rows, self.learning_rate)
+            return
+
+        def work(r):
+            params[r] = params[r] - self.learning_rate * grads[r]
+        _for_blocks(work, _row_blocks(rows))
+
+
+class _BatchedAdam(object):
+    def __init__(self, optimizer, params):
+        self.o = optimizer
+        self.m = np.zeros_like(params)
+        self.v = np.zeros_like(params)
+        self.count = np.zeros(params.shape[0], dtype=np.int64)
+
+    def update(self, grads, params, rows):
+        """params[rows] <- Adam.update(grads[rows], params[rows]) with every seed's own moments and
+        step counter, in place: the operations of adam.py:110-165 in their order, element by
+        element (a * x + b * y is formed as (a * x) + (b * y) there and here)."""
+        o = self.o
+        for count in np.unique(self.count[rows]):  # (seeds that stopped earlier keep their own)
+            sel = rows[self.count[rows] == count]
+            if o.apply_learning_rate_decay:
+                learning_rate = (o.initial_learning_rate
+                                 * np.exp(-np.divide(count, o.learning_rate_decay)))
+            else:
+                learning_rate = o.initial_learning_rate
+            step = count + 1
+            corr_1 = 1 - np.power(o.beta_1, step)
+            corr_2 = 1 - np.power(o.beta_2, step)
+            if not o.apply_scale_grads and _native_ok(grads, params, self.m, self.v):
+                # the same operations on host threads of libqocx (qocx_host_optimizer_update)
+                from qoc_amd import engine
+                engine.host_optimizer_update(
+                    1, params, grads, self.m, self.v, sel, learning_rate, o.beta_1, o.beta_2,
+                    o.epsilon, corr_1, corr_2, o.clip_grads if o.apply_clip_grads else None)
+                self.count[sel] = step
+                continue
+
+            def work(r):
+                g = grads[r]
+                if o.apply_scale_grads:
+                    norms = np.array([np.linalg.norm(row) for row in g])
+                    g = (g / norms[:, None]) * o.scale_grads
+                if o.apply_clip_grads:
+                    g = np.clip(g, -o.clip_grads, o.clip_grads)
+                m, v = self.m[r], self.v[r]  # views for a slice, copies for an index array
+                t = np.multiply(g, 1 - o.beta_1)
+                np.multiply(m, o.beta_1, out=m)
+                m += t                                    # gradient_moment
+                np.square(g, out=t)
+                t *= (1 - o.beta_2)
+                np.multiply(v, o.beta_2, out=v)
+                v += t                                    # gradient_square_moment
+                if not isinstance(r, slice):
+                    self.m[r] = m
+                    self.v[r] = v
+                u = np.divide(v, corr_2)                  # square_hat
+                np.sqrt(u, out=u)
+                u += o.epsilon
+                np.divide(m, corr_1, out=t)               # moment_hat
+                np.divide(t, u, out=t)
+                t *= learning_rate
+                if isinstance(r, slice):
+                    p = params[r]
+                    p -= t
+                else:
+                    params[r] = params[r] - t
+            _for_blocks(work, _row_blocks(sel))
+            self.count[sel] = step
+
+
+def _batched_stepper(optimizer, params):
+    """The [B, P] form of the built-in step-wise optimizers; None for any other plugin (those keep
+    one deep copy per seed and their own update())."""
+    if type(optimizer) is Adam:
+        return _BatchedAdam(optimizer, params)
+    if type(optimizer) is SGD:
+        return _BatchedSGD(optimizer, params)
+    return None
+
+
+def _cost_format_batch(params, pstate):
+    """_cost_format on all rows of params [B, P] at once: (B x Nc x K) controls, clipped in place
+    (a view of params for real controls, as in the single-seed driver), conditions per seed."""
+    B = params.shape[0]
+    shape = (B,) + tuple(pstate.controls_shape)
+    if pstate.complex_controls:
+        half = params.shape[1] // 2
+        controls = (params[:, :half] + 1j * params[:, half:]).reshape(shape)
+    else:
+        controls = params.reshape(shape)
+        if _native_ok(params) and controls.base is not None:
+            from qoc_amd import engine
+            engine.host_clip_controls(controls, pstate.max_control_norms)
+            if pstate.impose_control_conditions is not None:
+                controls = np.stack([pstate.impose_control_conditions(controls[b])
+                                     for b in range(B)])
+            return controls
+    for i, max_norm in enumerate(pstate.max_control_norms):  # clip_control_norms, all seeds
+        column = controls[:, :, i]
+        moduli = np.abs(column)
+        over = np.less(max_norm, moduli)
+        if over.any():
+            column[over] = (column[over] / moduli[over]) * max_norm
+    if pstate.impose_control_conditions is not None:
+        controls = np.stack([pstate.impose_control_conditions(controls[b]) for b in range(B)])
+    return controls
+
+
+def _strip_batch(complex_controls, arrays):
+    """strip_controls on every row: (B x Nc x K) -> [B, P]."""
+    flat = np.reshape(arrays, (arrays.shape[0], -1))
+    if complex_controls:
+        flat = np.hstack((np.real(flat), np.imag(flat)))
+    return flat
+
+
 def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, evolution_time,
                                       hamiltonian, initial_states, system_eval_count,
                                       initial_controls, complex_controls=False, cost_eval_step=1,
@@ -220,10 +386,14 @@ def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, 
         complex_controls=complex_controls, costs=costs, cost_eval_step=cost_eval_step,
         interpolation_policy=interpolation_policy, magnus_policy=magnus_policy,
         need_gradients=True, latency_mode=B <= 128)
-    params = [strip_controls(complex_controls, c) for c in seeds]
-    optimizers = [_optimizer_clone(optimizer, p) for p in params]
+    params = (np.stack([strip_controls(complex_controls, c) for c in seeds]) if B
+              else np.zeros((0, control_eval_count * control_count)))
+    params = np.array(params, dtype=np.float64)
+    stepper = _batched_stepper(optimizer, params)
+    optimizers = None if stepper is not None else [_optimizer_clone(optimizer, p) for p in params]
     active = np.ones(B, dtype=bool)
     result = GrapeSchroedingerBatchResult(B)
+    best_controls = best_finals = None
     should_log = log_iteration_step != 0
     if should_log and comm.rank == 0:
         print("iter   |  summed error  |   min error    |  active seeds \n"
@@ -231,20 +401,22 @@ def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, 
     for iteration in range(iteration_count):
         # cost-function format of every seed (clipping acts in place on the optimizer's params
         # for real controls, exactly as in the single-seed driver)
-        controls = [_cost_format(params[b], pstate) for b in range(B)]
+        controls = _cost_format_batch(params, pstate)
         if B > 0:
-            errors, grads, finals, _ = evaluator.evaluate_batch(np.stack(controls), want_grad=True)
+            errors, grads, finals, _ = evaluator.evaluate_batch(controls, want_grad=True)
         else:
             errors, grads, finals = np.zeros(0), np.zeros((0,) + shape), np.zeros(0)
-        for b in range(B):
-            if not active[b]:
-                continue
-            result.iterations_run[b] = iteration + 1
-            if errors[b] < result.best_error[b]:
-                result.best_controls[b] = controls[b]
-                result.best_error[b] = errors[b]
-                result.best_final_states[b] = finals[b]
-                result.best_iteration[b] = iteration
+        errors = np.asarray(errors)
+        result.iterations_run[active] = iteration + 1
+        improved = active & (errors < result.best_error)  # strict, as :333 of the reference
+        if improved.any():
+            if best_controls is None:
+                best_controls = np.zeros_like(controls)
+                best_finals = np.zeros_like(finals)
+            best_controls[improved] = controls[improved]
+            best_finals[improved] = finals[improved]
+            result.best_error[improved] = errors[improved]
+            result.best_iteration[improved] = iteration
         if should_log and (iteration % log_iteration_step == 0 or iteration == iteration_count - 1):
             local = np.array([float(np.sum(errors[active])) if B else 0.0])
             total = comm.allreduce_sum(local)[0]
@@ -253,16 +425,23 @@ def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, 
             if comm.rank == 0:
                 print("{:^6d} | {:^1.8e} | {:^1.8e} | {:^6d}".format(iteration, total, low,
                                                                      int(count)))
-        for b in range(B):
-            if not active[b]:
-                continue
-            if errors[b] <= min_error:  # the optimizer loop of this seed ends (terminate = True)
-                active[b] = False
-                continue
-            params[b] = optimizers[b].update(strip_controls(complex_controls, grads[b]), params[b])
+        # a seed at error <= min_error ends its optimizer loop (terminate = True): frozen from here
+        active &= ~(errors <= min_error)
+        rows = np.nonzero(active)[0]
+        if len(rows):
+            flat_grads = _strip_batch(complex_controls, np.asarray(grads))
+            if stepper is not None:
+                stepper.update(flat_grads, params, rows)
+            else:
+                for b in rows:
+                    params[b] = optimizers[b].update(flat_grads[b], params[b])
         still = comm.allreduce_sum(np.array([float(np.sum(active))]))[0]
         if still == 0:
             break
+    for b in range(B):
+        if result.best_iteration[b] >= 0:
+            result.best_controls[b] = best_controls[b]
+            result.best_final_states[b] = best_finals[b]
     best_local = float(np.min(result.best_error)) if B else np.inf
     result.global_best_error = float(-comm.allreduce_max(np.array([-best_local]))[0])
     return result

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <map>
 #include <vector>
 
@@ -387,6 +388,56 @@ int load_rccl(qocx_ctx* ctx) {
     return 0;
 }
 
+}  // namespace
+
+// ---- host-side helpers of the multi-start GRAPE driver (include/qocx.h) ---------------------------
+namespace {
+template <class F>
+void host_parallel_rows(int64_t count, F f) {
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>((int64_t)hw, count / 8));
+    if (nthreads <= 1) {
+        f(0, count);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int64_t per = (count + nthreads - 1) / nthreads;
+    for (int64_t t = 1; t < nthreads; ++t) {
+        const int64_t lo = t * per, hi = std::min(count, lo + per);
+        if (lo < hi) pool.emplace_back([=] { f(lo, hi); });
+    }
+    f(0, std::min(count, per));  // the calling thread takes the first share
+    for (auto& th : pool) th.join();
+}
+
+// One row of Adam.update. Every product and sum is rounded on its own, as NumPy's array
+// operations are (no contraction into fused multiply-adds); division and square root are the
+// IEEE ones in scalar and in vector form alike, so the AVX2 clone gives the same bits.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+void adam_row(double* __restrict x, const double* __restrict g, double* __restrict m,
+              double* __restrict v, int64_t p, double learning_rate, double beta_1, double beta_2,
+              double one_m_b1, double one_m_b2, double epsilon, double corr_1, double corr_2,
+              int apply_clip, double clip) {
+#pragma clang fp contract(off)
+    for (int64_t i = 0; i < p; ++i) {
+        double gi = g[i];
+        if (apply_clip) gi = gi < -clip ? -clip : (gi > clip ? clip : gi);
+        const double a = beta_1 * m[i], b = one_m_b1 * gi;
+        const double mi = a + b;
+        const double sq = gi * gi;
+        const double c = beta_2 * v[i], d = one_m_b2 * sq;
+        const double vi = c + d;
+        m[i] = mi;
+        v[i] = vi;
+        const double mh = mi / corr_1, vh = vi / corr_2;
+        const double den = sqrt(vh) + epsilon;
+        const double q = mh / den;
+        const double s = learning_rate * q;
+        x[i] = x[i] - s;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -2325,6 +2376,51 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
         strncpy(report, rep.c_str(), report_len - 1);
         report[report_len - 1] = 0;
     }
+    return 0;
+}
+
+int qocx_host_clip_controls(double* controls, int64_t batch, int64_t nc, int32_t k,
+                            const double* max_norms) {
+    if (!controls || !max_norms || batch < 0 || nc < 0 || k < 0) return fail(QOCX_ERR_ARG, "bad argument");
+    host_parallel_rows(batch, [=](int64_t lo, int64_t hi) {
+        for (int64_t b = lo; b < hi; ++b) {
+            double* row = controls + (size_t)b * nc * k;
+            for (int64_t j = 0; j < nc; ++j)
+                for (int32_t c = 0; c < k; ++c) {
+                    const double v = row[j * k + c], mod = fabs(v);
+                    if (max_norms[c] < mod) row[j * k + c] = (v / mod) * max_norms[c];
+                }
+        }
+    });
+    return 0;
+}
+
+int qocx_host_optimizer_update(int32_t kind, double* params, const double* grads, double* moment,
+                               double* square_moment, int64_t p, const int64_t* rows,
+                               int64_t row_count, double learning_rate, double beta_1,
+                               double beta_2, double epsilon, double corr_1, double corr_2,
+                               int32_t apply_clip_grads, double clip_grads) {
+    if (!params || !grads || !rows || p < 0 || row_count < 0) return fail(QOCX_ERR_ARG, "bad argument");
+    if (kind != 0 && (!moment || !square_moment)) return fail(QOCX_ERR_ARG, "moments missing");
+    const double one_m_b1 = 1 - beta_1, one_m_b2 = 1 - beta_2;
+    host_parallel_rows(row_count, [=](int64_t lo, int64_t hi) {
+// every product and sum is rounded on its own, as NumPy's array operations are
+#pragma clang fp contract(off)
+        for (int64_t r = lo; r < hi; ++r) {
+            const size_t off = (size_t)rows[r] * (size_t)p;
+            double* x = params + off;
+            const double* g = grads + off;
+            if (kind == 0) {
+                for (int64_t i = 0; i < p; ++i) {
+                    const double s = learning_rate * g[i];
+                    x[i] = x[i] - s;
+                }
+                continue;
+            }
+            adam_row(x, g, moment + off, square_moment + off, p, learning_rate, beta_1, beta_2,
+                     one_m_b1, one_m_b2, epsilon, corr_1, corr_2, apply_clip_grads, clip_grads);
+        }
+    });
     return 0;
 }
 

@@ -29,6 +29,37 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int32)
 
 
+def host_clip_controls(controls, max_norms):
+    """clip_control_norms (qoc/core/common.py:8-30) on a C-contiguous float64 (B x Nc x K) array,
+    IN PLACE, on host threads (qocx_host_clip_controls; no GPU involved)."""
+    lib = load_library()
+    max_norms = np.ascontiguousarray(max_norms, dtype=np.float64)
+    rc = lib.qocx_host_clip_controls(controls.ctypes.data_as(_c_double_p), controls.shape[0],
+                                     controls.shape[1], controls.shape[2],
+                                     max_norms.ctypes.data_as(_c_double_p))
+    if rc != 0:
+        raise QocxError(rc, "qocx_host_clip_controls")
+
+
+def host_optimizer_update(kind, params, grads, moment, square_moment, rows, learning_rate,
+                          beta_1=0.0, beta_2=0.0, epsilon=0.0, corr_1=1.0, corr_2=1.0,
+                          clip_grads=None):
+    """Adam (kind 1) / SGD (kind 0) update of the rows `rows` of C-contiguous float64 [B][P]
+    arrays, in place, in the reference's operation order (qocx_host_optimizer_update)."""
+    lib = load_library()
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    none = ctypes.cast(None, _c_double_p)
+    rc = lib.qocx_host_optimizer_update(
+        kind, params.ctypes.data_as(_c_double_p), grads.ctypes.data_as(_c_double_p),
+        moment.ctypes.data_as(_c_double_p) if moment is not None else none,
+        square_moment.ctypes.data_as(_c_double_p) if square_moment is not None else none,
+        params.shape[1], rows.ctypes.data_as(ctypes.POINTER(_I64)), len(rows),
+        float(learning_rate), float(beta_1), float(beta_2), float(epsilon), float(corr_1),
+        float(corr_2), 0 if clip_grads is None else 1, 0.0 if clip_grads is None else float(clip_grads))
+    if rc != 0:
+        raise QocxError(rc, "qocx_host_optimizer_update")
+
+
 class QocxError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("libqocx error {}: {}".format(code, message))
@@ -116,6 +147,11 @@ SIGNATURES = {
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
+    "qocx_host_clip_controls": (ctypes.c_int, [_c_double_p, _I64, _I64, _I32, _c_double_p]),
+    "qocx_host_optimizer_update": (ctypes.c_int, [
+        _I32, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _I64, ctypes.POINTER(_I64), _I64,
+        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+        ctypes.c_double, _I32, ctypes.c_double]),
 }
 
 _lib = None
