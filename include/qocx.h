@@ -250,6 +250,13 @@ int qocx_set_pipeline(qocx_ctx* ctx, int32_t time_segments);
 int qocx_comm_unique_id(uint8_t* id128);
 int qocx_comm_init(qocx_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world);
 int qocx_comm_allreduce_sum(qocx_ctx* ctx, double* buf_host, int64_t count);
+/* The path's single collective, device resident: out[0] = sum over the seeds of the last
+ * evaluation of the cost, out[1 ..] = sum over the seeds of the gradient ([nc][K]); the sums are
+ * formed on the device (fixed order: deterministic), all-reduced over the ranks of the
+ * communicator with ONE ncclAllReduce on the device buffer when allreduce != 0 (qocx_comm_init
+ * must have run), and only 8 (1 + nc K) bytes travel to the host. count = 1 + nc * K, or 1 for
+ * the cost alone. */
+int qocx_reduce_results(qocx_ctx* ctx, int32_t allreduce, double* out, int64_t count);
 int qocx_comm_allreduce_max(qocx_ctx* ctx, double* buf_host, int64_t count);
 int qocx_comm_barrier(qocx_ctx* ctx);
 int qocx_comm_destroy(qocx_ctx* ctx);

@@ -961,10 +961,18 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
 
     // Unit adjoint (qocx_sweep_common.h): a property of the PROBLEM and of the context's knobs, never
     // of the batch size, chunking or segmentation - results stay bit-identical across those.
+    // "latency" (the host sets it for the entry points that evaluate ONE control set at a time):
+    // where the unit adjoint applies, the two-sided pipeline on four time segments is the lowest
+    // latency there is - one seed, n = 32, 1000 steps, forward + gradient: 3.6 ms against 4.15 ms
+    // with the blocked sweep and 6.4 ms with one launch of the column-chain sweep; n = 8, 500
+    // steps: 1.1 against 2.1 / 1.8 ms (profiles/r03_latency.jsonl) - so it takes precedence
+    // over "sweep_impl" = 3 there.
+    const bool latency = ctx->knob("latency", 0) != 0;
+    const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen &&
+                           ctx->nodes == 1 && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
     const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 &&
-                            S <= qocx::sweep3_max_states(ctx->nb);
-    const bool unit = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen &&
-                      ctx->nodes == 1 && ctx->nb <= 2 && !sweep3_sel && ctx->knob("unit_adjoint", 1);
+                            S <= qocx::sweep3_max_states(ctx->nb) && !(latency && unit_core);
+    const bool unit = unit_core && !sweep3_sel;
     if (unit)
         if (ctx->lam_scale.ensure((size_t)B * S)) return QOCX_ERR_HIP;
     // chunk size from the memory budget
@@ -1016,6 +1024,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         const int bc = std::min(chunk, B - b0);
         int nseg = ctx->pipe_user > 0 ? ctx->pipe_user
                                       : ((size_t)bc * nsteps >= 16384 && nsteps >= 64 ? 8 : 1);
+        if (ctx->pipe_user <= 0 && nseg == 1 && latency && unit && nsteps >= 64) nseg = 4;
         nseg = std::max(1, std::min(std::min(nseg, max_seg), nsteps));
         hipStream_t ss = (nseg == 1) ? cs : ctx->sweep_streams[0];
         // segment boundaries; the last two segments are shorter, because the forward sweep of the
@@ -1033,6 +1042,16 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 // do once they exist is exposed, so they are the short ones
                 wgt[nseg / 2 - 1] = 0.5; wgt[nseg / 2] = 0.5;
             } else if (nseg >= 4) { wgt[nseg - 2] = 0.6; wgt[nseg - 1] = 0.35; }
+            if (const char* env = getenv("QOCX_SEG_WEIGHTS")) {  // experiments: "w0,w1,..."
+                std::vector<double> user;
+                for (const char* p = env; *p;) {
+                    char* end = nullptr;
+                    user.push_back(strtod(p, &end));
+                    if (end == p) break;
+                    p = (*end == ',') ? end + 1 : end;
+                }
+                if ((int)user.size() == nseg) wgt = user;
+            }
             double tot = 0, run = 0;
             for (double w : wgt) tot += w;
             lo[0] = 0;
@@ -1044,6 +1063,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             for (int i = nseg - 1; i > 0; --i) lo[i] = std::min(lo[i], lo[i + 1] - 1);
         }
 
+        const int dbg_skip_early = (int)ctx->knob("dbg_skip", 0);  // bit 3: K1a stores no Q (timing)
         qocx::FactorArgs fa;
         fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
         fa.interp = ctx->interp.p;
@@ -1052,6 +1072,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
         fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
         fa.n = ctx->n;
+        fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         qocx::LuArgs la;
@@ -2079,7 +2100,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
-                                  "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf"};
+                                  "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
@@ -2206,6 +2227,31 @@ static int comm_allreduce(qocx_ctx* ctx, double* buf, int64_t count, int op) {
         return fail(QOCX_ERR_RCCL, std::string("ncclAllReduce: ") +
                                        (ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(e) : "?"));
     HIP_TRY(hipMemcpyAsync(buf, ctx->comm_buf.p, count * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int qocx_reduce_results(qocx_ctx* ctx, int32_t allreduce, double* out, int64_t count) {
+    if (!ctx || !out) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->have_results) return fail(QOCX_ERR_STATE, "no evaluation results");
+    if (allreduce && !ctx->comm) return fail(QOCX_ERR_STATE, "communicator not initialised");
+    const int per_seed = count > 1 ? ctx->nc * ctx->K : 0;  // count == 1: the cost only
+    if (count != 1 + per_seed || (per_seed > 0 && !ctx->have_grads))
+        return fail(QOCX_ERR_ARG, "count must be 1, or 1 + control_eval_count * control_count after "
+                                  "an evaluation with gradients");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm_buf.ensure((size_t)count)) return QOCX_ERR_HIP;
+    qocx::launch_reduce_results(ctx->cost_out.p, ctx->grads.p, ctx->B, per_seed, ctx->comm_buf.p,
+                                ctx->stream);
+    if (allreduce) {  // ncclFloat64 = 8 ; ncclSum = 0
+        int e = ctx->rccl.AllReduce(ctx->comm_buf.p, ctx->comm_buf.p, (size_t)count, 8, 0, ctx->comm,
+                                    ctx->stream);
+        if (e != 0)
+            return fail(QOCX_ERR_RCCL, std::string("ncclAllReduce: ") +
+                                           (ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(e) : "?"));
+    }
+    HIP_TRY(hipMemcpyAsync(out, ctx->comm_buf.p, count * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;

@@ -40,6 +40,7 @@ struct FactorArgs {
     int step0, seg_len;        // this launch covers steps [step0, step0 + seg_len) of every seed
     int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
     int n;                     // Hilbert size (used by the sixteen-tile K1a: <= 48 -> nine tiles); 0: unknown
+    int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
     double dt;
     // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
@@ -235,6 +236,9 @@ void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);
+// out[0] = sum_b cost[b]; out[1 + j] = sum_b grads[b][j], j < per_seed (seeds in index order)
+void launch_reduce_results(const double* cost, const double* grads, int batch, int per_seed,
+                           double* out, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);

@@ -27,6 +27,7 @@
 //              per instruction. Every matrix in HBM (Q, LU, H0, G_k) is such a column-major
 //              image.
 //   F-layout : lane l (any group) holds the full row l % NP (index c*NP + i of the image).
+#include <algorithm>
 #include <type_traits>
 
 #include "qocx_wave.h"
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     // a piece under the flags of the running (sub-step, state)
     auto dma_fire = [&](auto PIECE) __attribute__((always_inline)) {
         if constexpr (decltype(PIECE)::value < IMG_PIECES) {
-            if (pf_fire_q) dma_one(PIECE);
+            if (pf_fire_q && !(args.dbg & 1024)) dma_one(PIECE);  // (dbg: timing experiment)
         } else {
             if (pf_fire_l) dma_one(PIECE);
         }
@@ -1617,6 +1618,23 @@ __global__ void scatter_kernel(ScatterArgs args) {
     args.grads[idx] = acc;
 }
 
+// Sum over the seeds, in seed order (deterministic): thread j adds up element j of every seed's
+// gradient; thread 0 of block 0 also the costs. 16 KB of results from 4 MB of per-seed gradients.
+__global__ void reduce_results_kernel(const double* cost, const double* grads, int batch,
+                                      int per_seed, double* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < per_seed) {
+        double acc = 0;
+        for (int b = 0; b < batch; ++b) acc += grads[(size_t)b * per_seed + j];
+        out[1 + j] = acc;
+    }
+    if (j == 0) {
+        double acc = 0;
+        for (int b = 0; b < batch; ++b) acc += cost[b];
+        out[0] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // self test of the wave primitives
 // ------------------------------------------------------------------------------------------
@@ -1786,6 +1804,12 @@ void launch_scatter(const ScatterArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.B * a.nc * a.K;
     if (total == 0) return;
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_reduce_results(const double* cost, const double* grads, int batch, int per_seed,
+                           double* out, hipStream_t st) {
+    const int threads = 64, blocks = std::max(1, (per_seed + threads - 1) / threads);
+    hipLaunchKernelGGL(reduce_results_kernel, dim3(blocks), dim3(threads), 0, st, cost, grads, batch,
+                       per_seed, out);
 }
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(64), 0, st, out, iters);

@@ -344,14 +344,14 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (16 * W + c) * 32 + 16 * ti + 4 * r + q;
-            out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
+            if (out.q_img) out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
             out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
         }
     if (GIVE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (4 * r + q) * 32 + 16 + c;  // element (16 + c, 4r + q)
-            out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
+            if (out.q_img) out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
             out.p_img[idx] = make_double2(v.re[0][r] + u.re[0][r], -(v.im[0][r] + u.im[0][r]));
         }
     }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t m = (size_t)b * args.nsteps + step;
     Out out;
-    out.q_img = args.q_img + m * MAT;
+    out.q_img = args.skip_q ? nullptr : args.q_img + m * MAT;  // (skip_q: timing experiment)
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;

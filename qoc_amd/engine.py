@@ -135,6 +135,7 @@ SIGNATURES = {
     "qocx_set_pipeline": (ctypes.c_int, [_VP, _I32]),
     "qocx_comm_unique_id": (ctypes.c_int, [_U8P]),
     "qocx_comm_init": (ctypes.c_int, [_VP, _U8P, _I32, _I32]),
+    "qocx_reduce_results": (ctypes.c_int, [_VP, _I32, _c_double_p, _I64]),
     "qocx_comm_allreduce_sum": (ctypes.c_int, [_VP, _c_double_p, _I64]),
     "qocx_comm_allreduce_max": (ctypes.c_int, [_VP, _c_double_p, _I64]),
     "qocx_comm_barrier": (ctypes.c_int, [_VP]),
@@ -503,6 +504,17 @@ class Engine(object):
     def comm_init(self, unique_id, rank, world):
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.qocx_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def reduce_results(self, allreduce=False, want_grad=True):
+        """(sum of the costs, sum of the gradients [Nc x K] or None) over the seeds of the last
+        evaluation, summed on the device and - allreduce=True - over the ranks of the communicator
+        by one ncclAllReduce on the device buffer (qocx_reduce_results)."""
+        nc, k = self._problem["Nc"], self._problem["K"]
+        want_grad = want_grad and k > 0
+        count = 1 + (nc * k if want_grad else 0)
+        out = np.zeros(count)
+        self._check(self._lib.qocx_reduce_results(self._ctx, 1 if allreduce else 0, _dp(out), count))
+        return float(out[0]), (out[1:].reshape(nc, k) if want_grad else None)
 
     def comm_allreduce_sum(self, array):
         array = np.ascontiguousarray(array, dtype=np.float64)

@@ -95,6 +95,18 @@ def test_rccl_single_rank(setup):
     comm.barrier()
     total, grad = parallel.summed_cost_and_gradient(np.ones(3), np.ones((3, 5, 2)), comm)
     assert total == 3.0 and np.array_equal(grad, 3 * np.ones((5, 2)))
+    # the device-resident form of the same collective: seeds summed by a
+    # kernel, ncclAllReduce on the device buffer, 16 KB to the host
+    configure()
+    engine.upload_controls(controls[:24])
+    engine.eval_resident(True)
+    cost, grads, _ = engine.download_results(want_grad=True, want_final=False)
+    for c in (comm, parallel.SingleComm()):
+        total, grad = parallel.summed_results_resident(engine, c)
+        assert abs(total - cost.sum()) <= 1e-12 * abs(cost.sum())
+        assert np.max(np.abs(grad - grads.sum(axis=0))) <= 1e-12 * np.max(np.abs(grads.sum(axis=0)))
+    total_only, none = parallel.summed_results_resident(engine, comm, want_grad=False)
+    assert none is None and total_only == total
     engine.comm_destroy()
 
 

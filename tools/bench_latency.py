@@ -20,22 +20,29 @@ from tests import gpu_helpers as gh  # noqa: E402
 
 
 def main():
+    """Variants: the column-chain sweep in one launch (impl 1, pipeline 1), the blocked sweep
+    (impl 3, round 2's latency mode) and the two-sided pipeline of round 3 (impl 1, 4 / 8 time
+    segments: forward and adjoint sweep of the ONE seed side by side)."""
     eng = Engine(0)
     for name in ("c2_transmon", "c3_subset"):
         case = cases_mod.case_by_name(name)
         gh.setup_engine(eng, case)
         u = gh.real_controls(case, case.controls[:1])
-        for _ in range(5):
-            eng.evaluate(u, True)
-        for want_grad in (False, True):
-            t0 = time.perf_counter()
-            reps = 50
-            for _ in range(reps):
-                eng.evaluate(u, want_grad)
-            wall = (time.perf_counter() - t0) / reps
-            print(json.dumps(dict(case=name, n=case.n, steps=case.N - 1, want_grad=want_grad,
-                                  ms_per_eval=round(wall * 1e3, 3),
-                                  us_per_step=round(wall * 1e6 / (case.N - 1), 2))), flush=True)
+        for impl, pipe in ((1, 1), (3, 1), (1, 4), (1, 8)):
+            eng.set_knob("sweep_impl", impl)
+            eng.set_pipeline(pipe)
+            for _ in range(5):
+                eng.evaluate(u, True)
+            for want_grad in (False, True):
+                t0 = time.perf_counter()
+                reps = 50
+                for _ in range(reps):
+                    eng.evaluate(u, want_grad)
+                wall = (time.perf_counter() - t0) / reps
+                print(json.dumps(dict(case=name, n=case.n, steps=case.N - 1, want_grad=want_grad,
+                                      sweep_impl=impl, time_segments=pipe,
+                                      ms_per_eval=round(wall * 1e3, 3),
+                                      us_per_step=round(wall * 1e6 / (case.N - 1), 2))), flush=True)
 
 
 if __name__ == "__main__":
