@@ -1064,6 +1064,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         }
 
         const int dbg_skip_early = (int)ctx->knob("dbg_skip", 0);  // bit 3: K1a stores no Q (timing)
+        const bool one_wave_k1a = getenv("QOCX_PQ1") != nullptr;  // (experiments: the one-wave K1a)
         qocx::FactorArgs fa;
         fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
         fa.interp = ctx->interp.p;
@@ -1075,9 +1076,14 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
+        // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)
+        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && ctx->knob("fuse_lu", 0) != 0;
+        fa.fuse_lu = fused_lu ? 1 : 0;
+        fa.dinv = ctx->dinv.p; fa.perm = ctx->perm.p; fa.iperm = ctx->iperm.p;
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
+        la.dbg = (dbg_skip_early & 16) ? 1 : 0;
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
@@ -1145,8 +1151,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                           ? ctx->inj_bars.p + (size_t)b0 * ctx->inj_count * S * np : nullptr;
 
         auto factor_segment = [&](int i) -> int {
-            const int len = lo[i + 1] - lo[i];
-            fa.step0 = lo[i]; fa.seg_len = len;
+            // (Measured and dropped: K1a / K1b of a segment as 2, 4 or 8 pairs of sub-launches, so
+            // that K1b might find P in the last-level cache: 13.1 / 13.8 / 15.5 ms against 12.7 -
+            // the launch tails cost more than any cache hit returns.)
+            const int plo = lo[i], len = lo[i + 1] - lo[i];
+            fa.step0 = plo; fa.seg_len = len;
             time_begin(ctx, 0, cs);
             if (explicit_gen) {
                 // generators sampled by the host (opaque Hamiltonian): [seed][step] row-major
@@ -1154,7 +1163,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 qocx::launch_pq_explicit(ctx->nb, ctx->gen_rm.p + (size_t)b0 * nsteps * mat, np, fe,
                                          bc * len, cs);
             } else if (nodes > 1) {
-                ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
+                ma.step0 = plo; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
                 qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
                 qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, bc * len, cs);
@@ -1162,14 +1171,16 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 qocx::launch_pq(ctx->nb, fa, len, bc, cs);
             }
             time_end(ctx, cs);
-            la.step0 = lo[i]; la.seg_len = len;
+            la.step0 = plo; la.seg_len = len;
             // (K1b on a stream of its own, beside the next segment's K1a: with the v5 kernels no
             // gain; with the two-wave K1a (240 registers) and K1b (160) sharing SIMDs 1 % - K1a
             // then takes 1.08 ms per launch beside K1b instead of 0.80 + 0.32 ms in sequence.
             // Not kept: one more stream and eight more events for 0.14 ms.)
-            time_begin(ctx, 4, cs);
-            qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
-            time_end(ctx, cs);
+            if (!fused_lu) {
+                time_begin(ctx, 4, cs);
+                qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
+                time_end(ctx, cs);
+            }
             if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], cs));
             return 0;
         };
@@ -2100,7 +2111,8 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
-                                  "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency"};
+                                  "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
+                                  "fuse_lu"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
@@ -2298,12 +2310,15 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     memset(&fa, 0, sizeof(fa));
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
     fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
+    const bool fused_lu = nb == 2 && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 0) != 0;
+    fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
+    fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
     la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
     la.status = ctx->status.p;
     la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
-    qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
+    if (!fused_lu) qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<double2> img((size_t)count * mat), dv((size_t)count * np);

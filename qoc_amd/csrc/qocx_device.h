@@ -41,6 +41,12 @@ struct FactorArgs {
     int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
     int n;                     // Hilbert size (used by the sixteen-tile K1a: <= 48 -> nine tiles); 0: unknown
     int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
+    // two-wave K1a (17 <= n <= 32) with K1b fused in: P stays in LDS, wave 0 factors it, only the
+    // factors (and 1/U_kk, the permutation) go to HBM; launch_lu is then not called
+    int fuse_lu = 0;
+    double2* dinv = nullptr;
+    int* perm = nullptr;
+    int* iperm = nullptr;
     double dt;
     // outputs, indexed by (b * nsteps + step); column-major NP x NP images
     double2* q_img;
@@ -57,6 +63,7 @@ struct LuArgs {
     int* status;
     int nsteps, step0, seg_len;  // work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len
     int n;                       // Hilbert size (sixteen-tile K1b: <= 48 -> 48 elimination steps); 0: unknown
+    int dbg = 0;                 // timing experiment (dbg_skip bit 4): loads and stores only
 };
 
 struct SweepArgs {

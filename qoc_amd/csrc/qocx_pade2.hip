@@ -17,6 +17,7 @@
 // A-operand slot holding a, a^2, a^6, w2 in turn, and M = one 16 x 16 complex tile for the
 // mirror hand-over of a^4. The Q / P images are stored straight from the C-layout registers.
 #include "qocx_wave.h"
+#include "qocx_lu.h"
 
 namespace qocx {
 
@@ -143,7 +144,16 @@ struct Out {
     double2* p_img;
     int* s_out;
     int* status;
+    // K1b fused in (FactorArgs::fuse_lu): P goes to an LDS image and wave 0 factors it from there
+    LuArgs lu;
+    bool fuse;
+    size_t m;
 };
+
+// LDS image of P for the fused factorisation: column-major, LP complex per column (the C-layout
+// stores of a wave walk the columns: pitch 33 spreads them over the banks)
+constexpr int LP = 33;
+static_assert(32 * LP * 16 <= SLOT_F64 * 8, "the P image reuses the A-operand slot");
 
 // W: the wave's column block. Every wave executes the same number of barriers.
 template <bool HERM, int W, class Gen>
@@ -339,21 +349,39 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // fixed r the four q-lanes of a column hold rows 4r..4r+3, i.e. one 64-byte run of the
     // column-major image. HERM: Q = P^H, so wave 1 also writes tile (1,0) of each image as the
     // mirror of its tile (0,1) of the other one (256-byte runs).
+    //
+    // Fused K1b (out.fuse): P does not go to HBM at all. Both waves put their tiles of P
+    // into an LDS image (the A-operand slot, free once every wave has finished the last product),
+    // wave 1 leaves, and wave 0 runs the one-wave LU (qocx_lu.h) from that image; only the factors
+    // travel. The stand-alone K1b moves 32 KB per matrix through HBM (P in, L\U out) and is bound
+    // by exactly that: 0.31 ms per 32 000 matrices, 0.21 ms of it with the arithmetic removed
+    // (profiles/r03_k1b_memory_floor.jsonl).
+    const bool fused = out.fuse;
+    double2* simg = reinterpret_cast<double2*>(sl);
+    if (fused) __syncthreads();  // 10: every read of the slot (w2) is done
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (16 * W + c) * 32 + 16 * ti + 4 * r + q;
             if (out.q_img) out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
-            out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
+            const double2 pe = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
+            if (fused) simg[(16 * W + c) * LP + 16 * ti + 4 * r + q] = pe;
+            else out.p_img[idx] = pe;
         }
     if (GIVE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (4 * r + q) * 32 + 16 + c;  // element (16 + c, 4r + q)
             if (out.q_img) out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
-            out.p_img[idx] = make_double2(v.re[0][r] + u.re[0][r], -(v.im[0][r] + u.im[0][r]));
+            const double2 pe = make_double2(v.re[0][r] + u.re[0][r], -(v.im[0][r] + u.im[0][r]));
+            if (fused) simg[(4 * r + q) * LP + 16 + c] = pe;
+            else out.p_img[idx] = pe;
         }
+    }
+    if (fused) {
+        __syncthreads();  // 11: the image is complete
+        if (W == 0) lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
     }
 }
 
@@ -370,6 +398,11 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
+    out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;
+    out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
+    out.fuse = args.fuse_lu != 0;
+    out.m = m;
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
@@ -427,6 +460,11 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
+    out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;
+    out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
+    out.fuse = args.fuse_lu != 0;
+    out.m = m;
     const double2* am = a_in + m * (size_t)n * n;
     auto gen = [&](Col& a, int wcol) {
 #pragma unroll

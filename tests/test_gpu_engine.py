@@ -152,7 +152,16 @@ def test_unit_adjoint_and_two_sided_pipeline(engine, name):
             one_sided = engine.evaluate(u, True)
             for a, b, c in zip(unit, two_sided, one_sided):
                 assert np.array_equal(a, b) and np.array_equal(a, c)
+        if case.n > 16:
+            # K1b fused into the two-wave K1a (P stays in LDS; knob "fuse_lu", off by default: no
+            # faster): the same factors, bit for bit
+            engine.set_pipeline(0)
+            engine.set_knob("fuse_lu", 1)
+            fused = engine.evaluate(u, True)
+            for a, b in zip(unit, fused):
+                assert np.array_equal(a, b)
     finally:
+        engine.set_knob("fuse_lu", 0)
         engine.set_knob("unit_adjoint", 1)
         engine.set_knob("bidir", 1)
         engine.set_pipeline(0)
