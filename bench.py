@@ -63,7 +63,7 @@ def make_controls(first_seed, count):
     return out
 
 
-PMC_SUMMARY = "profiles/r02_pmc_hbm.json"
+PMC_SUMMARY = "profiles/r03_pmc_hbm.json"
 
 
 def pmc_traffic_bytes(kernel, units_per_launch):

@@ -314,6 +314,31 @@ int qocx_debug_lindblad_knobs(qocx_ctx* ctx, int64_t stage_budget_seeds, int32_t
  * next to the spec peak. */
 int qocx_debug_mfma_peak(qocx_ctx* ctx, int32_t waves_per_simd, int32_t iters, double* tflops);
 
+/* ---- multi-start GRAPE with the optimizer states resident on the device ------------------------
+ * The reference's driver iteration - clip the controls, evaluate, keep the best so far, apply the
+ * optimizer (qoc/core/schroedingerdiscrete.py:293-353, common.py:8-30, optimizers/adam.py:110-165,
+ * sgd.py) - for the B control sets that qocx_upload_controls left in HBM, without a trip to the host:
+ * per iteration 8 B bytes of costs come back, B flags go in. Real controls, built-in Adam / SGD
+ * (no scale_grads). IEEE operations in the reference's order, no contraction: every seed walks its
+ * single-seed trajectory bit for bit.
+ *   qocx_opt_begin          after qocx_upload_controls: zero the Adam moments, allocate the
+ *                           best-so-far buffers for the current batch.
+ *   qocx_opt_clip           clip_control_norms on the resident controls, in place; the squaring
+ *                           capacity of the next evaluation is re-derived from max_norms [K].
+ *   qocx_download_costs     the B costs of the last evaluation.
+ *   qocx_opt_step           improved[b] != 0: best controls / final states of seed b := those of the
+ *                           last evaluation; then update[b] != 0: seed b takes the optimizer step
+ *                           (kind 0 SGD, 1 Adam) with the gradients of the last evaluation;
+ *                           corr_i = 1 - beta_i^step and the learning rate are the caller's scalars.
+ *   qocx_opt_download_best  best controls [B][Nc][K] and best final states [B][S][n] complex. */
+int qocx_opt_begin(qocx_ctx* ctx);
+int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms);
+int qocx_download_costs(qocx_ctx* ctx, double* cost_out);
+int qocx_opt_step(qocx_ctx* ctx, int32_t kind, const uint8_t* improved, const uint8_t* update,
+                  double learning_rate, double beta_1, double beta_2, double epsilon, double corr_1,
+                  double corr_2, int32_t apply_clip_grads, double clip_grads);
+int qocx_opt_download_best(qocx_ctx* ctx, double* controls_out, double* final_out);
+
 /* ---- host-side helpers of the multi-start GRAPE driver (no GPU work, no context) --------------
  * The reference's driver loop clips the controls and applies its optimizer plugin to ONE control
  * set per process (qoc/core/common.py:8-30, qoc/standard/optimizers/adam.py:110-165, sgd.py). The

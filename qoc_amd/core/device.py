@@ -107,6 +107,7 @@ class SchroedingerEvaluator(object):
         self.system_eval_count = system_eval_count
         self.final_system_eval_step = system_eval_count - 1
         self.costs = list(costs)
+        self.magnus_policy = magnus_policy
         dt = evolution_time / (system_eval_count - 1)
         times = [step * dt + dt * c for step in range(system_eval_count - 1)
                  for c in magnus_policy.nodes]
@@ -191,6 +192,14 @@ class SchroedingerEvaluator(object):
                     raise NotImplementedError("cost {} has no controls_bar()".format(cost))
                 grad = bar if grad is None else grad + bar
         return value, grad
+
+    def resident_capable(self):
+        """True when a multi-start driver may keep controls and optimizer states on the device
+        (engine.opt_*): structured Hamiltonian, real controls, every cost evaluated on the device,
+        MagnusPolicy.M2, and a backend that has the entry points (the real engine)."""
+        return (self.opaque_hamiltonian is None and not self.complex_controls
+                and self.control_count > 0 and not self.host_costs and not self.opaque_costs
+                and self.magnus_policy == MagnusPolicy.M2 and hasattr(self.backend, "opt_step"))
 
     def evaluate_batch(self, controls_batch, want_grad=True, want_step_states=False):
         """

@@ -336,6 +336,60 @@ def _strip_batch(complex_controls, arrays):
     return flat
 
 
+def _grape_batch_resident(engine, optimizer, params, shape, max_control_norms, iteration_count,
+                          log_iteration_step, min_error, comm, result):
+    """The loop of grape_schroedinger_discrete_batch with everything but the decisions on the
+    device: engine.opt_clip -> eval_resident -> B costs to the host -> engine.opt_step."""
+    B = params.shape[0]
+    is_adam = type(optimizer) is Adam
+    engine.upload_controls(params.reshape((B,) + tuple(shape)))
+    engine.opt_begin()
+    active = np.ones(B, dtype=bool)
+    count = 0  # optimizer steps taken so far (every active seed has taken all of them)
+    should_log = log_iteration_step != 0
+    for iteration in range(iteration_count):
+        engine.opt_clip(max_control_norms)
+        engine.eval_resident(True)
+        errors = engine.download_costs()
+        result.iterations_run[active] = iteration + 1
+        improved = active & (errors < result.best_error)  # strict, as :333 of the reference
+        result.best_error[improved] = errors[improved]
+        result.best_iteration[improved] = iteration
+        if should_log and (iteration % log_iteration_step == 0 or iteration == iteration_count - 1):
+            total = comm.allreduce_sum(np.array([float(np.sum(errors[active]))]))[0]
+            low = -comm.allreduce_max(np.array([-float(np.min(errors))]))[0]
+            seeds = comm.allreduce_sum(np.array([float(np.sum(active))]))[0]
+            if comm.rank == 0:
+                print("{:^6d} | {:^1.8e} | {:^1.8e} | {:^6d}".format(iteration, total, low,
+                                                                     int(seeds)))
+        active &= ~(errors <= min_error)
+        if is_adam:
+            o = optimizer
+            if o.apply_learning_rate_decay:
+                learning_rate = (o.initial_learning_rate
+                                 * np.exp(-np.divide(count, o.learning_rate_decay)))
+            else:
+                learning_rate = o.initial_learning_rate
+            step = count + 1
+            engine.opt_step(1, improved, active, learning_rate, o.beta_1, o.beta_2, o.epsilon,
+                            1 - np.power(o.beta_1, step), 1 - np.power(o.beta_2, step),
+                            o.clip_grads if o.apply_clip_grads else None)
+        else:
+            engine.opt_step(0, improved, active, optimizer.learning_rate)
+        count += 1
+        still = comm.allreduce_sum(np.array([float(np.sum(active))]))[0]
+        if still == 0:
+            break
+    best_controls, best_finals = engine.opt_download_best()
+    for b in range(B):
+        if result.best_iteration[b] >= 0:
+            result.best_controls[b] = best_controls[b]
+            result.best_final_states[b] = best_finals[b][..., None]
+    best_local = float(np.min(result.best_error)) if B else np.inf
+    result.global_best_error = float(-comm.allreduce_max(np.array([-best_local]))[0])
+    return result
+
+
 def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, evolution_time,
                                       hamiltonian, initial_states, system_eval_count,
                                       initial_controls, complex_controls=False, cost_eval_step=1,
@@ -398,6 +452,15 @@ def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, 
     if should_log and comm.rank == 0:
         print("iter   |  summed error  |   min error    |  active seeds \n"
               "===========================================================")
+    # Device-resident form: controls, gradients, Adam moments and the best
+    # so far stay in HBM; per iteration the host sees B costs and sends 2 B flags. The same
+    # iteration, the same arithmetic (qocx_optim.hip: IEEE operations in the reference's order).
+    resident = (B > 0 and stepper is not None and impose_control_conditions is None
+                and not getattr(optimizer, "apply_scale_grads", False)
+                and hasattr(evaluator, "resident_capable") and evaluator.resident_capable())
+    if resident:
+        return _grape_batch_resident(evaluator.backend, optimizer, params, shape, max_control_norms,
+                                     iteration_count, log_iteration_step, min_error, comm, result)
     for iteration in range(iteration_count):
         # cost-function format of every seed (clipping acts in place on the optimizer's params
         # for real controls, exactly as in the single-seed driver)

@@ -195,6 +195,11 @@ struct qocx_ctx {
     std::vector<hipStream_t> sweep_streams;
     std::vector<hipEvent_t> ev_factored, ev_swept, ev_fwd;
     bool unit_ok = false;          // the only cost is one separable final cost (qocx_sweep_common.h)
+    // multi-start driver on the device (qocx_opt_*)
+    DevBuf<double> opt_m, opt_v, opt_best_controls, opt_max_norms;
+    DevBuf<double2> opt_best_final;
+    DevBuf<unsigned char> opt_flags;  // [2][B]: improved | update
+    int opt_batch = 0;
     DevBuf<double2> lam_scale;     // unit adjoint: [B][S]
     DevBuf<int> offs_x;            // unit adjoint: [chunk][nsteps + 1]
     int keep_step_states = 0;
@@ -521,6 +526,11 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->inj_bars.release();
     ctx->mbar_rm.release();
     ctx->magnus_scratch.release();
+    ctx->lam_scale.release();
+    ctx->offs_x.release();
+    ctx->opt_m.release(); ctx->opt_v.release(); ctx->opt_best_controls.release();
+    ctx->opt_max_norms.release(); ctx->opt_best_final.release(); ctx->opt_flags.release();
+    ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
     DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
                              &ctx->g_timg, &ctx->psi0, &ctx->cost_vectors, &ctx->final_out,
                              &ctx->step_states, &ctx->q_img, &ctx->lu_img, &ctx->dinv,
@@ -2241,6 +2251,117 @@ static int comm_allreduce(qocx_ctx* ctx, double* buf, int64_t count, int op) {
     HIP_TRY(hipMemcpyAsync(buf, ctx->comm_buf.p, count * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int qocx_opt_begin(qocx_ctx* ctx) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (!ctx->has_problem || ctx->B < 1 || ctx->K < 1 || ctx->explicit_mode)
+        return fail(QOCX_ERR_STATE, "qocx_opt_begin needs uploaded controls of a structured problem");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t total = (size_t)ctx->B * ctx->nc * ctx->K;
+    if (ctx->opt_m.ensure(total) || ctx->opt_v.ensure(total) || ctx->opt_best_controls.ensure(total) ||
+        ctx->opt_best_final.ensure((size_t)ctx->B * ctx->S * ctx->np) ||
+        ctx->opt_flags.ensure(2 * (size_t)ctx->B) || ctx->opt_max_norms.ensure((size_t)ctx->K))
+        return QOCX_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->opt_m.p, 0, total * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->opt_v.p, 0, total * sizeof(double), ctx->stream));
+    ctx->opt_batch = ctx->B;
+    return 0;
+}
+
+int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms) {
+    if (!ctx || !max_norms) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (ctx->opt_batch != ctx->B || ctx->B < 1) return fail(QOCX_ERR_STATE, "qocx_opt_begin has not run for this batch");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // after the clip |u_k| <= max_norms[k]: the squaring capacity follows from that bound
+    double bound = ctx->h0_norm_max;
+    for (int k = 0; k < ctx->K; ++k) {
+        if (!(max_norms[k] >= 0)) return fail(QOCX_ERR_ARG, "max_norms must be non-negative");
+        bound += max_norms[k] * ctx->g_norm_max[k];
+    }
+    bound *= fabs(ctx->dt);
+    if (ctx->nodes != 1) return fail(QOCX_ERR_STATE, "device-resident optimizer: MagnusPolicy.M2 only");
+    if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite bound");
+    const int sb = pade_scale_count(bound);
+    if (sb > 10)
+        return fail(QOCX_ERR_CAPACITY,
+                    "||dt H||_1 bound needs more than 2^10 squaring sub-steps per step; reduce dt");
+    ctx->sbound = std::max(ctx->sbound, sb);
+    ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
+    HIP_TRY(hipMemcpyAsync(ctx->opt_max_norms.p, max_norms, ctx->K * sizeof(double),
+                           hipMemcpyHostToDevice, ctx->stream));
+    qocx::launch_clip_controls(ctx->controls.p, (size_t)ctx->B * ctx->nc * ctx->K, ctx->K,
+                               ctx->opt_max_norms.p, ctx->stream);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // max_norms is the caller's memory
+    ctx->have_results = false;
+    return 0;
+}
+
+int qocx_download_costs(qocx_ctx* ctx, double* cost_out) {
+    if (!ctx || !cost_out) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->have_results) return fail(QOCX_ERR_STATE, "no evaluation results");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(cost_out, ctx->cost_out.p, (size_t)ctx->B * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int qocx_opt_step(qocx_ctx* ctx, int32_t kind, const uint8_t* improved, const uint8_t* update,
+                  double learning_rate, double beta_1, double beta_2, double epsilon, double corr_1,
+                  double corr_2, int32_t apply_clip_grads, double clip_grads) {
+    if (!ctx || !improved || !update) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (kind != 0 && kind != 1) return fail(QOCX_ERR_ARG, "kind must be 0 (SGD) or 1 (Adam)");
+    if (ctx->opt_batch != ctx->B || ctx->B < 1) return fail(QOCX_ERR_STATE, "qocx_opt_begin has not run for this batch");
+    if (!ctx->have_results || !ctx->have_grads) return fail(QOCX_ERR_STATE, "no gradients to step with");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int B = ctx->B;
+    const size_t per_seed = (size_t)ctx->nc * ctx->K;
+    HIP_TRY(hipMemcpyAsync(ctx->opt_flags.p, improved, B, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->opt_flags.p + B, update, B, hipMemcpyHostToDevice, ctx->stream));
+    qocx::launch_keep_best(ctx->controls.p, ctx->opt_best_controls.p, per_seed, ctx->final_out.p,
+                           ctx->opt_best_final.p, (size_t)ctx->S * ctx->np, ctx->opt_flags.p, B,
+                           ctx->stream);
+    qocx::OptimArgs a;
+    a.kind = kind;
+    a.params = ctx->controls.p; a.grads = ctx->grads.p;
+    a.moment = ctx->opt_m.p; a.square_moment = ctx->opt_v.p;
+    a.update = ctx->opt_flags.p + B;
+    a.per_seed = per_seed;
+    a.learning_rate = learning_rate; a.beta_1 = beta_1; a.beta_2 = beta_2;
+    a.one_m_b1 = 1 - beta_1; a.one_m_b2 = 1 - beta_2;
+    a.epsilon = epsilon; a.corr_1 = corr_1; a.corr_2 = corr_2;
+    a.clip = clip_grads; a.apply_clip = apply_clip_grads ? 1 : 0;
+    qocx::launch_optimizer_update(a, B, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the flag arrays are the caller's memory
+    ctx->have_results = false;  // the resident controls are no longer those of the last evaluation
+    return 0;
+}
+
+int qocx_opt_download_best(qocx_ctx* ctx, double* controls_out, double* final_out) {
+    if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
+    if (ctx->opt_batch != ctx->B || ctx->B < 1) return fail(QOCX_ERR_STATE, "qocx_opt_begin has not run for this batch");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int B = ctx->B, np = ctx->np, S = ctx->S, n = ctx->n;
+    if (controls_out)
+        HIP_TRY(hipMemcpyAsync(controls_out, ctx->opt_best_controls.p,
+                               (size_t)B * ctx->nc * ctx->K * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    std::vector<double2> fin;
+    if (final_out) {
+        fin.resize((size_t)B * S * np);
+        HIP_TRY(hipMemcpyAsync(fin.data(), ctx->opt_best_final.p, fin.size() * sizeof(double2),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (final_out)
+        for (size_t v = 0; v < (size_t)B * S; ++v)
+            for (int i = 0; i < n; ++i) {
+                final_out[2 * (v * n + i)] = fin[v * np + i].x;
+                final_out[2 * (v * n + i) + 1] = fin[v * np + i].y;
+            }
     return 0;
 }
 

@@ -219,6 +219,24 @@ struct LindbladArgs {
     unsigned long long* stamps;  // diagnostic build: [B][6 waves][8] cycle sums, or nullptr
 };
 
+// Multi-start driver on the device (qocx_optim.hip)
+struct OptimArgs {
+    int kind;  // 0 SGD, 1 Adam
+    double* params;              // [B][per_seed] = the resident controls
+    const double* grads;         // [B][per_seed]
+    double* moment;              // Adam: [B][per_seed]
+    double* square_moment;
+    const unsigned char* update; // [B]: seeds that take the step
+    size_t per_seed;
+    double learning_rate, beta_1, beta_2, one_m_b1, one_m_b2, epsilon, corr_1, corr_2, clip;
+    int apply_clip;
+};
+void launch_clip_controls(double* controls, size_t total, int k, const double* max_norms, hipStream_t st);
+void launch_keep_best(const double* controls, double* best_controls, size_t per_seed,
+                      const double2* final_states, double2* best_final, size_t final_per_seed,
+                      const unsigned char* improved, int batch, hipStream_t st);
+void launch_optimizer_update(const OptimArgs& a, int batch, hipStream_t st);
+
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
 int lindblad_lds_size(int n, int S, int nops, int mode, int K);
 size_t lindblad_scratch_elems(int n, int S);

@@ -1482,20 +1482,44 @@ __global__ void scatter_kernel(ScatterArgs args) {
     args.grads[idx] = acc;
 }
 
-// Sum over the seeds, in seed order (deterministic): thread j adds up element j of every seed's
-// gradient; thread 0 of block 0 also the costs. 16 KB of results from 4 MB of per-seed gradients.
-__global__ void reduce_results_kernel(const double* cost, const double* grads, int batch,
-                                      int per_seed, double* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < per_seed) {
-        double acc = 0;
-        for (int b = 0; b < batch; ++b) acc += grads[(size_t)b * per_seed + j];
-        out[1 + j] = acc;
+// Sum over the seeds in a fixed order (deterministic): a block of 256 threads handles 16 gradient
+// elements x 16 seed groups; every thread adds up its group's seeds (b = group, group + 16, ...),
+// the 16 partial sums of an element are then added in group order. Block 0 also sums the costs.
+// 16 KB of results from 4 MB of per-seed gradients.
+__global__ __launch_bounds__(256) void reduce_results_kernel(const double* cost, const double* grads,
+                                                             int batch, int per_seed, double* out) {
+    __shared__ double part[16][17];
+    const int jl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jl;
+    double acc = 0;
+    if (j < per_seed)
+        for (int b = grp; b < batch; b += 16) acc += grads[(size_t)b * per_seed + j];
+    part[grp][jl] = acc;
+    __syncthreads();
+    if (grp == 0 && j < per_seed) {
+        double total = 0;
+        for (int g = 0; g < 16; ++g) total += part[g][jl];
+        out[1 + j] = total;
     }
-    if (j == 0) {
-        double acc = 0;
-        for (int b = 0; b < batch; ++b) acc += cost[b];
-        out[0] = acc;
+    if (blockIdx.x == 0) {  // the costs, by the same scheme on 256 threads
+        __syncthreads();
+        double c = 0;
+        for (int b = threadIdx.x; b < batch; b += 256) c += cost[b];
+        // 256 partial sums -> 16 -> 1, in index order
+        __shared__ double cpart[256];
+        cpart[threadIdx.x] = c;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double t = 0;
+            for (int k = 0; k < 16; ++k) t += cpart[threadIdx.x * 16 + k];
+            part[0][threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int k = 0; k < 16; ++k) t += part[0][k];
+            out[0] = t;
+        }
     }
 }
 
@@ -1671,8 +1695,8 @@ void launch_scatter(const ScatterArgs& a, hipStream_t st) {
 }
 void launch_reduce_results(const double* cost, const double* grads, int batch, int per_seed,
                            double* out, hipStream_t st) {
-    const int threads = 64, blocks = std::max(1, (per_seed + threads - 1) / threads);
-    hipLaunchKernelGGL(reduce_results_kernel, dim3(blocks), dim3(threads), 0, st, cost, grads, batch,
+    const int blocks = std::max(1, (per_seed + 15) / 16);
+    hipLaunchKernelGGL(reduce_results_kernel, dim3(blocks), dim3(256), 0, st, cost, grads, batch,
                        per_seed, out);
 }
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {

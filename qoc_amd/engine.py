@@ -148,6 +148,14 @@ SIGNATURES = {
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
+    "qocx_opt_begin": (ctypes.c_int, [_VP]),
+    "qocx_opt_clip": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_download_costs": (ctypes.c_int, [_VP, _c_double_p]),
+    "qocx_opt_step": (ctypes.c_int, [
+        _VP, _I32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8), ctypes.c_double,
+        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I32,
+        ctypes.c_double]),
+    "qocx_opt_download_best": (ctypes.c_int, [_VP, _c_double_p, _c_double_p]),
     "qocx_host_clip_controls": (ctypes.c_int, [_c_double_p, _I64, _I64, _I32, _c_double_p]),
     "qocx_host_optimizer_update": (ctypes.c_int, [
         _I32, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _I64, ctypes.POINTER(_I64), _I64,
@@ -504,6 +512,37 @@ class Engine(object):
     def comm_init(self, unique_id, rank, world):
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.qocx_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    # -- multi-start driver with the optimizer states on the device -----------------------------
+    def opt_begin(self):
+        self._check(self._lib.qocx_opt_begin(self._ctx))
+
+    def opt_clip(self, max_norms):
+        max_norms = np.ascontiguousarray(max_norms, dtype=np.float64)
+        self._check(self._lib.qocx_opt_clip(self._ctx, _dp(max_norms)))
+
+    def download_costs(self):
+        cost = np.empty(self.batch, dtype=np.float64)
+        self._check(self._lib.qocx_download_costs(self._ctx, _dp(cost)))
+        return cost
+
+    def opt_step(self, kind, improved, update, learning_rate, beta_1=0.0, beta_2=0.0, epsilon=0.0,
+                 corr_1=1.0, corr_2=1.0, clip_grads=None):
+        improved = np.ascontiguousarray(improved, dtype=np.uint8)
+        update = np.ascontiguousarray(update, dtype=np.uint8)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        self._check(self._lib.qocx_opt_step(
+            self._ctx, int(kind), improved.ctypes.data_as(u8), update.ctypes.data_as(u8),
+            float(learning_rate), float(beta_1), float(beta_2), float(epsilon), float(corr_1),
+            float(corr_2), 0 if clip_grads is None else 1,
+            0.0 if clip_grads is None else float(clip_grads)))
+
+    def opt_download_best(self):
+        pr, B = self._problem, self.batch
+        controls = np.empty((B, pr["Nc"], pr["K"]), dtype=np.float64)
+        final = np.empty((B, pr["S"], pr["n"]), dtype=np.complex128)
+        self._check(self._lib.qocx_opt_download_best(self._ctx, _dp(controls), _dp(final)))
+        return controls, final
 
     def reduce_results(self, allreduce=False, want_grad=True):
         """(sum of the costs, sum of the gradients [Nc x K] or None) over the seeds of the last

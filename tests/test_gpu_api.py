@@ -181,6 +181,51 @@ def test_batch_grape_on_gpu_equals_eight_single_seed_runs():
     assert batch.best.best_error < np.max(batch.best_error) or np.ptp(batch.best_error) == 0
 
 
+@pytest.mark.parametrize("make", [
+    lambda cls: cls(learning_rate=5e-2, clip_grads=0.3),
+    lambda cls: cls(learning_rate=8e-2, learning_rate_decay=2.5, beta_1=0.8),
+    "sgd"])
+def test_device_resident_optimizer_equals_host_plugins(make):
+    """with the built-in Adam / SGD, real controls and device costs the
+    multi-start driver keeps controls, gradients, moments and the best so far in HBM (qocx_opt_*:
+    clip, update and bookkeeping kernels, IEEE operations in the reference's order). A subclass of
+    the same optimizer is "another plugin" and takes the host route (one NumPy plugin object per
+    seed, controls up and gradients down every iteration): both give the same trajectories bit for
+    bit - clipping of controls and gradients, learning-rate decay and per-seed termination in play."""
+    case = cases_mod.case_by_name("nc10_n101")
+    rng = np.random.default_rng(78)
+    u0 = 0.9 * rng.standard_normal((6, case.Nc, case.K))
+    u0 = np.clip(u0, -1.0, 1.0)
+    args = (case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
+            case.initial_states, case.N)
+    kw = dict(iteration_count=5, log_iteration_step=0, max_control_norms=np.full(case.K, 1.0))
+
+    class PluginAdam(Adam):
+        pass
+
+    class PluginSGD(SGD):
+        pass
+    if make == "sgd":
+        resident_opt, host_opt = SGD(learning_rate=0.7), PluginSGD(learning_rate=0.7)
+    else:
+        resident_opt, host_opt = make(Adam), make(PluginAdam)
+    probe = qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), optimizer=resident_opt,
+                                                      **dict(kw, iteration_count=2))
+    threshold = float(np.sort(probe.best_error)[1])  # two seeds stop early
+    runs = [qoc_amd.grape_schroedinger_discrete_batch(*args, u0.copy(), optimizer=opt,
+                                                      min_error=threshold, **kw)
+            for opt in (resident_opt, host_opt)]
+    a, b = runs
+    assert np.array_equal(a.best_error, b.best_error)
+    assert np.array_equal(a.best_iteration, b.best_iteration)
+    assert np.array_equal(a.iterations_run, b.iterations_run)
+    assert len(set(a.iterations_run.tolist())) >= 2
+    for s in range(6):
+        assert np.array_equal(a.best_controls[s], b.best_controls[s])
+        assert np.array_equal(a.best_final_states[s], b.best_final_states[s])
+    assert a.global_best_error == b.global_best_error
+
+
 @pytest.mark.parametrize("name", ["opaque_eps2_real", "opaque_stark_complex", "opaque_eps2_n36"])
 def test_opaque_hamiltonian_on_gpu(name):
     """a hamiltonian(controls, time) that is not linear in the controls (the

@@ -4,7 +4,7 @@
 # writes gpurun_out/prof_<tag>/ (raw) and gpurun_out/<tag>_*.{csv,json} (summaries to copy into
 # profiles/). Counter passes are separate runs with --pmc only (no trace domains beside them).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
