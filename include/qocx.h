@@ -230,7 +230,8 @@ int qocx_set_density_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, con
 
 /* Per-kernel timing, measured with HIP events on the context's stream.
  * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`
- * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu, 5 lindblad) the launch count and total ms
+ * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu, 5 lindblad, 6 lindblad_combine) the launch
+ * count and total ms
  * since the last reset. */
 int qocx_set_timing(qocx_ctx* ctx, int32_t enable);
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms);
@@ -295,7 +296,8 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
 int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
 /* With qocx_set_timing on: the kernel launches of the LAST evaluation as (which, start_ms, end_ms)
  * triples relative to its first launch (HIP events on the launch streams; which = the index of
- * qocx_get_timing: 0 K1a, 1 sweep, 2 K3, 3 scatter, 4 K1b, 5 Lindblad). out holds up to `capacity`
+ * qocx_get_timing: 0 K1a, 1 sweep, 2 K3, 3 scatter, 4 K1b, 5 Lindblad, 6 its combine kernel). out
+ * holds up to `capacity`
  * triples, *count receives how many there were. A view of how the pipeline overlaps. */
 int qocx_debug_timeline(qocx_ctx* ctx, double* out, int64_t capacity, int64_t* count);
 /* Force the variants of the Lindblad launch that large batches / little free HBM select:

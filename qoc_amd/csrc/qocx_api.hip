@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <string>
@@ -253,6 +254,8 @@ struct qocx_ctx {
         DevBuf<double2> inj_bars;
         DevBuf<double> gsub, cost_out, grads, controls;
         DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
+        DevBuf<double2> kbstages, lam_scale;  // two-sided evaluation (LindbladArgs::phase)
+        bool unit_ok = false;                 // one final TargetDensityInfidelity, one density
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
         // qocx_debug_lindblad_knobs (tests force the kernel variants large batches / little HBM use)
@@ -276,8 +279,8 @@ struct qocx_ctx {
     std::vector<double> timeline;  // (which, start, end) of the last evaluation's launches
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    int64_t t_launch[6] = {0, 0, 0, 0, 0, 0};
-    double t_ms[6] = {0, 0, 0, 0, 0, 0};
+    int64_t t_launch[7] = {0, 0, 0, 0, 0, 0, 0};
+    double t_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     // ---- comm ----
     Rccl rccl;
     void* comm = nullptr;
@@ -563,6 +566,8 @@ int qocx_destroy(qocx_ctx* ctx) {
         lb.inj_index.release();
         lb.inj_bars.release();
         lb.ystages.release();
+        lb.kbstages.release();
+        lb.lam_scale.release();
         lb.scratch.release();
         lb.a0_tab.release();
         lb.gp_tab.release();
@@ -1403,7 +1408,7 @@ int qocx_set_timing(qocx_ctx* ctx, int32_t enable) {
 }
 
 int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* total_ms) {
-    if (!ctx || which < 0 || which > 5) return fail(QOCX_ERR_ARG, "bad argument");
+    if (!ctx || which < 0 || which > 6) return fail(QOCX_ERR_ARG, "bad argument");
     if (launches) *launches = ctx->t_launch[which];
     if (total_ms) *total_ms = ctx->t_ms[which];
     return 0;
@@ -1411,7 +1416,7 @@ int qocx_get_timing(qocx_ctx* ctx, int32_t which, int64_t* launches, double* tot
 
 int qocx_reset_timing(qocx_ctx* ctx) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 7; ++i) {
         ctx->t_launch[i] = 0;
         ctx->t_ms[i] = 0;
     }
@@ -1767,6 +1772,8 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         dcosts.push_back(d);
     }
     lb.cost_count = (int)dcosts.size();
+    lb.unit_ok = dcosts.size() == 1 && !dcosts[0].step_cost &&
+                 dcosts[0].kind == QOCX_DEV_COST_TARGET_DENSITY && S == 1;
     if (lb.costs.upload(dcosts, ctx->stream) || upload_dumps(lb.cost_matrices, pool, n, ctx->stream) ||
         lb.cost_counts.upload(counts, ctx->stream))
         return QOCX_ERR_HIP;
@@ -1902,6 +1909,14 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     const size_t md = dump_elems(n);
     want_grad = (want_grad && K > 0) ? 1 : 0;
     if (K > 0 && !controls) return fail(QOCX_ERR_ARG, "controls is NULL");
+    const bool trace_host = getenv("QOCX_TRACE_HOST") != nullptr;
+    auto now_ms = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    };
+    const double t_enter = now_ms();
+    double t_alloc = 0, t_enq = 0, t_sync = 0;
 
     // Each seed picks its own sub-division count from ITS controls (|| Liouvillian || * length
     // <= 0.4 per sub-interval), so a seed's result never depends on its batch neighbours. Seeds
@@ -1962,12 +1977,25 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     // The stage values of the forward pass are kept for the adjoint (12 x the checkpoints of the
     // seeds in flight); a group of seeds that does not fit is launched in pieces that do, and
     // only if a piece would fall below 256 seeds does the adjoint recompute the stages instead.
+    // Two-sided evaluation (LindbladArgs::phase): where it applies the adjoint's stage cotangents
+    // need a buffer like the forward's stage values, and gsub holds complex numbers
+    const bool two_sided_ok = want_grad && lb.unit_ok && lb.inj_count == 0 && n <= 16 &&
+                              lb.nops == 2 && lb.multi_wave && !lb.global_scratch &&
+                              lb.fixed_ksub == 0 && lb.dbg_wave_mode != 1 &&
+                              (int)ctx->sweep_streams.size() >= 1 &&
+                              ctx->knob("lindblad_two_sided", 1) != 0;
+    if (two_sided_ok) {
+        gsub_total *= 2;
+        if (lb.lam_scale.ensure((size_t)B * S)) return QOCX_ERR_HIP;
+    }
     size_t stage_budget = 0;  // double2 elements
     if (want_grad) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        stage_budget = (size_t)(0.45 * (double)(free_b + lb.ystages.count * sizeof(double2))) /
+        stage_budget = (size_t)(0.45 * (double)(free_b + (lb.ystages.count + lb.kbstages.count) *
+                                                              sizeof(double2))) /
                        sizeof(double2);
+        if (two_sided_ok) stage_budget /= 2;  // kbar_i beside Y_i
         size_t want = 0;
         for (auto& kv : groups) {
             const size_t per_seed = (size_t)lb.grids[kv.first].nsub * S * md * 12;
@@ -1978,6 +2006,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 want = std::max(want, piece * per_seed);
         }
         if (want > 0 && lb.ystages.ensure(want)) return QOCX_ERR_HIP;
+        if (want > 0 && two_sided_ok && lb.kbstages.ensure(want)) return QOCX_ERR_HIP;
     }
     if (lb.global_scratch &&
         lb.scratch.ensure((size_t)B * qocx::lindblad_scratch_elems(n, S)))
@@ -1989,13 +2018,22 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         return QOCX_ERR_HIP;
     if (ctx->keep_step_states)
         if (lb.step_densities.ensure((size_t)B * (nsteps + 1) * S * md)) return QOCX_ERR_HIP;
-    std::vector<double> gathered;
     if (K > 0) {
-        gathered.resize((size_t)B * csz);
+        // gathered group by group into the pinned staging buffer (a pageable source of 2 MB costs
+        // the copy 10-25 ms of page pinning per call at 256 seeds; from pinned memory it is a DMA)
+        const size_t total = (size_t)B * csz;
+        if (ctx->pin_controls_cap < total) {
+            if (ctx->pin_controls) (void)hipHostFree(ctx->pin_controls);
+            ctx->pin_controls = nullptr;
+            ctx->pin_controls_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&ctx->pin_controls, total * sizeof(double), hipHostMallocDefault));
+            ctx->pin_controls_cap = total;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // nothing in flight still reads the staging buffer
         for (int pos = 0; pos < B; ++pos)
-            memcpy(gathered.data() + (size_t)pos * csz, controls + (size_t)lb.order[pos] * csz,
+            memcpy(ctx->pin_controls + (size_t)pos * csz, controls + (size_t)lb.order[pos] * csz,
                    csz * sizeof(double));
-        HIP_TRY(hipMemcpyAsync(lb.controls.p, gathered.data(), gathered.size() * sizeof(double),
+        HIP_TRY(hipMemcpyAsync(lb.controls.p, ctx->pin_controls, total * sizeof(double),
                                hipMemcpyHostToDevice, ctx->stream));
     }
     if (lb.inj_count > 0) {
@@ -2014,6 +2052,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         if (lb.inj_index.upload(index, ctx->stream) || lb.inj_bars.upload(dumps, ctx->stream))
             return QOCX_ERR_HIP;
     }
+    t_alloc = now_ms();
     size_t pos0 = 0, ckpt_off = 0, gsub_off = 0;
     for (auto& kv : groups) {
         const auto& gr = lb.grids[kv.first];
@@ -2071,14 +2110,51 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.inj_count = lb.inj_count;
             la.inj_index = lb.inj_count > 0 ? lb.inj_index.p : nullptr;
             la.inj_bars = lb.inj_count > 0 ? lb.inj_bars.p + pos0 * lb.inj_count * S * md : nullptr;
-            time_begin(ctx, 5, ctx->stream);
-            qocx::launch_lindblad(la, Bp, ctx->stream);
-            time_end(ctx, ctx->stream);
+            // Two-sided: forward pass and unit adjoint as two launches, then the combine kernel on
+            // the whole chip. While both launches find CUs of their own they run on two streams
+            // (2 Bp CUs busy instead of Bp); a bigger piece runs them one after the other - the
+            // same three kernels, so a seed's result does not depend on the batch it is part of.
+            const bool two_sided = two_sided_ok && keep_stages && multi && la.stamps == nullptr;
+            if (two_sided) {
+                const int side_limit = (int)ctx->knob("lindblad_side_limit", ctx->cu_count / 2);
+                hipStream_t side = Bp <= side_limit ? ctx->sweep_streams[0] : ctx->stream;
+                la.gsub = lb.gsub.p + 2 * gsub_off;
+                la.kbstages = lb.kbstages.p;
+                la.lam_scale = lb.lam_scale.p + pos0 * S;
+                // everything enqueued so far (uploads, earlier pieces that reuse the stage buffers)
+                if (side != ctx->stream) {
+                    HIP_TRY(hipEventRecord(ctx->ev_factored[0], ctx->stream));
+                    HIP_TRY(hipStreamWaitEvent(side, ctx->ev_factored[0], 0));
+                }
+                qocx::LindbladArgs fwd = la, adj = la;
+                fwd.phase = 1;
+                adj.phase = 2;
+                time_begin(ctx, 5, ctx->stream);
+                qocx::launch_lindblad(fwd, Bp, ctx->stream);
+                time_end(ctx, ctx->stream);
+                time_begin(ctx, 5, side);
+                qocx::launch_lindblad(adj, Bp, side);
+                time_end(ctx, side);
+                if (side != ctx->stream) {
+                    HIP_TRY(hipEventRecord(ctx->ev_swept[0], side));
+                    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_swept[0], 0));
+                }
+                time_begin(ctx, 6, ctx->stream);
+                qocx::launch_lindblad_combine(la, Bp, ctx->stream);
+                time_end(ctx, ctx->stream);
+            } else {
+                if (two_sided_ok) la.gsub = lb.gsub.p + 2 * gsub_off;  // (room for complex numbers)
+                time_begin(ctx, 5, ctx->stream);
+                qocx::launch_lindblad(la, Bp, ctx->stream);
+                time_end(ctx, ctx->stream);
+            }
             if (want_grad) {
                 qocx::ScatterArgs sc;
                 sc.gstep = la.gsub; sc.row_ptr = gr.row_ptr.p; sc.col_step = gr.col.p;
                 sc.weight = gr.weight.p; sc.grads = lb.grads.p + pos0 * csz;
                 sc.B = Bp; sc.nc = nc; sc.K = K; sc.nsteps = 2 * nsub;
+                sc.lam_scale = two_sided ? la.lam_scale : nullptr;
+                sc.S = S;
                 time_begin(ctx, 3, ctx->stream);
                 qocx::launch_scatter(sc, ctx->stream);
                 time_end(ctx, ctx->stream);
@@ -2089,6 +2165,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         }
     }
     HIP_TRY(hipGetLastError());
+    t_enq = now_ms();
     std::vector<double2> fin(final_out ? (size_t)B * S * md : 0);
     std::vector<double> cst(B), grd(want_grad && grad_out ? (size_t)B * csz : 0);
     HIP_TRY(hipMemcpyAsync(cst.data(), lb.cost_out.p, (size_t)B * sizeof(double),
@@ -2100,7 +2177,11 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
         HIP_TRY(hipMemcpyAsync(fin.data(), lb.final_out.p, fin.size() * sizeof(double2),
                                hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    t_sync = now_ms();
     time_collect(ctx);
+    if (trace_host)
+        fprintf(stderr, "qocx_eval_lindblad B=%d: set-up %.2f ms, enqueue %.2f ms, wait %.2f ms\n", B,
+                t_alloc - t_enter, t_enq - t_alloc, t_sync - t_enq);
     for (int pos = 0; pos < B; ++pos) {
         const int b = lb.order[pos];
         if (cost_out) cost_out[b] = cst[pos];
@@ -2122,7 +2203,8 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
-                                  "fuse_lu"};
+                                  "fuse_lu", "lindblad_two_sided",
+                                  "lindblad_side_limit"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

@@ -217,6 +217,16 @@ struct LindbladArgs {
     const double2* inj_bars;   // [B][inj_count][S] C-dumps
     int inj_count;
     unsigned long long* stamps;  // diagnostic build: [B][6 waves][8] cycle sums, or nullptr
+    // Two-sided evaluation (four-wave kernel, ONE final TargetDensityInfidelity, one density): the
+    // cotangent of the final density is a scalar times the target, and the adjoint of the discrete
+    // scheme is linear in it, so it runs on the TARGET beside the forward pass (phase 2 beside
+    // phase 1, two launches on two streams) and stores its stage cotangents kbar_i; a third kernel
+    // (lindblad_combine) contracts them with the forward stage values into complex control
+    // cotangents, which the scatter kernel scales (ScatterArgs::lam_scale). phase 0: the classic
+    // forward-then-adjoint launch.
+    int phase = 0;
+    double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
+    double2* lam_scale = nullptr;  // [B][S]: phase 1 out
 };
 
 // Multi-start driver on the device (qocx_optim.hip)
@@ -238,6 +248,7 @@ void launch_keep_best(const double* controls, double* best_controls, size_t per_
 void launch_optimizer_update(const OptimArgs& a, int batch, hipStream_t st);
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
+void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st);
 int lindblad_lds_size(int n, int S, int nops, int mode, int K);
 size_t lindblad_scratch_elems(int n, int S);
 

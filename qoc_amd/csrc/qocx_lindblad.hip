@@ -626,7 +626,8 @@ struct Wave {
                                                       Mat& lambda_new,
                                                       double (&ga)[QOCX_LINDBLAD_MAX_K],
                                                       double (&gb)[QOCX_LINDBLAD_MAX_K],
-                                                      const double2* ystore) const {
+                                                      const double2* ystore,
+                                                      double2* kbstore = nullptr) const {
         const int lane = lane_id();
         double2* ybuf = kdump + 3 * (size_t)MAT;
         double br[STAGES], bi[STAGES];  // this wave's component of every Ybar_j
@@ -667,6 +668,10 @@ struct Wave {
                 rhs_products<true>(acc, kb, gen, ci, opr);
                 dump_store(acc, parts + (size_t)wv * MAT);
                 clk->lap(3);
+            } else if (kbstore != nullptr) {
+                // two-sided evaluation: the stage cotangent goes to HBM, lindblad_combine forms
+                // the control cotangents from it and the forward pass's stage value
+                dump_store(kb, kbstore + (size_t)i * MAT);
             } else {
                 // control cotangent of this stage, beside the other waves' products:
                 // Re tr(Z Gp_k), Z = Y kbar^H - kbar^H Y
@@ -1015,7 +1020,8 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 
     // ---- forward ------------------------------------------------------------------------
     double cost = 0;
-    for (int q = 0; q < nsub; ++q) {
+    const int phase = QUARTER ? a.phase : 0;  // 1 / 2: the two launches of the two-sided evaluation
+    for (int q = 0; q < (phase == 2 ? 0 : nsub); ++q) {
         const SubStep ss = a.substeps[q];
         if (ss.first_of_step && lead) {
             if (ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
@@ -1046,10 +1052,23 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             block_sync();
         }
     }
-    if (lead) {
+    if (lead && phase != 2) {
         if ((a.nsteps % a.cost_eval_step) == 0) cost += density_costs(a, true, false, dens, nullptr);
         cost += density_costs(a, false, true, dens, nullptr);
         if (lane == 0) a.cost_out[b] = cost;
+        if (phase == 1) {
+            // cotangent of the final density = (f zr + i f zi) T, f = -scale / (S n |z|),
+            // z = tr(T^H rho) (density_costs): the scalar the scatter kernel applies
+            const DevCost c = a.costs[0];
+            Mat t, rho;
+            dump_load(t, a.cost_matrices + (size_t)c.vec_offset * MAT);
+            dump_load(rho, dens);
+            double zr, zi;
+            frob_inner(t, rho, zr, zi);
+            const double mag = sqrt(zr * zr + zi * zi);
+            const double f = mag > 0 ? -c.scale / ((double)S * a.n * mag) : 0.0;
+            if (lane == 0) a.lam_scale[(size_t)b * S] = make_double2(f * zr, f * zi);
+        }
         for (int s = 0; s < S; ++s) {
             Mat rho;
             dump_load(rho, dens + (size_t)s * MAT);
@@ -1059,7 +1078,7 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
                                     (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
         }
     }
-    if (!a.want_grad) {
+    if (!a.want_grad || phase == 1) {
         clock.finish(a.stamps, 6, wv);
         return;
     }
@@ -1079,7 +1098,12 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         }
         wave_sync();
     };
-    if (lead) {
+    if (lead && phase == 2) {  // lambda = the target
+        Mat t;
+        dump_load(t, a.cost_matrices + (size_t)a.costs[0].vec_offset * MAT);
+        dump_store(t, lam);
+        wave_sync();
+    } else if (lead) {
         Mat zero;
         mat_zero(zero);
         for (int s = 0; s < S; ++s) dump_store(zero, lam + (size_t)s * MAT);
@@ -1108,7 +1132,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
             if (QUARTER && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
-                w.adjoint_substep_q(ss, lambda, lambda_new, ga, gb, ys);
+                w.adjoint_substep_q(ss, lambda, lambda_new, ga, gb, ys,
+                                    phase == 2 ? a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
+                                               : nullptr);
             else if (REG && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.adjoint_substep_reg(ss, lambda, lambda_new, ga, gb, ys);
             else
@@ -1117,7 +1143,7 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             if (lead) dump_store(lambda_new, lam + (size_t)s * MAT);
             block_sync();
         }
-        if (w.z_wave() && lane == 0)
+        if (w.z_wave() && lane == 0 && phase != 2)
             for (int k = 0; k < K; ++k) {
                 a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + k] = ga[k];
                 a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + k] = gb[k];
@@ -1161,7 +1187,79 @@ void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
                        dim3(64 * I::waves(a.nops)), bytes, st, a);
 }
 
+// Two-sided evaluation, third kernel: one wave per (sub-interval, seed) contracts the forward
+// stage values Y_i with the stage cotangents kbar_i of the unit adjoint into
+//   gamma_k = tr(Z_i Gp_k),  Z_i = Y_i kbar_i^H - kbar_i^H Y_i   (complex; the classic launch keeps
+// its real part), split between the sub-interval's end points with weights (1 - c_i, c_i):
+// gsub[B][nsub][2][K][2]. Throughput work on the whole chip (nsub x B waves).
+__global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
+    typedef LB<1, false, false> I;
+    typedef I::Mat Mat;
+    __shared__ __attribute__((aligned(16))) char smem[2 * I::SLOT_BYTES];
+    const Slot slot_zk = I::slot_at(smem), slot_zy = I::slot_at(smem + I::SLOT_BYTES);
+    const int q = blockIdx.x, b = blockIdx.y, S = a.S, K = a.K, nsub = a.nsub;
+    double gar[QOCX_LINDBLAD_MAX_K], gai[QOCX_LINDBLAD_MAX_K], gbr[QOCX_LINDBLAD_MAX_K],
+        gbi[QOCX_LINDBLAD_MAX_K];
+#pragma unroll
+    for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) gar[k] = gai[k] = gbr[k] = gbi[k] = 0;
+    for (int s = 0; s < S; ++s) {
+        const size_t base = ((((size_t)b * nsub + q) * S + s) * STAGES) * I::MAT;
+        for (int i = 0; i < STAGES; ++i) {
+            Mat y, kb, kbd, z, z2;
+            I::dump_load(y, a.ystages + base + (size_t)i * I::MAT);
+            I::dump_load(kb, a.kbstages + base + (size_t)i * I::MAT);
+            wave_sync();
+            cmat_to_lds<1>(kb, slot_zk.re, slot_zk.im);
+            wave_sync();
+            I::load_adjoint(kbd, slot_zk);
+            I::mat_zero(z2);
+            I::template gemm<true>(z2, slot_zk, y);  // kbar^H Y
+            wave_sync();
+            cmat_to_lds<1>(y, slot_zy.re, slot_zy.im);
+            wave_sync();
+            I::mat_zero(z);
+            I::template gemm<false>(z, slot_zy, kbd);  // Y kbar^H
+            I::mat_axpy(z, -1.0, z2);
+            const double ci = RK_C_DEV[i];
+            for (int k = 0; k < K; ++k) {
+                Mat gt;
+                I::dump_load(gt, a.gpt_cimg + (size_t)k * I::MAT);
+                double pr = 0, pi = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                    pi += z.re[0][0][r] * gt.im[0][0][r] + z.im[0][0][r] * gt.re[0][0][r];
+                }
+                const double gr = wave_sum(pr), gi = wave_sum(pi);
+#pragma unroll
+                for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                    if (kk == k) {
+                        gar[kk] += (1.0 - ci) * gr;
+                        gai[kk] += (1.0 - ci) * gi;
+                        gbr[kk] += ci * gr;
+                        gbi[kk] += ci * gi;
+                    }
+            }
+        }
+    }
+    if (lane_id() == 0)
+#pragma unroll
+        for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+            if (kk < K) {
+                double* out = a.gsub + ((((size_t)b * nsub + q) * 2) * K + kk) * 2;
+                out[0] = gar[kk];
+                out[1] = gai[kk];
+                out[(size_t)K * 2] = gbr[kk];
+                out[(size_t)K * 2 + 1] = gbi[kk];
+            }
+}
+
 }  // namespace
+
+void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st) {
+    if (batch <= 0 || a.nsub <= 0) return;
+    hipLaunchKernelGGL(lindblad_combine_kernel, dim3(a.nsub, batch), dim3(64), 0, st, a);
+}
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     if (a.n > 16) launch_t<2, true, false>(a, batch, st);

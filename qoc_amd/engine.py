@@ -23,7 +23,7 @@ MAGNUS_CODES = {"M2": 2, "M4": 4, "M6": 6}
 
 ERR_SINGULAR = -4
 
-KERNEL_NAMES = ("pade_pq", "sweep", "krylov_grad", "scatter", "lu", "lindblad")
+KERNEL_NAMES = ("pade_pq", "sweep", "krylov_grad", "scatter", "lu", "lindblad", "lindblad_combine")
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int32)
