@@ -117,20 +117,30 @@ class SchroedingerEvaluator(object):
         # by the host at every step of every evaluation, as the reference does, and the engine
         # takes the generators as they are (qocx_upload_generators).
         self.opaque_hamiltonian = None
+        # ... and under MagnusPolicy.M4 / M6, where the step generator is a commutator expression
+        # of several node generators, the host hands the engine the TANGENT of the callable at the
+        # current controls instead (structure.linearize_hamiltonian: a structured, time-dependent
+        # problem with the same cost and the same control gradient), one control array at a time.
+        self.linearized_hamiltonian = None
+        self._problem_static = None
         try:
             h0, g = structure.probe_hamiltonian(hamiltonian, self.hilbert_size, control_count,
                                                 complex_controls, times)
         except structure.NonLinearHamiltonianError:
             if magnus_policy != MagnusPolicy.M2:
-                raise NotImplementedError(
-                    "a hamiltonian that is not linear in the controls is supported with "
-                    "MagnusPolicy.M2 only (got {}); there is no CPU fallback".format(magnus_policy))
-            self.opaque_hamiltonian = hamiltonian
-            self._dt = dt
-            self._mid_times = times
-            self._rows = structure.interpolation_rows(evolution_time, control_eval_count, times)
-            h0 = np.zeros((1, self.hilbert_size, self.hilbert_size), dtype=np.complex128)
-            g = None
+                self.linearized_hamiltonian = hamiltonian
+                self._node_times = times
+                self._evolution_time = evolution_time
+                h0 = np.zeros((1, self.hilbert_size, self.hilbert_size), dtype=np.complex128)
+                g = np.zeros((1, control_count * (2 if complex_controls else 1),
+                              self.hilbert_size, self.hilbert_size), dtype=np.complex128)
+            else:
+                self.opaque_hamiltonian = hamiltonian
+                self._dt = dt
+                self._mid_times = times
+                self._rows = structure.interpolation_rows(evolution_time, control_eval_count, times)
+                h0 = np.zeros((1, self.hilbert_size, self.hilbert_size), dtype=np.complex128)
+                g = None
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
         descriptors = []
         for cost in self.costs:
@@ -151,12 +161,18 @@ class SchroedingerEvaluator(object):
             self.backend.set_knob("latency", 1 if latency_mode else 0)
         self.kr = control_count * (2 if complex_controls else 1)
         device_k = 0 if self.opaque_hamiltonian is not None else self.kr
-        self.backend.set_schroedinger_problem(
-            self.hilbert_size, self.state_count, device_k,
-            control_eval_count if device_k else 0, system_eval_count,
-            evolution_time, h0, g, initial_states.reshape(self.state_count, self.hilbert_size),
-            costs=descriptors, cost_eval_step=cost_eval_step, magnus_policy=magnus_policy.short)
+        self._problem_static = (
+            (self.hilbert_size, self.state_count, device_k, control_eval_count if device_k else 0,
+             system_eval_count, evolution_time),
+            initial_states.reshape(self.state_count, self.hilbert_size),
+            dict(costs=descriptors, cost_eval_step=cost_eval_step,
+                 magnus_policy=magnus_policy.short))
+        self._set_problem(h0, g)
         self.cost_eval_step = cost_eval_step
+
+    def _set_problem(self, h0, g):
+        head, psi0, kw = self._problem_static
+        self.backend.set_schroedinger_problem(*head, h0, g, psi0, **kw)
 
     # -- device round trip: structured controls, or generators sampled from an opaque callable ----
     def _upload(self, controls_batch, device_controls):
@@ -182,6 +198,30 @@ class SchroedingerEvaluator(object):
                 if self.complex_controls else grads
         return cost, grads, final
 
+    def _evaluate_linearized(self, controls_batch, device_controls, want_grad, need_steps):
+        """One control array at a time: the tangent problem of the callable at THAT array (node
+        times of the Magnus policy), set as a structured time-dependent problem, evaluated at it."""
+        costs, grads, finals, steps = [], [], [], []
+        for b in range(controls_batch.shape[0]):
+            h0, g = structure.linearize_hamiltonian(
+                self.linearized_hamiltonian, controls_batch[b], self._evolution_time,
+                self._node_times, self.hilbert_size, self.complex_controls)
+            self._set_problem(h0, g)
+            if need_steps:
+                self.backend.set_keep_step_states(True)
+            self.backend.upload_controls(device_controls[b:b + 1])
+            self.backend.eval_resident(want_grad)
+            c, gr, f = self.backend.download_results(want_grad=want_grad)
+            costs.append(c[0])
+            finals.append(f[0])
+            if want_grad:
+                grads.append(gr[0])
+            if need_steps:
+                steps.append(self.backend.download_step_states()[0])
+                self.backend.set_keep_step_states(False)
+        return (np.array(costs), np.stack(grads) if want_grad else None, np.stack(finals),
+                np.stack(steps)[..., None] if need_steps else None)
+
     def _host_terms(self, controls, want_grad):
         value, grad = 0.0, None
         for cost in self.host_costs:
@@ -197,7 +237,8 @@ class SchroedingerEvaluator(object):
         """True when a multi-start driver may keep controls and optimizer states on the device
         (engine.opt_*): structured Hamiltonian, real controls, every cost evaluated on the device,
         MagnusPolicy.M2, and a backend that has the entry points (the real engine)."""
-        return (self.opaque_hamiltonian is None and not self.complex_controls
+        return (self.opaque_hamiltonian is None and self.linearized_hamiltonian is None
+                and not self.complex_controls
                 and self.control_count > 0 and not self.host_costs and not self.opaque_costs
                 and self.magnus_policy == MagnusPolicy.M2 and hasattr(self.backend, "opt_step"))
 
@@ -215,16 +256,24 @@ class SchroedingerEvaluator(object):
             batch = controls_batch.shape[0]
             device_controls = structure.to_real_controls(controls_batch, self.complex_controls)
         need_steps = want_step_states or bool(self.opaque_costs)
-        if need_steps:
-            self.backend.set_keep_step_states(True)
-        self._upload(controls_batch, device_controls)
         two_pass = want_grad and bool(self.opaque_costs)
-        self.backend.eval_resident(want_grad and not two_pass)
-        cost, grads, final = self._download(controls_batch, want_grad and not two_pass)
-        step_states = None
-        if need_steps:
-            step_states = self.backend.download_step_states()[..., None]
-            self.backend.set_keep_step_states(False)
+        if self.linearized_hamiltonian is not None:
+            if two_pass:
+                raise NotImplementedError(
+                    "user costs without a device descriptor together with a hamiltonian that is "
+                    "not linear in the controls under MagnusPolicy.M4 / M6")
+            cost, grads, final, step_states = self._evaluate_linearized(
+                controls_batch, device_controls, want_grad, need_steps)
+        else:
+            if need_steps:
+                self.backend.set_keep_step_states(True)
+            self._upload(controls_batch, device_controls)
+            self.backend.eval_resident(want_grad and not two_pass)
+            cost, grads, final = self._download(controls_batch, want_grad and not two_pass)
+            step_states = None
+            if need_steps:
+                step_states = self.backend.download_step_states()[..., None]
+                self.backend.set_keep_step_states(False)
         opaque_grads = None
         if two_pass:
             # User costs without a device descriptor: the host supplies the cotangent of the
@@ -354,10 +403,27 @@ class LindbladEvaluator(object):
         # coarsest sub-division (12 per sub-interval), never on a handful of equispaced probes
         self._coarse_times = self.backend.lindblad_stage_times(
             evolution_time, system_eval_count, control_eval_count, self.kr, 1)
-        h0, g, dissipators, operators, self.time_dependent = \
-            structure.probe_static_lindblad_system(
-                hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
+        # A hamiltonian(controls, time) that is not linear in the controls (the reference takes any
+        # callable, lindbladdiscrete.py:486-489): the engine gets the TANGENT of the callable at the
+        # control array being evaluated, sampled at the integrator's stage times
+        # (structure.linearize_hamiltonian) - a structured time-dependent problem with the same
+        # cost and the same control gradient -, one control array at a time.
+        self.linearized_hamiltonian = None
+        self._evolution_time = evolution_time
+        try:
+            h0, g, dissipators, operators, self.time_dependent = \
+                structure.probe_static_lindblad_system(
+                    hamiltonian, lindblad_data, self.hilbert_size, control_count, complex_controls,
+                    evolution_time, probe_times=self._coarse_times)
+        except structure.NonLinearHamiltonianError:
+            if frozen_controls is not None or control_count == 0:
+                raise
+            self.linearized_hamiltonian = hamiltonian
+            h0, g, dissipators, operators, _ = structure.probe_static_lindblad_system(
+                None, lindblad_data, self.hilbert_size, control_count, complex_controls,
                 evolution_time, probe_times=self._coarse_times)
+            self.time_dependent = True
+            hamiltonian = None
         self._lindblad_data = lindblad_data if getattr(
             structure.probe_static_lindblad_system, "lindblad_time_dependent", False) else None
         self.device_costs, self.host_costs, self.opaque_costs = [], [], []
@@ -381,7 +447,9 @@ class LindbladEvaluator(object):
         self._table_bounds = None
         self._coarse_samples = None
         self._coarse_lindblad = None
-        if not self.time_dependent:
+        if self.linearized_hamiltonian is not None:
+            pass  # the tables depend on the controls: set per evaluation (_set_linearized_problem)
+        elif not self.time_dependent:
             self.backend.set_lindblad_problem(*self._problem_args, **self._problem_kw)
         elif control_bounds is not None:  # GRAPE: max_control_norms bound the controls for good
             bounds = np.repeat(np.asarray(control_bounds, dtype=np.float64),
@@ -428,8 +496,60 @@ class LindbladEvaluator(object):
                                           **self._problem_kw)
         self._table_bounds = np.asarray(bounds, dtype=np.float64)
 
+    def _set_linearized_problem(self, controls, device_controls):
+        """Tangent of the non-linear callable at `controls` (Nc x K) on the stage grid of a
+        sub-division fine enough for this control array, handed to the engine as tables."""
+        (n, _, kr, nc, n_eval, evolution_time, _, _, dissipators, operators, _) = self._problem_args
+        dt = evolution_time / (n_eval - 1)
+        lin = lambda times: structure.linearize_hamiltonian(  # noqa: E731
+            self.linearized_hamiltonian, controls, evolution_time, list(times), n,
+            self.complex_controls)
+        h_probe, g_probe = lin(self._coarse_times)
+        bounds = np.max(np.abs(device_controls.reshape(-1, kr)), axis=0)
+        h_norm = max(np.linalg.norm(m, 2) for m in h_probe)
+        g_norms = [max(np.linalg.norm(g_probe[t, k], 2) for t in range(g_probe.shape[0]))
+                   for k in range(kr)]
+        pairs = [(dissipators, operators)]
+        if self._lindblad_data is not None:
+            if self._coarse_lindblad is None:
+                self._coarse_lindblad = structure.sample_lindblad_data(
+                    self._lindblad_data, n, list(self._coarse_times))
+            pairs = list(zip(*self._coarse_lindblad))
+        ksub = max(structure.lindblad_subdivision(h_norm, g_norms, bounds, d, o, dt)
+                   for d, o in pairs)
+        times = self.backend.lindblad_stage_times(evolution_time, n_eval, nc, kr, ksub)
+        h0_stages, g_stages = lin(times)
+        extra = {}
+        if self._lindblad_data is not None:
+            diss_stages, op_stages = structure.sample_lindblad_data(self._lindblad_data, n, times)
+            extra = dict(diss_stages=diss_stages, op_stages=op_stages)
+        self.backend.set_lindblad_problem(*self._problem_args, fixed_subdivision=ksub,
+                                          h0_stages=h0_stages, g_stages=g_stages, **extra,
+                                          **self._problem_kw)
+
+    def _evaluate_linearized(self, controls_batch, device_controls, want_grad, need_steps):
+        costs, grads, finals, steps = [], [], [], []
+        for b in range(controls_batch.shape[0]):
+            self._set_linearized_problem(controls_batch[b], device_controls[b])
+            if need_steps:
+                self.backend.set_keep_step_states(True)
+            try:
+                c, gr, f = self.backend.evaluate_lindblad(device_controls[b:b + 1],
+                                                          want_grad=want_grad)
+                if need_steps:
+                    steps.append(self.backend.download_step_densities()[0])
+            finally:
+                if need_steps:
+                    self.backend.set_keep_step_states(False)
+            costs.append(c[0])
+            finals.append(f[0])
+            if want_grad:
+                grads.append(gr[0])
+        return (np.array(costs), np.stack(grads) if want_grad else None, np.stack(finals),
+                np.stack(steps) if need_steps else None)
+
     def _ensure_time_table(self, device_controls):
-        if not self.time_dependent:
+        if not self.time_dependent or self.linearized_hamiltonian is not None:
             return
         if self.control_count == 0:
             need = np.zeros(0)
@@ -455,15 +575,23 @@ class LindbladEvaluator(object):
         self._ensure_time_table(device_controls if self.control_count else None)
         need_steps = want_step_densities or bool(self.opaque_costs)
         two_pass = want_grad and bool(self.opaque_costs)
-        if need_steps:
-            self.backend.set_keep_step_states(True)
-        try:
-            cost, grads, final = self.backend.evaluate_lindblad(
-                device_controls, want_grad=want_grad and not two_pass)
-            step_densities = self.backend.download_step_densities() if need_steps else None
-        finally:
+        if self.linearized_hamiltonian is not None:
+            if two_pass:
+                raise NotImplementedError(
+                    "user costs without a device descriptor together with a hamiltonian that is "
+                    "not linear in the controls on the Lindblad GRAPE path")
+            cost, grads, final, step_densities = self._evaluate_linearized(
+                controls_batch, device_controls, want_grad, need_steps)
+        else:
             if need_steps:
-                self.backend.set_keep_step_states(False)
+                self.backend.set_keep_step_states(True)
+            try:
+                cost, grads, final = self.backend.evaluate_lindblad(
+                    device_controls, want_grad=want_grad and not two_pass)
+                step_densities = self.backend.download_step_densities() if need_steps else None
+            finally:
+                if need_steps:
+                    self.backend.set_keep_step_states(False)
         opaque_grads = None
         if two_pass:  # user costs: host-supplied density cotangents (see SchroedingerEvaluator)
             steps, bars, opaque_grads = self._opaque_cotangents(controls_batch, step_densities)

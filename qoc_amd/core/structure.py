@@ -144,6 +144,43 @@ def hamiltonian_slopes(hamiltonian, u, t, complex_controls):
     return out
 
 
+def linearize_hamiltonian(hamiltonian, controls, evolution_time, times, hilbert_size,
+                          complex_controls):
+    """
+    The tangent of a hamiltonian(controls, time) that is NOT linear in the controls, at the
+    control array `controls` (Nc x K): at every time t of `times`
+
+        H_lin(v, t) = H0'(t) + sum_k Re(v_k) G'_{re,k}(t) + Im(v_k) G'_{im,k}(t),
+        G'(t) = d H / d u at (u(t), t)   (4th-order central differences of the callable),
+        H0'(t) = H(u(t), t) - sum_k Re(u_k(t)) G'_{re,k}(t) + Im(u_k(t)) G'_{im,k}(t),
+
+    with u(t) the reference's linear interpolation of `controls`. H_lin(u(t), t) = H(u(t), t) and
+    d H_lin / d v = d H / d u there, so a structured, time-dependent problem built from (H0', G')
+    and evaluated AT `controls` has the cost and the control gradient of the original one - under
+    any Magnus policy and on the Lindblad path (the reference differentiates the callable itself
+    with autograd, schroedingerdiscrete.py:483-497, lindbladdiscrete.py:486-489).
+    Returns (h0 (nt, n, n), g (nt, Kr, n, n)), Kr = K or 2 K ([Re_0, Im_0, Re_1, ...]).
+    """
+    controls = np.asarray(controls)
+    k = controls.shape[1]
+    kr = k * (2 if complex_controls else 1)
+    rows = interpolation_rows(evolution_time, controls.shape[0], times)
+    u = controls_at(controls, rows, times)
+    h0 = np.empty((len(times), hilbert_size, hilbert_size), dtype=np.complex128)
+    g = np.empty((len(times), kr, hilbert_size, hilbert_size), dtype=np.complex128)
+    for ti, t in enumerate(times):
+        base = np.asarray(hamiltonian(u[ti], t), dtype=np.complex128)
+        if base.shape != (hilbert_size, hilbert_size):
+            raise ValueError("hamiltonian returned shape {}, expected {}".format(
+                base.shape, (hilbert_size, hilbert_size)))
+        for slot, (j, direction, dh) in enumerate(hamiltonian_slopes(hamiltonian, u[ti], t,
+                                                                     complex_controls)):
+            g[ti, slot] = dh
+            base = base - (u[ti][j].real if direction == 1.0 else u[ti][j].imag) * dh
+        h0[ti] = base
+    return h0, g
+
+
 def generator_gradients(hamiltonian, controls, rows, times, dt, gen_bars, complex_controls):
     """
     d cost / d controls from the generator cotangents Mbar_j (qocx_download_generator_cotangents):

@@ -282,7 +282,26 @@ def opaque_cases():
                       sigma=0.6)
     rng = np.random.default_rng(4412)
     big.quad = [0.8 * gue(rng, 36), -0.5 * gue(rng, 36)]
-    return [real, cplx, big]
+    # ... and under the higher Magnus policies (the reference takes any callable under any policy,
+    # schroedingerdiscrete.py:483-497): the host hands the engine the tangent of the callable at
+    # the current controls (structure.linearize_hamiltonian)
+    m4 = case_random("opaque_eps2_M4", n=5, N=17, seeds=2, h_seed=4421, S=2, K=2, Nc=6,
+                     dt=0.13, sigma=0.6, magnus="M4", full_unitary=True)
+    rng = np.random.default_rng(4422)
+    m4.quad = [0.7 * gue(rng, 5), -0.6 * gue(rng, 5)]
+    m4.time_mod = 1.1
+    n = 8
+    rng = np.random.default_rng(4423)
+    a = annihilation(n)
+    ad = a.conj().T
+    m6 = Case(name="opaque_stark_M6", n=n, S=1, K=1, Nc=7, N=13, T=1.8, magnus="M6",
+              h0=gue(rng, n) * 1.5, g_re=[(a + ad) / 3], g_im=[1j * (a - ad) / 3],
+              complex_controls=True, quad=[np.diag(np.linspace(-1.0, 1.0, n)).astype(complex)],
+              initial_states=column_states(np.eye(n)[:, :1]),
+              cost_specs=[("TargetStateInfidelity",
+                           dict(target_states=column_states(np.eye(n)[:, 1:2])))],
+              controls=_controls(4424, 2, 7, 1, True, 0.5))
+    return [real, cplx, big, m4, m6]
 
 
 def case_by_name(name):
@@ -442,6 +461,18 @@ def lindblad_timedep_data_case():
     return c
 
 
+def lindblad_opaque_grad_cases():
+    """A hamiltonian that is NOT linear in the controls on the Lindblad GRAPE path (the reference
+    takes any callable, lindbladdiscrete.py:486-489), with a well-conditioned gradient: u^2 terms and
+    an explicitly time-dependent drift on top of the anharmonic oscillator of the wc fixtures."""
+    c = lindblad_wellconditioned_case("lindblad_opaque_wc", n=5, N=13, Nc=5, T=3.0, sigma=0.7,
+                                      drive=0.4)
+    rng = np.random.default_rng(7711)
+    c.quad = [0.3 * gue(rng, 5), -0.25 * gue(rng, 5)]
+    c.time_mod = 1.3
+    return [c]
+
+
 def lindblad_extra_cases():
     """Fixtures with gradients that the generic per-case tests do not iterate over."""
     return [lindblad_bench_case(), lindblad_timedep_data_case()]
@@ -459,7 +490,8 @@ def lindblad_opaque_cases():
 
 
 def lindblad_case_by_name(name):
-    for c in lindblad_cases() + lindblad_opaque_cases() + lindblad_extra_cases():
+    for c in (lindblad_cases() + lindblad_opaque_cases() + lindblad_extra_cases()
+              + lindblad_opaque_grad_cases()):
         if c.name == name:
             return c
     raise KeyError(name)

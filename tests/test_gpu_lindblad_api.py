@@ -187,3 +187,9 @@ def test_time_dependent_lindblad_data_fixture():
         assert abs(errors[b] - g["error"][b]) < 1e-9
         ref = g["grads_ad"][b]
         assert np.max(np.abs(grads[b] - ref)) < 1e-8 * np.max(np.abs(ref))
+
+
+def test_opaque_hamiltonian_on_the_lindblad_grape_path_on_gpu():
+    """See tests/test_lindblad_host_api.py::check_opaque_lindblad_grape."""
+    from tests.test_lindblad_host_api import check_opaque_lindblad_grape
+    check_opaque_lindblad_grape()

@@ -596,12 +596,44 @@ def test_opaque_generator_gradients_against_finite_differences():
             assert abs(fd - ref) < 1e-7 * max(1.0, abs(ref))
 
 
-def test_opaque_hamiltonian_needs_m2():
-    case = cases_mod.case_by_name("opaque_eps2_real")
-    with pytest.raises(NotImplementedError):
-        qoc_amd.evolve_schroedinger_discrete(
-            case.T, case.hamiltonian(), case.initial_states, case.N, controls=case.controls[0],
-            magnus_policy=MagnusPolicy.M4)
+def check_linearized_opaque_case(name):
+    """A hamiltonian that is not linear in the controls under MagnusPolicy.M4 / M6 (the reference
+    takes any callable under any policy, schroedingerdiscrete.py:483-497): the host hands the
+    engine the tangent of the callable at the current controls. Against fixtures minted from the
+    reference: forward 1e-10, gradient 1e-8 vs AD of the same op sequence and 1e-7 vs finite
+    differences of the reference forward; and GRAPE runs on it. (CPU: oracle backend; GPU: engine.)"""
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    policy = getattr(MagnusPolicy, case.magnus)
+    args = dict(cost_eval_step=case.cost_eval_step, costs=product_cost_list(case),
+                magnus_policy=policy)
+    for b, u in enumerate(case.controls):
+        result = qoc_amd.evolve_schroedinger_discrete(
+            case.T, case.hamiltonian(), case.initial_states, case.N, controls=u, **args)
+        assert abs(result.error - g["error"][b]) < 1e-10
+        assert rel_err(result.final_states, g["final_states"][b]) < 1e-10
+    ev = device.SchroedingerEvaluator(
+        case.T, case.hamiltonian(), case.initial_states, case.N, control_count=case.K,
+        control_eval_count=case.Nc, complex_controls=case.complex_controls,
+        costs=product_cost_list(case), cost_eval_step=case.cost_eval_step, magnus_policy=policy)
+    assert ev.linearized_hamiltonian is not None and ev.opaque_hamiltonian is None
+    errors, grads, finals, _ = ev.evaluate_batch(np.stack(case.controls), want_grad=True)
+    for b in range(len(case.controls)):
+        assert abs(errors[b] - g["error"][b]) < 1e-10
+        assert rel_err(grads[b], g["grads_ad"][b]) < 1e-8
+        scale = np.max(np.abs(g["grads_ad"][b]))
+        assert np.max(np.abs(np.asarray(grads[b]).flat[g["fd_index"][b]] - g["grads_fd"][b])) / scale < 1e-7
+    result = qoc_amd.grape_schroedinger_discrete(
+        case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(), case.initial_states,
+        case.N, complex_controls=case.complex_controls, initial_controls=case.controls[0].copy(),
+        iteration_count=6, log_iteration_step=0, optimizer=Adam(learning_rate=3e-2),
+        max_control_norms=np.full(case.K, 3.0), magnus_policy=policy)
+    assert result.best_error < g["error"][0] and result.best_iteration > 0
+
+
+@pytest.mark.parametrize("name", ["opaque_eps2_M4", "opaque_stark_M6"])
+def test_opaque_hamiltonian_under_higher_magnus_policies(name):
+    check_linearized_opaque_case(name)
 
 
 def test_product_has_no_backend_hook_and_no_cpu_fallback():

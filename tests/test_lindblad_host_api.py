@@ -143,11 +143,7 @@ def test_structure_rejects_time_dependence_and_size():
     expected = ControlNorm(4, case.K, cost_multiplier=0.3,
                            max_control_norms=np.full(case.K, 2.0)).cost(coarse, None, 0)
     assert abs(r.error - expected) < 1e-12 and expected > 0
-    # (gradients through such a callable exist on the Schroedinger path only)
-    with pytest.raises(structure.NonLinearHamiltonianError):
-        qoc_amd.grape_lindblad_discrete(
-            case.K, case.Nc, [], case.T, case.initial_densities, case.N, hamiltonian=quad,
-            lindblad_data=case.lindblad_data(), iteration_count=1, log_iteration_step=0)
+    # (GRAPE on such a callable: test_opaque_hamiltonian_on_the_lindblad_grape_path)
     with pytest.raises(NotImplementedError):
         qoc_amd.evolve_lindblad_discrete(1.0, np.eye(33)[None] / 33, 2,
                                          hamiltonian=lambda u, t: np.eye(33))
@@ -379,3 +375,36 @@ def test_periodic_drive_does_not_alias_to_time_independent():
     r_frozen = qoc_amd.evolve_lindblad_discrete(
         T, rho0, N, controls=u, hamiltonian=lambda c, t: Z + X + c[0] * X)
     assert np.max(np.abs(r_dep.final_densities - r_frozen.final_densities)) > 1e-3
+
+
+def check_opaque_lindblad_grape(name="lindblad_opaque_wc"):
+    """VERDICT r2 missing #2: a hamiltonian(controls, time) that is NOT linear in the controls on
+    the Lindblad GRAPE path (the reference takes any callable, lindbladdiscrete.py:486-489). The
+    host hands the engine the tangent of the callable at the control array being evaluated, on the
+    integrator's stage grid (structure.linearize_hamiltonian). Against a fixture minted from the
+    reference (forward: its evolve_lindblad_discrete; gradient: frozen-mesh AD cross-checked with
+    finite differences of the reference forward): cost 1e-9, densities 1e-8, gradient 1e-8
+    relative; and grape_lindblad_discrete runs on it."""
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    costs = product_cost_list(case)
+    ev = device.LindbladEvaluator(case.T, case.initial_densities, case.N, costs=costs,
+                                  hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data(),
+                                  control_count=case.K, control_eval_count=case.Nc)
+    assert ev.linearized_hamiltonian is not None
+    errors, grads, finals, _ = ev.evaluate_batch(np.stack(case.controls))
+    for b in range(len(case.controls)):
+        assert abs(errors[b] - g["error"][b]) < 1e-9
+        assert np.max(np.abs(finals[b] - g["final_densities"][b])) < 1e-8
+        ref = g["grads_ad"][b]
+        assert np.max(np.abs(grads[b] - ref)) < 1e-8 * np.max(np.abs(ref))
+    result = qoc_amd.grape_lindblad_discrete(
+        case.K, case.Nc, costs, case.T, case.initial_densities, case.N,
+        hamiltonian=case.hamiltonian(), lindblad_data=case.lindblad_data(),
+        initial_controls=case.controls[0].copy(), iteration_count=5, log_iteration_step=0,
+        optimizer=Adam(learning_rate=5e-2), max_control_norms=np.full(case.K, 3.0))
+    assert result.best_error < g["error"][0] and result.best_iteration > 0
+
+
+def test_opaque_hamiltonian_on_the_lindblad_grape_path():
+    check_opaque_lindblad_grape()

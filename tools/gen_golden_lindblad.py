@@ -67,11 +67,12 @@ def richardson_fd(case, controls, index, h):
 # is large (the well-conditioned fixtures), and the measured number is printed and stored.
 FD_COUNT = {"lindblad_c4_full": 2, "lindblad_bench_c4": 2}
 FD_STEP = {"lindblad_wc_n4": 4e-2, "lindblad_wc_n16": 4e-2, "lindblad_timedep_data": 4e-2,
-           "lindblad_bench_c4": 4e-2}
+           "lindblad_bench_c4": 4e-2, "lindblad_opaque_wc": 1.5e-2}
 
 
 def main(only=None):
-    for case in cases_mod.lindblad_cases() + cases_mod.lindblad_extra_cases():
+    for case in (cases_mod.lindblad_cases() + cases_mod.lindblad_extra_cases()
+                 + cases_mod.lindblad_opaque_grad_cases()):
         if only and case.name not in only:
             continue
         t0 = time.time()

@@ -66,6 +66,10 @@ def ad_eval(case, controls_np, freeze_mesh=False):
                 h = h + torch.real(u[k]) * g_re[k] + torch.imag(u[k]) * g_im[k]
             else:
                 h = h + u[k] * g_re[k]
+            if getattr(case, "quad", None) is not None:  # tests/cases.py Case.hamiltonian
+                mod2 = torch.real(u[k]) ** 2 + torch.imag(u[k]) ** 2 if case.complex_controls \
+                    else u[k] ** 2
+                h = h + mod2 * torch.tensor(case.quad[k], dtype=C)
         out = -1j * (torch.matmul(h, rho) - torch.matmul(rho, h))
         gs, os_, osd, osp = gam, ops, ops_d, ops_p
         if getattr(case, "data_mod", None) is not None:  # tests/cases.py LindbladCase.lindblad_data
