@@ -48,12 +48,13 @@ def total_registers(entry):
 def test_headline_kernels_share_a_simd():
     kernels = resources("qocx_kernels.hip")
     pade2 = resources("qocx_pade2.hip")
-    sweep = find(kernels, "sweep_kernelILi2ELi1ELb0E")
-    sweep4 = find(kernels, "sweep_kernelILi2ELi4ELb0E")
+    sweep = find(kernels, "sweep_kernelILi2ELi1ELb0ELb0E")
+    sweep1 = find(kernels, "sweep_kernelILi2ELi1ELb0ELb1E")  # one operand set in LDS (round 3)
+    sweep4 = find(kernels, "sweep_kernelILi2ELi4ELb0ELb0E")
     k1a = find(pade2, "pade_pq2_kernelILb1E")
     k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0E")
     lu = find(kernels, "lu_kernelILi2E")
-    for entry in (sweep, sweep4, k1a, k3, lu):
+    for entry in (sweep, sweep1, sweep4, k1a, k3, lu):
         assert entry["VGPRs Spill"] == 0 and entry["ScratchSize"] == 0
     granule = lambda r: (r + 7) // 8 * 8  # noqa: E731  (allocation granularity)
     assert granule(total_registers(k1a)) * 2 <= 512          # two K1a waves per SIMD
@@ -62,6 +63,8 @@ def test_headline_kernels_share_a_simd():
     # the sweep beside one wave of either throughput kernel
     assert granule(total_registers(sweep)) + granule(total_registers(k1a)) <= 512
     assert granule(total_registers(sweep)) + granule(total_registers(k3)) <= 512
+    assert granule(total_registers(sweep1)) + granule(total_registers(k1a)) <= 512
+    assert granule(total_registers(sweep1)) + granule(total_registers(k3)) <= 512
     assert granule(total_registers(sweep4)) + granule(total_registers(k3)) <= 512
 
 
