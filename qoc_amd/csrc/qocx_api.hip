@@ -1773,7 +1773,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     }
     lb.cost_count = (int)dcosts.size();
     lb.unit_ok = dcosts.size() == 1 && !dcosts[0].step_cost &&
-                 dcosts[0].kind == QOCX_DEV_COST_TARGET_DENSITY && S == 1;
+                 dcosts[0].kind == QOCX_DEV_COST_TARGET_DENSITY;
     if (lb.costs.upload(dcosts, ctx->stream) || upload_dumps(lb.cost_matrices, pool, n, ctx->stream) ||
         lb.cost_counts.upload(counts, ctx->stream))
         return QOCX_ERR_HIP;
@@ -1980,14 +1980,12 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     // Two-sided evaluation (LindbladArgs::phase): where it applies the adjoint's stage cotangents
     // need a buffer like the forward's stage values, and gsub holds complex numbers
     const bool two_sided_ok = want_grad && lb.unit_ok && lb.inj_count == 0 && n <= 16 &&
-                              lb.nops == 2 && lb.multi_wave && !lb.global_scratch &&
+                              lb.nops >= 1 && lb.multi_wave && !lb.global_scratch &&
                               lb.fixed_ksub == 0 && lb.dbg_wave_mode != 1 &&
                               (int)ctx->sweep_streams.size() >= 1 &&
                               ctx->knob("lindblad_two_sided", 1) != 0;
-    if (two_sided_ok) {
-        gsub_total *= 2;
+    if (two_sided_ok)
         if (lb.lam_scale.ensure((size_t)B * S)) return QOCX_ERR_HIP;
-    }
     size_t stage_budget = 0;  // double2 elements
     if (want_grad) {
         size_t free_b = 0, total_b = 0;
@@ -2118,7 +2116,6 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             if (two_sided) {
                 const int side_limit = (int)ctx->knob("lindblad_side_limit", ctx->cu_count / 2);
                 hipStream_t side = Bp <= side_limit ? ctx->sweep_streams[0] : ctx->stream;
-                la.gsub = lb.gsub.p + 2 * gsub_off;
                 la.kbstages = lb.kbstages.p;
                 la.lam_scale = lb.lam_scale.p + pos0 * S;
                 // everything enqueued so far (uploads, earlier pieces that reuse the stage buffers)
@@ -2143,7 +2140,6 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 qocx::launch_lindblad_combine(la, Bp, ctx->stream);
                 time_end(ctx, ctx->stream);
             } else {
-                if (two_sided_ok) la.gsub = lb.gsub.p + 2 * gsub_off;  // (room for complex numbers)
                 time_begin(ctx, 5, ctx->stream);
                 qocx::launch_lindblad(la, Bp, ctx->stream);
                 time_end(ctx, ctx->stream);
@@ -2153,8 +2149,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 sc.gstep = la.gsub; sc.row_ptr = gr.row_ptr.p; sc.col_step = gr.col.p;
                 sc.weight = gr.weight.p; sc.grads = lb.grads.p + pos0 * csz;
                 sc.B = Bp; sc.nc = nc; sc.K = K; sc.nsteps = 2 * nsub;
-                sc.lam_scale = two_sided ? la.lam_scale : nullptr;
-                sc.S = S;
+
                 time_begin(ctx, 3, ctx->stream);
                 qocx::launch_scatter(sc, ctx->stream);
                 time_end(ctx, ctx->stream);

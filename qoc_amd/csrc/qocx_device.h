@@ -217,13 +217,12 @@ struct LindbladArgs {
     const double2* inj_bars;   // [B][inj_count][S] C-dumps
     int inj_count;
     unsigned long long* stamps;  // diagnostic build: [B][6 waves][8] cycle sums, or nullptr
-    // Two-sided evaluation (four-wave kernel, ONE final TargetDensityInfidelity, one density): the
-    // cotangent of the final density is a scalar times the target, and the adjoint of the discrete
+    // Two-sided evaluation (several waves per seed, ONE final TargetDensityInfidelity): the
+    // cotangent of a final density is a scalar times its target, and the adjoint of the discrete
     // scheme is linear in it, so it runs on the TARGET beside the forward pass (phase 2 beside
     // phase 1, two launches on two streams) and stores its stage cotangents kbar_i; a third kernel
-    // (lindblad_combine) contracts them with the forward stage values into complex control
-    // cotangents, which the scatter kernel scales (ScatterArgs::lam_scale). phase 0: the classic
-    // forward-then-adjoint launch.
+    // (lindblad_combine) contracts them with the forward stage values and the scalars into the
+    // control cotangents. phase 0: the classic forward-then-adjoint launch.
     int phase = 0;
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out

@@ -860,7 +860,8 @@ struct Wave {
                                                     const Mat& lambda, Mat& lambda_new,
                                                     double (&ga)[QOCX_LINDBLAD_MAX_K],
                                                     double (&gb)[QOCX_LINDBLAD_MAX_K],
-                                                    const double2* ystore = nullptr) const {
+                                                    const double2* ystore = nullptr,
+                                                    double2* kbstore = nullptr) const {
         for (int i = STAGES - 1; i >= 0; --i) {
             // kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j)
             Mat kb;
@@ -878,7 +879,10 @@ struct Wave {
             Mat ybar;
             rhs_split<true>(ybar, kb, ss, (size_t)q * STAGES + i, ci);
             mat_axpy(lambda_new, 1.0, ybar);
-            if (z_wave()) {
+            if (z_wave() && kbstore != nullptr) {
+                // two-sided evaluation: lindblad_combine forms the control cotangents
+                dump_store(kb, kbstore + (size_t)i * MAT);
+            } else if (z_wave()) {
                 // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
                 // Z = Y kbar^H - kbar^H Y
                 Mat y, kbd, z, z2;
@@ -1020,7 +1024,8 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 
     // ---- forward ------------------------------------------------------------------------
     double cost = 0;
-    const int phase = QUARTER ? a.phase : 0;  // 1 / 2: the two launches of the two-sided evaluation
+    // 1 / 2: the two launches of the two-sided evaluation (several waves per seed, n <= 16)
+    const int phase = (MW && LNB == 1 && !GS) ? a.phase : 0;
     for (int q = 0; q < (phase == 2 ? 0 : nsub); ++q) {
         const SubStep ss = a.substeps[q];
         if (ss.first_of_step && lead) {
@@ -1057,17 +1062,19 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         cost += density_costs(a, false, true, dens, nullptr);
         if (lane == 0) a.cost_out[b] = cost;
         if (phase == 1) {
-            // cotangent of the final density = (f zr + i f zi) T, f = -scale / (S n |z|),
-            // z = tr(T^H rho) (density_costs): the scalar the scatter kernel applies
+            // cotangent of final density s = (f zr + i f zi) T_s, f = -scale / (S n |z|),
+            // z = tr(T_s^H rho_s) (density_costs): the scalars lindblad_combine applies
             const DevCost c = a.costs[0];
-            Mat t, rho;
-            dump_load(t, a.cost_matrices + (size_t)c.vec_offset * MAT);
-            dump_load(rho, dens);
-            double zr, zi;
-            frob_inner(t, rho, zr, zi);
-            const double mag = sqrt(zr * zr + zi * zi);
-            const double f = mag > 0 ? -c.scale / ((double)S * a.n * mag) : 0.0;
-            if (lane == 0) a.lam_scale[(size_t)b * S] = make_double2(f * zr, f * zi);
+            for (int s = 0; s < S; ++s) {
+                Mat t, rho;
+                dump_load(t, a.cost_matrices + ((size_t)c.vec_offset + s) * MAT);
+                dump_load(rho, dens + (size_t)s * MAT);
+                double zr, zi;
+                frob_inner(t, rho, zr, zi);
+                const double mag = sqrt(zr * zr + zi * zi);
+                const double f = mag > 0 ? -c.scale / ((double)S * a.n * mag) : 0.0;
+                if (lane == 0) a.lam_scale[(size_t)b * S + s] = make_double2(f * zr, f * zi);
+            }
         }
         for (int s = 0; s < S; ++s) {
             Mat rho;
@@ -1098,10 +1105,12 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         }
         wave_sync();
     };
-    if (lead && phase == 2) {  // lambda = the target
-        Mat t;
-        dump_load(t, a.cost_matrices + (size_t)a.costs[0].vec_offset * MAT);
-        dump_store(t, lam);
+    if (lead && phase == 2) {  // lambda_s = the target of density s
+        for (int s = 0; s < S; ++s) {
+            Mat t;
+            dump_load(t, a.cost_matrices + ((size_t)a.costs[0].vec_offset + s) * MAT);
+            dump_store(t, lam + (size_t)s * MAT);
+        }
         wave_sync();
     } else if (lead) {
         Mat zero;
@@ -1138,7 +1147,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             else if (REG && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.adjoint_substep_reg(ss, lambda, lambda_new, ga, gb, ys);
             else
-                w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys);
+                w.adjoint_substep(ss, q, y0, lambda, lambda_new, ga, gb, ys,
+                                  phase == 2 ? a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
+                                             : nullptr);
             block_sync();  // every wave has read lambda
             if (lead) dump_store(lambda_new, lam + (size_t)s * MAT);
             block_sync();
@@ -1189,20 +1200,22 @@ void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
 
 // Two-sided evaluation, third kernel: one wave per (sub-interval, seed) contracts the forward
 // stage values Y_i with the stage cotangents kbar_i of the unit adjoint into
-//   gamma_k = tr(Z_i Gp_k),  Z_i = Y_i kbar_i^H - kbar_i^H Y_i   (complex; the classic launch keeps
-// its real part), split between the sub-interval's end points with weights (1 - c_i, c_i):
-// gsub[B][nsub][2][K][2]. Throughput work on the whole chip (nsub x B waves).
+//   gamma_k = tr(Z_i Gp_k),  Z_i = Y_i kbar_i^H - kbar_i^H Y_i   (complex: kbar_i belongs to the
+// back-propagated TARGET; the true stage cotangent is c_s kbar_i with the scalar c_s phase 1 left
+// in lam_scale), adds Re(conj(c_s) gamma_k) over stages and densities and splits it between the
+// sub-interval's end points with weights (1 - c_i, c_i): gsub[B][nsub][2][K], as the classic
+// launch writes it. Throughput work on the whole chip (nsub x B waves).
 __global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
     typedef LB<1, false, false> I;
     typedef I::Mat Mat;
     __shared__ __attribute__((aligned(16))) char smem[2 * I::SLOT_BYTES];
     const Slot slot_zk = I::slot_at(smem), slot_zy = I::slot_at(smem + I::SLOT_BYTES);
     const int q = blockIdx.x, b = blockIdx.y, S = a.S, K = a.K, nsub = a.nsub;
-    double gar[QOCX_LINDBLAD_MAX_K], gai[QOCX_LINDBLAD_MAX_K], gbr[QOCX_LINDBLAD_MAX_K],
-        gbi[QOCX_LINDBLAD_MAX_K];
+    double ga[QOCX_LINDBLAD_MAX_K], gb[QOCX_LINDBLAD_MAX_K];
 #pragma unroll
-    for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) gar[k] = gai[k] = gbr[k] = gbi[k] = 0;
+    for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) ga[k] = gb[k] = 0;
     for (int s = 0; s < S; ++s) {
+        const double2 cs = a.lam_scale[(size_t)b * S + s];
         const size_t base = ((((size_t)b * nsub + q) * S + s) * STAGES) * I::MAT;
         for (int i = 0; i < STAGES; ++i) {
             Mat y, kb, kbd, z, z2;
@@ -1230,14 +1243,12 @@ __global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
                     pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
                     pi += z.re[0][0][r] * gt.im[0][0][r] + z.im[0][0][r] * gt.re[0][0][r];
                 }
-                const double gr = wave_sum(pr), gi = wave_sum(pi);
+                const double g = fma(cs.y, wave_sum(pi), cs.x * wave_sum(pr));  // Re(conj(c) gamma)
 #pragma unroll
                 for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
                     if (kk == k) {
-                        gar[kk] += (1.0 - ci) * gr;
-                        gai[kk] += (1.0 - ci) * gi;
-                        gbr[kk] += ci * gr;
-                        gbi[kk] += ci * gi;
+                        ga[kk] += (1.0 - ci) * g;
+                        gb[kk] += ci * g;
                     }
             }
         }
@@ -1246,11 +1257,8 @@ __global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
 #pragma unroll
         for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
             if (kk < K) {
-                double* out = a.gsub + ((((size_t)b * nsub + q) * 2) * K + kk) * 2;
-                out[0] = gar[kk];
-                out[1] = gai[kk];
-                out[(size_t)K * 2] = gbr[kk];
-                out[(size_t)K * 2 + 1] = gbi[kk];
+                a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + kk] = ga[kk];
+                a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + kk] = gb[kk];
             }
 }
 
