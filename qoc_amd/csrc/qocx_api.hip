@@ -1213,11 +1213,20 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             time_end(ctx, st);
             return 0;
         };
-        auto adjoint_segment = [&](int i, hipStream_t st) -> int {
-            sa.j_begin = lo[i]; sa.j_end = lo[i + 1]; sa.phase = 2;
+        auto forward_range = [&](int jb, int je, hipStream_t st) {  // steps [jb, je), no wait
+            sa.j_begin = jb; sa.j_end = je; sa.phase = 1;
             time_begin(ctx, 1, st);
             run_sweep(sa, bc, st);
             time_end(ctx, st);
+        };
+        auto adjoint_range = [&](int jb, int je, hipStream_t st) {
+            sa.j_begin = jb; sa.j_end = je; sa.phase = 2;
+            time_begin(ctx, 1, st);
+            run_sweep(sa, bc, st);
+            time_end(ctx, st);
+        };
+        auto adjoint_segment = [&](int i, hipStream_t st) -> int {
+            adjoint_range(lo[i], lo[i + 1], st);
             HIP_TRY(hipEventRecord(ctx->ev_swept[i], st));
             return 0;
         };
@@ -1241,13 +1250,13 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             ka.mbar_rm = want_grad ? ctx->genbar_rm.p + (size_t)b0 * nsteps * mat : nullptr;
         }
         ka.skew = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
-        auto krylov_segment = [&](int i) -> int {
-            const int len = lo[i + 1] - lo[i];
-            ka.step0 = lo[i];
+        auto krylov_range = [&](int jb, int je) -> int {
+            const int len = je - jb;
+            ka.step0 = jb;
             time_begin(ctx, 2, cs);
             if (!(dbg_skip & 4)) qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
             if (nodes > 1) {
-                ma.step0 = lo[i]; ma.seg_len = len; ma.total = (size_t)bc * len;
+                ma.step0 = jb; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
                 qocx::launch_magnus_vjp(ctx->nb, ma,
                                         (int)std::min<size_t>(ma.total, magnus_blocks), cs);
@@ -1255,6 +1264,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             time_end(ctx, cs);
             return 0;
         };
+        auto krylov_segment = [&](int i) -> int { return krylov_range(lo[i], lo[i + 1]); };
 #define QOCX_STEP(call)            \
     do {                           \
         const int rc_ = (call);    \
@@ -1264,6 +1274,18 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             hipStream_t sf = ctx->sweep_streams[0], sb = ctx->sweep_streams[1];
             // factor from both ends towards the middle; each sweep takes a segment as soon as it
             // is factored AND the sweep has finished the one before it (stream order)
+            // The sweeps and K3 may work in PIECES of a segment (knob "k3_split"), so that what is
+            // left of K3 once the sweeps have finished is a piece, not a segment.  Measured at
+            // configs[1]: 1 piece 12.86 ms, 2 -> 13.00, 3 -> 13.19, 4 -> 13.55 (every launch
+            // refills its pipeline), so the default is whole segments.
+            const int parts = (int)std::max<int64_t>(
+                1, std::min<int64_t>(ctx->knob("k3_split", 1), (int64_t)ctx->ev_fwd.size() / nseg));
+            const int P = nseg * parts;
+            auto piece_lo = [&](int p) {
+                const int i = p / parts, part = p % parts;
+                return lo[i] + (int)((int64_t)(lo[i + 1] - lo[i]) * part / parts);
+            };
+            auto piece_hi = [&](int p) { return (p % parts == parts - 1) ? lo[p / parts + 1] : piece_lo(p + 1); };
             std::vector<char> factored(nseg, 0);
             int next_f = 0, next_b = nseg - 1;
             for (int t = 0; t < nseg; ++t) {
@@ -1271,28 +1293,37 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 QOCX_STEP(factor_segment(i));
                 factored[i] = 1;
                 while (next_f < nseg && factored[next_f]) {
-                    QOCX_STEP(forward_segment(next_f, sf));
-                    HIP_TRY(hipEventRecord(ctx->ev_fwd[next_f], sf));
+                    HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_factored[next_f], 0));
+                    for (int part = 0; part < parts; ++part) {
+                        const int p = next_f * parts + part;
+                        if (piece_hi(p) > piece_lo(p)) forward_range(piece_lo(p), piece_hi(p), sf);
+                        HIP_TRY(hipEventRecord(ctx->ev_fwd[p], sf));
+                    }
                     ++next_f;
                 }
                 while (next_b >= 0 && factored[next_b]) {
                     HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_factored[next_b], 0));
-                    QOCX_STEP(adjoint_segment(next_b, sb));
+                    for (int part = parts - 1; part >= 0; --part) {
+                        const int p = next_b * parts + part;
+                        if (piece_hi(p) > piece_lo(p)) adjoint_range(piece_lo(p), piece_hi(p), sb);
+                        HIP_TRY(hipEventRecord(ctx->ev_swept[p], sb));
+                    }
                     --next_b;
                 }
             }
-            // K3 from the middle outwards: segment i is complete once the forward sweep (going
-            // up) and the adjoint sweep (going down) have both crossed it
+            // K3 from the middle outwards: a piece is complete once the forward sweep (going up)
+            // and the adjoint sweep (going down) have both crossed it
             std::vector<int> order;
-            for (int d = 0; d < nseg; ++d) {
-                const int up = nseg / 2 + d, down = nseg / 2 - 1 - d;
-                if (up < nseg) order.push_back(up);
+            for (int d = 0; d < P; ++d) {
+                const int up = P / 2 + d, down = P / 2 - 1 - d;
+                if (up < P) order.push_back(up);
                 if (down >= 0) order.push_back(down);
             }
-            for (int i : order) {
-                HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_fwd[i], 0));
-                HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[i], 0));
-                QOCX_STEP(krylov_segment(i));
+            for (int p : order) {
+                if (piece_hi(p) <= piece_lo(p)) continue;
+                HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_fwd[p], 0));
+                HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[p], 0));
+                QOCX_STEP(krylov_range(piece_lo(p), piece_hi(p)));
             }
         } else {
             // ---- factor + forward sweep, segment by segment --------------------------------
@@ -2199,7 +2230,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit"};
+                                  "lindblad_side_limit", "k3_split"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
