@@ -217,6 +217,11 @@ struct qocx_ctx {
     int cu_count = 256;
     int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
+    // M4 with time-independent H0 / G_k as a linear problem in Ke effective controls (M4LinArgs)
+    int m4lin_Ke = 0;  // 0: not available for this problem
+    DevBuf<double2> ge_cimg, ge_rimg, ge_timg;
+    DevBuf<qocx::StepInterp> interp_id;
+    DevBuf<double> veff, gnode;
     // explicit-generator mode (qocx_upload_generators): opaque Hamiltonians sampled by the host
     bool explicit_mode = false;
     int explicit_hermitian = 0;
@@ -531,6 +536,8 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->magnus_scratch.release();
     ctx->lam_scale.release();
     ctx->offs_x.release();
+    ctx->ge_cimg.release(); ctx->ge_rimg.release(); ctx->ge_timg.release();
+    ctx->interp_id.release(); ctx->veff.release(); ctx->gnode.release();
     ctx->opt_m.release(); ctx->opt_v.release(); ctx->opt_best_controls.release();
     ctx->opt_max_norms.release(); ctx->opt_best_final.release(); ctx->opt_flags.release();
     ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
@@ -671,6 +678,63 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
             }
         DevBuf<double2>& dst = pass == 0 ? ctx->g_cimg : (pass == 1 ? ctx->g_rimg : ctx->g_timg);
         if (dst.upload(gimg, ctx->stream)) return QOCX_ERR_HIP;
+    }
+
+    // M4, time-independent H0 / G_k: the commutators leave the time loop (M4LinArgs). Constant
+    // matrices G_k, A_k = -i [G_k, H0], B_kl = -i [G_k, G_l] (k < l); Hermitian when H0 and the
+    // G_k are (made so bit for bit, the Hermitian kernel forms rely on it).
+    ctx->m4lin_Ke = 0;
+    if (nodes == 2 && nt == 1 && K >= 1 && K <= QOCX_M4LIN_MAX_K) {
+        const int Ke = 2 * K + K * (K - 1) / 2;
+        const size_t nn = (size_t)n * n;
+        std::vector<double> ge((size_t)Ke * nn * 2);
+        std::copy(p->g, p->g + (size_t)K * nn * 2, ge.begin());
+        auto neg_i_commutator = [&](const double* x, const double* y, double* out) {
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) {
+                    double re = 0, im = 0;  // (x y - y x)[r][c]
+                    for (int q = 0; q < n; ++q) {
+                        const double* xa = x + 2 * ((size_t)r * n + q);
+                        const double* yb = y + 2 * ((size_t)q * n + c);
+                        const double* ya = y + 2 * ((size_t)r * n + q);
+                        const double* xb = x + 2 * ((size_t)q * n + c);
+                        re += xa[0] * yb[0] - xa[1] * yb[1] - (ya[0] * xb[0] - ya[1] * xb[1]);
+                        im += xa[0] * yb[1] + xa[1] * yb[0] - (ya[0] * xb[1] + ya[1] * xb[0]);
+                    }
+                    out[2 * ((size_t)r * n + c)] = im;       // -i (re + i im) = im - i re
+                    out[2 * ((size_t)r * n + c) + 1] = -re;
+                }
+            if (ctx->hermitian)
+                for (int r = 0; r < n; ++r)
+                    for (int c = r; c < n; ++c) {
+                        double* a = out + 2 * ((size_t)r * n + c);
+                        double* b = out + 2 * ((size_t)c * n + r);
+                        const double re = 0.5 * (a[0] + b[0]), im = (r == c) ? 0.0 : 0.5 * (a[1] - b[1]);
+                        a[0] = re; a[1] = im;
+                        b[0] = re; b[1] = -im;
+                    }
+        };
+        for (int k = 0; k < K; ++k)
+            neg_i_commutator(p->g + (size_t)k * nn * 2, p->h0, ge.data() + (size_t)(K + k) * nn * 2);
+        int e = 2 * K;
+        for (int k = 0; k < K; ++k)
+            for (int l = k + 1; l < K; ++l, ++e)
+                neg_i_commutator(p->g + (size_t)k * nn * 2, p->g + (size_t)l * nn * 2,
+                                 ge.data() + (size_t)e * nn * 2);
+        std::vector<double2> eimg((size_t)Ke * mat);
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int k = 0; k < Ke; ++k) {
+                const double* m = ge.data() + (size_t)k * nn * 2;
+                if (pass == 0) c_image(m, n, nb, eimg.data() + (size_t)k * mat);
+                else r_image(m, n, np, pass == 2, eimg.data() + (size_t)k * mat);
+            }
+            DevBuf<double2>& dst = pass == 0 ? ctx->ge_cimg : (pass == 1 ? ctx->ge_rimg : ctx->ge_timg);
+            if (dst.upload(eimg, ctx->stream)) return QOCX_ERR_HIP;
+        }
+        std::vector<qocx::StepInterp> ident(nsteps);
+        for (int j = 0; j < nsteps; ++j) ident[j] = qocx::StepInterp{j, j, 1.0, 0.0};
+        if (ctx->interp_id.upload(ident, ctx->stream)) return QOCX_ERR_HIP;
+        ctx->m4lin_Ke = Ke;
     }
 
     // initial states, padded
@@ -983,8 +1047,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // steps: 1.1 against 2.1 / 1.8 ms (profiles/r03_latency.jsonl) - so it takes precedence
     // over "sweep_impl" = 3 there.
     const bool latency = ctx->knob("latency", 0) != 0;
+    // M4 on the M2 kernels (M4LinArgs): the kernels see Ke controls given per step and one node
+    const bool m4lin = ctx->m4lin_Ke > 0 && ctx->nodes == 2 && !explicit_gen && ctx->knob("m4_linear", 1);
+    const int Kk = m4lin ? ctx->m4lin_Ke : K;  // controls as K1a / K3 see them
     const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen &&
-                           ctx->nodes == 1 && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
+                           (ctx->nodes == 1 || m4lin) && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
     const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 &&
                             S <= qocx::sweep3_max_states(ctx->nb) && !(latency && unit_core);
     const bool unit = unit_core && !sweep3_sel;
@@ -993,9 +1060,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // chunk size from the memory budget
     const size_t per_seed = (size_t)nsteps * ((size_t)mat * 32 + (size_t)np * 20 + 4) +
                             ctx->slot_cap * S * np * 32 + (size_t)(nsteps + 1) * 4 +
-                            (size_t)nsteps * ctx->nodes * std::max(K, 1) * 8 +
+                            (size_t)nsteps * ctx->nodes * std::max(Kk, 1) * 24 +
                             (ctx->nodes > 1 ? (size_t)nsteps * mat * 32 : 0);
-    const int nodes = ctx->nodes;
+    const int nodes = m4lin ? 1 : ctx->nodes;  // nodes of the generator kernels
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1012,7 +1079,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
         ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
         ctx->offs.ensure((size_t)chunk * (nsteps + 1)) ||
-        ctx->gstep.ensure(cm * nodes * std::max(K, 1) * (unit ? 2 : 1)) || ctx->cost_out.ensure(B) ||
+        ctx->gstep.ensure(cm * nodes * std::max(Kk, 1) * (unit ? 2 : 1)) || ctx->cost_out.ensure(B) ||
+        (m4lin && (ctx->veff.ensure(cm * Kk) || ctx->gnode.ensure(want_grad ? cm * 2 * K : 1))) ||
         (unit && ctx->offs_x.ensure((size_t)chunk * (nsteps + 1))) ||
         ctx->grads.ensure((size_t)B * ctx->nc * std::max(K, 1)) ||
         ctx->final_out.ensure((size_t)B * S * np))
@@ -1086,6 +1154,20 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.h0_cimg = ctx->h0_cimg.p;
         fa.g_cimg = ctx->g_cimg.p;
         fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+        qocx::M4LinArgs m4;
+        if (m4lin) {
+            m4.controls = fa.controls; m4.interp = ctx->interp.p;
+            m4.K = K; m4.Ke = Kk; m4.nc = ctx->nc; m4.nsteps = nsteps; m4.S = S;
+            m4.f0dt = (std::sqrt(3.0) / 12) * ctx->dt;
+            m4.veff = ctx->veff.p; m4.gstep = ctx->gstep.p; m4.gnode = ctx->gnode.p;
+            m4.lam_scale = unit ? ctx->lam_scale.p + (size_t)b0 * S : nullptr;
+            m4.total = (size_t)bc * nsteps;
+            time_begin(ctx, 0, cs);
+            qocx::launch_m4lin_controls(m4, cs);
+            time_end(ctx, cs);
+            fa.controls = ctx->veff.p; fa.interp = ctx->interp_id.p; fa.g_cimg = ctx->ge_cimg.p;
+            fa.K = Kk; fa.nc = nsteps;
+        }
         fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
         fa.n = ctx->n;
         fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
@@ -1232,10 +1314,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         };
         qocx::KrylovArgs ka;
         ka.controls = fa.controls;
-        ka.interp = ctx->interp.p;
+        ka.interp = fa.interp;
         ka.h0_rimg = ctx->h0_rimg.p; ka.h0_timg = ctx->h0_timg.p;
-        ka.g_rimg = ctx->g_rimg.p; ka.g_timg = ctx->g_timg.p;
-        ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
+        ka.g_rimg = m4lin ? ctx->ge_rimg.p : ctx->g_rimg.p;
+        ka.g_timg = m4lin ? ctx->ge_timg.p : ctx->g_timg.p;
+        ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
         ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
         ka.offs = ctx->offs.p;
         ka.offs_x = unit ? ctx->offs_x.p : nullptr;
@@ -1354,10 +1437,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
             sc.weight = ctx->weight.p;
             sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
-            sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * nodes;
+            sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * ctx->nodes;
             sc.lam_scale = unit ? ctx->lam_scale.p + (size_t)b0 * S : nullptr;
             sc.S = S;
             time_begin(ctx, 3, cs);
+            if (m4lin) {  // effective-control cotangents -> node cotangents (applies the scalar)
+                qocx::launch_m4lin_chain(m4, cs);
+                sc.gstep = ctx->gnode.p;
+                sc.lam_scale = nullptr;
+            }
             qocx::launch_scatter(sc, cs);
             time_end(ctx, cs);
         }
@@ -2230,7 +2318,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

@@ -157,6 +157,26 @@ struct MagnusArgs {
     size_t total;              // B * seg_len work items
 };
 
+// Magnus M4 with time-independent H0, G_k ("commutator-free" form, qocx_magnus.hip): the step
+// generator is LINEAR in effective controls with constant matrices,
+//   m4 = -i dt (H0 + sum_k v_k G_k + sum_k w_k A_k + sum_{k<l} z_kl B_kl),
+//   A_k = -i [G_k, H0], B_kl = -i [G_k, G_l],
+//   v_k = (u1_k + u2_k) / 2, w_k = F0 dt (u2_k - u1_k), z_kl = F0 dt (u2_k u1_l - u2_l u1_k)
+// with u1, u2 the controls at the two quadrature nodes, so the M2 kernels run it unchanged on
+// Ke = 2 K + K (K - 1) / 2 effective controls given per step.
+#define QOCX_M4LIN_MAX_K 8
+struct M4LinArgs {
+    const double* controls;    // [B][nc][K]
+    const StepInterp* interp;  // [nsteps * 2]
+    int K, Ke, nc, nsteps, S;
+    double f0dt;               // F0 * dt
+    double* veff;              // controls kernel out: [B][nsteps][Ke]
+    const double* gstep;       // chain kernel in: [B][nsteps][Ke] (x 2: complex, unit adjoint)
+    const double2* lam_scale;  // unit adjoint: [B][S] (see ScatterArgs), or nullptr
+    double* gnode;             // chain kernel out: [B][nsteps * 2][K]
+    size_t total;              // B * nsteps
+};
+
 struct ScatterArgs {
     const double* gstep;
     const int* row_ptr;   // [nc+1]
@@ -278,6 +298,8 @@ void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 size_t magnus_scratch_elems(int nb, int blocks);
+void launch_m4lin_controls(const M4LinArgs& a, hipStream_t st);
+void launch_m4lin_chain(const M4LinArgs& a, hipStream_t st);
 void launch_selftest(double* out, hipStream_t st);
 
 }  // namespace qocx

@@ -607,6 +607,75 @@ static void launch_vjp_t(const MagnusArgs& a, int blocks, hipStream_t st) {
                            st, a);
 }
 
+// ---- M4, time-independent H0 / G_k: effective controls and their chain rule (M4LinArgs) -------
+// One thread per (seed, step). mathmethods.py:96-122 with a(t) = -i (H0 + sum u_k(t) G_k).
+__global__ __launch_bounds__(256) void m4lin_controls_kernel(M4LinArgs args) {
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= args.total) return;
+    const int step = (int)(w % args.nsteps), K = args.K;
+    const size_t b = w / args.nsteps;
+    const double* ctl_b = args.controls + b * args.nc * K;
+    const StepInterp s1 = args.interp[(size_t)step * 2], s2 = args.interp[(size_t)step * 2 + 1];
+    double u1[QOCX_M4LIN_MAX_K], u2[QOCX_M4LIN_MAX_K];
+    double* v = args.veff + w * args.Ke;
+    for (int k = 0; k < K; ++k) {
+        u1[k] = control_at(ctl_b, s1, K, k);
+        u2[k] = control_at(ctl_b, s2, K, k);
+        v[k] = 0.5 * (u1[k] + u2[k]);
+        v[K + k] = args.f0dt * (u2[k] - u1[k]);
+    }
+    int e = 2 * K;
+    for (int k = 0; k < K; ++k)
+        for (int l = k + 1; l < K; ++l) v[e++] = args.f0dt * (u2[k] * u1[l] - u2[l] * u1[k]);
+}
+
+__global__ __launch_bounds__(256) void m4lin_chain_kernel(M4LinArgs args) {
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= args.total) return;
+    const int step = (int)(w % args.nsteps), K = args.K, Ke = args.Ke;
+    const size_t b = w / args.nsteps;
+    const double* ctl_b = args.controls + b * args.nc * K;
+    const StepInterp s1 = args.interp[(size_t)step * 2], s2 = args.interp[(size_t)step * 2 + 1];
+    double u1[QOCX_M4LIN_MAX_K], u2[QOCX_M4LIN_MAX_K], g1[QOCX_M4LIN_MAX_K], g2[QOCX_M4LIN_MAX_K];
+    // cotangent of effective control e
+    auto ge = [&](int e) -> double {
+        if (args.lam_scale != nullptr) {  // unit adjoint: Re(conj(c) gamma), as scatter_kernel
+            const double2 c = args.lam_scale[b * args.S];
+            const double* g = args.gstep + (w * Ke + e) * 2;
+            return fma(c.y, g[1], c.x * g[0]);
+        }
+        return args.gstep[w * Ke + e];
+    };
+    for (int k = 0; k < K; ++k) {
+        u1[k] = control_at(ctl_b, s1, K, k);
+        u2[k] = control_at(ctl_b, s2, K, k);
+        const double gv = ge(k), gw = ge(K + k);
+        g1[k] = 0.5 * gv - args.f0dt * gw;
+        g2[k] = 0.5 * gv + args.f0dt * gw;
+    }
+    int e = 2 * K;
+    for (int k = 0; k < K; ++k)
+        for (int l = k + 1; l < K; ++l) {
+            const double gz = args.f0dt * ge(e++);  // z = F0 dt (u2_k u1_l - u2_l u1_k)
+            g1[l] += gz * u2[k];
+            g1[k] -= gz * u2[l];
+            g2[k] += gz * u1[l];
+            g2[l] -= gz * u1[k];
+        }
+    double* out = args.gnode + (b * (size_t)args.nsteps * 2 + (size_t)step * 2) * K;
+    for (int k = 0; k < K; ++k) {
+        out[k] = g1[k];
+        out[K + k] = g2[k];
+    }
+}
+
+void launch_m4lin_controls(const M4LinArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(m4lin_controls_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_m4lin_chain(const M4LinArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(m4lin_chain_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+}
+
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st) {
     if (nb == 1) launch_fwd_t<1>(a, blocks, st);
     else if (nb == 2) launch_fwd_t<2>(a, blocks, st);

@@ -167,6 +167,61 @@ def test_unit_adjoint_and_two_sided_pipeline(engine, name):
         engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("n,K,herm", [(20, 3, True), (12, 2, True), (24, 2, False), (40, 3, True)])
+def test_m4_commutator_free_form(engine, n, K, herm):
+    """
+    MagnusPolicy.M4 with time-independent H0, G_k: the commutators [G_k, H0], [G_k, G_l] are
+    constant matrices, so the M4 generator is linear in 2 K + K (K - 1) / 2 effective controls
+    and runs on the M2 kernels (qocx_device.h M4LinArgs; knob "m4_linear"). Same numbers as the
+    Magnus kernels of qocx_magnus.hip (reference mathmethods.py:96-122) to rounding, same numbers
+    as the oracle at the parity tolerances, and - being a property of the problem - bit-identical
+    across batch chunks and time segments.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_random("m4lin_n%d" % n, n=n, N=13, seeds=3, h_seed=7300 + n, S=2, K=K,
+                                 Nc=7, dt=0.4, magnus="M4", sigma=1.0, full_unitary=True)
+    case.h0 = case.h0 * 3.0
+    if not herm:
+        rng = np.random.default_rng(77)
+        case.h0 = case.h0 - 0.1j * np.diag(rng.uniform(0, 1, n))
+    gh.setup_engine(engine, case)
+    u = gh.real_controls(case, case.controls)
+    try:
+        engine.set_knob("m4_linear", 0)
+        kernels = engine.evaluate(u, True)
+        engine.set_knob("m4_linear", 1)
+        linear = engine.evaluate(u, True)
+        assert np.max(np.abs(kernels[0] - linear[0])) <= 1e-12
+        assert rel_err(linear[2], kernels[2]) <= 1e-12
+        assert np.max(np.abs(kernels[1] - linear[1])) <= 1e-11 * np.max(np.abs(kernels[1]))
+        engine.set_knob("unit_adjoint", 0)
+        classic = engine.evaluate(u, True)
+        assert np.array_equal(classic[0], linear[0])
+        assert np.max(np.abs(classic[1] - linear[1])) <= 1e-12 * np.max(np.abs(classic[1]))
+        engine.set_knob("unit_adjoint", 1)
+        for chunk, pipe in ((1, 3), (2, 4), (0, 6)):
+            engine.set_chunk(chunk)
+            engine.set_pipeline(pipe)
+            out = engine.evaluate(u, True)
+            for a, b in zip(linear, out):
+                assert np.array_equal(a, b), (chunk, pipe)
+        h0, g = np.asarray(case.h0), [np.asarray(m) for m in case.g_re]
+        problem = onp.SchroedingerProblem(
+            case.T, lambda uu, t: h0 + sum(uu[k] * g[k] for k in range(K)), case.initial_states,
+            case.N, control_eval_count=case.Nc, magnus_policy="M4", control_count=K,
+            costs=[onp.TargetStateInfidelity(case.cost_specs[0][1]["target_states"])])
+        for b in range(len(u)):
+            err, gr, fin = onp.evaluate_with_grad(problem, u[b])
+            assert abs(err - linear[0][b]) <= 1e-10
+            assert rel_err(linear[2][b], fin[:, :, 0]) <= 1e-10
+            assert np.max(np.abs(gr - linear[1][b])) <= 1e-8 * np.max(np.abs(gr))
+    finally:
+        engine.set_knob("m4_linear", 1)
+        engine.set_knob("unit_adjoint", 1)
+        engine.set_chunk(0)
+        engine.set_pipeline(0)
+
+
 def test_error_paths(engine):
     """The C ABI reports misuse and numerical trouble loudly (include/qocx.h error codes)."""
     from qoc_amd.engine import Engine, QocxError
