@@ -236,11 +236,11 @@ class SchroedingerEvaluator(object):
     def resident_capable(self):
         """True when a multi-start driver may keep controls and optimizer states on the device
         (engine.opt_*): structured Hamiltonian, real controls, every cost evaluated on the device,
-        MagnusPolicy.M2, and a backend that has the entry points (the real engine)."""
+        and a backend that has the entry points (the real engine)."""
         return (self.opaque_hamiltonian is None and self.linearized_hamiltonian is None
                 and not self.complex_controls
                 and self.control_count > 0 and not self.host_costs and not self.opaque_costs
-                and self.magnus_policy == MagnusPolicy.M2 and hasattr(self.backend, "opt_step"))
+                and hasattr(self.backend, "opt_step"))
 
     def evaluate_batch(self, controls_batch, want_grad=True, want_step_states=False):
         """

@@ -853,6 +853,23 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     return 0;
 }
 
+}  // extern "C"
+
+// 1-norm bound of the step generator from the bound b >= ||dt a(t)|| of its node generators
+// (mathmethods.py:96-164: m2 = b; m4 = dt/2 (a1 + a2) + sqrt(3)/12 dt^2 [a2, a1]; m6)
+static double magnus_norm_bound(int nodes, double bound) {
+    if (nodes == 2) return bound + (std::sqrt(3.0) / 12) * 2 * bound * bound;
+    if (nodes == 3) {
+        const double b1 = bound, b2 = (std::sqrt(15.0) / 3) * 2 * bound, b3 = (10.0 / 3) * 4 * bound;
+        const double c12 = 2 * b1 * b2, x = 20 * b1 + b3 + c12, w = 2 * b3 + c12;
+        const double y = b2 + (1.0 / 60) * 2 * b1 * w;
+        return b1 + 0.5 * b3 + (1.0 / 240) * 2 * x * y;
+    }
+    return bound;
+}
+
+extern "C" {
+
 int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
     if (!ctx->has_problem) return fail(QOCX_ERR_STATE, "no problem set");
@@ -893,16 +910,7 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
         HIP_TRY(hipMemcpyAsync(ctx->controls.p, stage, total * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
     }
-    bound *= fabs(ctx->dt);
-    if (ctx->nodes == 2) {
-        // ||dt/2 (a1+a2) + sqrt(3)/12 dt^2 [a2,a1]||
-        bound = bound + (std::sqrt(3.0) / 12) * 2 * bound * bound;
-    } else if (ctx->nodes == 3) {
-        const double b1 = bound, b2 = (std::sqrt(15.0) / 3) * 2 * bound, b3 = (10.0 / 3) * 4 * bound;
-        const double c12 = 2 * b1 * b2, x = 20 * b1 + b3 + c12, w = 2 * b3 + c12;
-        const double y = b2 + (1.0 / 60) * 2 * b1 * w;
-        bound = b1 + 0.5 * b3 + (1.0 / 240) * 2 * x * y;
-    }
+    bound = magnus_norm_bound(ctx->nodes, bound * fabs(ctx->dt));
     if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or Hamiltonian");
     ctx->sbound = pade_scale_count(bound);
     if (ctx->sbound > 10)
@@ -2476,8 +2484,7 @@ int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms) {
         if (!(max_norms[k] >= 0)) return fail(QOCX_ERR_ARG, "max_norms must be non-negative");
         bound += max_norms[k] * ctx->g_norm_max[k];
     }
-    bound *= fabs(ctx->dt);
-    if (ctx->nodes != 1) return fail(QOCX_ERR_STATE, "device-resident optimizer: MagnusPolicy.M2 only");
+    bound = magnus_norm_bound(ctx->nodes, bound * fabs(ctx->dt));
     if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite bound");
     const int sb = pade_scale_count(bound);
     if (sb > 10)

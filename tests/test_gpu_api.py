@@ -184,7 +184,7 @@ def test_batch_grape_on_gpu_equals_eight_single_seed_runs():
 @pytest.mark.parametrize("make", [
     lambda cls: cls(learning_rate=5e-2, clip_grads=0.3),
     lambda cls: cls(learning_rate=8e-2, learning_rate_decay=2.5, beta_1=0.8),
-    "sgd"])
+    "sgd", "adam_M4"])
 def test_device_resident_optimizer_equals_host_plugins(make):
     """with the built-in Adam / SGD, real controls and device costs the
     multi-start driver keeps controls, gradients, moments and the best so far in HBM (qocx_opt_*:
@@ -199,6 +199,9 @@ def test_device_resident_optimizer_equals_host_plugins(make):
     args = (case.K, case.Nc, product_cost_list(case), case.T, case.hamiltonian(),
             case.initial_states, case.N)
     kw = dict(iteration_count=5, log_iteration_step=0, max_control_norms=np.full(case.K, 1.0))
+    if make == "adam_M4":  # any Magnus policy: the optimizer kernels only see costs and gradients
+        kw["magnus_policy"] = MagnusPolicy.M4
+        make = lambda cls: cls(learning_rate=5e-2)
 
     class PluginAdam(Adam):
         pass
