@@ -1179,6 +1179,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
         fa.n = ctx->n;
         fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
+        fa.pade_policy = (int)ctx->knob("pade_order", 0);  // 0: by norm (qocx_wave.h), 13: always 13
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)
@@ -2326,7 +2327,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
@@ -2634,6 +2635,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     memset(&fa, 0, sizeof(fa));
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
     fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
+    fa.pade_policy = (int)ctx->knob("pade_order", 0);
     const bool fused_lu = nb == 2 && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 0) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;

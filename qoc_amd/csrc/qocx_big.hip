@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsteps = args.nsteps, S = args.S, K = args.K;
     const size_t m = (size_t)b * nsteps + step;
-    const int sq = min(max(args.s_arr[m], 0), 30);
+    const int sq = step_squarings(args.s_arr[m]);
     const double dts = args.dt * ldexp(1.0, -sq);
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * K;

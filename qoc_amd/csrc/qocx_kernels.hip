@@ -988,7 +988,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     if (do_fwd) {
         if (fetcher) issue_dma(m0 + jb, 0, false);
         if (LOADER && fetcher && jb + 1 < je) issue_dma(m0 + jb + 1, 1, false);
-        int nsub_next = 1 << min(max(args.s_arr[m0 + jb], 0), 30);
+        int nsub_next = 1 << step_squarings(args.s_arr[m0 + jb]);
         for (int step = jb; step < je; ++step) {
             const int par = (step - jb) % NBUF;
             const int nsub = nsub_next;
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 pf_due = fetcher && (step + 1 < je) && !(args.dbg & 256);  // (dbg: timing experiment)
                 if (pf_due) set_prefetch(m0 + step + 1, (par + 1) % NBUF, false, m0 + step + 1);
             }
-            if (step + 1 < je) nsub_next = 1 << min(max(args.s_arr[m0 + step + 1], 0), 30);
+            if (step + 1 < je) nsub_next = 1 << step_squarings(args.s_arr[m0 + step + 1]);
             before_step(step);
             forward_step(sc, nsub);
             if (overflow) break;
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
         if constexpr (ONEBUF) issue_lu_only(ml, true);
         else if (fetcher) issue_dma(ml, 0, true);
         if (LOADER && fetcher && je - 2 >= jb) issue_dma(ml - 1, 1, true);
-        int nsub_next = 1 << min(max(args.s_arr[ml], 0), 30);
+        int nsub_next = 1 << step_squarings(args.s_arr[ml]);
         for (int step = je - 1, it = 0; step >= jb; --step, ++it) {
             const int par = it % NBUF;
             const int nsub = nsub_next;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 pf_due = fetcher && (step - 1 >= jb);
                 if (pf_due) set_prefetch(m0 + step - 1, par ^ 1, true, m0 + step - 1);
             }
-            if (step - 1 >= jb) nsub_next = 1 << min(max(args.s_arr[m0 + step - 1], 0), 30);
+            if (step - 1 >= jb) nsub_next = 1 << step_squarings(args.s_arr[m0 + step - 1]);
             adjoint_step(sc, nsub, step);
             if (overflow) break;
         }
@@ -1254,7 +1254,8 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
     const int nsteps = args.nsteps, S = args.S, K = args.K;
     const size_t m = (size_t)b * nsteps + step;
-    const int sq = min(max(args.s_arr[m], 0), 30);
+    const int sq = step_squarings(args.s_arr[m]);
+    const int order = step_order(args.s_arr[m]);
     const double dts = args.dt * ldexp(1.0, -sq);
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * K;
@@ -1330,17 +1331,25 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     // w_i = sigma (i odd) or delta (i even) - one matvec per rho instead of the two chains
     // a^j sigma, a^j delta - and, as each rho_i appears, the rank-1 update abar += tau_i rho_i^H.
     // The matvec a rho_i and the rank-1 update read the same LDS broadcast of rho_i.
-    auto chains = [&](const double (&are)[CPL], const double (&aim)[CPL], const double (&hre)[HC],
-                      const double (&him)[HC], double2 x, double2 p0, double2 p1,
-                      double (&abr)[CPL], double (&abi)[CPL]) __attribute__((always_inline)) {
+    // M: the Pade order K1a chose for this step (qocx_wave.h): chains of M terms, rho_{M-1} =
+    // b_M sigma (M is odd), coefficients of the [M/M] approximant.
+    // (Registers decide this kernel - three waves per SIMD at 168. A copy of the unrolled chains per
+    // order costs 90 more, rolled loops with M as a run-time bound 60 more; so ONE unrolled copy
+    // for order 13 whose iterations beyond M are skipped by wave-uniform branches.)
+    const int M = order;
+    const double* bt = pade_table(order);
+    auto chains = [&](const double (&are)[CPL], const double (&aim)[CPL],
+                      const double (&hre)[HC], const double (&him)[HC], double2 x, double2 p0,
+                      double2 p1, double (&abr)[CPL], double (&abi)[CPL]) __attribute__((always_inline)) {
         const double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
         const double dlr = p0.x - p1.x, dli = p0.y - p1.y;
         double tar = x.x, tai = x.y;
 #pragma unroll
         for (int jj = 0; jj < 13; ++jj) {
+            if (jj >= M) break;
             // (every lane group holds the same sums: all of them store, no exec-mask branch)
             tau_l[jj * NP + i] = make_double2(tar, tai);
-            if (jj < 12) {
+            if (jj < M - 1) {
                 wave_sync();
                 double s2r = 0, s2i = 0;
 #pragma unroll
@@ -1359,9 +1368,10 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                 tai = sum_groups<NB>(s2i);
             }
         }
-        double rr = PADE_B[13] * sgr, ri = PADE_B[13] * sgi;
+        double rr = bt[M] * sgr, ri = bt[M] * sgi;
 #pragma unroll
         for (int ii = 12; ii >= 0; --ii) {
+            if (ii >= M) continue;
             double2* slot = vv + (ii & 1) * NP;  // two slots in turn: one sync per step
             slot[i] = make_double2(rr, ri);
             wave_sync();
@@ -1380,7 +1390,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                 column_fence<NB>(cc);
             }
             if (ii > 0) {
-                const double coef = PADE_B[ii];
+                const double coef = bt[ii];
                 rr = fma(coef, (ii & 1) ? sgr : dlr, sum_groups<NB>(s0r));
                 ri = fma(coef, (ii & 1) ? sgi : dli, sum_groups<NB>(s0i));
             }

@@ -140,6 +140,7 @@ __device__ __forceinline__ void acc_finish(Col& c, const Acc3& a) {
 }
 
 struct Out {
+    int pade_policy;  // FactorArgs::pade_policy
     double2* q_img;
     double2* p_img;
     int* s_out;
@@ -235,14 +236,92 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             a.im[ti] *= scale;
         }
     }
-    if (W == 0 && lane == 0) *out.s_out = sq;
+    // Pade order from the upper bound of the norm (qocx_wave.h); both waves read the same numbers
+    const int order = bad ? 13 : pade_order_for(fmax(nrm[0], nrm[1]), out.pade_policy);
+    if (W == 0 && lane == 0) *out.s_out = step_entry(sq, order);
     stage_tile(sl, 0, W, a.re[0], a.im[0]);
     stage_tile(sl, 1, W, a.re[1], a.im[1]);
     __syncthreads();  // 2
 
+    Col u, v;
+    Acc3 acc;
+    if (order != 13) {
+        // ---- orders 3, 5, 7, 9 (Higham 2005, (10.33); the reference's pade3..pade9 have this
+        // shape, expm.py:119-150): x2 = a a, x4 = x2 x2, x6 = x2 x4, x8 = x2 x6 with x2 as the A
+        // operand throughout; w = sum b_{2j+1} x_{2j}, v = sum b_{2j} x_{2j} + b0 I, u = w a + b1 a.
+        // sq = 0 here (the norm is below theta_9). The finished products leave the registers as
+        // soon as they have gone into w and v and served as the next B operand.
+        const double* bt = pade_table(order);
+        Col w, x, y;
+        acc_zero<NT>(acc);
+        gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+            bre = a.re[kk >> 2][kk & 3];
+            bim = a.im[kk >> 2][kk & 3];
+        });
+        acc_finish<NT>(x, acc);  // x2
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            w.re[ti] = bt[3] * x.re[ti];
+            w.im[ti] = bt[3] * x.im[ti];
+            v.re[ti] = bt[2] * x.re[ti];
+            v.im[ti] = bt[2] * x.im[ti];
+            if (ti == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + q == c) v.re[ti][r] += bt[0];
+            }
+        }
+        __syncthreads();  // L1: every read of a is done
+        if (order >= 5) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x.re[ti], x.im[ti]);
+            if (GIVE) stage_mirror(sl, 1, 0, x.re[0], x.im[0], 1.0);
+            __syncthreads();  // L2
+            if (TAKE) load_tile(sl, 1, 0, x.re[1], x.im[1]);
+            for (int j = 2; 2 * j < order; ++j) {  // x_{2j} = x2 x_{2j-2}: j = 2 (x4), 3 (x6), 4 (x8)
+                acc_zero<NT>(acc);
+                gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+                    bre = x.re[kk >> 2][kk & 3];
+                    bim = x.im[kk >> 2][kk & 3];
+                });
+                acc_finish<NT>(y, acc);
+                const double bw = bt[2 * j + 1], bv = bt[2 * j];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    w.re[ti] += bw * y.re[ti];
+                    w.im[ti] += bw * y.im[ti];
+                    v.re[ti] += bv * y.re[ti];
+                    v.im[ti] += bv * y.im[ti];
+                }
+                if (2 * (j + 1) < order) {  // the next product takes it as its B operand
+                    if (HERM) __syncthreads();  // the mirror tile's previous content has been read
+                    if (GIVE) mirror_put(mt, y.re[0], y.im[0], 1.0);
+                    if (HERM) __syncthreads();
+                    if (TAKE) mirror_get(mt, y.re[1], y.im[1]);
+                    x = y;
+                }
+            }
+            __syncthreads();  // L3: every read of x2 is done
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, w.re[ti], w.im[ti]);
+        if (GIVE) stage_mirror(sl, 1, 0, w.re[0], w.im[0], 1.0);
+        gen(a, W);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            u.re[ti] = bt[1] * a.re[ti];
+            u.im[ti] = bt[1] * a.im[ti];
+        }
+        acc_init<NT>(acc, u);
+        __syncthreads();  // L4
+        gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
+            bre = a.re[kk >> 2][kk & 3];
+            bim = a.im[kk >> 2][kk & 3];
+        });
+        acc_finish<NT>(u, acc);
+    } else {
     // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
     Col x2, x4, x6;
-    Acc3 acc;
     acc_zero<NT>(acc);
     gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
         bre = a.re[kk >> 2][kk & 3];
@@ -284,7 +363,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
                  b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
                  b10 = PADE_B[10], b11 = PADE_B[11], b12 = PADE_B[12], b13 = PADE_B[13];
-    Col w2, v;
+    Col w2;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         w2.re[ti] = b7 * x6.re[ti] + b5 * x4.re[ti] + b3 * x2.re[ti];
@@ -331,7 +410,6 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             a.im[ti] *= scale;
         }
     }
-    Col u;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         u.re[ti] = b1 * a.re[ti];
@@ -344,6 +422,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         bim = a.im[kk >> 2][kk & 3];
     });
     acc_finish<NT>(u, acc);
+    }  // order 13
 
     // ---- P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers: for a
     // fixed r the four q-lanes of a column hold rows 4r..4r+3, i.e. one 64-byte run of the
@@ -397,6 +476,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.q_img = args.skip_q ? nullptr : args.q_img + m * MAT;  // (skip_q: timing experiment)
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
+    out.pade_policy = args.pade_policy;
     out.status = args.status;
     out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
     out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;
@@ -459,6 +539,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
     out.q_img = args.q_img + m * MAT;
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
+    out.pade_policy = args.pade_policy;
     out.status = args.status;
     out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
     out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;

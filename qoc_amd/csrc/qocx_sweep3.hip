@@ -230,7 +230,7 @@ struct S3Subs {
             sv = args.s_arr[w.m0 + (adjoint ? w.je - 1 - tt : w.jb + tt)];
         }
         const int s = __builtin_amdgcn_readlane(sv, t & 63);
-        return 1 << min(max(s, 0), 30);
+        return 1 << step_squarings(s);
     }
 };
 

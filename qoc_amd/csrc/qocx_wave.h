@@ -23,6 +23,58 @@ __device__ __constant__ const double PADE_B[14] = {
 
 #define QOCX_THETA13 5.371920351148152
 
+// Pade order by norm. The reference always evaluates the [13/13] approximant (expm.py:230-233:
+// its loop over PADE_ORDERS has no break, so 13 wins whenever the norm is below theta_13). The
+// device takes the order from the table the reference cites and carries (Higham 2005, Algorithm
+// 2.3; THETA at expm.py:194-209): for ||a||_1 <= theta_m the [m/m] approximant is exp(a + da) with
+// ||da|| <= 2^-53 ||a|| - the same matrix as the [13/13] one to rounding, and its derivative the
+// same to rounding (tests/test_device_model.py holds both to 1e-14 against the reference's
+// formulas) - for 2..5 matrix products instead of 6 in K1a and an adjoint chain of m instead of 13
+// terms in K3. Coefficients b_j = (2m - j)! m! / ((2m)! (m - j)! j!) scaled to integers, as in the
+// reference's table for m = 13 (expm.py:85-101). K1a decides from an UPPER bound of the norm (sum
+// of |re| + |im|), so the order is never lower than the norm allows; it travels to K3 in bits
+// 8..15 of the step's entry in s_arr (0: order 13; the squaring count is 0 for any other order).
+#define QOCX_THETA3 1.495585217958292e-2
+#define QOCX_THETA5 2.539398330063230e-1
+#define QOCX_THETA7 9.504178996162932e-1
+#define QOCX_THETA9 2.097847961257068
+__device__ __constant__ const double PADE_B3[4] = {120.0, 60.0, 12.0, 1.0};
+__device__ __constant__ const double PADE_B5[6] = {30240.0, 15120.0, 3360.0, 420.0, 30.0, 1.0};
+__device__ __constant__ const double PADE_B7[8] = {17297280.0, 8648640.0, 1995840.0, 277200.0,
+                                                   25200.0,    1512.0,    56.0,      1.0};
+__device__ __constant__ const double PADE_B9[10] = {17643225600.0, 8821612800.0, 2075673600.0,
+                                                    302702400.0,   30270240.0,   2162160.0,
+                                                    110880.0,      3960.0,       90.0,
+                                                    1.0};
+template <int M>
+__device__ __forceinline__ double pade_b(int j) {
+    if constexpr (M == 3) return PADE_B3[j];
+    else if constexpr (M == 5) return PADE_B5[j];
+    else if constexpr (M == 7) return PADE_B7[j];
+    else if constexpr (M == 9) return PADE_B9[j];
+    else return PADE_B[j];
+}
+__device__ __forceinline__ const double* pade_table(int order) {
+    return order == 3 ? PADE_B3 : (order == 5 ? PADE_B5 : (order == 7 ? PADE_B7 : (order == 9 ? PADE_B9 : PADE_B)));
+}
+// v: an upper bound of ||a||_1; policy 13: always 13 (as the reference executes)
+__device__ __forceinline__ int pade_order_for(double v, int policy) {
+    if (policy == 13) return 13;
+    if (v < QOCX_THETA3) return 3;
+    if (v < QOCX_THETA5) return 5;
+    if (v < QOCX_THETA7) return 7;
+    if (v < QOCX_THETA9) return 9;
+    return 13;  // also NaN
+}
+__device__ __forceinline__ int step_entry(int squarings, int order) {
+    return order == 13 ? squarings : (squarings | (order << 8));
+}
+__device__ __forceinline__ int step_squarings(int entry) { return min(max(entry & 0xff, 0), 30); }
+__device__ __forceinline__ int step_order(int entry) {
+    const int o = (entry >> 8) & 0xff;
+    return o == 0 ? 13 : o;
+}
+
 // ------------------------------------------------------------------------------------------
 // wave-level primitives
 // ------------------------------------------------------------------------------------------

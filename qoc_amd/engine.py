@@ -585,7 +585,9 @@ class Engine(object):
         self._check(self._lib.qocx_debug_pade_factor(
             self._ctx, count, n, _dp(a), _dp(q), _dp(lu), perm.ctypes.data_as(_c_int_p),
             _dp(dinv), s.ctypes.data_as(_c_int_p)))
-        return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s)
+        # entry of the step table: squarings in bits 0..7, Pade order in bits 8..15 (0: 13)
+        order = (s >> 8) & 0xff
+        return dict(q=q, lu=lu, perm=perm, dinv=dinv, s=s & 0xff, order=np.where(order == 0, 13, order))
 
     def set_knob(self, name, value):
         """Kernel-variant switch (include/qocx.h: qocx_debug_set_knob)."""

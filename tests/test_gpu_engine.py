@@ -45,10 +45,35 @@ def test_pade_factor_kernel(engine, n):
         g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
         a = -1j * (g + g.conj().T) / 2 if skew else g
         mats.append(a * (scale / onp.one_norm(a)))
+    # norms around the thresholds of the lower Pade orders (qocx_wave.h: order by norm)
+    for order in (3, 5, 7, 9):
+        for frac in (0.3, 0.7, 0.98, 1.02):
+            g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            a = -1j * (g + g.conj().T) / 2 if frac != 0.7 else g
+            mats.append(a * (dm.PADE_THETA[order] * frac / onp.one_norm(a)))
     mats = np.stack(mats)
-    out = engine.debug_pade_factor(mats)
+    for policy in (0, 13):
+        engine.set_knob("pade_order", policy)
+        out = engine.debug_pade_factor(mats)
+        engine.set_knob("pade_order", 0)
+        check_pade_factor(out, mats, policy)
+
+
+def check_pade_factor(out, mats, policy):
+    lower = 0
     for m, a in enumerate(mats):
-        f = dm.pade_factor(a)
+        # the kernel decides from an upper bound of the norm: never a lower order than the norm
+        # allows, and 13 whenever the policy says so
+        order = int(out["order"][m])
+        assert order in (3, 5, 7, 9, 13)
+        assert order >= dm.pade_order(onp.one_norm(a), policy)
+        bound = np.max(np.sum(np.abs(a.real) + np.abs(a.imag), axis=0))
+        if policy == 13:
+            assert order == 13
+        elif mats.shape[1] > 16 and mats.shape[1] <= 32:  # kernels that select the order
+            assert order == dm.pade_order(bound)
+        lower += order < 13
+        f = dm.pade_factor(a, order=order)
         assert out["s"][m] == f["s"]
         assert rel_err(out["q"][m], f["q"]) < 1e-12
         assert np.array_equal(out["perm"][m], f["perm"])
@@ -58,7 +83,9 @@ def test_pade_factor_kernel(engine, n):
         u = dm.solve_lu(out["lu"][m], out["perm"][m], out["q"][m])
         for _ in range(int(out["s"][m])):
             u = u @ u
-        assert rel_err(u, onp.expm_pade(a)) < 1e-10
+        assert rel_err(u, onp.expm_pade(a)) < (1e-10 if order == 13 else 1e-13)
+    if policy == 0 and 16 < mats.shape[1] <= 32:
+        assert lower >= 12
 
 
 @pytest.mark.parametrize("name", GRAD_CASES)
