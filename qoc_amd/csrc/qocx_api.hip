@@ -190,6 +190,7 @@ struct qocx_ctx {
     // ---- evaluation state ----
     int B = 0;
     int sbound = 0;
+    double norm_bound = 1e300;  // host bound of ||step generator||_1 of the uploaded controls / generators
     size_t slot_cap = 0;
     int chunk_user = 0;
     int pipe_user = 0;
@@ -913,6 +914,7 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
     bound = magnus_norm_bound(ctx->nodes, bound * fabs(ctx->dt));
     if (!(bound < 1e300)) return fail(QOCX_ERR_ARG, "non-finite controls or Hamiltonian");
     ctx->sbound = pade_scale_count(bound);
+    ctx->norm_bound = bound;
     if (ctx->sbound > 10)
         return fail(QOCX_ERR_CAPACITY,
                     "||dt H||_1 bound needs more than 2^10 squaring sub-steps per step; reduce dt");
@@ -955,6 +957,7 @@ int qocx_upload_generators(qocx_ctx* ctx, int32_t batch, const double* generator
     }
     if (!(worst < 1e300)) return fail(QOCX_ERR_ARG, "non-finite generator");
     ctx->sbound = pade_scale_count(worst);
+    ctx->norm_bound = worst;
     if (ctx->sbound > 10)
         return fail(QOCX_ERR_CAPACITY,
                     "||dt H||_1 needs more than 2^10 squaring sub-steps per step; reduce dt");
@@ -1180,10 +1183,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.n = ctx->n;
         fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
         fa.pade_policy = (int)ctx->knob("pade_order", 0);  // 0: by norm (qocx_wave.h), 13: always 13
+        fa.prefer_low = ctx->norm_bound < 2.097847961257068 ? 1 : 0;  // theta_9
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)
-        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && ctx->knob("fuse_lu", 0) != 0;
+        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && ctx->knob("fuse_lu", 1) != 0;
         fa.fuse_lu = fused_lu ? 1 : 0;
         fa.dinv = ctx->dinv.p; fa.perm = ctx->perm.p; fa.iperm = ctx->iperm.p;
         qocx::LuArgs la;
@@ -2492,6 +2496,7 @@ int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms) {
         return fail(QOCX_ERR_CAPACITY,
                     "||dt H||_1 bound needs more than 2^10 squaring sub-steps per step; reduce dt");
     ctx->sbound = std::max(ctx->sbound, sb);
+    ctx->norm_bound = std::max(ctx->norm_bound, bound);
     ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
     HIP_TRY(hipMemcpyAsync(ctx->opt_max_norms.p, max_norms, ctx->K * sizeof(double),
                            hipMemcpyHostToDevice, ctx->stream));
@@ -2636,7 +2641,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
     fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
     fa.pade_policy = (int)ctx->knob("pade_order", 0);
-    const bool fused_lu = nb == 2 && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 0) != 0;
+    const bool fused_lu = nb == 2 && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);

@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     const int nsteps = args.nsteps, S = args.S, K = args.K;
     const size_t m = (size_t)b * nsteps + step;
     const int sq = step_squarings(args.s_arr[m]);
+    // Pade order of the step (qocx_wave.h): chains of M terms; iterations of the unrolled loops
+    // beyond M are skipped by branches every wave of the workgroup takes alike
+    const int M = step_order(args.s_arr[m]);
+    const double* bt = pade_table(M);
     const double dts = args.dt * ldexp(1.0, -sq);
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * K;
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
             tai[0] = x.y;
 #pragma unroll
             for (int jj = 0; jj < 12; ++jj) {
+                if (jj + 1 >= M) break;
                 double s2r = 0, s2i = 0;
 #pragma unroll
                 for (int cc = 0; cc < CW; ++cc) {
@@ -321,9 +326,10 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
             }
             // Phase B: rho_12 = b13 sigma, rho_{i-1} = b_i w_i + a rho_i (w_i = sigma for odd i,
             // delta for even i); abar += tau_i rho_i^H as each rho_i appears
-            double rr = PADE_B[13] * sgr, ri = PADE_B[13] * sgi;
+            double rr = bt[M] * sgr, ri = bt[M] * sgi;
 #pragma unroll
             for (int ii = 12; ii >= 0; --ii) {
+                if (ii >= M) continue;
                 double s0r = 0, s0i = 0;
 #pragma unroll
                 for (int cc = 0; cc < CW; ++cc) {
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
                 }
                 if (ii > 0) {
                     xsum(s0r, s0i);
-                    const double coef = PADE_B[ii];
+                    const double coef = bt[ii];
                     rr = fma(coef, (ii & 1) ? sgr : dlr, s0r);
                     ri = fma(coef, (ii & 1) ? sgi : dli, s0i);
                 }

@@ -41,6 +41,8 @@ struct FactorArgs {
     int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
     int n;                     // Hilbert size (used by the sixteen-tile K1a: <= 48 -> nine tiles); 0: unknown
     int pade_policy = 0;       // 0: Pade order by norm (qocx_wave.h), 13: always [13/13]
+    int prefer_low = 0;        // the host's bound of ||dt a||_1 is below theta_9 (four-wave K1a: which
+                               // of its two paths is inlined, qocx_pade4.hip)
     int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
     // two-wave K1a (17 <= n <= 32) with K1b fused in: P stays in LDS, wave 0 factors it, only the
     // factors (and 1/U_kk, the permutation) go to HBM; launch_lu is then not called

@@ -43,8 +43,9 @@ namespace qocx {
 struct PqOut {
     double2* q_img;   // column-major Q
     double2* p_img;   // column-major P (LU'd in place by K1b)
-    int* s_out;       // squarings
+    int* s_out;       // squarings (and the Pade order: step_entry, qocx_wave.h)
     int* status;      // bit 1: non-finite norm
+    int pade_policy;  // FactorArgs::pade_policy
 };
 
 template <int NB>
@@ -206,6 +207,7 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
     }
     norm1 = wave_max(norm1);
     int sq = 0;
+    int order = pade_order_for(norm1, out.pade_policy);
     {
         double th = QOCX_THETA13;
         while (norm1 > th && sq < 30) {
@@ -215,16 +217,97 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
         if (!(norm1 <= th)) {  // inf / nan / absurd
             if (lane == 0) atomicOr(out.status, 2);
             sq = 0;
+            order = 13;
         }
     }
     const double scale = ldexp(1.0, -sq);
     if (sq > 0) cmat_scale<NB>(a, scale);
-    if (lane == 0) *out.s_out = sq;
+    if (lane == 0) *out.s_out = step_entry(sq, order);
 
-    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
-    CMat<NB> x2, x4, x6;
+    const int q = lane >> 4, c = lane & 15;
+    CMat<NB> u, v;
     cmat_to_lds3<NB>(a, lre, lim, lsum);
     wave_sync();
+    if (order != 13) {
+        // ---- orders 3, 5, 7, 9 (qocx_wave.h; the shape of the reference's pade3..pade9,
+        // expm.py:119-150): x2 = a a, x_{2j} = x2 x_{2j-2}; w = sum b_{2j+1} x_{2j},
+        // v = sum b_{2j} x_{2j} + b0 I, u = a w + b1 a. No squarings at these norms.
+        const double* bt = pade_table(order);
+        CMat<NB> w, x;
+        {
+            CAcc3<NB> acc;
+            acc3_zero<NB>(acc);
+            zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+                bre = a.re[kk >> 2][tj][kk & 3];
+                bim = a.im[kk >> 2][tj][kk & 3];
+            });
+            acc3_finish<NB>(x, acc);
+            if (UP) mirror_lower<NB>(x, 1.0, mscr);
+        }
+#pragma unroll
+        for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NB; ++tj) {
+                w.re[ti][tj] = bt[3] * x.re[ti][tj];
+                w.im[ti][tj] = bt[3] * x.im[ti][tj];
+                v.re[ti][tj] = bt[2] * x.re[ti][tj];
+                v.im[ti][tj] = bt[2] * x.im[ti][tj];
+                if (ti == tj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * r + q == c) v.re[ti][tj][r] += bt[0];
+                }
+            }
+        wave_sync();
+        if (order >= 5) {
+            cmat_to_lds3<NB>(x, lre, lim, lsum);  // x2 is the A operand of every further product
+            wave_sync();
+            for (int j = 2; 2 * j < order; ++j) {
+                CAcc3<NB> acc;
+                acc3_zero<NB>(acc);
+                zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+                    bre = x.re[kk >> 2][tj][kk & 3];
+                    bim = x.im[kk >> 2][tj][kk & 3];
+                });
+                acc3_finish<NB>(x, acc);  // (the product is complete: its B operand may go)
+                if (UP) mirror_lower<NB>(x, 1.0, mscr);
+                const double bw = bt[2 * j + 1], bv = bt[2 * j];
+#pragma unroll
+                for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NB; ++tj) {
+                        w.re[ti][tj] += bw * x.re[ti][tj];
+                        w.im[ti][tj] += bw * x.im[ti][tj];
+                        v.re[ti][tj] += bv * x.re[ti][tj];
+                        v.im[ti][tj] += bv * x.im[ti][tj];
+                    }
+            }
+            wave_sync();
+            gen(a);
+            cmat_to_lds3<NB>(a, lre, lim, lsum);
+            wave_sync();
+        }
+#pragma unroll
+        for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NB; ++tj) {
+                u.re[ti][tj] = bt[1] * a.re[ti][tj];
+                u.im[ti][tj] = bt[1] * a.im[ti][tj];
+            }
+        {
+            CAcc3<NB> acc;
+            acc3_init<NB>(acc, u);
+            zgemm3_acc<NB, UP>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+                bre = w.re[kk >> 2][tj][kk & 3];
+                bim = w.im[kk >> 2][tj][kk & 3];
+            });
+            acc3_finish<NB>(u, acc);
+            if (UP) mirror_lower<NB>(u, -1.0, mscr);
+        }
+        wave_sync();
+    } else {
+    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
+    CMat<NB> x2, x4, x6;
     {
         CAcc3<NB> acc;
         acc3_zero<NB>(acc);
@@ -267,8 +350,7 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
     const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
                  b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
                  b10 = PADE_B[10], b11 = PADE_B[11], b12 = PADE_B[12], b13 = PADE_B[13];
-    CMat<NB> w2, v;
-    const int q = lane >> 4, c = lane & 15;
+    CMat<NB> w2;
 #pragma unroll
     for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
@@ -314,7 +396,6 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
     }
     cmat_to_lds3<NB>(a, lre, lim, lsum);
     wave_sync();
-    CMat<NB> u;
 #pragma unroll
     for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
@@ -333,6 +414,7 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
         if (UP) mirror_lower<NB>(u, -1.0, mscr);
     }
     wave_sync();
+    }  // order 13
 
     // C-layout -> LDS -> R-layout -> column-major images (one contiguous KiB per store)
     CMat<NB> t;
@@ -371,6 +453,7 @@ __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
     out.p_img = args.lu_img + m * G::MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.pade_policy = args.pade_policy;
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
@@ -433,6 +516,7 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
     out.p_img = args.lu_img + m * G::MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.pade_policy = args.pade_policy;
     const double2* am = a_in + m * (size_t)n * n;
     auto gen = [&](CMat<NB>& a) {
 #pragma unroll

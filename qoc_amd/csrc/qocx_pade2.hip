@@ -252,7 +252,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         // sq = 0 here (the norm is below theta_9). The finished products leave the registers as
         // soon as they have gone into w and v and served as the next B operand.
         const double* bt = pade_table(order);
-        Col w, x, y;
+        Col w, x;
         acc_zero<NT>(acc);
         gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
             bre = a.re[kk >> 2][kk & 3];
@@ -284,21 +284,20 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
                     bre = x.re[kk >> 2][kk & 3];
                     bim = x.im[kk >> 2][kk & 3];
                 });
-                acc_finish<NT>(y, acc);
+                acc_finish<NT>(x, acc);  // (the product is complete: its B operand may go)
                 const double bw = bt[2 * j + 1], bv = bt[2 * j];
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti) {
-                    w.re[ti] += bw * y.re[ti];
-                    w.im[ti] += bw * y.im[ti];
-                    v.re[ti] += bv * y.re[ti];
-                    v.im[ti] += bv * y.im[ti];
+                    w.re[ti] += bw * x.re[ti];
+                    w.im[ti] += bw * x.im[ti];
+                    v.re[ti] += bv * x.re[ti];
+                    v.im[ti] += bv * x.im[ti];
                 }
                 if (2 * (j + 1) < order) {  // the next product takes it as its B operand
                     if (HERM) __syncthreads();  // the mirror tile's previous content has been read
-                    if (GIVE) mirror_put(mt, y.re[0], y.im[0], 1.0);
+                    if (GIVE) mirror_put(mt, x.re[0], x.im[0], 1.0);
                     if (HERM) __syncthreads();
-                    if (TAKE) mirror_get(mt, y.re[1], y.im[1]);
-                    x = y;
+                    if (TAKE) mirror_get(mt, x.re[1], x.im[1]);
                 }
             }
             __syncthreads();  // L3: every read of x2 is done

@@ -115,63 +115,141 @@ struct Out {
     double2* p_img;
     int* s_out;
     int* status;
+    int pade_policy;  // FactorArgs::pade_policy
 };
 
-// Every wave executes the same barriers; w = the wave's column block (wave-uniform).
+// P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers
+template <int NT>
+__device__ __forceinline__ void emit_pq(const Out& out, int w, double b0, const Col<NT>& u,
+                                        const Col<NT>& v) {
+    const int lane = lane_id();
+    const int q = lane >> 4, c = lane & 15;
+    // ---- P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers: for a
+    // fixed r the four q-lanes of a column hold rows 4r..4r+3 of one tile, i.e. one 64-byte run
+    // of the column-major image.
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = (16 * w + c) * NP + 16 * ti + 4 * r + q;
+            out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
+            out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
+        }
+    if constexpr (NT < 4) {
+        // the pad block of the 64 x 64 images: v = b0 I and u = 0 there, so P = Q = b0 I
+        constexpr int NA = Cfg<NT>::NA;
+#pragma unroll
+        for (int r = 0; r < (NP - NA) / 4; ++r) {  // rows NA..63 of this wave's columns
+            const int idx = (16 * w + c) * NP + NA + 4 * r + q;
+            out.q_img[idx] = make_double2(0, 0);
+            out.p_img[idx] = make_double2(0, 0);
+        }
+        for (int e = w * 64 + lane; e < (NP - NA) * NP; e += 64 * NT) {  // columns NA..63
+            const int col = NA + e / NP, row = e % NP;
+            const double2 val = make_double2(row == col ? b0 : 0.0, 0.0);
+            out.q_img[col * NP + row] = val;
+            out.p_img[col * NP + row] = val;
+        }
+    }
+}
+
+// Orders 3, 5, 7, 9 (qocx_wave.h). The generator is staged in the slot (barrier 2 has passed).
 template <int NT, class Gen>
-__device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
+__device__ __forceinline__ void low_order_impl(Gen gen, const Out& out, double* smem, int w, int order,
+                                               Col<NT>& a) {
     typedef Col<NT> Col;
     typedef Acc3<NT> Acc3;
     double* sl = smem;
-    double* nrm = sl + Cfg<NT>::SLOT_F64;
     const int lane = lane_id();
     const int q = lane >> 4, c = lane & 15;
-
-    // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
-    Col a;
-    gen(a, w);
-    {
-        double e = 0;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                e += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
-        e += __shfl_xor(e, 16);
-        e += __shfl_xor(e, 32);
-        e = wave_max(e);  // the largest column sum of this column block
-        if (lane == 0) nrm[w] = e;
-    }
-    __syncthreads();  // 1
-    double norm1 = fmax(fmax(nrm[0], nrm[1]), nrm[2]);
-    if constexpr (NT == 4) norm1 = fmax(norm1, nrm[3]);
-    int sq = 0;
-    {
-        double th = QOCX_THETA13;
-        while (norm1 > th && sq < 30) {
-            th *= 2.0;
-            ++sq;
-        }
-        if (!(norm1 <= th)) {  // inf / nan / absurd
-            if (w == 0 && lane == 0) atomicOr(out.status, 2);
-            sq = 0;
-        }
-    }
-    const double scale = ldexp(1.0, -sq);
-    if (sq > 0) {
+    const double b0 = pade_table(order)[0];
+    Acc3 acc;
+        Col u, v;
+        // ---- orders 3, 5, 7, 9 (qocx_wave.h; the shape of the reference's pade3..pade9,
+        // expm.py:119-150): x2 = a a, x_{2j} = x2 x_{2j-2}; wp = sum b_{2j+1} x_{2j},
+        // v = sum b_{2j} x_{2j} + b0 I, u = wp a + b1 a. No squarings at these norms.
+        const double* bt = pade_table(order);
+        Col wp, x;
+        acc_zero(acc);
+        gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+            bre = a.re[kk >> 2][kk & 3];
+            bim = a.im[kk >> 2][kk & 3];
+        });
+        acc_finish(x, acc);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
-            a.re[ti] *= scale;
-            a.im[ti] *= scale;
+            wp.re[ti] = bt[3] * x.re[ti];
+            wp.im[ti] = bt[3] * x.im[ti];
+            v.re[ti] = bt[2] * x.re[ti];
+            v.im[ti] = bt[2] * x.im[ti];
+            if (ti == w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + q == c) v.re[ti][r] += b0;
+            }
         }
-    }
-    if (w == 0 && lane == 0) *out.s_out = sq;
-    stage_col(sl, w, a);
-    __syncthreads();  // 2
+        __syncthreads();  // L1: every read of a is done
+        if (order >= 5) {
+            stage_col(sl, w, x);
+            __syncthreads();  // L2
+            for (int j = 2; 2 * j < order; ++j) {
+                acc_zero(acc);
+                gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+                    bre = x.re[kk >> 2][kk & 3];
+                    bim = x.im[kk >> 2][kk & 3];
+                });
+                acc_finish(x, acc);  // (the product is complete: its B operand may go)
+                const double bw = bt[2 * j + 1], bv = bt[2 * j];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    wp.re[ti] += bw * x.re[ti];
+                    wp.im[ti] += bw * x.im[ti];
+                    v.re[ti] += bv * x.re[ti];
+                    v.im[ti] += bv * x.im[ti];
+                }
+            }
+            __syncthreads();  // L3: every read of x2 is done
+        }
+        stage_col(sl, w, wp);
+        gen(a, w);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            u.re[ti] = bt[1] * a.re[ti];
+            u.im[ti] = bt[1] * a.im[ti];
+        }
+        acc_init(acc, u);
+        __syncthreads();  // L4
+        gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
+            bre = a.re[kk >> 2][kk & 3];
+            bim = a.im[kk >> 2][kk & 3];
+        });
+        acc_finish(u, acc);
+        emit_pq<NT>(out, w, b0, u, v);
+}
+template <int NT, class Gen>
+__device__ __attribute__((noinline)) void low_order_call(Gen gen, const Out& out, double* smem, int w,
+                                                         int order) {
+    Col<NT> a;
+    gen(a, w);
+    low_order_impl<NT>(gen, out, smem, w, order, a);
+}
 
-    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
-    Col x2, x4, x6;
+// Order 13 (expm.py:153-159). The generator is staged in the slot (barrier 2 has passed); `a` is
+// this wave's column block of it, scaled by 2^-sq.
+template <int NT, class Gen>
+__device__ __forceinline__ void high_order_impl(Gen gen, const Out& out, double* smem, int w, int sq,
+                                                Col<NT>& a) {
+    typedef Col<NT> Col;
+    typedef Acc3<NT> Acc3;
+    double* sl = smem;
+    const int lane = lane_id();
+    const int q = lane >> 4, c = lane & 15;
+    const double b0 = PADE_B[0];
+    const double scale = ldexp(1.0, -sq);
     Acc3 acc;
+    // ---- a2 = a a ; a4 = a2 a2 ; a6 = a2 a4 (expm.py:154-156) ----------------------------
+    Col u, v;
+    Col x2, x4, x6;
     acc_zero(acc);
     gemm3(acc, sl, [&](int kk, double& bre, double& bim) {
         bre = a.re[kk >> 2][kk & 3];
@@ -199,10 +277,10 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
 
     // ---- w2 = a6 (b13 a6 + b11 a4 + b9 a2) + b7 a6 + b5 a4 + b3 a2 (expm.py:157) ---------
     // ---- v  = a6 (b12 a6 + b10 a4 + b8 a2) + b6 a6 + b4 a4 + b2 a2 + b0 I (expm.py:158) --
-    const double b0 = PADE_B[0], b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
+    const double b1 = PADE_B[1], b2 = PADE_B[2], b3 = PADE_B[3], b4 = PADE_B[4],
                  b5 = PADE_B[5], b6 = PADE_B[6], b7 = PADE_B[7], b8 = PADE_B[8], b9 = PADE_B[9],
                  b10 = PADE_B[10], b11 = PADE_B[11], b12 = PADE_B[12], b13 = PADE_B[13];
-    Col w2, v;
+    Col w2;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         w2.re[ti] = b7 * x6.re[ti] + b5 * x4.re[ti] + b3 * x2.re[ti];
@@ -246,7 +324,6 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
             a.im[ti] *= scale;
         }
     }
-    Col u;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         u.re[ti] = b1 * a.re[ti];
@@ -260,36 +337,90 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
     });
     acc_finish(u, acc);
 
-    // ---- P = v - u ; Q = v + u (expm.py:246), straight from the C-layout registers: for a
-    // fixed r the four q-lanes of a column hold rows 4r..4r+3 of one tile, i.e. one 64-byte run
-    // of the column-major image.
+    emit_pq<NT>(out, w, b0, u, v);
+}
+template <int NT, class Gen>
+__device__ __attribute__((noinline)) void high_order_call(Gen gen, const Out& out, double* smem, int w,
+                                                          int sq) {
+    Col<NT> a;
+    gen(a, w);
+    if (sq > 0) {
+        const double scale = ldexp(1.0, -sq);
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
+        for (int ti = 0; ti < NT; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    high_order_impl<NT>(gen, out, smem, w, sq, a);
+}
+
+// Every wave executes the same barriers; w = the wave's column block (wave-uniform).
+template <int NT, bool LOWINL, class Gen>
+__device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
+    typedef Col<NT> Col;
+    double* sl = smem;
+    double* nrm = sl + Cfg<NT>::SLOT_F64;
+    const int lane = lane_id();
+
+    // ---- generator, 1-norm, scaling (expm.py:116, :238-241) -----------------------------
+    Col a;
+    gen(a, w);
+    {
+        double e = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = (16 * w + c) * NP + 16 * ti + 4 * r + q;
-            out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
-            out.p_img[idx] = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
-        }
-    if constexpr (NT < 4) {
-        // the pad block of the 64 x 64 images: v = b0 I and u = 0 there, so P = Q = b0 I
-        constexpr int NA = Cfg<NT>::NA;
+        for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int r = 0; r < (NP - NA) / 4; ++r) {  // rows NA..63 of this wave's columns
-            const int idx = (16 * w + c) * NP + NA + 4 * r + q;
-            out.q_img[idx] = make_double2(0, 0);
-            out.p_img[idx] = make_double2(0, 0);
+            for (int r = 0; r < 4; ++r)
+                e += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
+        e += __shfl_xor(e, 16);
+        e += __shfl_xor(e, 32);
+        e = wave_max(e);  // the largest column sum of this column block
+        if (lane == 0) nrm[w] = e;
+    }
+    __syncthreads();  // 1
+    double norm1 = fmax(fmax(nrm[0], nrm[1]), nrm[2]);
+    if constexpr (NT == 4) norm1 = fmax(norm1, nrm[3]);
+    int sq = 0;
+    int order = pade_order_for(norm1, out.pade_policy);  // every wave reads the same numbers
+    {
+        double th = QOCX_THETA13;
+        while (norm1 > th && sq < 30) {
+            th *= 2.0;
+            ++sq;
         }
-        for (int e = w * 64 + lane; e < (NP - NA) * NP; e += 64 * NT) {  // columns NA..63
-            const int col = NA + e / NP, row = e % NP;
-            const double2 val = make_double2(row == col ? b0 : 0.0, 0.0);
-            out.q_img[col * NP + row] = val;
-            out.p_img[col * NP + row] = val;
+        if (!(norm1 <= th)) {  // inf / nan / absurd
+            if (w == 0 && lane == 0) atomicOr(out.status, 2);
+            sq = 0;
+            order = 13;
         }
+    }
+    const double scale = ldexp(1.0, -sq);
+    if (sq > 0) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            a.re[ti] *= scale;
+            a.im[ti] *= scale;
+        }
+    }
+    if (w == 0 && lane == 0) *out.s_out = step_entry(sq, order);
+    stage_col(sl, w, a);
+    __syncthreads();  // 2
+
+    // The two paths are not allocated together: the sixteen-tile kernel has no registers to spare
+    // (both inlined, the [13/13] path spilled 94 registers instead of 22 and ran 11 % slower). One
+    // of them is a call; LOWINL - the host's choice from its bound of the norms, FactorArgs::
+    // prefer_low - says which one is inlined. Same arithmetic either way.
+    if (order != 13) {
+        if constexpr (LOWINL) low_order_impl<NT>(gen, out, smem, w, order, a);
+        else low_order_call<NT>(gen, out, smem, w, order);
+    } else {
+        if constexpr (LOWINL) high_order_call<NT>(gen, out, smem, w, sq);
+        else high_order_impl<NT>(gen, out, smem, w, sq, a);
     }
 }
 
-template <int NT>
+template <int NT, bool LOWINL>
 __global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -303,6 +434,7 @@ __global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.pade_policy = args.pade_policy;
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
@@ -341,11 +473,11 @@ __global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
             a.im[ti] = -dt * hre[ti];
         }
     };
-    body<NT>(gen, out, smem, w);
+    body<NT, LOWINL>(gen, out, smem, w);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
-template <int NT>
+template <int NT, bool LOWINL>
 __global__ __launch_bounds__(64 * NT) void pade_pq4_explicit_kernel(const double2* a_in, int n,
                                                                     FactorArgs args) {
     typedef Col<NT> Col;
@@ -361,6 +493,7 @@ __global__ __launch_bounds__(64 * NT) void pade_pq4_explicit_kernel(const double
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.status = args.status;
+    out.pade_policy = args.pade_policy;
     const double2* am = a_in + m * (size_t)n * n;
     auto gen = [&](Col& a, int wcol) {
 #pragma unroll
@@ -374,38 +507,54 @@ __global__ __launch_bounds__(64 * NT) void pade_pq4_explicit_kernel(const double
                 a.im[ti][r] = e.y;
             }
     };
-    body<NT>(gen, out, smem, w);
+    body<NT, LOWINL>(gen, out, smem, w);
 }
 
 }  // namespace pade4
 
-template <int NT>
+template <int NT, bool LOWINL>
 static void launch_pq4_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_kernel<NT, LOWINL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(pade4::pade_pq4_kernel<NT>, dim3(nsteps, batch), dim3(64 * NT), bytes, st, a);
+    hipLaunchKernelGGL((pade4::pade_pq4_kernel<NT, LOWINL>), dim3(nsteps, batch), dim3(64 * NT), bytes,
+                       st, a);
 }
-template <int NT>
+template <int NT, bool LOWINL>
 static void launch_pq4_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
                                   hipStream_t st) {
     constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(pade4::pade_pq4_explicit_kernel<NT>, dim3(count), dim3(64 * NT), bytes, st,
-                       a_in, n, a);
+        (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel<NT, LOWINL>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((pade4::pade_pq4_explicit_kernel<NT, LOWINL>), dim3(count), dim3(64 * NT), bytes,
+                       st, a_in, n, a);
 }
 
 // a.n: the Hilbert size (33..64). Up to 48 the three-wave form computes 9 of the 16 tiles.
+// a.prefer_low: the host's bound of the generator norms is below theta_9, so every step takes a
+// low Pade order - the variant with THAT path inlined runs (same results either way).
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    if (a.n > 0 && a.n <= 48) launch_pq4_t<3>(a, nsteps, batch, st);
-    else launch_pq4_t<4>(a, nsteps, batch, st);
+    const bool low = a.prefer_low != 0 && a.pade_policy != 13;
+    if (a.n > 0 && a.n <= 48) {
+        if (low) launch_pq4_t<3, true>(a, nsteps, batch, st);
+        else launch_pq4_t<3, false>(a, nsteps, batch, st);
+    } else {
+        if (low) launch_pq4_t<4, true>(a, nsteps, batch, st);
+        else launch_pq4_t<4, false>(a, nsteps, batch, st);
+    }
 }
 void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {
-    if (a.n > 0 && a.n <= 48) launch_pq4_explicit_t<3>(a_in, n, a, count, st);
-    else launch_pq4_explicit_t<4>(a_in, n, a, count, st);
+    const bool low = a.prefer_low != 0 && a.pade_policy != 13;
+    if (a.n > 0 && a.n <= 48) {
+        if (low) launch_pq4_explicit_t<3, true>(a_in, n, a, count, st);
+        else launch_pq4_explicit_t<3, false>(a_in, n, a, count, st);
+    } else {
+        if (low) launch_pq4_explicit_t<4, true>(a_in, n, a, count, st);
+        else launch_pq4_explicit_t<4, false>(a_in, n, a, count, st);
+    }
 }
 
 }  // namespace qocx

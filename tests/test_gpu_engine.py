@@ -70,8 +70,10 @@ def check_pade_factor(out, mats, policy):
         bound = np.max(np.sum(np.abs(a.real) + np.abs(a.imag), axis=0))
         if policy == 13:
             assert order == 13
-        elif mats.shape[1] > 16 and mats.shape[1] <= 32:  # kernels that select the order
+        elif mats.shape[1] > 16 and mats.shape[1] <= 32:  # two-wave K1a: from the square-root-free bound
             assert order == dm.pade_order(bound)
+        else:                                             # one- and four-wave K1a: from the exact norm
+            assert order == dm.pade_order(onp.one_norm(a))
         lower += order < 13
         f = dm.pade_factor(a, order=order)
         assert out["s"][m] == f["s"]
@@ -84,7 +86,7 @@ def check_pade_factor(out, mats, policy):
         for _ in range(int(out["s"][m])):
             u = u @ u
         assert rel_err(u, onp.expm_pade(a)) < (1e-10 if order == 13 else 1e-13)
-    if policy == 0 and 16 < mats.shape[1] <= 32:
+    if policy == 0:
         assert lower >= 12
 
 
@@ -180,15 +182,16 @@ def test_unit_adjoint_and_two_sided_pipeline(engine, name):
             for a, b, c in zip(unit, two_sided, one_sided):
                 assert np.array_equal(a, b) and np.array_equal(a, c)
         if case.n > 16:
-            # K1b fused into the two-wave K1a (P stays in LDS; knob "fuse_lu", off by default: no
-            # faster): the same factors, bit for bit
+            # K1b fused into the two-wave K1a (P stays in LDS; knob "fuse_lu", the default since
+            # the Pade order follows the norm) against the two kernels: the same
+            # factors, bit for bit
             engine.set_pipeline(0)
-            engine.set_knob("fuse_lu", 1)
-            fused = engine.evaluate(u, True)
-            for a, b in zip(unit, fused):
+            engine.set_knob("fuse_lu", 0)
+            apart = engine.evaluate(u, True)
+            for a, b in zip(unit, apart):
                 assert np.array_equal(a, b)
     finally:
-        engine.set_knob("fuse_lu", 0)
+        engine.set_knob("fuse_lu", 1)
         engine.set_knob("unit_adjoint", 1)
         engine.set_knob("bidir", 1)
         engine.set_pipeline(0)
