@@ -282,6 +282,26 @@ def main():
                             unit="propagator-steps/s",
                             note="qocx_eval_schroedinger: H2D of fresh controls (4 MB), "
                                  "evaluation, D2H of costs + gradients + final states, per step")
+    # Pade orders the engine chose on this workload (by the 1-norm of the step generators, Higham
+    # 2005 Algorithm 2.3 - the thresholds the reference's expm.py carries), and the same step with
+    # the order pinned to 13, which is what the reference itself always executes
+    orders = engine.pade_orders()
+    reference_order = None
+    if world == 1:
+        engine.set_knob("pade_order", 13)
+        one_step()
+        engine.synchronize()
+        t_r = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        engine.synchronize()
+        r13 = (time.perf_counter() - t_r) / args.steps
+        engine.set_knob("pade_order", 0)
+        one_step()
+        reference_order = dict(ms_per_step=r13 * 1e3, value=seeds * (N_EVAL - 1) / r13,
+                               unit="propagator-steps/s",
+                               note="knob pade_order = 13: every step on the [13/13] approximant, as "
+                                    "the reference executes it (expm.py:230-233)")
     secondary = None
     if world == 1 and not args.no_secondary:
         secondary = lindblad_secondary(engine)
@@ -290,10 +310,15 @@ def main():
     units_per_step = world * seeds * (N_EVAL - 1)
     value = units_per_step * args.steps / elapsed
 
-    # roofline of the dominant kernel (pade_pq): algorithmic flops = the Pade chain's 6 complex
-    # n^3 GEMMs per propagator step, 8 real flops per complex MAC.
+    # roofline of the dominant kernel (pade_pq): algorithmic flops = the complex n^3 GEMMs of the
+    # Pade chain per propagator step - 2 / 3 / 4 / 5 / 6 products for order 3 / 5 / 7 / 9 / 13, as
+    # executed on this workload - at 8 real flops per complex MAC. The LU
+    # factorisation fused into the kernel (8/3 n^3 VALU flops) is not counted.
     launches, total_ms = timing["pade_pq"]
-    k1_flops_per_unit = 8.0 * 6.0 * DIM ** 3
+    products = {3: 2, 5: 3, 7: 4, 9: 5, 13: 6}
+    steps_counted = max(1, sum(orders.values()))
+    mean_products = sum(products[o] * c for o, c in orders.items()) / steps_counted
+    k1_flops_per_unit = 8.0 * mean_products * DIM ** 3
     roofline = None
     if launches > 0 and total_ms > 0:
         avg_s = total_ms / launches * 1e-3
@@ -307,7 +332,9 @@ def main():
                         traffic_source="committed rocprofv3 --pmc passes of this command "
                                        "({}; FETCH_SIZE x2 + WRITE_SIZE), not collected in "
                                        "this run".format(PMC_SUMMARY),
-                        avg_launch_ms=total_ms / launches)
+                        avg_launch_ms=total_ms / launches,
+                        gemm_products_per_step=mean_products,
+                        flops_per_step=k1_flops_per_unit)
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in timing.items()}
     path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
     path_tflops = path_flops_per_unit * units_per_step * args.steps / elapsed / 1e12 / world
@@ -321,6 +348,9 @@ def main():
         "config": {"workload": "configs[2]: dim=32 Schroedinger, 1000 propagator steps, "
                                "{} seeds per GPU, K=2 real controls, S=1, M2".format(seeds),
                    "seeds_per_gpu": seeds, "hilbert_size": DIM, "system_eval_count": N_EVAL,
+                   "pade_orders": {str(o): c for o, c in orders.items() if c},
+                   "pade_policy": "order by ||dt H||_1 (Higham 2005 alg. 2.3 thresholds, "
+                                  "expm.py:194-209); reference_order has the always-13 rate",
                    "parallelism": "seed-sharded x{}".format(world)},
         "roofline": roofline,
         "kernel_ms_per_launch": kernel_ms,
@@ -330,6 +360,7 @@ def main():
         "value_definition": "controls resident in HBM when the clock starts (bench contract); "
                             "the host-buffer-to-host-buffer rate is host_to_host",
         "host_to_host": host_to_host,
+        "reference_order": reference_order,
         "secondary": secondary,
     }
     if rank == 0:

@@ -294,6 +294,13 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
  * inverter L | loader | inverter U'), 8 sums - shader-clock cycles per phase of the role's step loop, [7] = the
  * 100 MHz real-time counter over the role's life. out: [batch][4][8]. */
 int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
+/* Pade orders of the last Schroedinger evaluation (its last memory chunk): counts[0..4] = number of
+ * propagator steps evaluated with the [3/3], [5/5], [7/7], [9/9], [13/13] approximant. The engine
+ * takes the order from the 1-norm of the step generator by the thresholds of Higham 2005,
+ * Algorithm 2.3 - the table /root/reference/qoc/standard/functions/expm.py:194-209 carries; the
+ * reference itself always evaluates [13/13] (expm.py:230-233: its selection loop has no break),
+ * which the knob "pade_order" = 13 reproduces. Same matrix and same derivative to rounding. */
+int qocx_pade_orders(qocx_ctx* ctx, int64_t* counts);
 /* With qocx_set_timing on: the kernel launches of the LAST evaluation as (which, start_ms, end_ms)
  * triples relative to its first launch (HIP events on the launch streams; which = the index of
  * qocx_get_timing: 0 K1a, 1 sweep, 2 K3, 3 scatter, 4 K1b, 5 Lindblad, 6 its combine kernel). out

@@ -190,6 +190,7 @@ struct qocx_ctx {
     // ---- evaluation state ----
     int B = 0;
     int sbound = 0;
+    int last_chunk = 0;         // seeds of the last memory chunk of the last evaluation (its step table is in s_arr)
     double norm_bound = 1e300;  // host bound of ||step generator||_1 of the uploaded controls / generators
     size_t slot_cap = 0;
     int chunk_user = 0;
@@ -1116,6 +1117,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     hipStream_t cs = ctx->stream;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
+        ctx->last_chunk = bc;
         int nseg = ctx->pipe_user > 0 ? ctx->pipe_user
                                       : ((size_t)bc * nsteps >= 16384 && nsteps >= 64 ? 8 : 1);
         if (ctx->pipe_user <= 0 && nseg == 1 && latency && unit && nsteps >= 64) nseg = 4;
@@ -2343,6 +2345,22 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
 int qocx_lindblad_last_subintervals(qocx_ctx* ctx, int64_t* total) {
     if (!ctx || !total) return fail(QOCX_ERR_ARG, "NULL argument");
     *total = ctx->lb.last_subintervals;
+    return 0;
+}
+
+int qocx_pade_orders(qocx_ctx* ctx, int64_t* counts) {
+    if (!ctx || !counts) return fail(QOCX_ERR_ARG, "NULL argument");
+    if (!ctx->have_results) return fail(QOCX_ERR_STATE, "no evaluation results");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t total = (size_t)ctx->last_chunk * ctx->nsteps;
+    if (total == 0 || total > ctx->s_arr.count) return fail(QOCX_ERR_STATE, "no step table");
+    std::vector<int> entries(total);
+    HIP_TRY(hipMemcpy(entries.data(), ctx->s_arr.p, total * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    for (int e : entries) {
+        const int o = (e >> 8) & 0xff;  // step_entry (qocx_wave.h): 0 means 13
+        counts[o == 3 ? 0 : (o == 5 ? 1 : (o == 7 ? 2 : (o == 9 ? 3 : 4)))] += 1;
+    }
     return 0;
 }
 

@@ -147,6 +147,7 @@ SIGNATURES = {
     "qocx_debug_set_knob": (ctypes.c_int, [_VP, ctypes.c_char_p, _I64]),
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
+    "qocx_pade_orders": (ctypes.c_int, [_VP, ctypes.POINTER(_I64)]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
     "qocx_opt_begin": (ctypes.c_int, [_VP]),
     "qocx_opt_clip": (ctypes.c_int, [_VP, _c_double_p]),
@@ -474,6 +475,12 @@ class Engine(object):
     def set_pipeline(self, time_segments):
         """Number of time segments the evaluation pipeline is cut into (0 = automatic)."""
         self._check(self._lib.qocx_set_pipeline(self._ctx, int(time_segments)))
+
+    def pade_orders(self):
+        """{order: propagator steps} of the last evaluation (include/qocx.h: qocx_pade_orders)."""
+        counts = (_I64 * 5)()
+        self._check(self._lib.qocx_pade_orders(self._ctx, counts))
+        return {order: int(counts[i]) for i, order in enumerate((3, 5, 7, 9, 13))}
 
     def timeline(self, capacity=4096):
         """(which, start_ms, end_ms) of the last evaluation's kernel launches (timing on)."""
