@@ -617,6 +617,78 @@ __device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
 }
 
+// Two right-hand sides at once (two states of a seed on one wave): the two dependent chains are
+// independent of each other, so each fills the other's bubbles - the broadcasts of one pair of
+// z_k overlap the updates of the other - and the coefficient row is used twice.
+template <bool CONJ, unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_cfma2(double& are, double& aim, double& bre, double& bim,
+                                             double cre, double cim, double kar, double kai,
+                                             double kbr, double kbi) {
+    if (CONJ) {
+        asm volatile(
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_fma_f64 %[ar], -%[cr], %[kar], %[ar]\n\t"
+            "v_fma_f64 %[ai], -%[cr], %[kai], %[ai]\n\t"
+            "v_fma_f64 %[br], -%[cr], %[kbr], %[br]\n\t"
+            "v_fma_f64 %[bi], -%[cr], %[kbi], %[bi]\n\t"
+            "v_fma_f64 %[ar], -%[ci], %[kai], %[ar]\n\t"
+            "v_fma_f64 %[ai], %[ci], %[kar], %[ai]\n\t"
+            "v_fma_f64 %[br], -%[ci], %[kbi], %[br]\n\t"
+            "v_fma_f64 %[bi], %[ci], %[kbr], %[bi]\n\t"
+            "s_mov_b64 exec, -1"
+            : [ar] "+v"(are), [ai] "+v"(aim), [br] "+v"(bre), [bi] "+v"(bim)
+            : [cr] "v"(cre), [ci] "v"(cim), [kar] "s"(kar), [kai] "s"(kai), [kbr] "s"(kbr),
+              [kbi] "s"(kbi), [lo] "i"(LO), [hi] "i"(HI)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_fma_f64 %[ar], -%[cr], %[kar], %[ar]\n\t"
+            "v_fma_f64 %[ai], -%[cr], %[kai], %[ai]\n\t"
+            "v_fma_f64 %[br], -%[cr], %[kbr], %[br]\n\t"
+            "v_fma_f64 %[bi], -%[cr], %[kbi], %[bi]\n\t"
+            "v_fma_f64 %[ar], %[ci], %[kai], %[ar]\n\t"
+            "v_fma_f64 %[ai], -%[ci], %[kar], %[ai]\n\t"
+            "v_fma_f64 %[br], %[ci], %[kbi], %[br]\n\t"
+            "v_fma_f64 %[bi], -%[ci], %[kbr], %[bi]\n\t"
+            "s_mov_b64 exec, -1"
+            : [ar] "+v"(are), [ai] "+v"(aim), [br] "+v"(bre), [bi] "+v"(bim)
+            : [cr] "v"(cre), [ci] "v"(cim), [kar] "s"(kar), [kai] "s"(kai), [kbr] "s"(kbr),
+              [kbi] "s"(kbi), [lo] "i"(LO), [hi] "i"(HI)
+            : "memory");
+    }
+}
+
+template <int NB, bool LOWER, bool CONJ, int KK, class Hook>
+__device__ __forceinline__ void tri_step2(const double (&tre)[Geo<NB>::NP],
+                                          const double (&tim)[Geo<NB>::NP], double& are, double& aim,
+                                          double& bre, double& bim, Hook& hook) {
+    constexpr int NP = Geo<NB>::NP;
+    constexpr int k = LOWER ? KK : (NP - 1 - KK);
+    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
+    const double kar = readlane_f64(are, k), kai = readlane_f64(aim, k);
+    const double kbr = readlane_f64(bre, k), kbi = readlane_f64(bim, k);
+    hook(std::integral_constant<int, KK>());
+    masked_cfma2<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
+        are, aim, bre, bim, tre[k], tim[k], kar, kai, kbr, kbi);
+}
+template <int NB, bool LOWER, bool CONJ, class Hook, int... KK>
+__device__ __forceinline__ void tri_solve2_seq(const double (&tre)[Geo<NB>::NP],
+                                               const double (&tim)[Geo<NB>::NP], double& are,
+                                               double& aim, double& bre, double& bim, Hook& hook,
+                                               std::integer_sequence<int, KK...>) {
+    (tri_step2<NB, LOWER, CONJ, KK>(tre, tim, are, aim, bre, bim, hook), ...);
+}
+template <int NB, bool LOWER, bool CONJ, class Hook>
+__device__ __forceinline__ void tri_solve2(const double (&tre)[Geo<NB>::NP],
+                                           const double (&tim)[Geo<NB>::NP], double& are, double& aim,
+                                           double& bre, double& bim, Hook& hook) {
+    tri_solve2_seq<NB, LOWER, CONJ>(tre, tim, are, aim, bre, bim, hook,
+                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
+}
+
 // The same solves with the coefficients fetched from the LDS image stage by stage (NB = 4: a lane's
 // row of the LU image would be 256 registers; held there, the sweep wave owns a whole SIMD and only
 // one four-wave K3 workgroup fits on the other three). The coefficient of stage KK + 8 is requested
@@ -699,8 +771,9 @@ struct SweepLds {
     static constexpr int P_OFF = D_OFF + NBUF * 64 * 16;        // NBUF x PINTS int: perm | iperm
     static constexpr int PINTS = G::NP > 32 ? 128 : 64;        // iperm starts at PINTS / 2
     static constexpr int MAX_WAVES = 4;                        // waves per seed (multi-state)
-    static constexpr int TMP_OFF = P_OFF + NBUF * PINTS * 4;    // NP complex scratch per wave
-    static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * G::NP * 16;  // [S][NP] states, [S][NP] lambda
+    static constexpr int TMP_OFF = P_OFF + NBUF * PINTS * 4;    // TMPV x NP complex scratch per wave
+    static constexpr int TMPV = SweepLdsCoef<NB>::value ? 1 : 2;  // (two: the paired-state form)
+    static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * TMPV * G::NP * 16;  // [S][NP] states, [S][NP] lambda
     static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
     __host__ __device__ static constexpr int bytes_static(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
 };
@@ -780,6 +853,39 @@ __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec
     yim = sum_groups<NB>(ai);
 }
 
+// Two vectors against the same matrix: every matrix element is read from LDS once.
+template <int NB, bool CONJ, int BATCH>
+__device__ __forceinline__ void lds_matvec2(const double2* qb, const double2* veca, const double2* vecb,
+                                            int qlane, int h, double& yar, double& yai, double& ybr,
+                                            double& ybi) {
+    typedef Geo<NB> G;
+    constexpr int CPL = G::CPL, H = G::H;
+    double ar = 0, ai = 0, br = 0, bi = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < CPL; c0 += BATCH) {
+        double2 qv[BATCH], xa[BATCH], xb[BATCH];
+#pragma unroll
+        for (int cc = 0; cc < BATCH; ++cc) {
+            qv[cc] = qb[(c0 + cc) * 64 + qlane];
+            xa[cc] = veca[(c0 + cc) * H + h];
+            xb[cc] = vecb[(c0 + cc) * H + h];
+        }
+#pragma unroll
+        for (int cc = 0; cc < BATCH; ++cc) {
+            const double qi = CONJ ? -qv[cc].y : qv[cc].y;
+            ar = fma(-qi, xa[cc].y, fma(qv[cc].x, xa[cc].x, ar));
+            ai = fma(qi, xa[cc].x, fma(qv[cc].x, xa[cc].y, ai));
+            br = fma(-qi, xb[cc].y, fma(qv[cc].x, xb[cc].x, br));
+            bi = fma(qi, xb[cc].x, fma(qv[cc].x, xb[cc].y, bi));
+        }
+        asm volatile("" ::: "memory");
+    }
+    yar = sum_groups<NB>(ar);
+    yai = sum_groups<NB>(ai);
+    ybr = sum_groups<NB>(br);
+    ybi = sum_groups<NB>(bi);
+}
+
 // W waves per seed: the S states of a seed are dealt out to the waves of its workgroup (state s to
 // wave s % W). The operands of a step (Q, LU, 1/U_kk, perm) are fetched once, by wave 0, into LDS
 // buffers all waves read; a workgroup barrier at every step start says "the operands have landed
@@ -812,6 +918,9 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     // set of operands only - the step's fetch is issued at its start and waited for (PREFETCH off).
     constexpr bool PREFETCH = SweepPrefetch<NB>::value;
     constexpr bool LDSCOEF = SweepLdsCoef<NB>::value;
+    // two states of a seed at a time on a wave (tri_solve2, lds_matvec2) where a wave has several:
+    // the register-row solves of the multi-state forms
+    constexpr bool PAIRS = !ONEBUF && !LDSCOEF && !LOADER && W > 1;
     static_assert(PREFETCH || !LOADER, "the loader variant needs a ring of buffers");
     constexpr int NBUF = LOADER ? 3 : ((PREFETCH && !ONEBUF) ? 2 : 1);
     typedef SweepLds<NB, NBUF> L;
@@ -832,7 +941,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     // the wave that fetches: the extra one, or compute wave 0 from inside its solves
     const bool fetcher = LOADER ? (w == W) : (w == 0);
     const bool computes = !LOADER || (w < W);
-    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + (computes ? w : 0) * NP;
+    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF) + (computes ? w : 0) * L::TMPV * NP;
     double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
     auto block_sync = [&]() {
         if constexpr (LOADER) {
@@ -1026,7 +1135,35 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 overflow = true;
                 break;
             }
-            for (int s = s0; s < S; s += W) {
+            int s = s0;
+            if constexpr (PAIRS) {
+                // two states at a time (tri_solve2): same arithmetic per state, bit for bit
+                for (; s + W < S; s += 2 * W) {
+                    pf_fire_q = pf_fire_l = pf_due;
+                    double are, aim, bre, bim;
+                    lds_matvec2<NB, false, MVB>(qcur, vecs + s * NP, vecs + (s + W) * NP,
+                                                h * NP + sc.pm, h, are, aim, bre, bim);
+                    tri_solve2<NB, true, false>(r.lre, r.lim, are, aim, bre, bim, hook_a);
+                    const double ta = are * sc.dv.x - aim * sc.dv.y;
+                    aim = are * sc.dv.y + aim * sc.dv.x;
+                    are = ta;
+                    const double tb = bre * sc.dv.x - bim * sc.dv.y;
+                    bim = bre * sc.dv.y + bim * sc.dv.x;
+                    bre = tb;
+                    tri_solve2<NB, false, false>(r.lre, r.lim, are, aim, bre, bim, hook_b);
+                    finish_prefetch();
+                    wave_sync();
+                    {
+                        const double2 pa = make_double2(are, aim), pb = make_double2(bre, bim);
+                        vecs[s * NP + i] = pa;
+                        vecs[(s + W) * NP + i] = pb;
+                        states_b[((size_t)(slot + 1) * S + s) * NP + i] = pa;
+                        states_b[((size_t)(slot + 1) * S + s + W) * NP + i] = pb;
+                    }
+                    wave_sync();
+                }
+            }
+            for (; s < S; s += W) {
                 // the next step's operands: ONEBUF into the buffers of this step, once its last
                 // matvec has read Q; else into the other set during the first (sub-step, state)
                 pf_fire_q = pf_fire_l = pf_due && (!ONEBUF || sub == nsub - 1);
@@ -1183,7 +1320,41 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 break;
             }
             --slot;
-            for (int s = s0; s < S; s += W) {
+            int s = s0;
+            if constexpr (PAIRS) {
+                for (; s + W < S; s += 2 * W) {
+                    pf_fire_l = pf_fire_q = pf_due;
+                    const double2 la = lam[s * NP + i], lb = lam[(s + W) * NP + i];
+                    double are = la.x, aim = la.y, bre = lb.x, bim = lb.y;
+                    tri_solve2<NB, true, true>(r.lre, r.lim, are, aim, bre, bim, hook_a);
+                    const double ta = are * sc.dv.x + aim * sc.dv.y;
+                    aim = aim * sc.dv.x - are * sc.dv.y;
+                    are = ta;
+                    const double tb = bre * sc.dv.x + bim * sc.dv.y;
+                    bim = bim * sc.dv.x - bre * sc.dv.y;
+                    bre = tb;
+                    tri_solve2<NB, false, true>(r.lre, r.lim, are, aim, bre, bim, hook_b);
+                    finish_prefetch();
+                    const double xar = __shfl(are, sc.pm), xai = __shfl(aim, sc.pm);
+                    const double xbr = __shfl(bre, sc.pm), xbi = __shfl(bim, sc.pm);
+                    wave_sync();
+                    {
+                        const double2 xa = make_double2(xar, xai), xb = make_double2(xbr, xbi);
+                        tmp[i] = xa;
+                        tmp[NP + i] = xb;
+                        xs_b[((size_t)slot * S + s) * NP + i] = xa;
+                        xs_b[((size_t)slot * S + s + W) * NP + i] = xb;
+                    }
+                    wave_sync();
+                    double yar, yai, ybr, ybi;
+                    lds_matvec2<NB, true, MVB>(qcur, tmp, tmp + NP, lane, h, yar, yai, ybr, ybi);
+                    wave_sync();
+                    lam[s * NP + i] = make_double2(yar, yai);
+                    lam[(s + W) * NP + i] = make_double2(ybr, ybi);
+                    wave_sync();
+                }
+            }
+            for (; s < S; s += W) {
                 // (ONEBUF: the first sub-step processed fetches the step's own Q and the next
                 // step's LU image; pf_due / pf_qdue are cleared by finish_prefetch)
                 pf_fire_l = pf_due;
