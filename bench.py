@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seeds-per-gpu", type=int, default=SEEDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-order", action="store_true",
+                    help="skip the extra pass with the Pade order pinned to 13 (profiling runs: the "
+                         "kernel statistics then hold the timed configuration only)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[3] Lindblad measurement")
     ap.add_argument("--time-segments", type=int, default=0,
@@ -287,7 +290,7 @@ def main():
     # the order pinned to 13, which is what the reference itself always executes
     orders = engine.pade_orders()
     reference_order = None
-    if world == 1:
+    if world == 1 and not args.no_reference_order:
         engine.set_knob("pade_order", 13)
         one_step()
         engine.synchronize()

@@ -8,7 +8,7 @@ TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-order"
 # 1. kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 STATS=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
