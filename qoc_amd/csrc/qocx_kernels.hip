@@ -283,7 +283,7 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
                     }
             }
             wave_sync();
-            gen(a);
+            if constexpr (NB > 1) gen(a);  // (one tile: the generator stays in its 8 registers)
             cmat_to_lds3<NB>(a, lre, lim, lsum);
             wave_sync();
         }

@@ -305,7 +305,8 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, w.re[ti], w.im[ti]);
         if (GIVE) stage_mirror(sl, 1, 0, w.re[0], w.im[0], 1.0);
-        gen(a, W);
+        // (the generator stays in its 32 registers here - fewer products are alive than on the
+        // [13/13] path, which rebuilds it from 24 KB of images)
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             u.re[ti] = bt[1] * a.re[ti];
