@@ -1334,6 +1334,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ka.g_rimg = m4lin ? ctx->ge_rimg.p : ctx->g_rimg.p;
         ka.g_timg = m4lin ? ctx->ge_timg.p : ctx->g_timg.p;
         ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
+        ka.n = ctx->n;
         ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
         ka.offs = ctx->offs.p;
         ka.offs_x = unit ? ctx->offs_x.p : nullptr;

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
     // elimination step - the pad rows are zero left of the diagonal, so they are never pivots and
     // their multipliers vanish; their columns in HBM are final as they stand.
     const int kmax = (args.n > 0 && args.n <= 48) ? 48 : NP;
+    const bool live = __builtin_amdgcn_readfirstlane(CW * w < kmax ? 1 : 0) != 0;  // this wave has columns to update
     if (w == 0) factor_column(std::integral_constant<int, 0>());
     // Step k: one barrier, then every wave applies the step to its columns. LOOKAHEAD: the owner of
     // column k + 1 updates that column first, factors it and publishes step k + 1 (the other LDS
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
                 factor_column(std::integral_constant<int, k + 1>());
             }
         }
-        if (CW * w + CW - 1 > k + 1) {  // wave-uniform: columns beyond k + 1 are still active
+        // (n <= 48: the pivot rows are zero in the pad columns 48..63, nothing to update there)
+        if (live && CW * w + CW - 1 > k + 1) {  // wave-uniform: columns beyond k + 1 are still active
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const bool on = (CW * w + c > k + 1);  // column k + 1 was done above
@@ -165,7 +167,12 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
     if (kmax < NP) {  // the pad rows stay where they are: position = row, 1 / U_kk = 1 / b0
         if (lane >= kmax) {
             mypos = lane;
-            if (w == 0) args.dinv[m * NP + lane] = make_double2(1.0 / PADE_B[0], 0.0);
+            if (w == (lane >> 4)) {  // the owner of column `lane` holds the diagonal element b0 of
+                double d = 1.0;      // the step's Pade order (qocx_wave.h), untouched by the elimination
+#pragma unroll
+                for (int c = 0; c < CW; ++c) d = ((lane & 15) == c) ? pre[c] : d;
+                args.dinv[m * NP + lane] = make_double2(1.0 / d, 0.0);
+            }
         }
     }
     if (singular && lane == 0) atomicOr(args.status, 1);

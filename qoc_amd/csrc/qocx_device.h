@@ -123,6 +123,7 @@ struct KrylovArgs {
     const double2* g_rimg;
     const double2* g_timg;
     int K, nc, nsteps, nt, S;
+    int n = 0;  // Hilbert size (four-wave K3: <= 48 -> the zero pad columns are skipped); 0: unknown
     int step0;  // grid.x covers steps [step0, step0 + gridDim.x)
     int skew;   // 1: every H0(t), G_k(t) is exactly Hermitian (a^H = -a)
     double dt;
