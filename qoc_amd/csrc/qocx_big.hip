@@ -194,10 +194,11 @@ struct KrLds {
     double red[WV * 64];      // gradient partials: [k][w]
 };
 
-template <bool EXPLICIT, bool SKEW>
+// CC: columns per wave that can be non-zero - 16, or 12 for n <= 48 (c = 4 cc + w < 48)
+template <bool EXPLICIT, bool SKEW, int CC>
 __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     __shared__ __attribute__((aligned(16))) KrLds lds;
-    constexpr int HC = SKEW ? 1 : CW;
+    constexpr int HC = SKEW ? 1 : CC;
     const int step = args.step0 + blockIdx.x, b = blockIdx.y;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,12 +219,12 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     const double2* gt = args.g_timg + tsel * K * MAT;
 
     // this wave's columns c = 4 cc + w of a (rows) and of a^H (rows) of the scaled generator
-    double are[CW], aim[CW], hre[HC], him[HC];
+    double are[CC], aim[CC], hre[HC], him[HC];
     if constexpr (EXPLICIT) {
         const double2* mm = args.m_rm + m * MAT;  // row-major, padded
         const double sc = ldexp(1.0, -sq);
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc) {
+        for (int cc = 0; cc < CC; ++cc) {
             const int col = WV * cc + w;
             const double2 e = mm[(size_t)lane * NP + col];
             are[cc] = sc * e.x;
@@ -235,9 +236,9 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
             }
         }
     } else {
-        double xr[CW], xi[CW], tr_[HC], ti_[HC];
+        double xr[CC], xi[CC], tr_[HC], ti_[HC];
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc) {
+        for (int cc = 0; cc < CC; ++cc) {
             const int col = WV * cc + w;
             const double2 e = h0r[col * NP + lane];
             xr[cc] = e.x;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
         for (int k = 0; k < K; ++k) {
             const double uk = control_at(ctl_b, si, K, k);
 #pragma unroll
-            for (int cc = 0; cc < CW; ++cc) {
+            for (int cc = 0; cc < CC; ++cc) {
                 const int col = WV * cc + w;
                 const double2 e = gr[(size_t)k * MAT + col * NP + lane];
                 xr[cc] += uk * e.x;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
             }
         }
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc) {
+        for (int cc = 0; cc < CC; ++cc) {
             are[cc] = dts * xi[cc];  // a = -i dts H
             aim[cc] = -dts * xr[cc];
             if constexpr (!SKEW) {
@@ -293,9 +294,9 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     const int nsub = 1 << sq;
     if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) return;  // sweep overflowed (status bit 2)
 
-    double abr[CW], abi[CW];
+    double abr[CC], abi[CC];
 #pragma unroll
-    for (int cc = 0; cc < CW; ++cc) {
+    for (int cc = 0; cc < CC; ++cc) {
         abr[cc] = 0;
         abi[cc] = 0;
     }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
                 if (jj + 1 >= M) break;
                 double s2r = 0, s2i = 0;
 #pragma unroll
-                for (int cc = 0; cc < CW; ++cc) {
+                for (int cc = 0; cc < CC; ++cc) {
                     const int col = WV * cc + w;
                     const double vx = readlane_f64(tar[jj], col), vy = readlane_f64(tai[jj], col);
                     if constexpr (SKEW) {  // a^H = -a
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
                 if (ii >= M) continue;
                 double s0r = 0, s0i = 0;
 #pragma unroll
-                for (int cc = 0; cc < CW; ++cc) {
+                for (int cc = 0; cc < CC; ++cc) {
                     const int col = WV * cc + w;
                     const double rx = readlane_f64(rr, col), ry = readlane_f64(ri, col);
                     // tau * conj(rho)
@@ -362,8 +363,11 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
         double2* mb = args.mbar_rm + m * MAT;
         const double sc = ldexp(1.0, -sq);
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc)
+        for (int cc = 0; cc < CC; ++cc)
             mb[(size_t)lane * NP + WV * cc + w] = make_double2(sc * abr[cc], sc * abi[cc]);
+#pragma unroll
+        for (int cc = CC; cc < 16; ++cc)  // the pad columns of the cotangent are zero
+            mb[(size_t)lane * NP + WV * cc + w] = make_double2(0.0, 0.0);
     } else {
         // g_k = Re <abar, E_k>, E_k = d a / d u_k = -i dts G_k
         for (int k0 = 0; k0 < K; k0 += 64) {
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
             for (int k = 0; k < kn; ++k) {
                 double acc = 0;
 #pragma unroll
-                for (int cc = 0; cc < CW; ++cc) {
+                for (int cc = 0; cc < CC; ++cc) {
                     const double2 e = gr[(size_t)(k0 + k) * MAT + (WV * cc + w) * NP + lane];
                     acc = fma(abi[cc], -dts * e.x, fma(abr[cc], dts * e.y, acc));
                 }
@@ -395,14 +399,17 @@ void launch_lu4(const LuArgs& a, size_t count, hipStream_t st) {
 
 void launch_krylov4(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
     const dim3 grid(nsteps, batch), block(256);
-    if (a.m_rm != nullptr && a.skew)
-        hipLaunchKernelGGL((big::krylov4_kernel<true, true>), grid, block, 0, st, a);
-    else if (a.m_rm != nullptr)
-        hipLaunchKernelGGL((big::krylov4_kernel<true, false>), grid, block, 0, st, a);
-    else if (a.skew)
-        hipLaunchKernelGGL((big::krylov4_kernel<false, true>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((big::krylov4_kernel<false, false>), grid, block, 0, st, a);
+    const bool small = a.n > 0 && a.n <= 48;  // the pad columns 48..63 are zero: 12 columns per wave
+#define QOCX_K4(E, S)                                                                       \
+    do {                                                                                    \
+        if (small) hipLaunchKernelGGL((big::krylov4_kernel<E, S, 12>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((big::krylov4_kernel<E, S, 16>), grid, block, 0, st, a);       \
+    } while (0)
+    if (a.m_rm != nullptr && a.skew) QOCX_K4(true, true);
+    else if (a.m_rm != nullptr) QOCX_K4(true, false);
+    else if (a.skew) QOCX_K4(false, true);
+    else QOCX_K4(false, false);
+#undef QOCX_K4
 }
 
 }  // namespace qocx

@@ -78,11 +78,12 @@ def test_sixteen_tile_kernels_do_not_spill():
     lu = find(big, "lu4_kernel")
     assert lu["ScratchSize"] == 0 and lu["VGPRs Spill"] == 0
     assert (total_registers(lu) + 7) // 8 * 8 * 4 <= 512          # four K1b waves per SIMD
-    for frag in ("krylov4_kernelILb0ELb1E", "krylov4_kernelILb0ELb0E", "krylov4_kernelILb1ELb1E",
-                 "krylov4_kernelILb1ELb0E"):
-        k3 = find(big, frag)
-        assert k3["ScratchSize"] == 0, frag
-    assert total_registers(find(big, "krylov4_kernelILb0ELb1E")) <= 256   # two per SIMD (Hermitian H)
+    for cols in ("Li16E", "Li12E"):  # 16 columns per wave, or 12 (n <= 48: the pad columns are zero)
+        for frag in ("krylov4_kernelILb0ELb1E", "krylov4_kernelILb0ELb0E", "krylov4_kernelILb1ELb1E",
+                     "krylov4_kernelILb1ELb0E"):
+            k3 = find(big, frag + cols)
+            assert k3["ScratchSize"] == 0, frag
+        assert total_registers(find(big, "krylov4_kernelILb0ELb1E" + cols)) <= 256   # two per SIMD (Hermitian H)
     # two variants of each (qocx_pade4.hip): the [13/13] path inlined and the low-order path a
     # call (Lb0), or the other way round (Lb1, chosen when the host's norm bound is below theta_9)
     for frag in ("pade_pq4_kernelILi4ELb0E", "pade_pq4_explicit_kernelILi4ELb0E",
