@@ -90,13 +90,22 @@ def check_pade_factor(out, mats, policy):
         assert lower >= 12
 
 
+@pytest.mark.parametrize("pade_order", [0, 13])
 @pytest.mark.parametrize("name", GRAD_CASES)
-def test_engine_matches_golden(engine, name):
+def test_engine_matches_golden(engine, name, pade_order):
+    """Every reference-minted fixture at the parity gates, under both Pade policies: the order by
+    norm (default) and always [13/13], which is what the reference executes (knob "pade_order")."""
     from tests import gpu_helpers as gh
     case = cases_mod.case_by_name(name)
     g = golden(name)
     host_specs = gh.setup_engine(engine, case)
-    cost, grads, final = engine.evaluate(gh.real_controls(case, case.controls), want_grad=True)
+    engine.set_knob("pade_order", pade_order)
+    try:
+        cost, grads, final = engine.evaluate(gh.real_controls(case, case.controls), want_grad=True)
+        orders = engine.pade_orders()
+    finally:
+        engine.set_knob("pade_order", 0)
+    assert pade_order == 0 or orders[13] == sum(orders.values())
     grads = gh.complex_grads(case, grads)
     host_costs = [getattr(onp, k)(**kw) for k, kw in host_specs]
     for b in range(len(case.controls)):
