@@ -228,8 +228,10 @@ int qocx_lindblad_last_subintervals(qocx_ctx* ctx, int64_t* total);
 int qocx_set_density_cotangents(qocx_ctx* ctx, int32_t batch, int32_t count, const int32_t* steps,
                                 const double* bars);
 
-/* Per-kernel timing, measured with HIP events on the context's stream.
- * enable: 0/1. After evaluations, qocx_get_timing returns for kernel `which`
+/* Per-kernel timing, measured with HIP events on the launch streams.
+ * enable: 0 off, 1 every launch, 2 + k the launches of kernel k only (two events per timed launch
+ * cost the evaluation 2-3 % when all ~45 launches of it carry them; bench.py times its roofline
+ * kernel only inside the timed region). After evaluations, qocx_get_timing returns for kernel `which`
  * (0 pade_pq, 1 sweep, 2 krylov_grad, 3 scatter, 4 lu, 5 lindblad, 6 lindblad_combine) the launch
  * count and total ms
  * since the last reset. */

@@ -281,7 +281,8 @@ struct qocx_ctx {
         return it == knobs.end() ? dflt : it->second;
     }
     // ---- timing ----
-    int timing = 0;
+    int timing = 0;            // 0 off, 1 every launch, 2 + k the launches of kernel k only
+    bool time_active = false;  // the launch between the last time_begin / time_end is being timed
     std::vector<TimingRec> pending;
     std::vector<double> timeline;  // (which, start, end) of the last evaluation's launches
     std::vector<hipEvent_t> ev_pool;
@@ -350,7 +351,9 @@ hipEvent_t pooled_event(qocx_ctx* ctx) {
 }
 
 void time_begin(qocx_ctx* ctx, int which, hipStream_t st) {
-    if (!ctx->timing) return;
+    // timing 1: every launch; 2 + k: the launches of kernel k only (qocx_set_timing)
+    ctx->time_active = ctx->timing == 1 || (ctx->timing >= 2 && which == ctx->timing - 2);
+    if (!ctx->time_active) return;
     TimingRec r;
     r.which = which;
     r.a = pooled_event(ctx);
@@ -360,7 +363,7 @@ void time_begin(qocx_ctx* ctx, int which, hipStream_t st) {
 }
 
 void time_end(qocx_ctx* ctx, hipStream_t st) {
-    if (!ctx->timing) return;
+    if (!ctx->time_active) return;
     (void)hipEventRecord(ctx->pending.back().b, st);
 }
 
@@ -1538,7 +1541,9 @@ int qocx_eval_schroedinger(qocx_ctx* ctx, int32_t batch, const double* controls,
 
 int qocx_set_timing(qocx_ctx* ctx, int32_t enable) {
     if (!ctx) return fail(QOCX_ERR_ARG, "ctx is NULL");
-    ctx->timing = enable ? 1 : 0;
+    if (enable < 0 || enable > 8) return fail(QOCX_ERR_ARG, "timing mode must be 0, 1 or 2 + kernel index");
+    ctx->timing = enable;
+    ctx->time_active = false;
     return 0;
 }
 

@@ -491,8 +491,10 @@ class Engine(object):
         return out[:min(capacity, count.value)]
 
     # -- timing --------------------------------------------------------------------------------
-    def set_timing(self, enable):
-        self._check(self._lib.qocx_set_timing(self._ctx, int(bool(enable))))
+    def set_timing(self, enable, only=None):
+        """enable: every launch carries HIP events; only = a name of KERNEL_NAMES: that kernel only."""
+        mode = (2 + KERNEL_NAMES.index(only)) if (enable and only) else int(bool(enable))
+        self._check(self._lib.qocx_set_timing(self._ctx, mode))
 
     def reset_timing(self):
         self._check(self._lib.qocx_reset_timing(self._ctx))
