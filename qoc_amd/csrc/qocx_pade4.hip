@@ -421,7 +421,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
 }
 
 template <int NT, bool LOWINL>
-__global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
+__global__ __launch_bounds__(64 * NT, LOWINL ? 2 : 1) void pade_pq4_kernel(FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * NT) void pade_pq4_kernel(FactorArgs args) {
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
 template <int NT, bool LOWINL>
-__global__ __launch_bounds__(64 * NT) void pade_pq4_explicit_kernel(const double2* a_in, int n,
+__global__ __launch_bounds__(64 * NT, (NT == 3 && LOWINL) ? 2 : 1) void pade_pq4_explicit_kernel(const double2* a_in, int n,
                                                                     FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];

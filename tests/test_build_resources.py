@@ -94,4 +94,9 @@ def test_sixteen_tile_kernels_do_not_spill():
     for frag in ("pade_pq4_kernelILi4ELb1E", "pade_pq4_explicit_kernelILi4ELb1E",
                  "pade_pq4_kernelILi3ELb1E", "pade_pq4_explicit_kernelILi3ELb1E"):
         k1a = find(pade4, frag)
-        assert k1a["ScratchSize"] <= 512 and k1a["VGPRs Spill"] <= 96, (frag, k1a)
+        # (the structured kernels and the nine-tile explicit one are capped at 256 registers - two
+        # waves per SIMD: K1a 3.42 -> 1.98 ms per launch at n = 48, 4.77 -> 3.95 at n = 64 - and
+        # what they spill sits in the outlined [13/13] path, which these variants do not reach)
+        assert k1a["ScratchSize"] <= 1600 and k1a["VGPRs Spill"] <= 300, (frag, k1a)
+    assert find(pade4, "pade_pq4_kernelILi3ELb1E")["Occupancy"] == 2
+    assert find(pade4, "pade_pq4_kernelILi3ELb1E")["VGPRs Spill"] <= 32
