@@ -2339,7 +2339,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
@@ -2665,7 +2665,8 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     fa.q_img = q_d.p; fa.lu_img = lu_d.p; fa.s_arr = s_d.p; fa.status = ctx->status.p;
     fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
     fa.pade_policy = (int)ctx->knob("pade_order", 0);
-    const bool fused_lu = nb == 2 && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
+    const bool inverse = nb <= 2 && ctx->knob("lu_inverse", 0) != 0;  // P^-1 instead of the factors
+    const bool fused_lu = nb == 2 && !inverse && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
@@ -2673,6 +2674,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
     la.status = ctx->status.p;
     la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
+    la.inverse = inverse ? 1 : 0;
     if (!fused_lu) qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2684,6 +2686,20 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
         for (int m = 0; m < count; ++m)
             from_image(img.data() + (size_t)m * mat, n, np, nullptr, q_out + (size_t)m * n * n * 2);
     HIP_TRY(hipMemcpy(img.data(), lu_d.p, img.size() * 16, hipMemcpyDeviceToHost));
+    if (lu_out && inverse) {  // the image is P^-1, column-major
+        for (int m = 0; m < count; ++m)
+            from_image(img.data() + (size_t)m * mat, n, np, nullptr, lu_out + (size_t)m * n * n * 2);
+        if (s_out) {
+            HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
+            memcpy(s_out, sv.data(), count * sizeof(int));
+        }
+        a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release();
+        iperm_d.release(); s_d.release();
+        int st_inv = 0;
+        HIP_TRY(hipMemcpy(&st_inv, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (st_inv & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");
+        return 0;
+    }
     if (lu_out)
         for (int m = 0; m < count; ++m) {
             std::vector<int> rows(pm.begin() + (size_t)m * np, pm.begin() + (size_t)(m + 1) * np);

@@ -67,6 +67,7 @@ struct LuArgs {
     int nsteps, step0, seg_len;  // work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len
     int n;                       // Hilbert size (sixteen-tile K1b: <= 48 -> 48 elimination steps); 0: unknown
     int dbg = 0;                 // timing experiment (dbg_skip bit 4): loads and stores only
+    int inverse = 0;             // lu_img receives P^-1 instead of the factors (n <= 32; qocx_lu.h inv_body)
 };
 
 struct SweepArgs {

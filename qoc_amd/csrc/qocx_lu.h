@@ -158,6 +158,120 @@ __device__ __forceinline__ void lu_body(const LuArgs& args, size_t m, const doub
     }
 }
 
+// The INVERSE of P instead of its factors (LuArgs::inverse; the dense-state sweep of
+// qocx_sweepd.hip applies P^-1 and Q as MFMA GEMMs to all S states of a seed at once): in-place
+// Gauss-Jordan elimination with the same pivot rule and the same data layout as lu_body - rows
+// never move, the pivot row of a step goes through LDS, one complex FMA per element and step.
+// Step k with pivot row p, r = 1 / A[p][k]: R = r A[p][:], R[k] = r; every other row i takes
+// A[i][:] <- (A[i][:] with A[i][k] := 0) - A[i][k] R; row p becomes R. At the end the lane that was
+// the pivot row of step t holds row t of (Pi P)^-1; P^-1 = (Pi P)^-1 Pi puts its column c at column
+// perm[c]. The image args.lu_img + m * MAT receives P^-1 column-major. `prow`: NP complex of LDS.
+template <int NB>
+__device__ __forceinline__ void inv_body(const LuArgs& args, size_t m, const double2* src,
+                                         int src_pitch, double2* prow) {
+    typedef Geo<NB> G;
+    constexpr int NP = G::NP, CPL = G::CPL, H = G::H;
+    const int lane = lane_id(), i = lane % NP, h = lane / NP;
+    double2* img = args.lu_img + m * G::MAT;
+    double pre[CPL], pim[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+        const double2 e = src[(cc * H + h) * src_pitch + i];
+        pre[cc] = e.x;
+        pim[cc] = e.y;
+    }
+    int mypos = -1;
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int hk = k % H, ck = k / H;
+        // ---- pivot search: as lu_body (first maximum of |re| + |im| over the unpivoted rows)
+        const bool mine = (h == hk) && (mypos < 0);
+        const double mag = fabs(pre[ck]) + fabs(pim[ck]);
+        const unsigned long long bits =
+            mine ? ((unsigned long long)__double_as_longlong(mag) + 1ull) : 0ull;
+        const unsigned khi = (unsigned)(bits >> 32), klo = (unsigned)bits;
+        const int diag_lane = hk * NP + k;
+        const unsigned long long dbits =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, diag_lane) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)klo, diag_lane);
+        int lp;
+        if (dbits > 1ull && __ballot(bits > dbits) == 0ull) {  // wave-uniform
+            lp = diag_lane;
+        } else {
+            const unsigned mh = wave_max_u32(khi);
+            unsigned ml = 2u;
+            unsigned long long ball = __ballot(khi == mh);
+            if (__popcll(ball) > 1 || mh == 0u) {
+                ml = wave_max_u32(khi == mh ? klo : 0u);
+                ball = __ballot(khi == mh && klo == ml);
+            }
+            lp = __ffsll((long long)ball) - 1;
+            singular = singular || (mh == 0u && ml <= 1u);
+        }
+        const int p = lp % NP;
+        const double pr = readlane_f64(pre[ck], lp), pi = readlane_f64(pim[ck], lp);
+        const double rden = fast_rcp(pr * pr + pi * pi);
+        const double rre = pr * rden, rim = -pi * rden;
+        // this row's entry in column k (zero for the pivot row), known to every lane group
+        const bool own = (h == hk) && (i != p);
+        const double fre_own = own ? pre[ck] : 0.0, fim_own = own ? pim[ck] : 0.0;
+        double fre = fre_own, fim = fim_own;
+        if (H > 1) {
+            if (hk == 0) { fre = from_group<NB, 0>(fre_own, i); fim = from_group<NB, 0>(fim_own, i); }
+            if (hk == 1) { fre = from_group<NB, 1>(fre_own, i); fim = from_group<NB, 1>(fim_own, i); }
+            if (hk == 2) { fre = from_group<NB, 2>(fre_own, i); fim = from_group<NB, 2>(fim_own, i); }
+            if (hk == 3) { fre = from_group<NB, 3>(fre_own, i); fim = from_group<NB, 3>(fim_own, i); }
+        }
+        // ---- the scaled pivot row through LDS
+        if (i == p) {
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                const bool diag = (cc == ck) && (h == hk);
+                const double sre = pre[cc] * rre - pim[cc] * rim, sim = pre[cc] * rim + pim[cc] * rre;
+                prow[cc * H + h] = make_double2(diag ? rre : sre, diag ? rim : sim);
+            }
+        }
+        mypos = (i == p) ? k : mypos;
+        asm volatile("" : "+v"(mypos));
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) {
+            const double2 rv = prow[cc * H + h];
+            const bool diag = (cc == ck) && (h == hk);
+            const double are = diag ? 0.0 : pre[cc], aim = diag ? 0.0 : pim[cc];
+            const double nre = fma(fim, rv.y, fma(-fre, rv.x, are));
+            const double nim = fma(-fim, rv.x, fma(-fre, rv.y, aim));
+            pre[cc] = (i == p) ? rv.x : nre;
+            pim[cc] = (i == p) ? rv.y : nim;
+        }
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled steps from interleaving
+    }
+    if (singular && lane == 0) atomicOr(args.status, 1);
+    if (mypos < 0 || mypos >= NP) {  // only reachable with non-finite input
+        mypos = i;
+        atomicOr(args.status, 2);
+    }
+    // perm[t] = the row that was the pivot row of step t
+    int* ptab = reinterpret_cast<int*>(prow);
+    if (h == 0) ptab[mypos] = i;
+    wave_sync();
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+        const int col = min(max(ptab[cc * H + h], 0), NP - 1);
+        img[(size_t)col * NP + mypos] = make_double2(pre[cc], pim[cc]);
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void inv_kernel(LuArgs args) {
+    __shared__ __attribute__((aligned(16))) double2 prow[Geo<NB>::NP];
+    const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
+                     blockIdx.x % args.seg_len;
+    inv_body<NB>(args, m, args.lu_img + m * Geo<NB>::MAT, Geo<NB>::NP, prow);
+}
+
 template <int NB>
 __global__ __launch_bounds__(64) void lu_kernel(LuArgs args) {
     __shared__ __attribute__((aligned(16))) double2 prow[Geo<NB>::NP];

@@ -59,6 +59,30 @@ def test_pade_factor_kernel(engine, n):
         check_pade_factor(out, mats, policy)
 
 
+@pytest.mark.parametrize("n", [3, 16, 20, 32])
+def test_pade_inverse_kernel(engine, n):
+    """K1b's sibling for the dense-state sweep (qocx_lu.h inv_body; knob "lu_inverse"): P^-1 by
+    in-place Gauss-Jordan elimination with the factorisation's pivot rule, instead of the factors."""
+    rng = np.random.default_rng(300 + n)
+    mats = []
+    for scale, skew in [(0.1, True), (0.8, True), (3.0, False), (9.0, True), (40.0, False)]:
+        g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        a = -1j * (g + g.conj().T) / 2 if skew else g
+        mats.append(a * (scale / onp.one_norm(a)))
+    mats = np.stack(mats)
+    engine.set_knob("lu_inverse", 1)
+    try:
+        out = engine.debug_pade_factor(mats)
+    finally:
+        engine.set_knob("lu_inverse", 0)
+    for m, a in enumerate(mats):
+        f = dm.pade_factor(a, order=int(out["order"][m]))
+        p_mat = dm.pade_uv(f["a"], f["order"])
+        p_mat = p_mat[1] - p_mat[0]
+        assert rel_err(out["q"][m], f["q"]) < 1e-12
+        assert rel_err(out["lu"][m] @ p_mat, np.eye(n)) < 1e-12 * np.linalg.cond(p_mat)
+
+
 def check_pade_factor(out, mats, policy):
     lower = 0
     for m, a in enumerate(mats):
