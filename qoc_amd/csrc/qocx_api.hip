@@ -1065,9 +1065,12 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // M4 on the M2 kernels (M4LinArgs): the kernels see Ke controls given per step and one node
     const bool m4lin = ctx->m4lin_Ke > 0 && ctx->nodes == 2 && !explicit_gen && ctx->knob("m4_linear", 1);
     const int Kk = m4lin ? ctx->m4lin_Ke : K;  // controls as K1a / K3 see them
-    const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen &&
+    // Dense-state sweep (qocx_sweepd.hip): 8..32 states of a seed as the columns of MFMA GEMMs,
+    // with P^-1 in place of the LU factors (K1b's sibling inv_kernel). A property of the problem.
+    const bool dense = qocx::sweepd_supports(ctx->nb, S) && ctx->knob("sweep_dense", 1) != 0;
+    const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen && !dense &&
                            (ctx->nodes == 1 || m4lin) && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
-    const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 &&
+    const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 && !dense &&
                             S <= qocx::sweep3_max_states(ctx->nb) && !(latency && unit_core);
     const bool unit = unit_core && !sweep3_sel;
     if (unit)
@@ -1192,13 +1195,14 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)
-        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && ctx->knob("fuse_lu", 1) != 0;
+        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && !dense && ctx->knob("fuse_lu", 1) != 0;
         fa.fuse_lu = fused_lu ? 1 : 0;
         fa.dinv = ctx->dinv.p; fa.perm = ctx->perm.p; fa.iperm = ctx->iperm.p;
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
         la.dbg = (dbg_skip_early & 16) ? 1 : 0;
+        la.inverse = dense ? 1 : 0;
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
@@ -1257,7 +1261,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             if ((dbg_skip & 1) && (a.phase & 1)) return;
             if ((dbg_skip & 2) && (a.phase & 2)) return;
             const bool use3 = sweep3 && ((a.phase & 2) ? (s3_phases & 2) : (s3_phases & 1));
-            if (use3) qocx::launch_sweep3(ctx->nb, a, count, st);
+            if (dense) qocx::launch_sweepd(a, count, st);
+            else if (use3) qocx::launch_sweep3(ctx->nb, a, count, st);
             else qocx::launch_sweep(ctx->nb, a, count, st);
         };
         sa.inj_count = ctx->inj_count;

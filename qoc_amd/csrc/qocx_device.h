@@ -293,6 +293,9 @@ void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep_lds_bytes(int nb, int S);
 // blocked-inverse sweep (qocx_sweep3.hip): three wavefronts per seed
 void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st);
+// dense-state sweep (qocx_sweepd.hip): the states of a seed as GEMM columns; lu_img holds P^-1
+bool sweepd_supports(int nb, int S);
+void launch_sweepd(const SweepArgs& a, int batch, hipStream_t st);
 int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);

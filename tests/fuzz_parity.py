@@ -22,12 +22,12 @@ NODES = {"M2": (0.5,), "M4": (0.5 - 3 ** 0.5 / 6, 0.5 + 3 ** 0.5 / 6),
          "M6": (0.5 - 15 ** 0.5 / 10, 0.5, 0.5 + 15 ** 0.5 / 10)}
 
 
-def one(engine, rng, index, nmin=1, nmax=32):
+def one(engine, rng, index, nmin=1, nmax=32, smin=1, smax=4, results=None):
     n = int(rng.integers(nmin, nmax + 1))
     N = int(rng.integers(2, 14))
     K = int(rng.integers(1, 4))
     Nc = int(rng.integers(2, 16))
-    S = int(rng.integers(1, 5))
+    S = int(rng.integers(smin, smax + 1))
     ces = int(rng.integers(1, 4))
     policy = ("M2", "M2", "M4", "M6")[int(rng.integers(0, 4))]
     hermitian = rng.random() < 0.7
@@ -83,6 +83,8 @@ def one(engine, rng, index, nmin=1, nmax=32):
     problem = onp.SchroedingerProblem(T, hamiltonian, init[:, :, None], N, control_eval_count=Nc,
                                       costs=ocosts, cost_eval_step=ces, magnus_policy=policy,
                                       control_count=K)
+    if results is not None:
+        results.append((cost, grads, final))
     worst = 0.0
     for b in range(2):
         err, gr, fin = onp.evaluate_with_grad(problem, controls[b])

@@ -449,6 +449,47 @@ def test_segments_and_chunks_with_other_kernel_variants(engine, name):
         engine.set_pipeline(0)
 
 
+def test_dense_state_sweep(engine):
+    """8 <= S <= 32 states at 17 <= n <= 32 run on the dense-state sweep (qocx_sweepd.hip: P^-1 from
+    K1b's Gauss-Jordan sibling, two MFMA GEMMs per sub-step over all states; knob "sweep_dense"):
+    random problems - step costs of every kind, cost_eval_step, squarings, Hermitian or not, time
+    dependent or not, all Magnus policies - against the oracle at the parity gates, against the
+    column-chain sweep, and bit-identical across time segments and memory chunks."""
+    from tests import fuzz_parity
+    checked = 0
+    for index in range(24):
+        out = []
+        for dense in (1, 0):
+            engine.set_knob("sweep_dense", dense)
+            rng = np.random.default_rng(5000 + index)
+            worst, tag = fuzz_parity.one(engine, rng, index, nmin=17, nmax=32, smin=8, smax=32,
+                                         results=out)
+            if worst is None:
+                break
+            assert worst < 1.0, (dense, tag)
+        engine.set_knob("sweep_dense", 1)
+        if len(out) == 2:
+            checked += 1
+            for a, b in zip(*out):
+                assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(b))), tag
+    assert checked >= 18
+    case = cases_mod.case_by_name("c3_fullU_short")
+    from tests import gpu_helpers as gh
+    gh.setup_engine(engine, case)
+    u = gh.real_controls(case, np.concatenate([case.controls, 0.5 * case.controls, -case.controls]))
+    ref = engine.evaluate(u, True)
+    try:
+        for chunk, pipe in ((1, 3), (2, 4), (0, 8)):
+            engine.set_chunk(chunk)
+            engine.set_pipeline(pipe)
+            out = engine.evaluate(u, True)
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), (chunk, pipe)
+    finally:
+        engine.set_chunk(0)
+        engine.set_pipeline(0)
+
+
 def test_random_shapes_fuzz(engine):
     """tests/fuzz_parity.py: 80 random problems (sizes, grids, Magnus policies, Hermitian or not,
     time dependent or not, 0..4 squarings) against the oracle at the parity tolerances."""
