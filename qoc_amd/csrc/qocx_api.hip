@@ -1361,7 +1361,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             const int len = je - jb;
             ka.step0 = jb;
             time_begin(ctx, 2, cs);
-            if (!(dbg_skip & 4)) qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
+            if (dbg_skip & 4) {
+            } else if (dense && ctx->knob("krylov_dense", 0)) {
+                // (K3 on the matrix cores, qocx_sweepd.hip k3d: correct, and no faster - FP64 MFMA
+                // and FP64 VALU peaks are equal on this chip and the vector-unit K3 already runs at
+                // 44 TFLOP/s: 21.3 against 19.9 ms per 256 000 steps at S = 32. Off by default.)
+                qocx::launch_krylovd(ka, len, bc, cs);
+            } else {
+                qocx::launch_krylov(ctx->nb, ka, len, bc, cs);
+            }
             if (nodes > 1) {
                 ma.step0 = jb; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
@@ -2344,7 +2352,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

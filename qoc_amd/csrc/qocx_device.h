@@ -296,6 +296,7 @@ void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st);
 // dense-state sweep (qocx_sweepd.hip): the states of a seed as GEMM columns; lu_img holds P^-1
 bool sweepd_supports(int nb, int S);
 void launch_sweepd(const SweepArgs& a, int batch, hipStream_t st);
+void launch_krylovd(const KrylovArgs& a, int nsteps, int batch, hipStream_t st);  // K3 on the matrix cores
 int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);

@@ -459,19 +459,23 @@ def test_dense_state_sweep(engine):
     checked = 0
     for index in range(24):
         out = []
-        for dense in (1, 0):
+        # dense sweep + K3 on the matrix cores | dense sweep + vector-unit K3 (the default) | neither
+        for dense, k3 in ((1, 1), (1, 0), (0, 0)):
             engine.set_knob("sweep_dense", dense)
+            engine.set_knob("krylov_dense", k3)
             rng = np.random.default_rng(5000 + index)
             worst, tag = fuzz_parity.one(engine, rng, index, nmin=17, nmax=32, smin=8, smax=32,
                                          results=out)
             if worst is None:
                 break
-            assert worst < 1.0, (dense, tag)
+            assert worst < 1.0, (dense, k3, tag)
         engine.set_knob("sweep_dense", 1)
-        if len(out) == 2:
+        engine.set_knob("krylov_dense", 0)
+        if len(out) == 3:
             checked += 1
-            for a, b in zip(*out):
-                assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(b))), tag
+            for other in out[:2]:
+                for a, b in zip(other, out[2]):
+                    assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(b))), tag
     assert checked >= 18
     case = cases_mod.case_by_name("c3_fullU_short")
     from tests import gpu_helpers as gh
