@@ -130,6 +130,28 @@ def test_user_cost_in_grape_on_gpu(with_hook, name, ces):
     assert np.array_equal(e2, e0) and np.array_equal(g2, g0)
 
 
+def test_user_cost_on_dense_state_sweep():
+    """Host-supplied state cotangents through the dense-state sweep (S = 9: qocx_sweepd.hip turns
+    them from vectors into its state-matrix layout at every cost step): the hook route against the
+    finite-difference route of the same user cost, and step states kept for it."""
+    from tests.test_host_api import _UserOccupation
+    case = cases_mod.case_random("dense_user", n=20, N=13, seeds=2, h_seed=9100, S=9, K=2, dt=0.2,
+                                 sigma=0.8, full_unitary=True)
+    ces = 4
+    count = (case.N - 1) // ces
+    args = dict(control_count=case.K, control_eval_count=case.Nc, cost_eval_step=ces)
+    out = []
+    for with_hook in (True, False):
+        ev = device.SchroedingerEvaluator(
+            case.T, case.hamiltonian(), case.initial_states, case.N,
+            costs=product_cost_list(case) + [_UserOccupation(count, with_hook, cost_multiplier=0.7)],
+            **args)
+        out.append(ev.evaluate_batch(np.stack(list(case.controls))))
+    (e0, g0, f0, _), (e1, g1, f1, _) = out
+    assert np.max(np.abs(e0 - e1)) < 1e-12 and rel_err(f1, f0) < 1e-12
+    assert rel_err(g0, g1) < 1e-7
+
+
 def test_expm_and_example_on_gpu(capsys):
     import importlib.util
     import os
