@@ -1081,6 +1081,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                             (size_t)nsteps * ctx->nodes * std::max(Kk, 1) * 24 +
                             (ctx->nodes > 1 ? (size_t)nsteps * mat * 32 : 0);
     const int nodes = m4lin ? 1 : ctx->nodes;  // nodes of the generator kernels
+    // Magnus kernels as four-wave workgroups with every matrix in LDS (qocx_magnus4w.hip)
+    const bool magnus4w = nodes > 1 && qocx::magnus4w_supports(ctx->nb, K) && ctx->knob("magnus_4w", 1) != 0;
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1285,7 +1287,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             } else if (nodes > 1) {
                 ma.step0 = plo; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
-                qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
+                if (magnus4w) qocx::launch_magnus4w_fwd(ma, bc, cs);
+                else qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
                 qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, bc * len, cs);
             } else {
                 qocx::launch_pq(ctx->nb, fa, len, bc, cs);
@@ -1373,8 +1376,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             if (nodes > 1) {
                 ma.step0 = jb; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = nullptr; ma.mbar_rm = ka.mbar_rm; ma.gstep = ka.gstep;
-                qocx::launch_magnus_vjp(ctx->nb, ma,
-                                        (int)std::min<size_t>(ma.total, magnus_blocks), cs);
+                if (magnus4w) qocx::launch_magnus4w_vjp(ma, bc, cs);
+                else qocx::launch_magnus_vjp(ctx->nb, ma,
+                                             (int)std::min<size_t>(ma.total, magnus_blocks), cs);
             }
             time_end(ctx, cs);
             return 0;
@@ -2352,7 +2356,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

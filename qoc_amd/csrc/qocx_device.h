@@ -307,6 +307,10 @@ void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 size_t magnus_scratch_elems(int nb, int blocks);
+// four-wave, LDS-resident forms for 17 <= n <= 32 (qocx_magnus4w.hip); grid = (a.seg_len, batch)
+bool magnus4w_supports(int nb, int K);
+void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st);
+void launch_magnus4w_vjp(const MagnusArgs& a, int batch, hipStream_t st);
 void launch_m4lin_controls(const M4LinArgs& a, hipStream_t st);
 void launch_m4lin_chain(const M4LinArgs& a, hipStream_t st);
 void launch_selftest(double* out, hipStream_t st);

@@ -1,0 +1,398 @@
+// qocx_magnus4w.hip - Magnus M4 / M6 generators and their reverse rules for 17 <= n <= 32 as
+// FOUR-wave workgroups with every matrix resident in LDS.
+//
+// The one-wave kernels of qocx_magnus.hip hold whole 32 x 32 complex matrices in registers (32
+// per matrix and lane): 400-512 registers, one wave per SIMD, the M6 forms spill, and the named
+// intermediates travel through HBM scratch - 125 000 cycles per M6 forward step for 18 000 cycles
+// of matrix-core work. Here a workgroup owns one propagator step; the node generators, b1, b2, b3,
+// w, x, y and the cotangent being propagated are row-major LDS images of pitch 33 (fragments along
+// rows and along columns are both conflict free), wave w owns tile (w & 1, w >> 1) of every
+// result, a product is 24 MFMAs per wave (3M scheme) with both operands read from LDS - plain or
+// conjugate-transposed - and the cotangent accumulators b1bar, b2bar, b3bar, c12bar are one tile
+// per wave in registers. Same formulas as qocx_magnus.hip (reference: magnus_m4 / magnus_m6,
+// qoc/core/mathmethods.py:96-164; reverse rule of Z = XY - YX: Xbar = Zbar Y^H - Y^H Zbar,
+// Ybar = X^H Zbar - Zbar X^H), valid for any generators (no skew-Hermitian shortcut).
+#include "qocx_wave.h"
+
+namespace qocx {
+
+namespace magnus4w {
+
+constexpr int NP = 32, MAT = NP * NP, PM = 33, MELEM = NP * PM, MBYTES = MELEM * 16;
+constexpr double M4_F0 = 0.14433756729740643;  // sqrt(3)/12
+constexpr double M6_F0 = 1.2909944487358056;   // sqrt(15)/3
+constexpr double M6_F1 = 10.0 / 3.0;
+constexpr double M6_F2 = 0.5;
+constexpr double M6_F3 = 1.0 / 240.0;
+constexpr double M6_F4 = 1.0 / 60.0;
+// LDS matrices
+enum { L_B1 = 0, L_B2, L_B3, L_W, L_X, L_Y, L_Z, L_COUNT };
+constexpr int RED_OFF = L_COUNT * MBYTES;
+constexpr int LDS_BYTES = RED_OFF + 3 * 64 * 4 * 8;  // + partial sums [node][control][wave]
+
+struct Tile {
+    d4 re, im;
+};
+__device__ __forceinline__ Tile tile_zero() {
+    Tile t;
+    t.re = d4{0, 0, 0, 0};
+    t.im = d4{0, 0, 0, 0};
+    return t;
+}
+__device__ __forceinline__ void tile_axpy(Tile& y, double a, const Tile& x) {
+    y.re += a * x.re;
+    y.im += a * x.im;
+}
+
+struct Wave {
+    int q, c, ti, tj, lane, w, tid;
+    double2* lds;
+    __device__ __forceinline__ double2* mat(int which) const { return lds + (size_t)which * MELEM; }
+    // element (row 16 ti + 4 r + q, col 16 tj + c) of an LDS matrix <-> component r of a tile
+    __device__ __forceinline__ void store(const Tile& t, int which) const {
+        double2* m = mat(which);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            m[(16 * ti + 4 * r + q) * PM + 16 * tj + c] = make_double2(t.re[r], t.im[r]);
+    }
+    __device__ __forceinline__ Tile load(int which) const {
+        const double2* m = mat(which);
+        Tile t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = m[(16 * ti + 4 * r + q) * PM + 16 * tj + c];
+            t.re[r] = e.x;
+            t.im[r] = e.y;
+        }
+        return t;
+    }
+    // acc += sign * op(A) op(B), this wave's tile; op = plain or conjugate transpose
+    template <bool ADJ_A, bool ADJ_B>
+    __device__ __forceinline__ void mm(Tile& acc, int a_which, int b_which, double sign) const {
+        const double2* am = mat(a_which);
+        const double2* bm = mat(b_which);
+        double2 a[8], b[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (ADJ_A) {
+                const double2 v = am[(4 * kk + q) * PM + 16 * ti + c];  // conj(A[k][r])
+                a[kk] = make_double2(sign * v.x, -sign * v.y);
+            } else {
+                const double2 v = am[(16 * ti + c) * PM + 4 * kk + q];
+                a[kk] = make_double2(sign * v.x, sign * v.y);
+            }
+            if (ADJ_B) {
+                const double2 v = bm[(16 * tj + c) * PM + 4 * kk + q];  // conj(B[c][k])
+                b[kk] = make_double2(v.x, -v.y);
+            } else {
+                b[kk] = bm[(4 * kk + q) * PM + 16 * tj + c];
+            }
+        }
+        d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            t1 = mfma_f64(a[kk].x, b[kk].x, t1);
+            t2 = mfma_f64(a[kk].y, b[kk].y, t2);
+            t3 = mfma_f64(a[kk].x + a[kk].y, b[kk].x + b[kk].y, t3);
+        }
+        acc.re += t1 - t2;
+        acc.im += t3 - t1 - t2;
+    }
+    // Z = X Y - Y X   (convenience.py:16-29)
+    __device__ __forceinline__ Tile commutator(int x, int y) const {
+        Tile z = tile_zero();
+        mm<false, false>(z, x, y, 1.0);
+        mm<false, false>(z, y, x, -1.0);
+        return z;
+    }
+    // cotangents of Z = X Y - Y X with Zbar in LDS matrix `zb`
+    __device__ __forceinline__ void commutator_vjp(Tile& xbar, Tile& ybar, int x, int y, int zb) const {
+        xbar = tile_zero();
+        mm<false, true>(xbar, zb, y, 1.0);   //  Zbar Y^H
+        mm<true, false>(xbar, y, zb, -1.0);  // -Y^H Zbar
+        ybar = tile_zero();
+        mm<true, false>(ybar, x, zb, 1.0);   //  X^H Zbar
+        mm<false, true>(ybar, zb, x, -1.0);  // -Zbar X^H
+    }
+};
+
+// this wave's tile of a_q = -i (H0 + sum_k u_k(t_q) G_k) at quadrature node `node`
+__device__ __forceinline__ Tile node_generator(const Wave& wv, const MagnusArgs& args, int step, int node,
+                                               const double* ctl_b) {
+    const size_t col = (size_t)step * args.nodes + node;
+    const size_t tsel = (args.nt == 1) ? 0 : col;
+    const double2* h0 = args.h0_cimg + tsel * MAT;
+    const double2* g = args.g_cimg + tsel * args.K * MAT;
+    const StepInterp si = args.interp[col];
+    const int base = (wv.ti * 2 + wv.tj) * 4 * 64 + wv.lane;  // C-image: ((ti * 2 + tj) * 4 + r) * 64 + lane
+    d4 hre, him;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double2 e = h0[base + r * 64];
+        hre[r] = e.x;
+        him[r] = e.y;
+    }
+    for (int k = 0; k < args.K; ++k) {
+        const double uk = control_at(ctl_b, si, args.K, k);
+        const double2* gk = g + (size_t)k * MAT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = gk[base + r * 64];
+            hre[r] += uk * e.x;
+            him[r] += uk * e.y;
+        }
+    }
+    Tile a;
+    a.re = him;
+    a.im = -hre;
+    return a;
+}
+
+// g_k = Re <abar, -i G_k> of one node: this wave's partial sums -> red[(node * 64 + k) * 4 + w]
+__device__ __forceinline__ void contract_node(const Wave& wv, const Tile& abar, const MagnusArgs& args,
+                                              int step, int node, double* red) {
+    const size_t col = (size_t)step * args.nodes + node;
+    const size_t tsel = (args.nt == 1) ? 0 : col;
+    const double2* g = args.g_cimg + tsel * args.K * MAT;
+    const int base = (wv.ti * 2 + wv.tj) * 4 * 64 + wv.lane;
+    for (int k = 0; k < args.K; ++k) {
+        double acc = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = g[(size_t)k * MAT + base + r * 64];
+            acc += abar.re[r] * e.y - abar.im[r] * e.x;
+        }
+        acc = wave_sum(acc);
+        if (wv.lane == 0) red[(node * 64 + k) * 4 + wv.w] = acc;
+    }
+}
+
+__device__ __forceinline__ Wave make_wave(char* smem) {
+    Wave wv;
+    wv.tid = threadIdx.x;
+    wv.lane = wv.tid & 63;
+    wv.w = __builtin_amdgcn_readfirstlane(wv.tid >> 6);
+    wv.q = wv.lane >> 4;
+    wv.c = wv.lane & 15;
+    wv.ti = wv.w & 1;
+    wv.tj = wv.w >> 1;
+    wv.lds = reinterpret_cast<double2*>(smem);
+    return wv;
+}
+
+// b1, b2, b3 -> LDS (M6); returns nothing; every wave writes its tiles
+__device__ __forceinline__ void m6_nodes(const Wave& wv, const MagnusArgs& args, int step,
+                                         const double* ctl_b) {
+    const double dt = args.dt;
+    const Tile a1 = node_generator(wv, args, step, 0, ctl_b);
+    const Tile a2 = node_generator(wv, args, step, 1, ctl_b);
+    const Tile a3 = node_generator(wv, args, step, 2, ctl_b);
+    Tile b1 = tile_zero(), b2 = tile_zero(), b3 = tile_zero();
+    // b1 = dt a2 ; b2 = F0 dt (a3 - a1) ; b3 = F1 dt (a3 - 2 a2 + a1)   (mathmethods.py:153-155)
+    tile_axpy(b1, dt, a2);
+    tile_axpy(b2, -M6_F0 * dt, a1);
+    tile_axpy(b2, M6_F0 * dt, a3);
+    tile_axpy(b3, M6_F1 * dt, a1);
+    tile_axpy(b3, -2.0 * M6_F1 * dt, a2);
+    tile_axpy(b3, M6_F1 * dt, a3);
+    wv.store(b1, L_B1);
+    wv.store(b2, L_B2);
+    wv.store(b3, L_B3);
+}
+
+// the M6 intermediates w, x, y -> LDS; returns this wave's tile of m
+__device__ __forceinline__ Tile m6_forward(const Wave& wv, const MagnusArgs& args, int step,
+                                           const double* ctl_b) {
+    m6_nodes(wv, args, step, ctl_b);
+    __syncthreads();
+    // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12
+    const Tile c12 = wv.commutator(L_B1, L_B2);
+    const Tile b1 = wv.load(L_B1), b2 = wv.load(L_B2), b3 = wv.load(L_B3);
+    Tile wt = c12, xt = c12;
+    tile_axpy(wt, 2.0, b3);
+    tile_axpy(xt, -1.0, b3);
+    tile_axpy(xt, -20.0, b1);
+    wv.store(wt, L_W);
+    wv.store(xt, L_X);
+    __syncthreads();
+    // y = b2 - F4 [b1, w]
+    Tile yt = wv.commutator(L_B1, L_W);
+    yt.re *= -M6_F4;
+    yt.im *= -M6_F4;
+    tile_axpy(yt, 1.0, b2);
+    wv.store(yt, L_Y);
+    __syncthreads();
+    // m = b1 + F2 b3 + F3 [x, y]
+    Tile m = wv.commutator(L_X, L_Y);
+    m.re *= M6_F3;
+    m.im *= M6_F3;
+    tile_axpy(m, 1.0, b1);
+    tile_axpy(m, M6_F2, b3);
+    return m;
+}
+
+template <int NODES>
+__global__ __launch_bounds__(256) void magnus4w_fwd_kernel(MagnusArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Wave wv = make_wave(smem);
+    const int step = args.step0 + blockIdx.x;
+    const size_t b = blockIdx.y;
+    const size_t m = b * args.nsteps + step;
+    const double* ctl_b = args.controls + b * args.nc * args.K;
+    Tile mt;
+    if (NODES == 2) {
+        // m4 = dt/2 (a1 + a2) + F0 dt^2 [a2, a1]   (mathmethods.py:119-121)
+        const Tile a1 = node_generator(wv, args, step, 0, ctl_b);
+        const Tile a2 = node_generator(wv, args, step, 1, ctl_b);
+        wv.store(a1, L_B1);
+        wv.store(a2, L_B2);
+        __syncthreads();
+        mt = wv.commutator(L_B2, L_B1);
+        const double f = M4_F0 * args.dt * args.dt;
+        mt.re *= f;
+        mt.im *= f;
+        tile_axpy(mt, 0.5 * args.dt, a1);
+        tile_axpy(mt, 0.5 * args.dt, a2);
+    } else {
+        mt = m6_forward(wv, args, step, ctl_b);
+    }
+    double2* out = args.m_rm + m * MAT;  // row-major
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        out[(size_t)(16 * wv.ti + 4 * r + wv.q) * NP + 16 * wv.tj + wv.c] = make_double2(mt.re[r], mt.im[r]);
+}
+
+template <int NODES>
+__global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Wave wv = make_wave(smem);
+    double* red = reinterpret_cast<double*>(smem + RED_OFF);
+    const int step = args.step0 + blockIdx.x;
+    const size_t b = blockIdx.y;
+    const size_t m = b * args.nsteps + step;
+    const double* ctl_b = args.controls + b * args.nc * args.K;
+    const double dt = args.dt;
+    Tile mbar;
+    {
+        const double2* in = args.mbar_rm + m * MAT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = in[(size_t)(16 * wv.ti + 4 * r + wv.q) * NP + 16 * wv.tj + wv.c];
+            mbar.re[r] = e.x;
+            mbar.im[r] = e.y;
+        }
+    }
+    if (NODES == 2) {
+        // a1bar = dt/2 mbar + d[a2, a1]/d a1 ; a2bar likewise (cbar = F0 dt^2 mbar)
+        wv.store(node_generator(wv, args, step, 0, ctl_b), L_B1);
+        wv.store(node_generator(wv, args, step, 1, ctl_b), L_B2);
+        Tile cbar = mbar;
+        const double f = M4_F0 * dt * dt;
+        cbar.re *= f;
+        cbar.im *= f;
+        wv.store(cbar, L_Z);
+        __syncthreads();
+        Tile a2bar, a1bar;
+        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_Z);
+        tile_axpy(a1bar, 0.5 * dt, mbar);
+        tile_axpy(a2bar, 0.5 * dt, mbar);
+        contract_node(wv, a1bar, args, step, 0, red);
+        contract_node(wv, a2bar, args, step, 1, red);
+    } else {
+        (void)m6_forward(wv, args, step, ctl_b);  // b1, b2, b3, w, x, y in LDS
+        // (xbar, ybar) = vjp of [x, y] with F3 mbar
+        Tile zb = mbar;
+        zb.re *= M6_F3;
+        zb.im *= M6_F3;
+        wv.store(zb, L_Z);
+        __syncthreads();
+        Tile xbar, ybar;
+        wv.commutator_vjp(xbar, ybar, L_X, L_Y, L_Z);
+        // b1bar = mbar - 20 xbar ; b3bar = F2 mbar - xbar ; c12bar = xbar ; b2bar = ybar
+        Tile b1bar = mbar, b3bar = tile_zero(), c12bar = xbar, b2bar = ybar;
+        tile_axpy(b1bar, -20.0, xbar);
+        tile_axpy(b3bar, M6_F2, mbar);
+        tile_axpy(b3bar, -1.0, xbar);
+        // y = b2 - F4 [b1, w]: innerbar = -F4 ybar ; (d1, wbar) = vjp of [b1, w]
+        Tile inner = ybar;
+        inner.re *= -M6_F4;
+        inner.im *= -M6_F4;
+        __syncthreads();  // every wave has read Zbar
+        wv.store(inner, L_Z);
+        __syncthreads();
+        Tile d1, wbar;
+        wv.commutator_vjp(d1, wbar, L_B1, L_W, L_Z);
+        tile_axpy(b1bar, 1.0, d1);
+        tile_axpy(b3bar, 2.0, wbar);
+        tile_axpy(c12bar, 1.0, wbar);
+        // c12 = [b1, b2]
+        __syncthreads();
+        wv.store(c12bar, L_Z);
+        __syncthreads();
+        Tile d2;
+        wv.commutator_vjp(d1, d2, L_B1, L_B2, L_Z);
+        tile_axpy(b1bar, 1.0, d1);
+        tile_axpy(b2bar, 1.0, d2);
+        // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
+        // a3bar = F0 dt b2bar + F1 dt b3bar
+        Tile abar = tile_zero();
+        tile_axpy(abar, -M6_F0 * dt, b2bar);
+        tile_axpy(abar, M6_F1 * dt, b3bar);
+        contract_node(wv, abar, args, step, 0, red);
+        abar = tile_zero();
+        tile_axpy(abar, dt, b1bar);
+        tile_axpy(abar, -2.0 * M6_F1 * dt, b3bar);
+        contract_node(wv, abar, args, step, 1, red);
+        abar = tile_zero();
+        tile_axpy(abar, M6_F0 * dt, b2bar);
+        tile_axpy(abar, M6_F1 * dt, b3bar);
+        contract_node(wv, abar, args, step, 2, red);
+    }
+    __syncthreads();
+    for (int e = wv.tid; e < NODES * args.K; e += 256) {
+        const int node = e / args.K, k = e % args.K;
+        const double* p = red + (node * 64 + k) * 4;
+        args.gstep[((b * (size_t)args.nsteps + step) * NODES + node) * args.K + k] =
+            (p[0] + p[1]) + (p[2] + p[3]);
+    }
+}
+
+}  // namespace magnus4w
+
+bool magnus4w_supports(int nb, int K) { return nb == 2 && K <= 64; }
+
+template <class Kern>
+static void magnus4w_attr(Kern k) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              magnus4w::LDS_BYTES);
+}
+
+static void magnus4w_prepare() {
+    static bool attr_set = false;
+    if (attr_set) return;
+    magnus4w_attr(magnus4w::magnus4w_fwd_kernel<2>);
+    magnus4w_attr(magnus4w::magnus4w_fwd_kernel<3>);
+    magnus4w_attr(magnus4w::magnus4w_vjp_kernel<2>);
+    magnus4w_attr(magnus4w::magnus4w_vjp_kernel<3>);
+    attr_set = true;
+}
+
+void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st) {
+    magnus4w_prepare();
+    const dim3 grid(a.seg_len, batch), block(256);
+    if (a.nodes == 2)
+        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<2>), grid, block, magnus4w::LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<3>), grid, block, magnus4w::LDS_BYTES, st, a);
+}
+
+void launch_magnus4w_vjp(const MagnusArgs& a, int batch, hipStream_t st) {
+    magnus4w_prepare();
+    const dim3 grid(a.seg_len, batch), block(256);
+    if (a.nodes == 2)
+        hipLaunchKernelGGL((magnus4w::magnus4w_vjp_kernel<2>), grid, block, magnus4w::LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL((magnus4w::magnus4w_vjp_kernel<3>), grid, block, magnus4w::LDS_BYTES, st, a);
+}
+
+}  // namespace qocx
