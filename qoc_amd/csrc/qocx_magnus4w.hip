@@ -26,9 +26,12 @@ constexpr double M6_F2 = 0.5;
 constexpr double M6_F3 = 1.0 / 240.0;
 constexpr double M6_F4 = 1.0 / 60.0;
 // LDS matrices
-enum { L_B1 = 0, L_B2, L_B3, L_W, L_X, L_Y, L_Z, L_COUNT };
+// (b3 is never an operand of a product: it stays in registers. The forward kernel needs four
+// matrices at a time - y takes the place of b2 - and so fits twice on a CU.)
+enum { L_B1 = 0, L_B2, L_W, L_X, L_COUNT };
 constexpr int RED_OFF = L_COUNT * MBYTES;
 constexpr int LDS_BYTES = RED_OFF + 3 * 64 * 4 * 8;  // + partial sums [node][control][wave]
+constexpr int LDS_BYTES_FWD = 4 * MBYTES;
 
 struct Tile {
     d4 re, im;
@@ -180,14 +183,16 @@ __device__ __forceinline__ Wave make_wave(char* smem) {
     return wv;
 }
 
-// b1, b2, b3 -> LDS (M6); returns nothing; every wave writes its tiles
+// b1, b2 -> LDS (M6), b3 in registers; every wave writes its tiles
 __device__ __forceinline__ void m6_nodes(const Wave& wv, const MagnusArgs& args, int step,
-                                         const double* ctl_b) {
+                                         const double* ctl_b, Tile& b1, Tile& b2, Tile& b3) {
     const double dt = args.dt;
     const Tile a1 = node_generator(wv, args, step, 0, ctl_b);
     const Tile a2 = node_generator(wv, args, step, 1, ctl_b);
     const Tile a3 = node_generator(wv, args, step, 2, ctl_b);
-    Tile b1 = tile_zero(), b2 = tile_zero(), b3 = tile_zero();
+    b1 = tile_zero();
+    b2 = tile_zero();
+    b3 = tile_zero();
     // b1 = dt a2 ; b2 = F0 dt (a3 - a1) ; b3 = F1 dt (a3 - 2 a2 + a1)   (mathmethods.py:153-155)
     tile_axpy(b1, dt, a2);
     tile_axpy(b2, -M6_F0 * dt, a1);
@@ -197,33 +202,36 @@ __device__ __forceinline__ void m6_nodes(const Wave& wv, const MagnusArgs& args,
     tile_axpy(b3, M6_F1 * dt, a3);
     wv.store(b1, L_B1);
     wv.store(b2, L_B2);
-    wv.store(b3, L_B3);
 }
 
-// the M6 intermediates w, x, y -> LDS; returns this wave's tile of m
+// the M6 intermediates w, x, y -> LDS; returns this wave's tile of m. FWD_ONLY: y replaces b2
+template <bool FWD_ONLY>
 __device__ __forceinline__ Tile m6_forward(const Wave& wv, const MagnusArgs& args, int step,
                                            const double* ctl_b) {
-    m6_nodes(wv, args, step, ctl_b);
+    static_assert(FWD_ONLY, "the reverse kernel schedules its own matrices");
+    constexpr int Y_SLOT = L_B2;
+    constexpr int W_SLOT = L_W, X_SLOT = L_X;
+    Tile b1, b2, b3;
+    m6_nodes(wv, args, step, ctl_b, b1, b2, b3);
     __syncthreads();
     // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12
     const Tile c12 = wv.commutator(L_B1, L_B2);
-    const Tile b1 = wv.load(L_B1), b2 = wv.load(L_B2), b3 = wv.load(L_B3);
     Tile wt = c12, xt = c12;
     tile_axpy(wt, 2.0, b3);
     tile_axpy(xt, -1.0, b3);
     tile_axpy(xt, -20.0, b1);
-    wv.store(wt, L_W);
-    wv.store(xt, L_X);
+    wv.store(wt, W_SLOT);
+    wv.store(xt, X_SLOT);
     __syncthreads();
     // y = b2 - F4 [b1, w]
-    Tile yt = wv.commutator(L_B1, L_W);
+    Tile yt = wv.commutator(L_B1, W_SLOT);
     yt.re *= -M6_F4;
     yt.im *= -M6_F4;
     tile_axpy(yt, 1.0, b2);
-    wv.store(yt, L_Y);
+    wv.store(yt, Y_SLOT);  // (FWD_ONLY: the b2 matrix was last read before the barrier above)
     __syncthreads();
     // m = b1 + F2 b3 + F3 [x, y]
-    Tile m = wv.commutator(L_X, L_Y);
+    Tile m = wv.commutator(X_SLOT, Y_SLOT);
     m.re *= M6_F3;
     m.im *= M6_F3;
     tile_axpy(m, 1.0, b1);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void magnus4w_fwd_kernel(MagnusArgs args) {
         tile_axpy(mt, 0.5 * args.dt, a1);
         tile_axpy(mt, 0.5 * args.dt, a2);
     } else {
-        mt = m6_forward(wv, args, step, ctl_b);
+        mt = m6_forward<true>(wv, args, step, ctl_b);
     }
     double2* out = args.m_rm + m * MAT;  // row-major
 #pragma unroll
@@ -290,47 +298,69 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         const double f = M4_F0 * dt * dt;
         cbar.re *= f;
         cbar.im *= f;
-        wv.store(cbar, L_Z);
+        wv.store(cbar, L_W);
         __syncthreads();
         Tile a2bar, a1bar;
-        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_Z);
+        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_W);
         tile_axpy(a1bar, 0.5 * dt, mbar);
         tile_axpy(a2bar, 0.5 * dt, mbar);
         contract_node(wv, a1bar, args, step, 0, red);
         contract_node(wv, a2bar, args, step, 1, red);
     } else {
-        (void)m6_forward(wv, args, step, ctl_b);  // b1, b2, b3, w, x, y in LDS
-        // (xbar, ybar) = vjp of [x, y] with F3 mbar
+        // Four LDS matrices s0..s3 hold the operands of the product group at hand; everything else
+        // waits as one tile per wave in registers and is put back when it becomes an operand.
+        constexpr int S0 = 0, S1 = 1, S2 = 2, S3 = 3;
+        Tile b1, b2, b3;
+        m6_nodes(wv, args, step, ctl_b, b1, b2, b3);  // b1 -> s0, b2 -> s1
+        __syncthreads();
+        // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12 ; y = b2 - F4 [b1, w]
+        const Tile c12 = wv.commutator(S0, S1);
+        Tile wt = c12, xt = c12;
+        tile_axpy(wt, 2.0, b3);
+        tile_axpy(xt, -1.0, b3);
+        tile_axpy(xt, -20.0, b1);
+        wv.store(wt, S2);
+        wv.store(xt, S3);
+        __syncthreads();
+        Tile yt = wv.commutator(S0, S2);
+        yt.re *= -M6_F4;
+        yt.im *= -M6_F4;
+        tile_axpy(yt, 1.0, b2);
+        // (xbar, ybar) = vjp of [x, y] with F3 mbar: x in s3, y -> s1, Zbar -> s0
         Tile zb = mbar;
         zb.re *= M6_F3;
         zb.im *= M6_F3;
-        wv.store(zb, L_Z);
+        __syncthreads();  // b1 (s0) and b2 (s1) have been read
+        wv.store(yt, S1);
+        wv.store(zb, S0);
         __syncthreads();
         Tile xbar, ybar;
-        wv.commutator_vjp(xbar, ybar, L_X, L_Y, L_Z);
+        wv.commutator_vjp(xbar, ybar, S3, S1, S0);
         // b1bar = mbar - 20 xbar ; b3bar = F2 mbar - xbar ; c12bar = xbar ; b2bar = ybar
         Tile b1bar = mbar, b3bar = tile_zero(), c12bar = xbar, b2bar = ybar;
         tile_axpy(b1bar, -20.0, xbar);
         tile_axpy(b3bar, M6_F2, mbar);
         tile_axpy(b3bar, -1.0, xbar);
-        // y = b2 - F4 [b1, w]: innerbar = -F4 ybar ; (d1, wbar) = vjp of [b1, w]
+        // y = b2 - F4 [b1, w]: innerbar = -F4 ybar ; (d1, wbar) = vjp of [b1, w]: b1 -> s1, w in s2
         Tile inner = ybar;
         inner.re *= -M6_F4;
         inner.im *= -M6_F4;
-        __syncthreads();  // every wave has read Zbar
-        wv.store(inner, L_Z);
+        __syncthreads();
+        wv.store(b1, S1);
+        wv.store(inner, S0);
         __syncthreads();
         Tile d1, wbar;
-        wv.commutator_vjp(d1, wbar, L_B1, L_W, L_Z);
+        wv.commutator_vjp(d1, wbar, S1, S2, S0);
         tile_axpy(b1bar, 1.0, d1);
         tile_axpy(b3bar, 2.0, wbar);
         tile_axpy(c12bar, 1.0, wbar);
-        // c12 = [b1, b2]
+        // c12 = [b1, b2]: b1 in s1, b2 -> s2
         __syncthreads();
-        wv.store(c12bar, L_Z);
+        wv.store(b2, S2);
+        wv.store(c12bar, S0);
         __syncthreads();
         Tile d2;
-        wv.commutator_vjp(d1, d2, L_B1, L_B2, L_Z);
+        wv.commutator_vjp(d1, d2, S1, S2, S0);
         tile_axpy(b1bar, 1.0, d1);
         tile_axpy(b2bar, 1.0, d2);
         // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
@@ -381,9 +411,9 @@ void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st) {
     magnus4w_prepare();
     const dim3 grid(a.seg_len, batch), block(256);
     if (a.nodes == 2)
-        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<2>), grid, block, magnus4w::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<2>), grid, block, magnus4w::LDS_BYTES_FWD, st, a);
     else
-        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<3>), grid, block, magnus4w::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((magnus4w::magnus4w_fwd_kernel<3>), grid, block, magnus4w::LDS_BYTES_FWD, st, a);
 }
 
 void launch_magnus4w_vjp(const MagnusArgs& a, int batch, hipStream_t st) {
