@@ -11,7 +11,7 @@
 // conjugate-transposed - and the cotangent accumulators b1bar, b2bar, b3bar, c12bar are one tile
 // per wave in registers. Same formulas as qocx_magnus.hip (reference: magnus_m4 / magnus_m6,
 // qoc/core/mathmethods.py:96-164; reverse rule of Z = XY - YX: Xbar = Zbar Y^H - Y^H Zbar,
-// Ybar = X^H Zbar - Zbar X^H), valid for any generators (no skew-Hermitian shortcut).
+// Ybar = X^H Zbar - Zbar X^H), with the one-product commutators for skew-Hermitian node generators.
 #include "qocx_wave.h"
 
 namespace qocx {
@@ -49,6 +49,7 @@ __device__ __forceinline__ void tile_axpy(Tile& y, double a, const Tile& x) {
 
 struct Wave {
     int q, c, ti, tj, lane, w, tid;
+    bool skew;
     double2* lds;
     __device__ __forceinline__ double2* mat(int which) const { return lds + (size_t)which * MELEM; }
     // element (row 16 ti + 4 r + q, col 16 tj + c) of an LDS matrix <-> component r of a tile
@@ -101,15 +102,63 @@ struct Wave {
         acc.re += t1 - t2;
         acc.im += t3 - t1 - t2;
     }
-    // Z = X Y - Y X   (convenience.py:16-29)
-    __device__ __forceinline__ Tile commutator(int x, int y) const {
+    // this wave's tile of M^H, M an LDS matrix
+    __device__ __forceinline__ Tile load_adjoint(int which) const {
+        const double2* m = mat(which);
+        Tile t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = m[(16 * tj + c) * PM + 16 * ti + 4 * r + q];
+            t.re[r] = e.x;
+            t.im[r] = -e.y;
+        }
+        return t;
+    }
+    // Z = X Y - Y X   (convenience.py:16-29). skew (every node generator skew-Hermitian, i.e. Hermitian
+    // H0(t), G_k(t): then so are b1, b2, b3, every commutator and M itself): Y X = (X Y)^H, ONE product;
+    // the tiles of (X Y)^H come through the free LDS matrix `scratch`. Workgroup barriers inside.
+    __device__ __forceinline__ Tile commutator(int x, int y, int scratch) const {
         Tile z = tile_zero();
         mm<false, false>(z, x, y, 1.0);
+        if (skew) {
+            store(z, scratch);
+            __syncthreads();
+            tile_axpy(z, -1.0, load_adjoint(scratch));
+            __syncthreads();  // `scratch` may be written again
+            return z;
+        }
         mm<false, false>(z, y, x, -1.0);
         return z;
     }
-    // cotangents of Z = X Y - Y X with Zbar in LDS matrix `zb`
-    __device__ __forceinline__ void commutator_vjp(Tile& xbar, Tile& ybar, int x, int y, int zb) const {
+    // Cotangents of Z = X Y - Y X with Zbar in LDS matrix `zb` (complete on entry). General:
+    // Xbar = Zbar Y^H - Y^H Zbar, Ybar = X^H Zbar - Zbar X^H. skew: only the skew-Hermitian part of a
+    // cotangent reaches the controls (the contraction is with -i G_k) and the forward maps send skew
+    // perturbations to skew ones, so with Zs = (Zbar - Zbar^H) / 2: Xbar = V - V^H, V = Y Zs;
+    // Ybar = W - W^H, W = Zs X - two products instead of four. `sa`, `sb`: LDS matrices that are free
+    // once the products have read their operands (they may be x's and y's own). Barriers inside.
+    __device__ __forceinline__ void commutator_vjp(Tile& xbar, Tile& ybar, int x, int y, int zb, int sa,
+                                                   int sb) const {
+        if (skew) {
+            Tile zs = load(zb);
+            tile_axpy(zs, -1.0, load_adjoint(zb));
+            zs.re *= 0.5;
+            zs.im *= 0.5;
+            __syncthreads();  // Zbar has been read
+            store(zs, zb);
+            __syncthreads();
+            xbar = tile_zero();
+            mm<false, false>(xbar, y, zb, 1.0);  // V = Y Zs
+            ybar = tile_zero();
+            mm<false, false>(ybar, zb, x, 1.0);  // W = Zs X
+            __syncthreads();  // the operands have been read
+            store(xbar, sa);
+            store(ybar, sb);
+            __syncthreads();
+            tile_axpy(xbar, -1.0, load_adjoint(sa));
+            tile_axpy(ybar, -1.0, load_adjoint(sb));
+            __syncthreads();
+            return;
+        }
         xbar = tile_zero();
         mm<false, true>(xbar, zb, y, 1.0);   //  Zbar Y^H
         mm<true, false>(xbar, y, zb, -1.0);  // -Y^H Zbar
@@ -170,8 +219,9 @@ __device__ __forceinline__ void contract_node(const Wave& wv, const Tile& abar, 
     }
 }
 
-__device__ __forceinline__ Wave make_wave(char* smem) {
+__device__ __forceinline__ Wave make_wave(char* smem, const MagnusArgs& args) {
     Wave wv;
+    wv.skew = args.skew != 0;
     wv.tid = threadIdx.x;
     wv.lane = wv.tid & 63;
     wv.w = __builtin_amdgcn_readfirstlane(wv.tid >> 6);
@@ -215,7 +265,7 @@ __device__ __forceinline__ Tile m6_forward(const Wave& wv, const MagnusArgs& arg
     m6_nodes(wv, args, step, ctl_b, b1, b2, b3);
     __syncthreads();
     // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12
-    const Tile c12 = wv.commutator(L_B1, L_B2);
+    const Tile c12 = wv.commutator(L_B1, L_B2, W_SLOT);
     Tile wt = c12, xt = c12;
     tile_axpy(wt, 2.0, b3);
     tile_axpy(xt, -1.0, b3);
@@ -223,15 +273,15 @@ __device__ __forceinline__ Tile m6_forward(const Wave& wv, const MagnusArgs& arg
     wv.store(wt, W_SLOT);
     wv.store(xt, X_SLOT);
     __syncthreads();
-    // y = b2 - F4 [b1, w]
-    Tile yt = wv.commutator(L_B1, W_SLOT);
+    // y = b2 - F4 [b1, w]  (the b2 matrix is free: scratch)
+    Tile yt = wv.commutator(L_B1, W_SLOT, L_B2);
     yt.re *= -M6_F4;
     yt.im *= -M6_F4;
     tile_axpy(yt, 1.0, b2);
     wv.store(yt, Y_SLOT);  // (FWD_ONLY: the b2 matrix was last read before the barrier above)
     __syncthreads();
     // m = b1 + F2 b3 + F3 [x, y]
-    Tile m = wv.commutator(X_SLOT, Y_SLOT);
+    Tile m = wv.commutator(X_SLOT, Y_SLOT, L_B1);  // (b1 is in registers: its matrix is scratch)
     m.re *= M6_F3;
     m.im *= M6_F3;
     tile_axpy(m, 1.0, b1);
@@ -242,7 +292,7 @@ __device__ __forceinline__ Tile m6_forward(const Wave& wv, const MagnusArgs& arg
 template <int NODES>
 __global__ __launch_bounds__(256) void magnus4w_fwd_kernel(MagnusArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Wave wv = make_wave(smem);
+    const Wave wv = make_wave(smem, args);
     const int step = args.step0 + blockIdx.x;
     const size_t b = blockIdx.y;
     const size_t m = b * args.nsteps + step;
@@ -255,7 +305,7 @@ __global__ __launch_bounds__(256) void magnus4w_fwd_kernel(MagnusArgs args) {
         wv.store(a1, L_B1);
         wv.store(a2, L_B2);
         __syncthreads();
-        mt = wv.commutator(L_B2, L_B1);
+        mt = wv.commutator(L_B2, L_B1, L_W);
         const double f = M4_F0 * args.dt * args.dt;
         mt.re *= f;
         mt.im *= f;
@@ -273,7 +323,7 @@ __global__ __launch_bounds__(256) void magnus4w_fwd_kernel(MagnusArgs args) {
 template <int NODES>
 __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Wave wv = make_wave(smem);
+    const Wave wv = make_wave(smem, args);
     double* red = reinterpret_cast<double*>(smem + RED_OFF);
     const int step = args.step0 + blockIdx.x;
     const size_t b = blockIdx.y;
@@ -301,7 +351,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         wv.store(cbar, L_W);
         __syncthreads();
         Tile a2bar, a1bar;
-        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_W);
+        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_W, L_X, L_B1);
         tile_axpy(a1bar, 0.5 * dt, mbar);
         tile_axpy(a2bar, 0.5 * dt, mbar);
         contract_node(wv, a1bar, args, step, 0, red);
@@ -314,7 +364,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         m6_nodes(wv, args, step, ctl_b, b1, b2, b3);  // b1 -> s0, b2 -> s1
         __syncthreads();
         // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12 ; y = b2 - F4 [b1, w]
-        const Tile c12 = wv.commutator(S0, S1);
+        const Tile c12 = wv.commutator(S0, S1, S2);
         Tile wt = c12, xt = c12;
         tile_axpy(wt, 2.0, b3);
         tile_axpy(xt, -1.0, b3);
@@ -322,7 +372,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         wv.store(wt, S2);
         wv.store(xt, S3);
         __syncthreads();
-        Tile yt = wv.commutator(S0, S2);
+        Tile yt = wv.commutator(S0, S2, S1);  // (the b2 matrix is scratch: b2 is in registers)
         yt.re *= -M6_F4;
         yt.im *= -M6_F4;
         tile_axpy(yt, 1.0, b2);
@@ -335,7 +385,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         wv.store(zb, S0);
         __syncthreads();
         Tile xbar, ybar;
-        wv.commutator_vjp(xbar, ybar, S3, S1, S0);
+        wv.commutator_vjp(xbar, ybar, S3, S1, S0, S3, S1);
         // b1bar = mbar - 20 xbar ; b3bar = F2 mbar - xbar ; c12bar = xbar ; b2bar = ybar
         Tile b1bar = mbar, b3bar = tile_zero(), c12bar = xbar, b2bar = ybar;
         tile_axpy(b1bar, -20.0, xbar);
@@ -350,7 +400,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         wv.store(inner, S0);
         __syncthreads();
         Tile d1, wbar;
-        wv.commutator_vjp(d1, wbar, S1, S2, S0);
+        wv.commutator_vjp(d1, wbar, S1, S2, S0, S3, S2);
         tile_axpy(b1bar, 1.0, d1);
         tile_axpy(b3bar, 2.0, wbar);
         tile_axpy(c12bar, 1.0, wbar);
@@ -360,7 +410,7 @@ __global__ __launch_bounds__(256) void magnus4w_vjp_kernel(MagnusArgs args) {
         wv.store(c12bar, S0);
         __syncthreads();
         Tile d2;
-        wv.commutator_vjp(d1, d2, S1, S2, S0);
+        wv.commutator_vjp(d1, d2, S1, S2, S0, S3, S2);
         tile_axpy(b1bar, 1.0, d1);
         tile_axpy(b2bar, 1.0, d2);
         // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
