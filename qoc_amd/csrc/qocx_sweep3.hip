@@ -285,6 +285,9 @@ __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w
         pm_cur = pm_next;
     };
     auto pass = [&](bool adjoint) {
+        // (unit adjoint behind a forward pass in the same launch - one time segment, je = nsteps:
+        // the x slots are counted down from the capacity, as in the compute wave)
+        if (adjoint && args.unit_adjoint && w.do_fwd) slot = (int)w.cap;
         const int first = adjoint ? w.je - 1 : w.jb, d = adjoint ? -1 : 1;
         auto clampstep = [&](int st) { return min(max(st, w.jb), w.je - 1); };
         // prologue: LU of steps 0, 1, 2 and Q of steps 0, 1 (pass order); all of it lands here
@@ -303,6 +306,7 @@ __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w
             const int step = first + d * t;
             const int nsub = subs.get(args, w, adjoint, t);
             if (!adjoint && (size_t)slot + nsub >= w.cap) return false;
+            if (adjoint && args.unit_adjoint && slot - nsub < 0) return false;  // (as the compute wave)
             clk.lap(0);
             if (t + 3 < w.T) {
                 // LU of step t+3, Q of step t+2: each has two iterations to land
@@ -340,6 +344,9 @@ __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk&
     StampClock<STAMP> clk;
     clk.start();
     auto pass = [&](bool adjoint) {
+        // (unit adjoint behind a forward pass in the same launch - one time segment, je = nsteps:
+        // the x slots are counted down from the capacity, as in the compute wave)
+        if (adjoint && args.unit_adjoint && w.do_fwd) slot = (int)w.cap;
         s3_barrier();  // P0
         if (!(args.dbg & 1)) invert_blocks<NB, UPPER>(s3_slot<NB>(smem, 0), s3_inv<NB>(smem, 0), lane);
         s3_barrier();  // P1
@@ -347,6 +354,7 @@ __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk&
         for (int t = 0; t < w.T; ++t) {
             const int nsub = subs.get(args, w, adjoint, t);
             if (!adjoint && (size_t)slot + nsub >= w.cap) return false;
+            if (adjoint && args.unit_adjoint && slot - nsub < 0) return false;
             clk.lap(0);
             if (t + 1 < w.T && !(args.dbg & 1))
                 invert_blocks<NB, UPPER>(s3_slot<NB>(smem, t + 1), s3_inv<NB>(smem, t + 1), lane);
@@ -581,6 +589,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
                         vecs[s * NP + i];
             if (lane == 0) offs_b[nsteps] = slot;
             cost += eval_costs<NB>(args, false, true, vecs, nullptr, h, i);
+            if (args.unit_adjoint && args.want_grad) unit_adjoint_scales<NB>(args, vecs, b, h, i);
             if (g0)
                 for (int s = 0; s < S; ++s)
                     args.final_out[((size_t)b * S + s) * NP + i] = vecs[s * NP + i];
@@ -609,7 +618,15 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
             }
         wave_sync();
     };
-    if (je == nsteps) {
+    // unit adjoint (qocx_sweep_common.h): lambda = the targets, the x slots are counted down from
+    // the capacity and recorded per step in offs_x - the sweep does not need the forward sweep
+    const bool unit = args.unit_adjoint != 0;
+    int* offs_x = unit ? args.offs_x + (size_t)b * (nsteps + 1) : nullptr;
+    if (unit && w.do_fwd) slot = (je == nsteps) ? (int)w.cap : offs_x[je];  // (phase 3: the roles agree, see the kernel)
+    if (je == nsteps && unit) {
+        unit_adjoint_seed<NB>(args, lam, 0, 1, h, i);
+        wave_sync();
+    } else if (je == nsteps) {
         if (!w.do_fwd)
             for (int s = 0; s < S; ++s)
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
@@ -636,6 +653,10 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
         const int nsub = subs_adj.get(args, w, true, t);
         const bool cost_step = (cost_phase_adj == 0) && step != 0 && args.has_step_costs;
         cost_phase_adj = (cost_phase_adj == 0) ? ces_adj - 1 : cost_phase_adj - 1;
+        if (unit && slot - nsub < 0) {  // (unit adjoint: nobody has checked the capacity before)
+            if (lane == 0) atomicOr(args.status, 4);
+            return;
+        }
         const char* sl = s3_slot<NB>(smem, t);
         const char* iv = s3_inv<NB>(smem, t);
         const int* pslot = reinterpret_cast<const int*>(sl + L::SLOT_P);
@@ -688,6 +709,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
         }
         if (step != 0) inject(step);
         slot -= nsub;
+        if (unit && lane == 0) offs_x[step] = slot;
         clk.lap(0);
         s3_barrier();
         clk.lap(4);
@@ -718,6 +740,9 @@ __global__ __launch_bounds__(256, 2) void sweep3_kernel(SweepArgs args) {
     const int* offs_b = args.offs + (size_t)blockIdx.x * (args.nsteps + 1);
     int slot = 0;
     if (w.do_fwd) slot = (w.jb == 0) ? 0 : offs_b[w.jb];
+    else if (args.unit_adjoint)  // x slots of their own, counted down from the capacity
+        slot = (w.je == args.nsteps) ? (int)w.cap
+                                     : args.offs_x[(size_t)blockIdx.x * (args.nsteps + 1) + w.je];
     else slot = offs_b[w.je];
     if (role == 2) s3_loader<NB, STAMP>(args, w, smem, slot);
     else if (role == 1) s3_inverter<NB, STAMP, false>(args, w, smem, slot);

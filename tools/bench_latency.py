@@ -21,14 +21,15 @@ from tests import gpu_helpers as gh  # noqa: E402
 
 def main():
     """Variants: the column-chain sweep in one launch (impl 1, pipeline 1), the blocked sweep
-    (impl 3, round 2's latency mode) and the two-sided pipeline of round 3 (impl 1, 4 / 8 time
-    segments: forward and adjoint sweep of the ONE seed side by side)."""
+    (impl 3, round 2's latency mode) and the two-sided pipeline of round 3 (4 / 8 time segments:
+    forward and adjoint sweep of the ONE seed side by side) on the column-chain sweep (impl 1) and
+    on the blocked sweep (impl 3)."""
     eng = Engine(0)
     for name in ("c2_transmon", "c3_subset"):
         case = cases_mod.case_by_name(name)
         gh.setup_engine(eng, case)
         u = gh.real_controls(case, case.controls[:1])
-        for impl, pipe in ((1, 1), (3, 1), (1, 4), (1, 8)):
+        for impl, pipe in ((1, 1), (3, 1), (1, 4), (1, 8), (3, 4), (3, 8)):
             eng.set_knob("sweep_impl", impl)
             eng.set_pipeline(pipe)
             for _ in range(5):
