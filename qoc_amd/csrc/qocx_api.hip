@@ -1068,11 +1068,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // Dense-state sweep (qocx_sweepd.hip): 8..32 states of a seed as the columns of MFMA GEMMs,
     // with P^-1 in place of the LU factors (K1b's sibling inv_kernel). A property of the problem.
     const bool dense = qocx::sweepd_supports(ctx->nb, S) && ctx->knob("sweep_dense", 1) != 0;
+    // Inverse-image sweep (qocx_sweepi.hip): in latency mode a sub-step is two matrix-vector products
+    // with P^-1 from inv_kernel instead of two triangular solves
+    const bool inverse_sweep = latency && !dense && qocx::sweepi_supports(ctx->nb, S) &&
+                               ctx->knob("sweep_inverse", 1) != 0;
     const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen && !dense &&
                            (ctx->nodes == 1 || m4lin) && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
     // (latency mode, n <= 16: the column-chain sweep is the faster one there - 1.8 against 2.2 us
     // per step - so the two-sided pipeline keeps it; 17 <= n <= 32: two-sided on the blocked sweep)
-    const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 && !dense &&
+    const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 && !dense && !inverse_sweep &&
                             S <= qocx::sweep3_max_states(ctx->nb) &&
                             !(latency && unit_core && ctx->nb == 1);
     const bool unit = unit_core;  // (both sweeps offer it)
@@ -1200,14 +1204,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)
-        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && !dense && ctx->knob("fuse_lu", 1) != 0;
+        const bool fused_lu = ctx->nb == 2 && !one_wave_k1a && !dense && !inverse_sweep &&
+                              ctx->knob("fuse_lu", 1) != 0;
         fa.fuse_lu = fused_lu ? 1 : 0;
         fa.dinv = ctx->dinv.p; fa.perm = ctx->perm.p; fa.iperm = ctx->iperm.p;
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
         la.dbg = (dbg_skip_early & 16) ? 1 : 0;
-        la.inverse = dense ? 1 : 0;
+        la.inverse = (dense || inverse_sweep) ? 1 : 0;
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
@@ -1267,6 +1272,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             if ((dbg_skip & 2) && (a.phase & 2)) return;
             const bool use3 = sweep3 && ((a.phase & 2) ? (s3_phases & 2) : (s3_phases & 1));
             if (dense) qocx::launch_sweepd(a, count, st);
+            else if (inverse_sweep) qocx::launch_sweepi(ctx->nb, a, count, st);
             else if (use3) qocx::launch_sweep3(ctx->nb, a, count, st);
             else qocx::launch_sweep(ctx->nb, a, count, st);
         };
@@ -2359,7 +2365,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w", "sweep_inverse"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;

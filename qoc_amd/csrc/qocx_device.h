@@ -297,6 +297,9 @@ void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st);
 bool sweepd_supports(int nb, int S);
 void launch_sweepd(const SweepArgs& a, int batch, hipStream_t st);
 void launch_krylovd(const KrylovArgs& a, int nsteps, int batch, hipStream_t st);  // K3 on the matrix cores
+// inverse-image sweep of latency mode (qocx_sweepi.hip): two matrix-vector products per sub-step
+bool sweepi_supports(int nb, int S);
+void launch_sweepi(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_scatter(const ScatterArgs& a, hipStream_t st);

@@ -449,6 +449,53 @@ def test_segments_and_chunks_with_other_kernel_variants(engine, name):
         engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("name", ["c2_transmon", "c3_subset", "small_complex_M2", "small_complex_M6",
+                                  "nc10_n101", "scaled_n8", "nonhermitian_n24", "magnus_n20_M4"])
+def test_latency_mode_inverse_image_sweep(engine, name):
+    """Latency mode (one control set at a time; knob "latency") runs the inverse-image sweep of
+    qocx_sweepi.hip - P^-1 from inv_kernel, a sub-step = two matrix-vector products, fetch waves beside
+    the compute wave, two-sided where the unit adjoint applies (knob "sweep_inverse"): against the
+    golden fixtures at the parity gates, against the column-chain sweep, and the same numbers for
+    every time segmentation."""
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_by_name(name)
+    g = golden(name)
+    host_specs = gh.setup_engine(engine, case)
+    host_costs = [getattr(onp, k)(**kw) for k, kw in host_specs]
+    u = gh.real_controls(case, case.controls)
+    try:
+        engine.set_knob("latency", 1)
+        engine.set_knob("sweep_inverse", 0)
+        chain = engine.evaluate(u, True)
+        engine.set_knob("sweep_inverse", 1)
+        ref = engine.evaluate(u, True)
+        for a, b in zip(ref, chain):
+            assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(b)))
+        for pipe in (1, 2, 4, 7):
+            engine.set_pipeline(pipe)
+            out = engine.evaluate(u, True)
+            for a, b in zip(ref, out):
+                assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(a))), pipe
+        engine.set_pipeline(0)
+        fwd = engine.evaluate(u, False)
+        assert np.array_equal(fwd[0], ref[0]) and np.array_equal(fwd[2], ref[2])
+    finally:
+        engine.set_knob("latency", 0)
+        engine.set_knob("sweep_inverse", 1)
+        engine.set_pipeline(0)
+    cost, grads, final = ref
+    grads = gh.complex_grads(case, grads)
+    for b in range(len(case.controls)):
+        err = cost[b]
+        gb = grads[b].astype(np.complex128)
+        for c in host_costs:
+            err = err + c.cost(case.controls[b], None, case.N - 1)
+            gb = gb + c.controls_bar(case.controls[b], None, case.N - 1)
+        assert abs(err - g["error"][b]) <= 1e-10 * max(1.0, abs(g["error"][b]))
+        assert rel_err(final[b][:, :, None], g["final_states"][b]) < 1e-10
+        assert rel_err(gb, g["grads_ad"][b]) < 1e-8
+
+
 def test_dense_state_sweep(engine):
     """8 <= S <= 32 states at 17 <= n <= 32 run on the dense-state sweep (qocx_sweepd.hip: P^-1 from
     K1b's Gauss-Jordan sibling, two MFMA GEMMs per sub-step over all states; knob "sweep_dense"):

@@ -29,8 +29,12 @@ def main():
         case = cases_mod.case_by_name(name)
         gh.setup_engine(eng, case)
         u = gh.real_controls(case, case.controls[:1])
-        for impl, pipe in ((1, 1), (3, 1), (1, 4), (1, 8), (3, 4), (3, 8)):
+        # the last variant is what the single-control-set entry points get (knob "latency": the
+        # inverse-image sweep of qocx_sweepi.hip, two-sided on four time segments)
+        for impl, pipe, latency in ((1, 1, 0), (3, 1, 0), (1, 4, 0), (1, 8, 0), (3, 4, 0), (3, 8, 0),
+                                    (3, 0, 1)):
             eng.set_knob("sweep_impl", impl)
+            eng.set_knob("latency", latency)
             eng.set_pipeline(pipe)
             for _ in range(5):
                 eng.evaluate(u, True)
@@ -41,9 +45,10 @@ def main():
                     eng.evaluate(u, want_grad)
                 wall = (time.perf_counter() - t0) / reps
                 print(json.dumps(dict(case=name, n=case.n, steps=case.N - 1, want_grad=want_grad,
-                                      sweep_impl=impl, time_segments=pipe,
+                                      sweep_impl=impl, time_segments=pipe, latency_mode=latency,
                                       ms_per_eval=round(wall * 1e3, 3),
                                       us_per_step=round(wall * 1e6 / (case.N - 1), 2))), flush=True)
+        eng.set_knob("latency", 0)
 
 
 if __name__ == "__main__":
