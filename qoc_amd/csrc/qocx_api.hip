@@ -1068,9 +1068,13 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
     // Dense-state sweep (qocx_sweepd.hip): 8..32 states of a seed as the columns of MFMA GEMMs,
     // with P^-1 in place of the LU factors (K1b's sibling inv_kernel). A property of the problem.
     const bool dense = qocx::sweepd_supports(ctx->nb, S) && ctx->knob("sweep_dense", 1) != 0;
-    // Inverse-image sweep (qocx_sweepi.hip): in latency mode a sub-step is two matrix-vector products
-    // with P^-1 from inv_kernel instead of two triangular solves
-    const bool inverse_sweep = latency && !dense && qocx::sweepi_supports(ctx->nb, S) &&
+    // Inverse-image sweep (qocx_sweepi.hip): a sub-step is two matrix-vector products with P^-1 from
+    // inv_kernel instead of two triangular solves. In latency mode (one control set: the sweep chain
+    // is all there is), and always at n <= 16, where Gauss-Jordan on a 16 x 16 matrix costs what its
+    // LU costs (0.10 against 0.085 ms per 32 000) and the evaluation is bound by the sweeps: 256 seeds
+    // x 1000 steps at n = 8: 3.65 -> 2.79 ms. A property of the problem size, not of the batch.
+    const bool inverse_sweep = (latency || (ctx->nb == 1 && ctx->knob("sweep_inverse_small", 1))) &&
+                               !dense && qocx::sweepi_supports(ctx->nb, S) &&
                                ctx->knob("sweep_inverse", 1) != 0;
     const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen && !dense &&
                            (ctx->nodes == 1 || m4lin) && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
@@ -2365,7 +2369,7 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
                                   "sweep3_phases", "lindblad_stamps", "magnus_general",
                                   "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
                                   "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w", "sweep_inverse"};
+                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w", "sweep_inverse", "sweep_inverse_small"};
     for (const char* k : known)
         if (strcmp(k, name) == 0) {
             ctx->knobs[name] = value;
