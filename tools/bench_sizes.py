@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 48, 64]
     for dim in sizes:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_ab.py"), "--rounds", "3",
-                              "--evals", "2", "--dim", str(dim)], capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_ab.py"), "--rounds", "8",
+                              "--evals", "4", "--dim", str(dim)], capture_output=True, text=True)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         if not line:
             print(json.dumps(dict(dim=dim, error=out.stderr[-300:])), flush=True)
