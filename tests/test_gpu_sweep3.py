@@ -22,6 +22,9 @@ def engine():
     from qoc_amd.engine import Engine
     e = Engine(0)
     e.set_knob("sweep_impl", 3)
+    # (n <= 16 would otherwise take the inverse-image sweep of qocx_sweepi.hip, whose tests are in
+    # test_gpu_engine.py: this module is about the blocked sweep at both tile sizes)
+    e.set_knob("sweep_inverse_small", 0)
     yield e
     e.close()
 
