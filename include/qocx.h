@@ -289,7 +289,25 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *                   inversion, 1 no solves, 2 no LU fetch, 3 no Q fetch, 4 no Q touch.
  *   "sweep3_stamps" 1: run the stamped diagnostic build (qocx_debug_read_stamps).
  *   "sweep_loader"  column-chain sweep only. 0 (default): the compute wave issues the LDS-DMA from
- *                   inside its triangular solves; 1: a dedicated fetch wave per seed does. */
+ *                   inside its triangular solves; 1: a dedicated fetch wave per seed does.
+ * Round 3 (each 1 by default unless noted; 0 restores the older path):
+ *   "pade_order"    0 (default): Pade order 3 / 5 / 7 / 9 / 13 by the 1-norm of the step generator;
+ *                   13: always [13/13], as the reference executes it (qocx_pade_orders).
+ *   "unit_adjoint"  one final TargetStateInfidelity: the adjoint sweep back-propagates the targets.
+ *   "bidir"         with it: forward and adjoint sweep side by side, factorisation from both ends.
+ *   "fuse_lu"       17 <= n <= 32: the LU factorisation runs inside the Pade kernel.
+ *   "latency"       0 (default; the host sets 1 for entry points that evaluate ONE control set):
+ *                   four time segments, the inverse-image sweep.
+ *   "sweep_inverse" latency mode: sub-steps as two matrix-vector products with P^-1 (qocx_sweepi.hip);
+ *   "sweep_inverse_small": the same sweep for every batch at n <= 16.
+ *   "sweep_dense"   8 <= S <= 32 states at 17 <= n <= 32 as MFMA GEMM columns (qocx_sweepd.hip);
+ *   "krylov_dense"  (default 0) K3 on the matrix cores for those problems; "lu_inverse": the debug
+ *                   factor entry point returns P^-1.
+ *   "m4_linear"     MagnusPolicy.M4 with time-independent H0, G_k on the M2 kernels (commutators
+ *                   hoisted into constant matrices); "magnus_4w": four-wave LDS-resident Magnus
+ *                   kernels at 17 <= n <= 32.
+ *   "lindblad_two_sided", "lindblad_side_limit": forward and unit-adjoint Lindblad passes side by side.
+ *   "k3_split", "dbg_skip": timing experiments. */
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
 /* After evaluations with the knob "sweep3_stamps" = 1 (a diagnostic build of the sweep that
  * executes in-kernel clock stamps; never the product kernel): per seed, per role (compute |
