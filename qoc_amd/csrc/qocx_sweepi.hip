@@ -303,6 +303,8 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
 
 }  // namespace sweepi
 
+// (the states of a seed go through the one compute wave one after the other: measured at n = 16,
+// S = 16 that costs 9.6 us per step against 6.6 for the four-wave column chains - up to eight)
 bool sweepi_supports(int nb, int S) {
     return (nb == 1 || nb == 2) && S >= 1 && S <= 8;
 }

@@ -496,6 +496,29 @@ def test_latency_mode_inverse_image_sweep(engine, name):
         assert rel_err(gb, g["grads_ad"][b]) < 1e-8
 
 
+def test_inverse_image_sweep_several_states_small_n(engine):
+    """n <= 16 with up to eight states on the inverse-image sweep (qocx_sweepi.hip) in every batch:
+    random problems against the oracle and against the column-chain sweep."""
+    from tests import fuzz_parity
+    checked = 0
+    for index in range(16):
+        out = []
+        for inverse in (1, 0):
+            engine.set_knob("sweep_inverse_small", inverse)
+            rng = np.random.default_rng(6000 + index)
+            worst, tag = fuzz_parity.one(engine, rng, index, nmin=2, nmax=16, smin=3, smax=8,
+                                         results=out)
+            if worst is None:
+                break
+            assert worst < 1.0, (inverse, tag)
+        engine.set_knob("sweep_inverse_small", 1)
+        if len(out) == 2:
+            checked += 1
+            for a, b in zip(*out):
+                assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(b))), tag
+    assert checked >= 12
+
+
 def test_dense_state_sweep(engine):
     """8 <= S <= 32 states at 17 <= n <= 32 run on the dense-state sweep (qocx_sweepd.hip: P^-1 from
     K1b's Gauss-Jordan sibling, two MFMA GEMMs per sub-step over all states; knob "sweep_dense"):
