@@ -11,7 +11,7 @@
 // steps and nothing else.
 //
 // Workgroup = one seed: wave 0 computes, the other waves (two at NP = 32, one at NP = 16) stream the
-// step operands in by LDS-DMA, two steps ahead in a ring of three buffer sets (counted vmcnt), one
+// step operands in by LDS-DMA, several steps ahead in a ring of buffer sets (counted vmcnt), one
 // raw workgroup barrier per step. The adjoint gathers the transposed images, so x = P^-H lambda'
 // and lambda = Q^H x are the same product with conjugated elements. Everything else follows
 // sweep_kernel: time segments (phase, j_begin, j_end), squaring sub-steps, every state cost,
@@ -28,9 +28,12 @@ struct Cfg {
     typedef Geo<NB> G;
     static constexpr int NP = G::NP, MAT = G::MAT;
     static constexpr int PIECES = MAT / 64;              // KiB pieces per image
-    static constexpr int LOADERS = NB == 2 ? 2 : 1;      // fetch waves
+    static constexpr int LOADERS = NB == 2 ? 2 : 1;      // fetch waves (four / two measured: no faster)
     static constexpr int PER_LOADER = 2 * PIECES / LOADERS;  // DMA instructions per loader and step
-    static constexpr int RING = 3;
+    // buffer sets in the ring: a fetch takes ~2 us to land, a step ~0.4 us to compute, so the
+    // fetches run RING - 1 steps ahead (three sets: 1.1 us per step at either size)
+    static constexpr int RING = NB == 2 ? 4 : 8;
+    static constexpr int AHEAD = RING - 1;
     static constexpr int Q_OFF = 0;                              // RING x Q image
     static constexpr int PI_OFF = Q_OFF + RING * MAT * 16;       // RING x P^-1 image
     static constexpr int TMP_OFF = PI_OFF + RING * MAT * 16;     // NP complex
@@ -118,16 +121,28 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
     // one pass of a fetch wave over the T steps of the launch, `first` + d t being step t
     auto loader_pass = [&](bool adjoint, int slot) {
         const int first = adjoint ? je - 1 : jb, d = adjoint ? -1 : 1;
-        issue(m0 + first, 0, adjoint);
-        if (T > 1) issue(m0 + first + d, 1, adjoint);
+        for (int p = 0; p < C::AHEAD && p < T; ++p) issue(m0 + first + d * p, p, adjoint);
+        int entry_next = args.s_arr[m0 + first];  // (read one step ahead: off the critical path)
         for (int t = 0; t < T; ++t) {
-            const int nsub = 1 << step_squarings(args.s_arr[m0 + first + d * t]);
+            const int nsub = 1 << step_squarings(entry_next);
+            if (t + 1 < T) entry_next = args.s_arr[m0 + first + d * (t + 1)];
             if (!adjoint && (size_t)slot + nsub >= cap) return false;
             if (adjoint && unit && slot - nsub < 0) return false;
-            if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_LOADER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            raw_barrier();  // step t has landed / the compute wave has left step t - 1
-            if (t + 2 < T) issue(m0 + first + d * (t + 2), (t + 2) % C::RING, adjoint);
+            // step t has landed once at most the fetches of the younger steps are in flight
+            const int younger = min(C::AHEAD - 1, T - 1 - t);
+            static_assert((C::AHEAD - 1) * C::PER_LOADER < 64, "vmcnt is a six-bit counter");
+            switch (younger) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * C::PER_LOADER) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::PER_LOADER) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((3 * C::PER_LOADER) & 63) : "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((4 * C::PER_LOADER) & 63) : "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((5 * C::PER_LOADER) & 63) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((6 * C::PER_LOADER) & 63) : "memory"); break;
+            }
+            raw_barrier();  // ... / the compute wave has left step t - 1, whose buffers are free
+            if (t + C::AHEAD < T)
+                issue(m0 + first + d * (t + C::AHEAD), (t + C::AHEAD) % C::RING, adjoint);
             slot += adjoint ? -nsub : nsub;
         }
         raw_barrier();  // the compute wave has left the last step
@@ -172,9 +187,11 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
                 if (g0) vecs[s * NP + i] = states_b[((size_t)slot * S + s) * NP + i];
         }
         wave_sync();
+        int entry_next = args.s_arr[m0 + jb];  // the step table, one step ahead of its use
         for (int t = 0; t < T; ++t) {
             const int step = jb + t;
-            const int nsub = 1 << step_squarings(args.s_arr[m0 + step]);
+            const int nsub = 1 << step_squarings(entry_next);
+            if (t + 1 < T) entry_next = args.s_arr[m0 + step + 1];
             if ((size_t)slot + nsub >= cap) {
                 atomicOr(args.status, 4);
                 return;
@@ -260,9 +277,11 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
         wave_sync();
     }
     if (do_fwd) raw_barrier();  // A0
+    int entry_adj = args.s_arr[m0 + je - 1];
     for (int t = 0; t < T; ++t) {
         const int step = je - 1 - t;
-        const int nsub = 1 << step_squarings(args.s_arr[m0 + step]);
+        const int nsub = 1 << step_squarings(entry_adj);
+        if (t + 1 < T) entry_adj = args.s_arr[m0 + step - 1];
         if (unit && slot - nsub < 0) {
             atomicOr(args.status, 4);
             return;
