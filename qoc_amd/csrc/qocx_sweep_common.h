@@ -167,6 +167,20 @@ __device__ __forceinline__ double sum_groups(double v) {
         auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
         return make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
     }
+    if (Geo<NB>::H == 4) {
+        // rows of 16 lanes: (g0 + g1) + (g2 + g3) by the two swap instructions of gfx950 - no trip
+        // through the LDS crossbar (ds_bpermute), which was most of a 16 x 16 matrix-vector product;
+        // the same pairs, so the same sums bit for bit
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const double s = make_f64((int)a[0], (int)b[0]) + make_f64((int)a[1], (int)b[1]);
+        lo = (unsigned)__double2loint(s);
+        hi = (unsigned)__double2hiint(s);
+        auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return make_f64((int)c[0], (int)d[0]) + make_f64((int)c[1], (int)d[1]);
+    }
 #pragma unroll
     for (int d = Geo<NB>::NP; d < 64; d <<= 1) v += __shfl_xor(v, d);
     return v;
