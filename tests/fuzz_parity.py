@@ -4,7 +4,7 @@ oracle. Complements the fixed fixtures: sizes 1..32, random step counts / contro
 counts / time steps (so that 0..4 squarings occur), all three Magnus policies, Hermitian and
 non-Hermitian generators, all state-cost kinds at once.
 
-    python -m tests.fuzz_parity [count] [seed]
+    python -m tests.fuzz_parity [count] [seed] [nmin] [nmax] [smin] [smax]
 """
 import os
 import sys
@@ -100,12 +100,14 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    smin = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    smax = int(sys.argv[6]) if len(sys.argv) > 6 else 4
     rng = np.random.default_rng(seed)
     engine = Engine(0)
     bad = skipped = 0
     overall = 0.0
     for index in range(count):
-        worst, tag = one(engine, rng, index, nmin, nmax)
+        worst, tag = one(engine, rng, index, nmin, nmax, smin, smax)
         if worst is None:
             skipped += 1
             continue
