@@ -1077,7 +1077,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                                !dense && qocx::sweepi_supports(ctx->nb, S) &&
                                ctx->knob("sweep_inverse", 1) != 0;
     const bool unit_core = ctx->unit_ok && want_grad && ctx->inj_count == 0 && !explicit_gen && !dense &&
-                           (ctx->nodes == 1 || m4lin) && ctx->nb <= 2 && ctx->knob("unit_adjoint", 1);
+                           (ctx->nodes == 1 || m4lin) && ctx->knob("unit_adjoint", 1);
     // (latency mode, n <= 16: the column-chain sweep is the faster one there - 1.8 against 2.2 us
     // per step - so the two-sided pipeline keeps it; 17 <= n <= 32: two-sided on the blocked sweep)
     const bool sweep3_sel = ctx->knob("sweep_impl", 1) == 3 && ctx->nb <= 2 && !dense && !inverse_sweep &&

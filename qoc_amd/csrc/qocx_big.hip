@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
 struct KrLds {
     double2 part[2][WV][NP];  // partial row sums, by parity
     double red[WV * 64];      // gradient partials: [k][w]
+    double red_im[WV * 64];   // unit adjoint: the imaginary parts of gamma
 };
 
 // CC: columns per wave that can be non-zero - 16, or 12 for n <= 48 (c = 4 cc + w < 48)
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     const int t0 = args.offs[(size_t)b * (nsteps + 1) + step];
     const int nsub = 1 << sq;
     if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) return;  // sweep overflowed (status bit 2)
+    // unit adjoint (krylov_grad_body, qocx_kernels.hip): x sits at slots of its own and is the
+    // back-propagated target; gstep receives the complex gamma per (step, control)
+    const bool unit = args.offs_x != nullptr;
+    const int tx = unit ? args.offs_x[(size_t)b * (nsteps + 1) + step] : t0;
+    if (tx < 0 || (size_t)tx + (size_t)nsub > cap) return;
 
     double abr[CC], abi[CC];
 #pragma unroll
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
     for (int sub = 0; sub < nsub; ++sub)
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
-            const double2 x = xs_b[(t * S + s) * NP + lane];
+            const double2 x = xs_b[(((size_t)tx + sub) * S + s) * NP + lane];
             const double2 p0 = states_b[(t * S + s) * NP + lane];
             const double2 p1 = states_b[((t + 1) * S + s) * NP + lane];
             const double sgr = p0.x + p1.x, sgi = p0.y + p1.y;
@@ -373,19 +379,33 @@ __global__ __launch_bounds__(256) void krylov4_kernel(KrylovArgs args) {
         for (int k0 = 0; k0 < K; k0 += 64) {
             const int kn = min(64, K - k0);
             for (int k = 0; k < kn; ++k) {
-                double acc = 0;
+                double acc = 0, acc_im = 0;
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc) {
                     const double2 e = gr[(size_t)(k0 + k) * MAT + (WV * cc + w) * NP + lane];
                     acc = fma(abi[cc], -dts * e.x, fma(abr[cc], dts * e.y, acc));
+                    acc_im = fma(abi[cc], -dts * e.y, fma(abr[cc], -dts * e.x, acc_im));
                 }
                 acc = wave_sum(acc);
-                if (lane == 0) lds.red[k * WV + w] = acc;
+                if (unit) acc_im = wave_sum(acc_im);
+                if (lane == 0) {
+                    lds.red[k * WV + w] = acc;
+                    lds.red_im[k * WV + w] = acc_im;
+                }
             }
             __syncthreads();
-            if (w == 0 && lane < kn)
-                args.gstep[m * K + k0 + lane] = (lds.red[lane * WV] + lds.red[lane * WV + 1]) +
-                                                (lds.red[lane * WV + 2] + lds.red[lane * WV + 3]);
+            if (w == 0 && lane < kn) {
+                const double re = (lds.red[lane * WV] + lds.red[lane * WV + 1]) +
+                                  (lds.red[lane * WV + 2] + lds.red[lane * WV + 3]);
+                if (unit) {
+                    const double im = (lds.red_im[lane * WV] + lds.red_im[lane * WV + 1]) +
+                                      (lds.red_im[lane * WV + 2] + lds.red_im[lane * WV + 3]);
+                    args.gstep[(m * K + k0 + lane) * 2] = re;
+                    args.gstep[(m * K + k0 + lane) * 2 + 1] = im;
+                } else {
+                    args.gstep[m * K + k0 + lane] = re;
+                }
+            }
             __syncthreads();
         }
     }
