@@ -149,6 +149,44 @@ def lindblad_problem():
     return h0, g, gam, ops, rho0, target
 
 
+def latency_secondary(engine, reps=200):
+    """ms per forward + gradient evaluation of ONE control set: BASELINE configs[1] (dim = 8 single
+    transmon, 500 steps, 1 seed) and the headline shape with one seed - what a GRAPE iteration of
+    an ordinary qoc script waits for (knob "latency", as the single-control-set entry points set it)."""
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    out = []
+    engine.set_timing(False)
+    for label, n, steps in (("configs[1]: dim=8 transmon, 500 steps, 1 seed", 8, 500),
+                            ("dim=32 (headline shape), 1000 steps, 1 seed", DIM, N_EVAL - 1)):
+        if n == 8:  # a + a^dagger / i (a - a^dagger) drives on a weakly anharmonic oscillator
+            a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128)
+            ad = a.conj().T
+            h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
+            g = [a + ad, 1j * (a - ad)]
+            psi0 = np.eye(n, dtype=np.complex128)[:1]
+            target = np.eye(n, dtype=np.complex128)[1:2]
+        else:
+            h0, g, psi0, target = make_problem()
+        engine.set_schroedinger_problem(
+            n, 1, K_CTRL, steps + 1, steps + 1, DT * steps, h0[None], np.stack(g)[None], psi0,
+            costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+        u = 0.1 * np.random.default_rng(77).standard_normal((1, steps + 1, K_CTRL))
+        engine.set_knob("latency", 1)
+        engine.set_knob("sweep_impl", 3)
+        for _ in range(5):
+            engine.evaluate(u, True)
+        engine.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            engine.evaluate(u, True)
+        wall = (time.perf_counter() - t0) / reps
+        engine.set_knob("latency", 0)
+        engine.set_knob("sweep_impl", 1)
+        out.append(dict(workload=label, ms_per_evaluation=wall * 1e3,
+                        value=steps / wall, unit="propagator-steps/s"))
+    return out
+
+
 def lindblad_secondary(engine, reps=3):
     """ms per fwd+grad evaluation of configs[3] and the roofline of the Lindblad kernel.
     Algorithmic work per sub-interval (one 12-stage DOP853 step of one seed): the
@@ -312,9 +350,11 @@ def main():
                                note="knob pade_order = 13: every step on the [13/13] approximant, as "
                                     "the reference executes it (expm.py:230-233)")
     secondary = None
+    latency = None
     if world == 1 and not args.no_secondary:
         engine.set_timing(True)
         secondary = lindblad_secondary(engine)
+        latency = latency_secondary(engine)
     engine.set_timing(False)
 
     units_per_step = world * seeds * (N_EVAL - 1)
@@ -375,6 +415,7 @@ def main():
         "host_to_host": host_to_host,
         "reference_order": reference_order,
         "secondary": secondary,
+        "latency": latency,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
