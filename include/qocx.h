@@ -276,26 +276,24 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
                            double* q_out, double* lu_out, int32_t* perm_out,
                            double* dinv_out, int32_t* s_out);
 int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t report_len);
-/* Kernel-variant switches for A/B measurements in one process and for tests that pin a variant
- * (results never depend on them beyond rounding). Known names:
+/* Kernel-variant switches for A/B measurements in one process and for tests that pin a variant.
+ * Every knob libqocx.so accepts selects between paths that give the same numbers to rounding;
+ * no environment variable changes which kernels the product library runs. Known names:
  *   "sweep_impl"    1 (default): column-chain sweep (one wavefront per seed; best inside the
  *                   segmented pipeline of large batches); 3: blocked-inverse sweep (four wavefronts
  *                   per seed: compute | inverter L | loader | inverter U'; qocx_sweep3.hip), 1.5x
  *                   faster per step when the sweep has the chip to itself (<= 128 seeds). One
  *                   implementation serves all batch sizes of a context, so results stay bit
- *                   identical across batching. Environment QOCX_SWEEP_IMPL presets it.
+ *                   identical across batching.
  *   "sweep3_phases" with the blocked sweep selected: bit 0 forward launches, bit 1 adjoint.
- *   "sweep3_dbg"    timing diagnostics of the blocked sweep, results are garbage: bit 0 no block
- *                   inversion, 1 no solves, 2 no LU fetch, 3 no Q fetch, 4 no Q touch.
- *   "sweep3_stamps" 1: run the stamped diagnostic build (qocx_debug_read_stamps).
  *   "sweep_loader"  column-chain sweep only. 0 (default): the compute wave issues the LDS-DMA from
  *                   inside its triangular solves; 1: a dedicated fetch wave per seed does.
- * Round 3 (each 1 by default unless noted; 0 restores the older path):
  *   "pade_order"    0 (default): Pade order 3 / 5 / 7 / 9 / 13 by the 1-norm of the step generator;
  *                   13: always [13/13], as the reference executes it (qocx_pade_orders).
  *   "unit_adjoint"  one final TargetStateInfidelity: the adjoint sweep back-propagates the targets.
  *   "bidir"         with it: forward and adjoint sweep side by side, factorisation from both ends.
- *   "fuse_lu"       17 <= n <= 32: the LU factorisation runs inside the Pade kernel.
+ *   "fuse_lu"       17 <= n <= 32: the LU factorisation runs inside the Pade kernel;
+ *   "lu_mfma"       (round 4) ... and takes its Schur updates to the matrix cores (qocx_lu4.h).
  *   "latency"       0 (default; the host sets 1 for entry points that evaluate ONE control set):
  *                   four time segments, the inverse-image sweep.
  *   "sweep_inverse" latency mode: sub-steps as two matrix-vector products with P^-1 (qocx_sweepi.hip);
@@ -305,10 +303,20 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *                   factor entry point returns P^-1.
  *   "m4_linear"     MagnusPolicy.M4 with time-independent H0, G_k on the M2 kernels (commutators
  *                   hoisted into constant matrices); "magnus_4w": four-wave LDS-resident Magnus
- *                   kernels at 17 <= n <= 32.
+ *                   kernels at 17 <= n <= 32; "magnus_general": the general commutator forms.
  *   "lindblad_two_sided", "lindblad_side_limit": forward and unit-adjoint Lindblad passes side by side.
- *   "k3_split", "dbg_skip": timing experiments. */
+ *   "sweep_onebuf", "k3_split": launch shapes of the sweep / of K3.
+ * Diagnostic knobs - libqocx_diag.so only (make diag, -DQOCX_DIAG; the product library answers
+ * QOCX_ERR_ARG): "dbg_skip", "sweep3_dbg", "k1a_dbg" switch parts of an evaluation off for timing
+ * (results are garbage); "sweep3_stamps", "lindblad_stamps", "k1a_stamps" run kernel builds that
+ * execute in-kernel clock stamps (qocx_debug_read_stamps). The diagnostic library also reads the
+ * QOCX_* environment switches of earlier experiments (qoc_amd/csrc/qocx_diag.h). */
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value);
+/* 1: a variant knob (every build), 2: a diagnostic knob this library accepts, -2: a diagnostic
+ * knob this (product) library rejects, 0: unknown. No context, no GPU needed. */
+int qocx_knob_kind(const char* name);
+/* 1 for libqocx_diag.so, 0 for the product library. */
+int qocx_build_is_diag(void);
 /* After evaluations with the knob "sweep3_stamps" = 1 (a diagnostic build of the sweep that
  * executes in-kernel clock stamps; never the product kernel): per seed, per role (compute |
  * inverter L | loader | inverter U'), 8 sums - shader-clock cycles per phase of the role's step loop, [7] = the

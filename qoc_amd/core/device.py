@@ -200,7 +200,11 @@ class SchroedingerEvaluator(object):
 
     def _evaluate_linearized(self, controls_batch, device_controls, want_grad, need_steps):
         """One control array at a time: the tangent problem of the callable at THAT array (node
-        times of the Magnus policy), set as a structured time-dependent problem, evaluated at it."""
+        times of the Magnus policy), set as a structured time-dependent problem, evaluated at it.
+        Host cost per array: (4 K + 1) evaluations of the callable per node time for the tangent, one
+        re-upload of the nsteps x nodes x (1 + K) tables and a one-seed evaluation - the route of
+        callables that are not linear in the controls, which the reference evaluates one control
+        array at a time as well. The backend is left holding the tangent problem of the LAST array."""
         costs, grads, finals, steps = [], [], [], []
         for b in range(controls_batch.shape[0]):
             h0, g = structure.linearize_hamiltonian(
@@ -209,16 +213,19 @@ class SchroedingerEvaluator(object):
             self._set_problem(h0, g)
             if need_steps:
                 self.backend.set_keep_step_states(True)
-            self.backend.upload_controls(device_controls[b:b + 1])
-            self.backend.eval_resident(want_grad)
-            c, gr, f = self.backend.download_results(want_grad=want_grad)
-            costs.append(c[0])
-            finals.append(f[0])
-            if want_grad:
-                grads.append(gr[0])
-            if need_steps:
-                steps.append(self.backend.download_step_states()[0])
-                self.backend.set_keep_step_states(False)
+            try:
+                self.backend.upload_controls(device_controls[b:b + 1])
+                self.backend.eval_resident(want_grad)
+                c, gr, f = self.backend.download_results(want_grad=want_grad)
+                costs.append(c[0])
+                finals.append(f[0])
+                if want_grad:
+                    grads.append(gr[0])
+                if need_steps:
+                    steps.append(self.backend.download_step_states()[0])
+            finally:  # (an engine error must not leave step-state keeping on)
+                if need_steps:
+                    self.backend.set_keep_step_states(False)
         return (np.array(costs), np.stack(grads) if want_grad else None, np.stack(finals),
                 np.stack(steps)[..., None] if need_steps else None)
 

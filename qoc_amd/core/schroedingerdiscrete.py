@@ -206,8 +206,22 @@ def _for_blocks(work, blocks):
     list(_POOL.map(work, blocks))
 
 
+_NATIVE_HOST = None
+
+
 def _native_ok(*arrays):
-    return all(a.dtype == np.float64 and a.flags.c_contiguous for a in arrays)
+    """The [B, P] host routines of libqocx (clip, Adam / SGD on host threads) can take these
+    arrays. Without the library (a CPU box running the host logic against the oracle backend)
+    the NumPy block path below each call site does the same arithmetic."""
+    global _NATIVE_HOST
+    if _NATIVE_HOST is None:
+        try:
+            from qoc_amd import engine
+            engine.load_library()
+            _NATIVE_HOST = True
+        except (ImportError, OSError, AttributeError):
+            _NATIVE_HOST = False
+    return _NATIVE_HOST and all(a.dtype == np.float64 and a.flags.c_contiguous for a in arrays)
 
 
 class _BatchedSGD(object):
@@ -421,6 +435,8 @@ def grape_schroedinger_discrete_batch(control_count, control_eval_count, costs, 
                          "control_count), got shape {}".format(initial_controls.shape))
     comm = comm if comm is not None else parallel.SingleComm()
     lo, hi = parallel.shard_bounds(initial_controls.shape[0], comm.rank, comm.world)
+    if max_control_norms is None:  # the default of initialize_controls, also for a rank without seeds
+        max_control_norms = np.ones(control_count)
     seeds = []
     for b in range(lo, hi):
         controls_b, max_control_norms = initialize_controls(

@@ -18,6 +18,7 @@
 #include "../../include/qocx.h"
 #include "dop853_tableau.h"
 #include "qocx_device.h"
+#include "qocx_diag.h"
 
 namespace {
 
@@ -519,8 +520,9 @@ int qocx_create(int device, qocx_ctx** out) {
         ctx->ev_swept.push_back(e2);
         ctx->ev_fwd.push_back(e3);
     }
-    if (const char* env = getenv("QOCX_SWEEP_IMPL")) ctx->knobs["sweep_impl"] = atoi(env);  // test runs
-    if (const char* env = getenv("QOCX_SWEEP_LOADER")) ctx->knobs["sweep_loader"] = atoi(env);
+    // (diagnostic build only, qocx_diag.h: fuzz runs of the whole suite on another sweep)
+    if (const char* env = qocx::diag_getenv("QOCX_SWEEP_IMPL")) ctx->knobs["sweep_impl"] = atoi(env);
+    if (const char* env = qocx::diag_getenv("QOCX_SWEEP_LOADER")) ctx->knobs["sweep_loader"] = atoi(env);
     *out = ctx;
     return 0;
 }
@@ -1157,7 +1159,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 // do once they exist is exposed, so they are the short ones
                 wgt[nseg / 2 - 1] = 0.5; wgt[nseg / 2] = 0.5;
             } else if (nseg >= 4) { wgt[nseg - 2] = 0.6; wgt[nseg - 1] = 0.35; }
-            if (const char* env = getenv("QOCX_SEG_WEIGHTS")) {  // experiments: "w0,w1,..."
+            if (const char* env = qocx::diag_getenv("QOCX_SEG_WEIGHTS")) {  // experiments: "w0,w1,..."
                 std::vector<double> user;
                 for (const char* p = env; *p;) {
                     char* end = nullptr;
@@ -1179,7 +1181,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         }
 
         const int dbg_skip_early = (int)ctx->knob("dbg_skip", 0);  // bit 3: K1a stores no Q (timing)
-        const bool one_wave_k1a = getenv("QOCX_PQ1") != nullptr;  // (experiments: the one-wave K1a)
+        const bool one_wave_k1a = qocx::diag_getenv("QOCX_PQ1") != nullptr;  // (experiments: the one-wave K1a)
         qocx::FactorArgs fa;
         fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
         fa.interp = ctx->interp.p;
@@ -1203,6 +1205,15 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         fa.hermitian = explicit_gen ? ctx->explicit_hermitian : ctx->hermitian;
         fa.n = ctx->n;
         fa.skip_q = (dbg_skip_early & 8) ? 1 : 0;
+        fa.dbg = (int)ctx->knob("k1a_dbg", 0);  // (diagnostic build: qocx_device.h)
+        fa.stamps = nullptr;
+        if (qocx::kDiagBuild && ctx->knob("k1a_stamps", 0)) {
+            if (ctx->stamps.ensure(1024 * 16)) return QOCX_ERR_HIP;
+            HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, 1024 * 16 * sizeof(unsigned long long), cs));
+            HIP_TRY(hipStreamSynchronize(cs));
+            fa.stamps = ctx->stamps.p;
+        }
+        fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
         fa.pade_policy = (int)ctx->knob("pade_order", 0);  // 0: by norm (qocx_wave.h), 13: always 13
         fa.prefer_low = ctx->norm_bound < 2.097847961257068 ? 1 : 0;  // theta_9
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
@@ -1782,7 +1793,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     // that layout fits LDS: the recursion in time is serial, this shortens every stage
     ctx->lb.multi_wave = (!ctx->lb.global_scratch && L > 0 &&
                           qocx::lindblad_lds_size(n, S, L, 2, K) <= 160 * 1024 &&
-                          !getenv("QOCX_LINDBLAD_SINGLE_WAVE")) ? 1 : 0;
+                          !qocx::diag_getenv("QOCX_LINDBLAD_SINGLE_WAVE")) ? 1 : 0;
     ctx->lb.cache_gen = (ctx->lb.multi_wave && p->fixed_subdivision <= 0 &&
                          qocx::lindblad_lds_size(n, S, L, 3, K) <= 160 * 1024) ? 1 : 0;
     auto& lb = ctx->lb;
@@ -2079,7 +2090,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     const size_t md = dump_elems(n);
     want_grad = (want_grad && K > 0) ? 1 : 0;
     if (K > 0 && !controls) return fail(QOCX_ERR_ARG, "controls is NULL");
-    const bool trace_host = getenv("QOCX_TRACE_HOST") != nullptr;
+    const bool trace_host = qocx::diag_getenv("QOCX_TRACE_HOST") != nullptr;
     auto now_ms = [] {
         timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -2363,18 +2374,38 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     return 0;
 }
 
+// Knobs: the variant switches every build accepts (each of them selects between paths that give
+// the same numbers to rounding) and the diagnostic ones that exist in libqocx_diag.so only
+// (qocx_diag.h): timing experiments that return garbage and the stamped kernel builds.
+static const char* const kVariantKnobs[] = {
+    "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
+    "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
+    "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma"};
+static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
+                                         "k1a_stamps", "k1a_dbg", "peak_mode"};
+
+int qocx_knob_kind(const char* name) {
+    if (!name) return 0;
+    for (const char* k : kVariantKnobs)
+        if (strcmp(k, name) == 0) return 1;
+    for (const char* k : kDiagKnobs)
+        if (strcmp(k, name) == 0) return qocx::kDiagBuild ? 2 : -2;
+    return 0;
+}
+
+int qocx_build_is_diag(void) { return qocx::kDiagBuild ? 1 : 0; }
+
 int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(QOCX_ERR_ARG, "NULL argument");
-    static const char* known[] = {"sweep_loader", "sweep_impl", "sweep3_dbg", "sweep3_stamps",
-                                  "sweep3_phases", "lindblad_stamps", "magnus_general",
-                                  "dbg_skip", "bidir", "unit_adjoint", "sweep_onebuf", "latency",
-                                  "fuse_lu", "lindblad_two_sided",
-                                  "lindblad_side_limit", "k3_split", "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w", "sweep_inverse", "sweep_inverse_small"};
-    for (const char* k : known)
-        if (strcmp(k, name) == 0) {
-            ctx->knobs[name] = value;
-            return 0;
-        }
+    const int kind = qocx_knob_kind(name);
+    if (kind > 0) {
+        ctx->knobs[name] = value;
+        return 0;
+    }
+    if (kind == -2)
+        return fail(QOCX_ERR_ARG, std::string("diagnostic knob '") + name +
+                                      "' exists in libqocx_diag.so only (make diag, -DQOCX_DIAG)");
     return fail(QOCX_ERR_ARG, std::string("unknown knob: ") + name);
 }
 
@@ -2554,8 +2585,11 @@ int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms) {
     ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
     HIP_TRY(hipMemcpyAsync(ctx->opt_max_norms.p, max_norms, ctx->K * sizeof(double),
                            hipMemcpyHostToDevice, ctx->stream));
+    if (((size_t)ctx->B * ctx->nc * ctx->K + 255) / 256 > 0x7fffffffu || (size_t)ctx->nc * ctx->K > 65535u * 256u)
+        return fail(QOCX_ERR_ARG, "control arrays too large for the optimizer kernels' grids");
     qocx::launch_clip_controls(ctx->controls.p, (size_t)ctx->B * ctx->nc * ctx->K, ctx->K,
                                ctx->opt_max_norms.p, ctx->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // max_norms is the caller's memory
     ctx->have_results = false;
     return 0;
@@ -2696,8 +2730,9 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     fa.nsteps = count; fa.step0 = 0; fa.seg_len = count; fa.n = n;
     fa.pade_policy = (int)ctx->knob("pade_order", 0);
     const bool inverse = nb <= 2 && ctx->knob("lu_inverse", 0) != 0;  // P^-1 instead of the factors
-    const bool fused_lu = nb == 2 && !inverse && getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
+    const bool fused_lu = nb == 2 && !inverse && qocx::diag_getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
+    fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
@@ -2779,10 +2814,22 @@ int qocx_debug_mfma_peak(qocx_ctx* ctx, int32_t waves_per_simd, int32_t iters, d
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
+    const int peak_mode = (int)ctx->knob("peak_mode", 0);  // (diagnostic build: pipe_mix_kernel)
+    (void)peak_mode;
+#ifdef QOCX_DIAG
+    if (peak_mode > 0) {
+        qocx::launch_pipe_mix(out.p, blocks, 64, peak_mode, ctx->stream);
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        qocx::launch_pipe_mix(out.p, blocks, iters, peak_mode, ctx->stream);
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+    } else
+#endif
+    {
     qocx::launch_mfma_peak(out.p, blocks, 64, ctx->stream);  // warm-up
     HIP_TRY(hipEventRecord(e0, ctx->stream));
     qocx::launch_mfma_peak(out.p, blocks, iters, ctx->stream);
     HIP_TRY(hipEventRecord(e1, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));

@@ -44,6 +44,12 @@ struct FactorArgs {
     int prefer_low = 0;        // the host's bound of ||dt a||_1 is below theta_9 (four-wave K1a: which
                                // of its two paths is inlined, qocx_pade4.hip)
     int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
+    // diagnostic build only (qocx_diag.h; knobs "k1a_dbg", "k1a_stamps"): bits 0-1 s_setprio level of
+    // the fused factorisation, bit 2 no factorisation at all (garbage), and the cycle sums of the
+    // stamped build, [2 waves][8]
+    int dbg = 0;
+    unsigned long long* stamps = nullptr;
+    int lu_mfma = 0;           // fused K1b with its Schur updates on the matrix cores (qocx_lu4.h)
     // two-wave K1a (17 <= n <= 32) with K1b fused in: P stays in LDS, wave 0 factors it, only the
     // factors (and 1/U_kk, the permutation) go to HBM; launch_lu is then not called
     int fuse_lu = 0;
@@ -307,6 +313,9 @@ void launch_scatter(const ScatterArgs& a, hipStream_t st);
 void launch_reduce_results(const double* cost, const double* grads, int batch, int per_seed,
                            double* out, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);
+#ifdef QOCX_DIAG
+void launch_pipe_mix(double* out, int blocks, int iters, int mode, hipStream_t st);
+#endif
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 size_t magnus_scratch_elems(int nb, int blocks);

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     // a piece under the flags of the running (sub-step, state)
     auto dma_fire = [&](auto PIECE) __attribute__((always_inline)) {
         if constexpr (decltype(PIECE)::value < IMG_PIECES) {
-            if (pf_fire_q && !(args.dbg & 1024)) dma_one(PIECE);  // (dbg: timing experiment)
+            if (pf_fire_q && !(QOCX_DBG_BITS(args.dbg) & 1024)) dma_one(PIECE);  // (dbg: timing experiment)
         } else {
             if (pf_fire_l) dma_one(PIECE);
         }
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 if (pf_due) set_prefetch(m0 + step + 2, (par + 2) % NBUF, false, m0 + step + 2);
                 issue_all_due();
             } else if constexpr (PREFETCH) {
-                pf_due = fetcher && (step + 1 < je) && !(args.dbg & 256);  // (dbg: timing experiment)
+                pf_due = fetcher && (step + 1 < je) && !(QOCX_DBG_BITS(args.dbg) & 256);  // (dbg: timing experiment)
                 if (pf_due) set_prefetch(m0 + step + 1, (par + 1) % NBUF, false, m0 + step + 1);
             }
             if (step + 1 < je) nsub_next = 1 << step_squarings(args.s_arr[m0 + step + 1]);
@@ -1441,8 +1441,8 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 if (pf_due) set_prefetch(m0 + step - 2, (par + 2) % NBUF, true, m0 + step - 2);
                 issue_all_due();
             } else if constexpr (ONEBUF) {
-                pf_due = (step - 1 >= jb) && !(args.dbg & 512);
-                pf_qdue = !(args.dbg & 512);
+                pf_due = (step - 1 >= jb) && !(QOCX_DBG_BITS(args.dbg) & 512);
+                pf_qdue = !(QOCX_DBG_BITS(args.dbg) & 512);
                 set_prefetch(pf_due ? m0 + step - 1 : m0 + step, 0, true, m0 + step);
             } else if constexpr (PREFETCH) {
                 pf_due = fetcher && (step - 1 >= jb);
@@ -1825,6 +1825,62 @@ __global__ __launch_bounds__(64) void mfma_peak_kernel(double* out, int iters) {
     if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = 1.0;  // keeps the chains alive
 }
 
+#ifdef QOCX_DIAG
+// Do FP64 MFMA and FP64 / FP32 vector work of two waves on one SIMD overlap? (knob "peak_mode" of
+// the diagnostic build.) Every wave runs `iters` rounds of 512 cycles of issue: 8 MFMAs (64 cycles
+// each) or 128 vector FMAs (4 cycles each). mode 1: all waves FP64 vector; 2: odd workgroups FP64
+// vector, even MFMA; 3: all FP32 vector; 4: odd FP32 vector, even MFMA.
+__global__ __launch_bounds__(64) void pipe_mix_kernel(double* out, int iters, int mode) {
+    // mixed modes: the role follows the wave slot this wave landed in (HW_ID bits 3:0), so that with
+    // two resident waves per SIMD every SIMD holds one wave of each kind
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    const bool vec = (mode == 1 || mode == 3) || ((mode == 2 || mode == 4) && (slot & 1));
+    const bool f32 = mode >= 3;
+    const double a = 1.0 + 1e-9 * lane_id(), b = 1.0 - 1e-9 * lane_id();
+    if (!vec) {
+        d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+        for (int it = 0; it < iters; ++it) {
+            c0 = mfma_f64(a, b, c0); c1 = mfma_f64(a, b, c1); c2 = mfma_f64(a, b, c2); c3 = mfma_f64(a, b, c3);
+            c4 = mfma_f64(a, b, c4); c5 = mfma_f64(a, b, c5); c6 = mfma_f64(a, b, c6); c7 = mfma_f64(a, b, c7);
+        }
+        const d4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+        if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = 1.0;
+    } else if (!f32) {
+        double c[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = 1e-3 * k;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) c[k] = fma(c[k], a, b);
+        }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += c[k];
+        if (s == -1.0) out[0] = 1.0;
+    } else {
+        float c[16];
+        const float af = (float)a, bf = (float)b;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = 1e-3f * k;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) c[k] = fmaf(c[k], af, bf);
+        }
+        float s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += c[k];
+        if (s == -1.0f) out[0] = 1.0;
+    }
+}
+void launch_pipe_mix(double* out, int blocks, int iters, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(pipe_mix_kernel, dim3(blocks), dim3(64), 0, st, out, iters, mode);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -1888,13 +1944,13 @@ static void launch_sweep_onebuf(const SweepArgs& a, int batch, hipStream_t st) {
 template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
     if (SweepPrefetch<NB>::value && a.onebuf && a.S == 1 && !a.loader &&
-        getenv("QOCX_SWEEP_W") == nullptr) {
+        diag_getenv("QOCX_SWEEP_W") == nullptr) {
         launch_sweep_onebuf<NB>(a, batch, st);
         return;
     }
     // waves per seed: the states are independent chains, up to four of them run side by side
     // (eight were measured at S = 32: no faster, the adjoint phase is K3 bound by then)
-    static const int forced = getenv("QOCX_SWEEP_W") ? atoi(getenv("QOCX_SWEEP_W")) : 0;  // experiments
+    static const int forced = diag_getenv("QOCX_SWEEP_W") ? atoi(diag_getenv("QOCX_SWEEP_W")) : 0;  // experiments
     const int w = forced > 0 ? forced : (a.S >= 4 ? 4 : (a.S >= 2 ? 2 : 1));
     if (w >= 4) launch_sweep_w<NB, 4>(a, batch, st);
     else if (w >= 2) launch_sweep_w<NB, 2>(a, batch, st);
@@ -1919,7 +1975,7 @@ static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStrea
 }
 
 static bool one_wave_pq() {
-    static const bool v = getenv("QOCX_PQ1") != nullptr;
+    static const bool v = diag_getenv("QOCX_PQ1") != nullptr;
     return v;
 }
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {

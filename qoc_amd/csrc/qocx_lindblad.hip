@@ -1272,8 +1272,10 @@ void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st) {
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
+#ifdef QOCX_DIAG
     else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr)
-        launch_t<1, false, true, true, true>(a, batch, st);  // diagnostic build (in-kernel stamps)
+        launch_t<1, false, true, true, true>(a, batch, st);  // stamped build (qocx_diag.h)
+#endif
     else if (a.multi_wave && a.nops == 2) launch_t<1, false, true, true>(a, batch, st);
     else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
     else launch_t<1, false, false>(a, batch, st);

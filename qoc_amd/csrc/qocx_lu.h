@@ -50,7 +50,7 @@ __device__ __forceinline__ void lu_body(const LuArgs& args, size_t m, const doub
     int mypos = -1;
     bool singular = false;
     double my_dre = 0, my_dim = 0;
-    if (args.dbg & 1) {  // timing experiment: the memory traffic of K1b without its arithmetic
+    if (QOCX_DBG_BITS(args.dbg) & 1) {  // timing experiment: the memory traffic of K1b without its arithmetic
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) img[cc * 64 + lane] = make_double2(pre[cc] + 1.0, pim[cc]);
         if (h == 0) {

@@ -23,17 +23,17 @@ __global__ void clip_controls_kernel(double* controls, size_t total, int k, cons
 __global__ void keep_best_kernel(const double* controls, double* best_controls, size_t per_seed,
                                  const double2* final_states, double2* best_final, size_t final_per_seed,
                                  const unsigned char* improved) {
-    const size_t b = blockIdx.y;
+    const size_t b = blockIdx.x;  // (the seed index on grid.x: no 65535 limit on the batch)
     if (!improved[b]) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (idx < per_seed) best_controls[b * per_seed + idx] = controls[b * per_seed + idx];
     if (idx < final_per_seed) best_final[b * final_per_seed + idx] = final_states[b * final_per_seed + idx];
 }
 
 __global__ void optimizer_update_kernel(OptimArgs a) {
-    const size_t b = blockIdx.y;
+    const size_t b = blockIdx.x;
     if (!a.update[b]) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (idx >= a.per_seed) return;
     const size_t e = b * a.per_seed + idx;
     double g = a.grads[e];
@@ -67,13 +67,13 @@ void launch_keep_best(const double* controls, double* best_controls, size_t per_
                       const unsigned char* improved, int batch, hipStream_t st) {
     const size_t widest = per_seed > final_per_seed ? per_seed : final_per_seed;
     if (batch <= 0 || widest == 0) return;
-    hipLaunchKernelGGL(keep_best_kernel, dim3((unsigned)((widest + 255) / 256), batch), dim3(256), 0, st,
+    hipLaunchKernelGGL(keep_best_kernel, dim3(batch, (unsigned)((widest + 255) / 256)), dim3(256), 0, st,
                        controls, best_controls, per_seed, final_states, best_final, final_per_seed,
                        improved);
 }
 void launch_optimizer_update(const OptimArgs& a, int batch, hipStream_t st) {
     if (batch <= 0 || a.per_seed == 0) return;
-    hipLaunchKernelGGL(optimizer_update_kernel, dim3((unsigned)((a.per_seed + 255) / 256), batch),
+    hipLaunchKernelGGL(optimizer_update_kernel, dim3(batch, (unsigned)((a.per_seed + 255) / 256)),
                        dim3(256), 0, st, a);
 }
 

@@ -18,6 +18,7 @@
 // mirror hand-over of a^4. The Q / P images are stored straight from the C-layout registers.
 #include "qocx_wave.h"
 #include "qocx_lu.h"
+#include "qocx_lu4.h"
 
 namespace qocx {
 
@@ -149,16 +150,33 @@ struct Out {
     LuArgs lu;
     bool fuse;
     size_t m;
+    bool lu_mfma;                 // the factorisation's Schur updates on the matrix cores (qocx_lu4.h)
+    int dbg;                      // FactorArgs::dbg (diagnostic build)
+    unsigned long long* stamps;   // FactorArgs::stamps
 };
+
+// barrier of the stamped build (qocx_diag.h): the time up to the barrier goes to phase `ph`, the
+// wait itself to phase 2
+#define K1A_SYNC(ph)          \
+    do {                      \
+        clk.lap(ph);          \
+        __syncthreads();      \
+        clk.lap(2);           \
+    } while (0)
 
 // LDS image of P for the fused factorisation: column-major, LP complex per column (the C-layout
 // stores of a wave walk the columns: pitch 33 spreads them over the banks)
 constexpr int LP = 33;
 static_assert(32 * LP * 16 <= SLOT_F64 * 8, "the P image reuses the A-operand slot");
+static_assert(lu4::XB_COMPLEX * 16 <= MTILE_F64 * 8, "the panel buffer of qocx_lu4.h reuses the mirror tile");
 
 // W: the wave's column block. Every wave executes the same number of barriers.
-template <bool HERM, int W, class Gen>
+template <bool HERM, int W, bool STAMP, class Gen>
 __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
+    // stamped build: cycles per phase of this wave - 0 generator / norm / staging, 1 products,
+    // 2 barrier waits, 3 P / Q images, 4 factorisation
+    StampClock<STAMP> clk;
+    clk.start();
     // tiles this wave computes: rows [0, NT) of column block W
     constexpr int NT = (HERM && W == 0) ? 1 : 2;
     constexpr bool GIVE = HERM && W == 1;   // hands tile (1,0) to wave 0
@@ -208,7 +226,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             nrm[2 + W] = bl;
         }
     }
-    __syncthreads();  // 1
+    K1A_SYNC(0);  // 1
     bool bad = false, bad_lower = false;
     int sq = squarings(fmax(nrm[0], nrm[1]), bad);
     const int sq_lower = squarings(fmax(nrm[2], nrm[3]), bad_lower);
@@ -221,7 +239,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
                 e += sqrt(a.re[ti][r] * a.re[ti][r] + a.im[ti][r] * a.im[ti][r]);
         e = column_max(e);
         if (lane == 0) nrm[4 + W] = e;
-        __syncthreads();
+        K1A_SYNC(1);
         sq = squarings(fmax(nrm[4], nrm[5]), bad);
     }
     if (bad) {
@@ -241,7 +259,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     if (W == 0 && lane == 0) *out.s_out = step_entry(sq, order);
     stage_tile(sl, 0, W, a.re[0], a.im[0]);
     stage_tile(sl, 1, W, a.re[1], a.im[1]);
-    __syncthreads();  // 2
+    K1A_SYNC(0);  // 2
 
     Col u, v;
     Acc3 acc;
@@ -271,12 +289,12 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
                     if (4 * r + q == c) v.re[ti][r] += bt[0];
             }
         }
-        __syncthreads();  // L1: every read of a is done
+        K1A_SYNC(1);  // L1: every read of a is done
         if (order >= 5) {
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x.re[ti], x.im[ti]);
             if (GIVE) stage_mirror(sl, 1, 0, x.re[0], x.im[0], 1.0);
-            __syncthreads();  // L2
+            K1A_SYNC(1);  // L2
             if (TAKE) load_tile(sl, 1, 0, x.re[1], x.im[1]);
             for (int j = 2; 2 * j < order; ++j) {  // x_{2j} = x2 x_{2j-2}: j = 2 (x4), 3 (x6), 4 (x8)
                 acc_zero<NT>(acc);
@@ -294,13 +312,13 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
                     v.im[ti] += bv * x.im[ti];
                 }
                 if (2 * (j + 1) < order) {  // the next product takes it as its B operand
-                    if (HERM) __syncthreads();  // the mirror tile's previous content has been read
+                    if (HERM) K1A_SYNC(1);  // the mirror tile's previous content has been read
                     if (GIVE) mirror_put(mt, x.re[0], x.im[0], 1.0);
-                    if (HERM) __syncthreads();
+                    if (HERM) K1A_SYNC(1);
                     if (TAKE) mirror_get(mt, x.re[1], x.im[1]);
                 }
             }
-            __syncthreads();  // L3: every read of x2 is done
+            K1A_SYNC(1);  // L3: every read of x2 is done
         }
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, w.re[ti], w.im[ti]);
@@ -313,7 +331,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             u.im[ti] = bt[1] * a.im[ti];
         }
         acc_init<NT>(acc, u);
-        __syncthreads();  // L4
+        K1A_SYNC(1);  // L4
         gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
             bre = a.re[kk >> 2][kk & 3];
             bim = a.im[kk >> 2][kk & 3];
@@ -328,11 +346,11 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         bim = a.im[kk >> 2][kk & 3];
     });
     acc_finish<NT>(x2, acc);
-    __syncthreads();  // 3: every read of a is done
+    K1A_SYNC(1);  // 3: every read of a is done
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x2.re[ti], x2.im[ti]);
     if (GIVE) stage_mirror(sl, 1, 0, x2.re[0], x2.im[0], 1.0);
-    __syncthreads();  // 4
+    K1A_SYNC(1);  // 4
     if (TAKE) load_tile(sl, 1, 0, x2.re[1], x2.im[1]);
 
     acc_zero<NT>(acc);
@@ -342,7 +360,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     });
     acc_finish<NT>(x4, acc);
     if (GIVE) mirror_put(mt, x4.re[0], x4.im[0], 1.0);
-    __syncthreads();  // 5
+    K1A_SYNC(1);  // 5
     if (TAKE) mirror_get(mt, x4.re[1], x4.im[1]);
 
     acc_zero<NT>(acc);
@@ -351,11 +369,11 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         bim = x4.im[kk >> 2][kk & 3];
     });
     acc_finish<NT>(x6, acc);
-    __syncthreads();  // 6: every read of a2 is done
+    K1A_SYNC(1);  // 6: every read of a2 is done
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, x6.re[ti], x6.im[ti]);
     if (GIVE) stage_mirror(sl, 1, 0, x6.re[0], x6.im[0], 1.0);
-    __syncthreads();  // 7
+    K1A_SYNC(1);  // 7
     if (TAKE) load_tile(sl, 1, 0, x6.re[1], x6.im[1]);
 
     // ---- w2 = a6 (b13 a6 + b11 a4 + b9 a2) + b7 a6 + b5 a4 + b3 a2 (expm.py:157) ---------
@@ -393,7 +411,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         bim = b12 * x6.im[tb][r] + b10 * x4.im[tb][r] + b8 * x2.im[tb][r];
     });
     acc_finish<NT>(v, acc);
-    __syncthreads();  // 8: every read of a6 is done
+    K1A_SYNC(1);  // 8: every read of a6 is done
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) stage_tile(sl, ti, W, w2.re[ti], w2.im[ti]);
     if (GIVE) stage_mirror(sl, 1, 0, w2.re[0], w2.im[0], 1.0);
@@ -416,7 +434,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         u.im[ti] = b1 * a.im[ti];
     }
     acc_init<NT>(acc, u);
-    __syncthreads();  // 9
+    K1A_SYNC(1);  // 9
     gemm3<NT>(acc, sl, [&](int kk, double& bre, double& bim) {
         bre = a.re[kk >> 2][kk & 3];
         bim = a.im[kk >> 2][kk & 3];
@@ -437,13 +455,14 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // (profiles/r03_k1b_memory_floor.jsonl).
     const bool fused = out.fuse;
     double2* simg = reinterpret_cast<double2*>(sl);
-    if (fused) __syncthreads();  // 10: every read of the slot (w2) is done
+    if (fused) K1A_SYNC(1);  // 10: every read of the slot (w2) is done
+    else clk.lap(1);
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (16 * W + c) * 32 + 16 * ti + 4 * r + q;
-            if (out.q_img) out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
+            if (!QOCX_DBG_BITS(out.q_img == nullptr)) out.q_img[idx] = make_double2(v.re[ti][r] + u.re[ti][r], v.im[ti][r] + u.im[ti][r]);
             const double2 pe = make_double2(v.re[ti][r] - u.re[ti][r], v.im[ti][r] - u.im[ti][r]);
             if (fused) simg[(16 * W + c) * LP + 16 * ti + 4 * r + q] = pe;
             else out.p_img[idx] = pe;
@@ -452,19 +471,41 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = (4 * r + q) * 32 + 16 + c;  // element (16 + c, 4r + q)
-            if (out.q_img) out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
+            if (!QOCX_DBG_BITS(out.q_img == nullptr)) out.q_img[idx] = make_double2(v.re[0][r] - u.re[0][r], -(v.im[0][r] - u.im[0][r]));
             const double2 pe = make_double2(v.re[0][r] + u.re[0][r], -(v.im[0][r] + u.im[0][r]));
             if (fused) simg[(4 * r + q) * LP + 16 + c] = pe;
             else out.p_img[idx] = pe;
         }
     }
     if (fused) {
-        __syncthreads();  // 11: the image is complete
-        if (W == 0) lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+        K1A_SYNC(3);  // 11: the image is complete
+        if (W == 0 && !(QOCX_DBG_BITS(out.dbg) & 4)) {
+            if (QOCX_DBG_BITS(out.dbg) & 3) {  // (experiment: the factorisation's wave goes first on its SIMD)
+                if ((out.dbg & 3) == 1) __builtin_amdgcn_s_setprio(1);
+                else if ((out.dbg & 3) == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+            // diagonal pivots and rank-4 updates on the matrix cores first (qocx_lu4.h); a matrix
+            // whose pivots leave the diagonal takes the general elimination, from the same image
+            bool done = false;
+            if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+            if (!done) lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+        }
+        clk.lap(4);
+    } else {
+        clk.lap(3);
+    }
+    if constexpr (STAMP) {
+        clk.acc[7] = __builtin_amdgcn_s_memrealtime() - clk.acc[7];
+        if (lane_id() == 0 && out.stamps != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)  // 1024 sets of sums, or the atomics serialise the whole launch
+                atomicAdd(out.stamps + ((blockIdx.x + 7 * blockIdx.y) & 1023) * 16 + W * 8 + k, clk.acc[k]);
+        }
     }
 }
 
-template <bool HERM>
+template <bool HERM, bool STAMP = false>
 __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -473,7 +514,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t m = (size_t)b * args.nsteps + step;
     Out out;
-    out.q_img = args.skip_q ? nullptr : args.q_img + m * MAT;  // (skip_q: timing experiment)
+    out.q_img = QOCX_DBG_BITS(args.skip_q) ? nullptr : args.q_img + m * MAT;  // (skip_q: timing experiment)
     out.p_img = args.lu_img + m * MAT;
     out.s_out = args.s_arr + m;
     out.pade_policy = args.pade_policy;
@@ -483,6 +524,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
+    out.dbg = args.dbg; out.stamps = args.stamps; out.lu_mfma = args.lu_mfma != 0;
     const StepInterp si = args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
@@ -520,8 +562,8 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
             a.im[ti] = -dt * hre[ti];
         }
     };
-    if (w == 0) body<HERM, 0>(gen, out, smem);
-    else body<HERM, 1>(gen, out, smem);
+    if (w == 0) body<HERM, 0, STAMP>(gen, out, smem);
+    else body<HERM, 1, STAMP>(gen, out, smem);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (Magnus M4/M6, debug)
@@ -546,6 +588,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
     out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
+    out.dbg = 0; out.stamps = nullptr; out.lu_mfma = args.lu_mfma != 0;
     const double2* am = a_in + m * (size_t)n * n;
     auto gen = [&](Col& a, int wcol) {
 #pragma unroll
@@ -559,13 +602,20 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
                 a.im[ti][r] = e.y;
             }
     };
-    if (w == 0) body<HERM, 0>(gen, out, smem);
-    else body<HERM, 1>(gen, out, smem);
+    if (w == 0) body<HERM, 0, false>(gen, out, smem);
+    else body<HERM, 1, false>(gen, out, smem);
 }
 
 }  // namespace pade2
 
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+#ifdef QOCX_DIAG
+    if (a.stamps != nullptr && a.hermitian) {  // stamped build (qocx_diag.h)
+        hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, true>), dim3(nsteps, batch), dim3(128),
+                           pade2::LDS_BYTES, st, a);
+        return;
+    }
+#endif
     if (a.hermitian)
         hipLaunchKernelGGL(pade2::pade_pq2_kernel<true>, dim3(nsteps, batch), dim3(128),
                            pade2::LDS_BYTES, st, a);

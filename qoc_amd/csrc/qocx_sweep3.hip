@@ -265,7 +265,7 @@ __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w
         const int pm_next = load_perm(next_step);
         char* sl = s3_slot<NB>(smem, t);
         char* ql = smem + L::Q_OFF + (tq % L::QRING) * L::IMG;
-        if (!(args.dbg & 4)) {
+        if (!(QOCX_DBG_BITS(args.dbg) & 4)) {
             const double2* src = args.lu_img + (w.m0 + step) * MAT + (size_t)(lane / NP) * NP +
                                  min(max(pm_cur, 0), NP - 1);
 #pragma unroll
@@ -274,7 +274,7 @@ __device__ __forceinline__ void s3_loader(const SweepArgs& args, const S3Walk& w
             dma16(args.dinv + (w.m0 + step) * NP + i, reinterpret_cast<double2*>(sl + L::SLOT_D));
             dma4(args.perm + (w.m0 + step) * NP + i, reinterpret_cast<int*>(sl + L::SLOT_P));
         }
-        if (!(args.dbg & 8) && qstep >= w.jb && qstep < w.je) {
+        if (!(QOCX_DBG_BITS(args.dbg) & 8) && qstep >= w.jb && qstep < w.je) {
             const double2* src = args.q_img + (w.m0 + qstep) * MAT + (size_t)(lane / NP) * NP +
                                  min(max(pm_prev, 0), NP - 1);
 #pragma unroll
@@ -348,7 +348,7 @@ __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk&
         // the x slots are counted down from the capacity, as in the compute wave)
         if (adjoint && args.unit_adjoint && w.do_fwd) slot = (int)w.cap;
         s3_barrier();  // P0
-        if (!(args.dbg & 1)) invert_blocks<NB, UPPER>(s3_slot<NB>(smem, 0), s3_inv<NB>(smem, 0), lane);
+        if (!(QOCX_DBG_BITS(args.dbg) & 1)) invert_blocks<NB, UPPER>(s3_slot<NB>(smem, 0), s3_inv<NB>(smem, 0), lane);
         s3_barrier();  // P1
         S3Subs subs;
         for (int t = 0; t < w.T; ++t) {
@@ -356,7 +356,7 @@ __device__ __forceinline__ void s3_inverter(const SweepArgs& args, const S3Walk&
             if (!adjoint && (size_t)slot + nsub >= w.cap) return false;
             if (adjoint && args.unit_adjoint && slot - nsub < 0) return false;
             clk.lap(0);
-            if (t + 1 < w.T && !(args.dbg & 1))
+            if (t + 1 < w.T && !(QOCX_DBG_BITS(args.dbg) & 1))
                 invert_blocks<NB, UPPER>(s3_slot<NB>(smem, t + 1), s3_inv<NB>(smem, t + 1), lane);
             clk.lap(1);                 // inversion
             slot += adjoint ? -nsub : nsub;
@@ -562,7 +562,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
                 clk.lap(1);             // b = (Pi Q) psi
                 for (int s = 0; s < S; ++s) {
                     double xre = bvec[s * NP + i].x, xim = bvec[s * NP + i].y;
-                    if (!(args.dbg & 2)) solve_forward(sl, iv, s, xre, xim);
+                    if (!(QOCX_DBG_BITS(args.dbg) & 2)) solve_forward(sl, iv, s, xre, xim);
                     wave_sync();
                     const double2 p = make_double2(xre, xim);
                     vecs[s * NP + i] = p;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void s3_compute(const SweepArgs& args, const S3Walk& 
             const int sub_slot = slot - nsub + sub;
             for (int s = 0; s < S; ++s) {
                 double vre = lam[s * NP + i].x, vim = lam[s * NP + i].y;
-                if (!(args.dbg & 2)) solve_adjoint(sl, iv, s, vre, vim);
+                if (!(QOCX_DBG_BITS(args.dbg) & 2)) solve_adjoint(sl, iv, s, vre, vim);
                 clk.lap(3);             // solves
                 // x = Pi^T v goes to K3 in the original row order; lambda = (Pi Q)^H v
                 if (g0) xs_b[((size_t)sub_slot * S + s) * NP + prow] = make_double2(vre, vim);
@@ -767,7 +767,9 @@ int sweep3_max_states(int nb) {
 
 void launch_sweep3(int nb, const SweepArgs& a, int batch, hipStream_t st) {
     if (nb == 1) launch_sweep3_t<1, false>(a, batch, st);
-    else if (a.stamps != nullptr) launch_sweep3_t<2, true>(a, batch, st);  // diagnostic build
+#ifdef QOCX_DIAG
+    else if (a.stamps != nullptr) launch_sweep3_t<2, true>(a, batch, st);  // stamped build (qocx_diag.h)
+#endif
     else launch_sweep3_t<2, false>(a, batch, st);
 }
 

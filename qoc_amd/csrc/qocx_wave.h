@@ -10,6 +10,7 @@
 #include <utility>
 
 #include "qocx_device.h"
+#include "qocx_diag.h"
 
 namespace qocx {
 

@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(_HERE, "libqocx.so")
+# the measurement build (make -C qoc_amd/csrc diag): loaded by the scripts under tools/ only
+DIAG_LIBRARY_PATH = os.path.join(_HERE, "libqocx_diag.so")
 
 COST_TARGET_COHERENT = 0
 COST_TARGET_INCOHERENT = 1
@@ -145,6 +147,8 @@ SIGNATURES = {
     "qocx_debug_selftest": (ctypes.c_int, [_VP, _c_int_p, ctypes.c_char_p, _I32]),
     "qocx_debug_lindblad_knobs": (ctypes.c_int, [_VP, _I64, _I32, _I32]),
     "qocx_debug_set_knob": (ctypes.c_int, [_VP, ctypes.c_char_p, _I64]),
+    "qocx_knob_kind": (ctypes.c_int, [ctypes.c_char_p]),
+    "qocx_build_is_diag": (ctypes.c_int, []),
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_pade_orders": (ctypes.c_int, [_VP, ctypes.POINTER(_I64)]),

@@ -52,11 +52,20 @@ def test_pade_factor_kernel(engine, n):
             a = -1j * (g + g.conj().T) / 2 if frac != 0.7 else g
             mats.append(a * (dm.PADE_THETA[order] * frac / onp.one_norm(a)))
     mats = np.stack(mats)
+    default_mfma = 1
     for policy in (0, 13):
-        engine.set_knob("pade_order", policy)
-        out = engine.debug_pade_factor(mats)
-        engine.set_knob("pade_order", 0)
-        check_pade_factor(out, mats, policy)
+        # 17 <= n <= 32: the fused factorisation with its Schur updates on the matrix cores
+        # (qocx_lu4.h: diagonal pivots, checked; the large-norm cases here leave the diagonal and
+        # take the general elimination) and the one-wave elimination alone
+        for lu_mfma in ((1, 0) if 16 < n <= 32 else (default_mfma,)):
+            engine.set_knob("pade_order", policy)
+            engine.set_knob("lu_mfma", lu_mfma)
+            try:
+                out = engine.debug_pade_factor(mats)
+            finally:
+                engine.set_knob("pade_order", 0)
+                engine.set_knob("lu_mfma", default_mfma)
+            check_pade_factor(out, mats, policy)
 
 
 @pytest.mark.parametrize("n", [3, 16, 20, 32])

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--states", type=int, default=1,
                     help="S > 1: orthonormal random initial states and targets")
     args = ap.parse_args()
+    from tools import diaglib
+    diaglib.load()  # the measurement build: diagnostic knobs (qocx_diag.h)
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 
     engine = Engine(0)

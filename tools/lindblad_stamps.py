@@ -19,6 +19,8 @@ WAVES = ["generator terms", "operator 1", "operator 2", "control cotangents"]
 
 
 def main():
+    from tools import diaglib
+    diaglib.load()  # the measurement build: diagnostic knobs (qocx_diag.h)
     from qoc_amd.engine import Engine, COST_TARGET_DENSITY
     engine = Engine(0)
     h0, g, gam, ops, rho0, target = bench.lindblad_problem()

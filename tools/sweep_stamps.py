@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--seeds", type=int, default=bench.SEEDS_PER_GPU)
     ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
+    from tools import diaglib
+    diaglib.load()  # the measurement build: diagnostic knobs (qocx_diag.h)
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
     engine = Engine(0)
     h0, g, psi0, target = bench.make_problem()
