@@ -63,7 +63,24 @@ def make_controls(first_seed, count):
     return out
 
 
-PMC_SUMMARY = "profiles/r03_pmc_hbm.json"
+PMC_SUMMARY = "profiles/r04_pmc_hbm.json"
+PMC_SQ_SUMMARY = "profiles/r04_pmc_sq.json"  # SQ counters of the same command (tools/profile_round.sh)
+
+
+def pmc_executed_mfma_flops(kernel, units_per_dispatch=32000):
+    """
+    Executed FP64 MFMA flops per propagator step of `kernel` from the committed SQ counter pass
+    (SQ_INSTS_VALU_MFMA_MOPS_F64 per dispatch; one v_mfma_f64_16x16x4_f64 = 2048 flop counts 4, i.e.
+    512 flop per counted operation - calibrated in round 2 against the instruction count of the
+    kernel). None if the summary is absent.
+    """
+    try:
+        with open(os.path.join(ROOT, PMC_SQ_SUMMARY)) as f:
+            summary = json.load(f)
+        entry = [v for k, v in summary.items() if k.startswith(kernel)][0]
+        return entry["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / units_per_dispatch
+    except (OSError, KeyError, ValueError, IndexError, TypeError):
+        return None
 
 
 def pmc_traffic_bytes(kernel, units_per_launch):
@@ -106,27 +123,45 @@ def _cpu_worker(seed_ids):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(seeds_per_worker=40):
-    """Oracle fwd+grad on a bounded sample: `cores` worker processes x seeds_per_worker seeds,
-    plus the single-core figure (one seed at a time, the reference's execution model)."""
+def host_cores():
+    """(cores this process may run on, cores of the machine). The GPU box gives a one-GPU job a
+    CPU share (16 of its cores): the scheduler affinity, not os.cpu_count(), is what can be used."""
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):  # pragma: no cover
+        usable = total
+    return max(1, usable), total
+
+
+def cpu_baseline(budget_seconds=12.0):
+    """Oracle fwd+grad on a bounded sample: one worker process per usable core (all of them: the
+    CPU share of the box), each with a block of seeds sized from a timed
+    probe so that the sample takes about `budget_seconds`; plus the single-core figure (one seed
+    at a time, the reference's execution model)."""
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    jobs = [[w * seeds_per_worker + i for i in range(seeds_per_worker)] for w in range(cores)]
+    cores, total = host_cores()
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [[0]] * cores)  # process start, imports, BLAS warm-up: not timed
+        probe = max(pool.map(_cpu_worker, [[1]] * cores))  # one seed per worker, all cores busy
+        seeds_per_worker = int(max(4, min(64, round(budget_seconds / max(probe, 1e-3)))))
+        jobs = [[w * seeds_per_worker + i for i in range(seeds_per_worker)] for w in range(cores)]
         t0 = time.perf_counter()
         pool.map(_cpu_worker, jobs)
         wall = time.perf_counter() - t0
-        single_seconds = pool.apply(_cpu_worker, (list(range(1000, 1024)),))  # others idle
+        single_seconds = pool.apply(_cpu_worker, (list(range(1000, 1012)),))  # others idle
     steps = cores * seeds_per_worker * (N_EVAL - 1)
-    return dict(value=steps / wall, unit="propagator-steps/s", cores=cores, kind="port",
+    return dict(value=steps / wall, unit="propagator-steps/s", cores=cores, cores_available=total,
+                cores_note="cores = the scheduler affinity of this process (the CPU share the box "
+                           "gives a one-GPU job), all of them used; cores_available = os.cpu_count()",
+                kind="port",
                 sample="{} seeds x {} steps (oracle/qoc_numpy.py fwd+grad, {} processes, "
                        "1 BLAS thread each, {:.1f}s wall, warm processes)".format(
                            cores * seeds_per_worker, N_EVAL - 1, cores, wall),
-                single_core=dict(value=24 * (N_EVAL - 1) / single_seconds,
+                single_core=dict(value=12 * (N_EVAL - 1) / single_seconds,
                                  unit="propagator-steps/s", cores=1,
-                                 sample="24 seeds x {} steps, one process, 1 BLAS thread, "
+                                 sample="12 seeds x {} steps, one process, 1 BLAS thread, "
                                         "{:.1f}s".format(N_EVAL - 1, single_seconds)))
 
 
@@ -259,8 +294,17 @@ def main():
                     help="tuning knob: time segments of the pipeline (0 = the engine's choice)")
     args = ap.parse_args()
 
-    from qoc_amd.engine import Engine, COST_TARGET_COHERENT
     from qoc_amd import parallel
+    standin = os.environ.get("QOCX_BENCH_STANDIN")
+    if standin:
+        # CPU rehearsal of the multi-rank control flow (tests/test_bench_main.py): a stand-in engine
+        # module in the place of libqocx, gloo in the place of RCCL. The line says so in `data`;
+        # nothing of the hot path is computed or measured.
+        import importlib
+        mod = importlib.import_module(standin)
+        Engine, COST_TARGET_COHERENT = mod.Engine, mod.COST_TARGET_COHERENT
+    else:
+        from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 
     rank, world, local_rank = parallel.env_world()
     if world != args.gpus:
@@ -316,7 +360,7 @@ def main():
     # the same evaluation host buffer to host buffer (rank 0 of a single-GPU run): fresh controls
     # from host memory every step, costs + gradients + final states back in host memory
     host_to_host = None
-    if world == 1:
+    if world == 1 and not standin:
         fresh = [make_controls(5000 + 300 * k, seeds) for k in range(3)]
         for warm in fresh:  # first-touch of the result staging on this route
             engine.evaluate(warm, want_grad=True)
@@ -334,7 +378,7 @@ def main():
     # the order pinned to 13, which is what the reference itself always executes
     orders = engine.pade_orders()
     reference_order = None
-    if world == 1 and not args.no_reference_order:
+    if world == 1 and not args.no_reference_order and not standin:
         engine.set_knob("pade_order", 13)
         one_step()
         engine.synchronize()
@@ -351,7 +395,7 @@ def main():
                                     "the reference executes it (expm.py:230-233)")
     secondary = None
     latency = None
-    if world == 1 and not args.no_secondary:
+    if world == 1 and not args.no_secondary and not standin:
         engine.set_timing(True)
         secondary = lindblad_secondary(engine)
         latency = latency_secondary(engine)
@@ -385,6 +429,14 @@ def main():
                         avg_launch_ms=total_ms / launches,
                         gemm_products_per_step=mean_products,
                         flops_per_step=k1_flops_per_unit)
+        # what the matrix cores executed (3M scheme, Hermitian tiles, the factorisation's Schur
+        # updates), from the committed SQ counter pass: MFMA operations per step x 512 flop
+        executed = pmc_executed_mfma_flops("qocx::pade2::pade_pq2_kernel<true")
+        if executed is not None:
+            roofline["executed_mfma_flops_per_step"] = executed
+            roofline["frac_executed"] = executed * units_per_launch / avg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS
+            roofline["frac_executed_source"] = ("SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed rocprofv3 "
+                                                "--pmc pass ({}) over this run's launch time".format(PMC_SQ_SUMMARY))
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in warm_timing.items()}
     kernel_ms["pade_pq"] = total_ms / launches if launches else kernel_ms["pade_pq"]
     path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
@@ -395,7 +447,8 @@ def main():
         "value": value, "unit": "propagator-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if not standin else "STAND-IN ENGINE ({}): control-flow rehearsal, no "
+                                                "measurement".format(standin),
         "config": {"workload": "configs[2]: dim=32 Schroedinger, 1000 propagator steps, "
                                "{} seeds per GPU, K=2 real controls, S=1, M2".format(seeds),
                    "seeds_per_gpu": seeds, "hilbert_size": DIM, "system_eval_count": N_EVAL,
@@ -410,15 +463,19 @@ def main():
         "step_ms": step_ms,
         "path_algorithmic_tflops_per_gpu": path_tflops,
         "check": {"sum_cost": total_cost, "grad_l2": float(np.linalg.norm(total_grad))},
-        "value_definition": "controls resident in HBM when the clock starts (bench contract); "
-                            "the host-buffer-to-host-buffer rate is host_to_host",
+        "value_definition": "controls resident in HBM when the clock starts (bench contract), Pade "
+                            "order by norm; value_host_to_host: fresh controls from host memory and "
+                            "results back in host memory every step (SURVEY 8d); value_reference_order: "
+                            "every step on the [13/13] approximant as the reference executes it",
+        "value_host_to_host": host_to_host["value"] if host_to_host else None,
+        "value_reference_order": reference_order["value"] if reference_order else None,
         "host_to_host": host_to_host,
         "reference_order": reference_order,
         "secondary": secondary,
         "latency": latency,
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not standin:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     engine.close()

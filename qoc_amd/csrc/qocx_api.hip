@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -225,6 +226,7 @@ struct qocx_ctx {
     DevBuf<double2> ge_cimg, ge_rimg, ge_timg;
     DevBuf<qocx::StepInterp> interp_id;
     DevBuf<double> veff, gnode;
+    DevBuf<double> ustep, g_norm_dev;  // step table (launch_step_table): u_k(t_mid) per step; ||G_k||_1
     // explicit-generator mode (qocx_upload_generators): opaque Hamiltonians sampled by the host
     bool explicit_mode = false;
     int explicit_hermitian = 0;
@@ -545,6 +547,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->offs_x.release();
     ctx->ge_cimg.release(); ctx->ge_rimg.release(); ctx->ge_timg.release();
     ctx->interp_id.release(); ctx->veff.release(); ctx->gnode.release();
+    ctx->ustep.release(); ctx->g_norm_dev.release();
     ctx->opt_m.release(); ctx->opt_v.release(); ctx->opt_best_controls.release();
     ctx->opt_max_norms.release(); ctx->opt_best_final.release(); ctx->opt_flags.release();
     ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
@@ -686,6 +689,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
         DevBuf<double2>& dst = pass == 0 ? ctx->g_cimg : (pass == 1 ? ctx->g_rimg : ctx->g_timg);
         if (dst.upload(gimg, ctx->stream)) return QOCX_ERR_HIP;
     }
+    if (K > 0 && ctx->g_norm_dev.upload(ctx->g_norm_max, ctx->stream)) return QOCX_ERR_HIP;  // step table
 
     // M4, time-independent H0 / G_k: the commutators leave the time loop (M4LinArgs). Constant
     // matrices G_k, A_k = -i [G_k, H0], B_kl = -i [G_k, G_l] (k < l); Hermitian when H0 and the
@@ -1223,6 +1227,23 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                               ctx->knob("fuse_lu", 1) != 0;
         fa.fuse_lu = fused_lu ? 1 : 0;
         fa.dinv = ctx->dinv.p; fa.perm = ctx->perm.p; fa.iperm = ctx->iperm.p;
+        // Step table (two-wave K1a, structured M2 problem): one small kernel interpolates the
+        // controls of every step and decides its Pade order and squaring count from the bound
+        // dt (||H0||_1 + sum |u_k| ||G_k||_1); K1a and K3 then read both instead of interpolating
+        // and (K1a) reducing a norm behind a barrier. Knob "step_table" 0 restores the old path.
+        const bool step_table = ctx->nb == 2 && !one_wave_k1a && !explicit_gen && nodes == 1 && !m4lin &&
+                                !dense && K > 0 && ctx->g_norm_dev.p != nullptr &&
+                                ctx->knob("step_table", 1) != 0;
+        if (step_table) {
+            if (ctx->ustep.ensure((size_t)bc * nsteps * K)) return QOCX_ERR_HIP;
+            qocx::StepTableArgs ta;
+            ta.controls = fa.controls; ta.interp = fa.interp; ta.K = K; ta.nc = ctx->nc;
+            ta.nsteps = nsteps; ta.batch = bc; ta.dt = ctx->dt; ta.h0_norm = ctx->h0_norm_max;
+            ta.g_norm = ctx->g_norm_dev.p; ta.pade_policy = fa.pade_policy;
+            ta.ustep = ctx->ustep.p; ta.s_arr = fa.s_arr; ta.status = fa.status;
+            qocx::launch_step_table(ta, cs);
+            fa.controls = ctx->ustep.p; fa.nc = nsteps; fa.direct = 1;
+        }
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
@@ -1369,6 +1390,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ka.g_rimg = m4lin ? ctx->ge_rimg.p : ctx->g_rimg.p;
         ka.g_timg = m4lin ? ctx->ge_timg.p : ctx->g_timg.p;
         ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
+        ka.direct = fa.direct;
         ka.n = ctx->n;
         ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
         ka.offs = ctx->offs.p;
@@ -2381,7 +2403,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 
@@ -2522,6 +2544,22 @@ int qocx_comm_init(qocx_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t wo
     init_fn f = (init_fn)dlsym(ctx->rccl.lib, "ncclCommInitRank");
     ncclUniqueIdBytes uid;
     memcpy(uid.internal, id128, 128);
+    if (world < 1 || rank < 0 || rank >= world) return fail(QOCX_ERR_ARG, "rank / world out of range");
+    if (!f) return fail(QOCX_ERR_RCCL, "librccl has no ncclCommInitRank");
+    if (getenv("QOCX_RCCL_DEBUG")) {  // (a log line only: what this rank hands to ncclCommInitRank)
+        unsigned long long sum = 1469598103934665603ull;  // FNV-1a of the id: equal on every rank
+        for (int i = 0; i < 128; ++i) sum = (sum ^ id128[i]) * 1099511628211ull;
+        char bus[64] = "?";
+        (void)hipDeviceGetPCIBusId(bus, sizeof(bus), ctx->device);
+        int version = 0;
+        typedef int (*ver_fn)(int*);
+        if (ver_fn v = (ver_fn)dlsym(ctx->rccl.lib, "ncclGetVersion")) (void)v(&version);
+        const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        fprintf(stderr, "[qocx rccl] ncclCommInitRank rank=%d world=%d hip_device=%d pci=%s id_fnv=%016llx "
+                        "rccl_version=%d HSA_ENABLE_IPC_MODE_LEGACY=%s pid=%d\n",
+                rank, world, ctx->device, bus, sum, version, ipc ? ipc : "(unset)", (int)getpid());
+        fflush(stderr);
+    }
     int e = f(&ctx->comm, world, uid, rank);
     if (e != 0)
         return fail(QOCX_ERR_RCCL, std::string("ncclCommInitRank: ") +

@@ -50,6 +50,11 @@ struct FactorArgs {
     int dbg = 0;
     unsigned long long* stamps = nullptr;
     int lu_mfma = 0;           // fused K1b with its Schur updates on the matrix cores (qocx_lu4.h)
+    // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
+    // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
+    // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel
+    // neither interpolates nor forms a norm.
+    int direct = 0;
     // two-wave K1a (17 <= n <= 32) with K1b fused in: P stays in LDS, wave 0 factors it, only the
     // factors (and 1/U_kk, the permutation) go to HBM; launch_lu is then not called
     int fuse_lu = 0;
@@ -63,6 +68,22 @@ struct FactorArgs {
     int* s_arr;
     int* status;
 };
+
+// u_k(t_mid) of every (seed, step) by the reference's interpolation formula, and the step's entry
+// of s_arr (Pade order, squarings: qocx_wave.h) from the norm bound of that step's generator.
+struct StepTableArgs {
+    const double* controls;    // [B][nc][K]
+    const StepInterp* interp;  // [nsteps]
+    int K, nc, nsteps, batch;
+    double dt;                 // the bound is |dt| (h0_norm + sum_k |u_k| g_norm[k])
+    double h0_norm;            // max over time of ||H0(t)||_1
+    const double* g_norm;      // [K] max over time of ||G_k(t)||_1 (device memory)
+    int pade_policy;           // 0: order by norm, 13: always [13/13]
+    double* ustep;             // out: [B][nsteps][K]
+    int* s_arr;                // out: [B][nsteps]
+    int* status;               // bit 1: non-finite controls
+};
+void launch_step_table(const StepTableArgs& a, hipStream_t st);
 
 struct LuArgs {
     double2* lu_img;  // in: P, out: L\\U of the row-permuted P (column-major)
@@ -130,6 +151,7 @@ struct KrylovArgs {
     const double2* g_rimg;
     const double2* g_timg;
     int K, nc, nsteps, nt, S;
+    int direct = 0;  // controls is the step table [B][nsteps][K] (FactorArgs::direct)
     int n = 0;  // Hilbert size (four-wave K3: <= 48 -> the zero pad columns are skipped); 0: unknown
     int step0;  // grid.x covers steps [step0, step0 + gridDim.x)
     int skew;   // 1: every H0(t), G_k(t) is exactly Hermitian (a^H = -a)

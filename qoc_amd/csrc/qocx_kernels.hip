@@ -1512,7 +1512,8 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     const int sq = step_squarings(args.s_arr[m]);
     const int order = step_order(args.s_arr[m]);
     const double dts = args.dt * ldexp(1.0, -sq);
-    const StepInterp si = args.interp[step];
+    // (direct: the step table - interpolated controls per step, no interpolation here)
+    const StepInterp si = args.direct ? StepInterp{0, 0, 1.0, 0.0} : args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
     const double2* h0r = args.h0_rimg + tsel * G::MAT;
@@ -1555,7 +1556,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
                 column_fence<NB>(cc);
             }
             for (int k = 0; k < K; ++k) {
-                const double uk = control_at(ctl_b, si, K, k);
+                const double uk = args.direct ? ctl_b[(size_t)step * K + k] : control_at(ctl_b, si, K, k);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     const double2 e = (gr + (size_t)k * G::MAT + cc * 64)[off];
@@ -1723,6 +1724,46 @@ template <int NB, bool EXPLICIT>
 __global__ __launch_bounds__(64, NB < 4 ? 2 : 1) void krylov_grad_skew_kernel(KrylovArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     krylov_grad_body<NB, EXPLICIT, true>(args, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// Step table: one thread per (seed, step). u_k(t_mid) by the reference's formula (control_at), the
+// bound dt (||H0||_1 + sum |u_k| ||G_k||_1) >= ||a||_1 of the step's generator, and from it the
+// Pade order (Higham's thresholds) and the squaring count - decisions K1a used to take from the
+// norm of the matrix it had just built, at the price of two reductions and a workgroup barrier in
+// front of its first product.
+__global__ __launch_bounds__(256) void step_table_kernel(StepTableArgs args) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)args.batch * args.nsteps) return;
+    const int b = (int)(idx / args.nsteps), step = (int)(idx % args.nsteps);
+    const StepInterp si = args.interp[step];
+    const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
+    double bound = args.h0_norm;
+    for (int k = 0; k < args.K; ++k) {
+        const double uk = control_at(ctl_b, si, args.K, k);
+        args.ustep[idx * args.K + k] = uk;
+        bound = fma(fabs(uk), args.g_norm[k], bound);
+    }
+    bound *= fabs(args.dt);
+    int sq = 0, order = 13;
+    if (!(bound < 1e300)) {  // inf / nan
+        atomicOr(args.status, 2);
+    } else {
+        order = pade_order_for(bound, args.pade_policy);
+        if (order == 13) {
+            double th = QOCX_THETA13;
+            while (bound > th && sq < 30) {
+                th *= 2.0;
+                ++sq;
+            }
+        }
+    }
+    args.s_arr[idx] = step_entry(sq, order);
+}
+void launch_step_table(const StepTableArgs& a, hipStream_t st) {
+    const size_t total = (size_t)a.batch * a.nsteps;
+    if (total == 0) return;
+    hipLaunchKernelGGL(step_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------

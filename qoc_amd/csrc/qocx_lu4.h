@@ -51,8 +51,8 @@ __device__ __forceinline__ Cx cfms(const Cx& a, const Cx& b, const Cx& c) {
 
 // One block step J (pivots k0 .. k0 + 3, k0 = 4 J). Returns false (wave-uniform) if a pivot was
 // not the diagonal.
-template <int J>
-__device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, double2* dinv) {
+template <int J, class Clk>
+__device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, double2* dinv, Clk& clk) {
     constexpr int k0 = 4 * J, t0 = J >> 2, r0 = J & 3, c0 = 4 * (J & 3);
     const int lane = lane_id(), q = lane >> 4, c = lane & 15, half = lane >> 5, idx = lane & 31;
 
@@ -87,6 +87,7 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
             dd[r][cc] = Cx{e.x, e.y};
         }
 
+    clk.lap(5);  // (stamped build: panels out of the tiles and back as panel entries / pivot block)
     // ---- four pivots: the pivot block in every lane, the panel entries of this lane
     Cx f[4], rk[4];
     bool bad = false;
@@ -114,6 +115,7 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
             for (int t = kk + 1; t < 4; ++t) x[t] = cfms(x[t], f[kk], dd[kk][t]);
         }
     }
+    clk.lap(6);  // (stamped build: the four pivots)
     if (bad) return false;
 
     // ---- the finished entries leave for the image (column-major, rows in their original order:
@@ -168,6 +170,7 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
         (void)are;
         wave_sync();  // the fragments have been read before the next block step rewrites the buffer
     }
+    clk.lap(4);  // (stamped build: stores, fragments, MFMA issue)
     return true;
 }
 
@@ -175,8 +178,9 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
 // sits at `src` in LDS; `xb`: XB_COMPLEX complex of LDS owned by this wave. Returns false if the
 // diagonal-pivot attempt was abandoned: nothing the caller relies on has been written then (the
 // image, 1/U_kk and the permutation are rewritten by the general kernel), `src` is untouched.
+template <class Clk>
 __device__ __forceinline__ bool lu_mfma_body(const LuArgs& args, size_t m, const double2* src, int pitch,
-                                             double2* xb) {
+                                             double2* xb, Clk& clk) {
     const int lane = lane_id(), q = lane >> 4, c = lane & 15;
     Tiles T;
 #pragma unroll
@@ -191,14 +195,14 @@ __device__ __forceinline__ bool lu_mfma_body(const LuArgs& args, size_t m, const
             }
     double2* img = args.lu_img + m * 1024;
     double2* dinv = args.dinv + m * 32;
-    if (!block_step<0>(T, xb, img, dinv)) return false;
-    if (!block_step<1>(T, xb, img, dinv)) return false;
-    if (!block_step<2>(T, xb, img, dinv)) return false;
-    if (!block_step<3>(T, xb, img, dinv)) return false;
-    if (!block_step<4>(T, xb, img, dinv)) return false;
-    if (!block_step<5>(T, xb, img, dinv)) return false;
-    if (!block_step<6>(T, xb, img, dinv)) return false;
-    if (!block_step<7>(T, xb, img, dinv)) return false;
+    if (!block_step<0>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<1>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<2>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<3>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<4>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<5>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<6>(T, xb, img, dinv, clk)) return false;
+    if (!block_step<7>(T, xb, img, dinv, clk)) return false;
     if (lane < 32) {
         args.perm[m * 32 + lane] = lane;
         args.iperm[m * 32 + lane] = lane;

@@ -171,7 +171,7 @@ static_assert(32 * LP * 16 <= SLOT_F64 * 8, "the P image reuses the A-operand sl
 static_assert(lu4::XB_COMPLEX * 16 <= MTILE_F64 * 8, "the panel buffer of qocx_lu4.h reuses the mirror tile");
 
 // W: the wave's column block. Every wave executes the same number of barriers.
-template <bool HERM, int W, bool STAMP, class Gen>
+template <bool HERM, int W, bool STAMP, bool PRESET, class Gen>
 __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // stamped build: cycles per phase of this wave - 0 generator / norm / staging, 1 products,
     // 2 barrier waits, 3 P / Q images, 4 factorisation
@@ -194,6 +194,22 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // falls in. Two bounds without square roots, |z| <= |re| + |im| and |z| >= max(|re|, |im|),
     // usually name the same interval (always when the norm is well below theta, the common
     // case); only if they disagree is the exact norm formed (16 FP64 square roots per lane).
+    int sq = 0, order = 13;
+    if constexpr (PRESET) {
+        // step table (launch_step_table): order and squaring count were decided from the bound
+        // dt (||H0||_1 + sum |u_k| ||G_k||_1) when the controls of the step were interpolated
+        const int entry = *out.s_out;
+        sq = step_squarings(entry);
+        order = step_order(entry);
+        if (sq > 0) {
+            const double scale = ldexp(1.0, -sq);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                a.re[ti] *= scale;
+                a.im[ti] *= scale;
+            }
+        }
+    } else {
     auto squarings = [](double v, bool& bad) {
         double th = QOCX_THETA13;
         int n = 0;
@@ -228,7 +244,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     }
     K1A_SYNC(0);  // 1
     bool bad = false, bad_lower = false;
-    int sq = squarings(fmax(nrm[0], nrm[1]), bad);
+    sq = squarings(fmax(nrm[0], nrm[1]), bad);
     const int sq_lower = squarings(fmax(nrm[2], nrm[3]), bad_lower);
     if (!bad && sq != sq_lower) {  // the same decision in both waves: they read the same numbers
         double e = 0;
@@ -255,8 +271,9 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
         }
     }
     // Pade order from the upper bound of the norm (qocx_wave.h); both waves read the same numbers
-    const int order = bad ? 13 : pade_order_for(fmax(nrm[0], nrm[1]), out.pade_policy);
+    order = bad ? 13 : pade_order_for(fmax(nrm[0], nrm[1]), out.pade_policy);
     if (W == 0 && lane == 0) *out.s_out = step_entry(sq, order);
+    }
     stage_tile(sl, 0, W, a.re[0], a.im[0]);
     stage_tile(sl, 1, W, a.re[1], a.im[1]);
     K1A_SYNC(0);  // 2
@@ -488,7 +505,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             // diagonal pivots and rank-4 updates on the matrix cores first (qocx_lu4.h); a matrix
             // whose pivots leave the diagonal takes the general elimination, from the same image
             bool done = false;
-            if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+            if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt), clk);
             if (!done) lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
         }
         clk.lap(4);
@@ -505,7 +522,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     }
 }
 
-template <bool HERM, bool STAMP = false>
+template <bool HERM, bool STAMP = false, bool PRESET = false>
 __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -525,7 +542,8 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.fuse = args.fuse_lu != 0;
     out.m = m;
     out.dbg = args.dbg; out.stamps = args.stamps; out.lu_mfma = args.lu_mfma != 0;
-    const StepInterp si = args.interp[step];
+    // (PRESET: the step table - controls is [B][nsteps][K], interpolated already)
+    const StepInterp si = PRESET ? StepInterp{0, 0, 1.0, 0.0} : args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
     const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
     const double2* h0 = args.h0_cimg + tsel * MAT;
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
                 him[ti][r] = e.y;
             }
         for (int k = 0; k < K; ++k) {
-            const double uk = control_at(ctl_b, si, K, k);
+            const double uk = PRESET ? ctl_b[(size_t)step * K + k] : control_at(ctl_b, si, K, k);
             const double2* gk = g + (size_t)k * MAT;
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
@@ -562,8 +580,8 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
             a.im[ti] = -dt * hre[ti];
         }
     };
-    if (w == 0) body<HERM, 0, STAMP>(gen, out, smem);
-    else body<HERM, 1, STAMP>(gen, out, smem);
+    if (w == 0) body<HERM, 0, STAMP, PRESET>(gen, out, smem);
+    else body<HERM, 1, STAMP, PRESET>(gen, out, smem);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (Magnus M4/M6, debug)
@@ -602,8 +620,8 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
                 a.im[ti][r] = e.y;
             }
     };
-    if (w == 0) body<HERM, 0, false>(gen, out, smem);
-    else body<HERM, 1, false>(gen, out, smem);
+    if (w == 0) body<HERM, 0, false, false>(gen, out, smem);
+    else body<HERM, 1, false, false>(gen, out, smem);
 }
 
 }  // namespace pade2
@@ -611,16 +629,26 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
 #ifdef QOCX_DIAG
     if (a.stamps != nullptr && a.hermitian) {  // stamped build (qocx_diag.h)
-        hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, true>), dim3(nsteps, batch), dim3(128),
-                           pade2::LDS_BYTES, st, a);
+        if (a.direct)
+            hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, true, true>), dim3(nsteps, batch), dim3(128),
+                               pade2::LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, true, false>), dim3(nsteps, batch), dim3(128),
+                               pade2::LDS_BYTES, st, a);
         return;
     }
 #endif
-    if (a.hermitian)
-        hipLaunchKernelGGL(pade2::pade_pq2_kernel<true>, dim3(nsteps, batch), dim3(128),
+    if (a.hermitian && a.direct)
+        hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, false, true>), dim3(nsteps, batch), dim3(128),
+                           pade2::LDS_BYTES, st, a);
+    else if (a.hermitian)
+        hipLaunchKernelGGL((pade2::pade_pq2_kernel<true, false, false>), dim3(nsteps, batch), dim3(128),
+                           pade2::LDS_BYTES, st, a);
+    else if (a.direct)
+        hipLaunchKernelGGL((pade2::pade_pq2_kernel<false, false, true>), dim3(nsteps, batch), dim3(128),
                            pade2::LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL(pade2::pade_pq2_kernel<false>, dim3(nsteps, batch), dim3(128),
+        hipLaunchKernelGGL((pade2::pade_pq2_kernel<false, false, false>), dim3(nsteps, batch), dim3(128),
                            pade2::LDS_BYTES, st, a);
 }
 void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {

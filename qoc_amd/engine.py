@@ -182,6 +182,10 @@ def load_library(path=None):
             "qoc_amd: the HIP engine {} is missing. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback.".format(path))
+    # multi-process GPU work on this platform needs dmabuf IPC (RCCL between the ranks of a node
+    # fails with hipIpcGetMemHandle: invalid argument otherwise); the HSA runtime reads the variable
+    # when it initialises, which no call has triggered yet. A value the user has set is kept.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -100,3 +100,25 @@ def test_sixteen_tile_kernels_do_not_spill():
         assert k1a["ScratchSize"] <= 1600 and k1a["VGPRs Spill"] <= 300, (frag, k1a)
     assert find(pade4, "pade_pq4_kernelILi3ELb1E")["Occupancy"] == 2
     assert find(pade4, "pade_pq4_kernelILi3ELb1E")["VGPRs Spill"] <= 32
+
+
+def test_release_library_has_no_diagnostic_switches():
+    """the knobs that return garbage (timing experiments), the stamped kernel
+    builds and the QOCX_* environment switches exist in libqocx_diag.so only (-DQOCX_DIAG,
+    qoc_amd/csrc/qocx_diag.h); the product library rejects the knobs and does not even contain the
+    variable names."""
+    from qoc_amd import engine
+    lib = engine.load_library()
+    assert lib.qocx_build_is_diag() == 0
+    for name in (b"dbg_skip", b"sweep3_dbg", b"sweep3_stamps", b"lindblad_stamps", b"k1a_dbg",
+                 b"k1a_stamps", b"peak_mode"):
+        assert lib.qocx_knob_kind(name) == -2, name
+    for name in (b"pade_order", b"fuse_lu", b"lu_mfma", b"bidir", b"unit_adjoint", b"sweep_impl"):
+        assert lib.qocx_knob_kind(name) == 1, name
+    assert lib.qocx_knob_kind(b"no_such_knob") == 0
+    blob = open(engine.LIBRARY_PATH, "rb").read()
+    for env in (b"QOCX_PQ1", b"QOCX_SWEEP_W", b"QOCX_SEG_WEIGHTS", b"QOCX_SWEEP_IMPL",
+                b"QOCX_SWEEP_LOADER", b"QOCX_LINDBLAD_SINGLE_WAVE", b"QOCX_TRACE_HOST"):
+        assert env not in blob, env
+    # the stamped kernel instantiations are not in the product library either
+    assert b"pade_pq2_kernelILb1ELb1E" not in blob

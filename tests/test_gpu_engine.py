@@ -600,3 +600,12 @@ def test_random_shapes_fuzz_big(engine):
         checked += 1
         assert worst < 1.0, tag
     assert checked > 15
+
+
+def test_product_library_rejects_diagnostic_knobs(engine):
+    """The timing experiments whose results are garbage are not reachable through libqocx.so."""
+    from qoc_amd.engine import QocxError
+    for name in ("dbg_skip", "sweep3_dbg", "k1a_dbg", "sweep3_stamps"):
+        with pytest.raises(QocxError):
+            engine.set_knob(name, 1)
+    engine.set_knob("pade_order", 0)  # a variant knob is accepted

@@ -65,9 +65,9 @@ def richardson_fd(case, controls, index, h):
 # adaptive integration that reproduces itself to ~1e-10 (more over 500 steps), so a difference
 # quotient with step h carries noise ~1e-10 / h: the gate is 2e-7 relative where the gradient
 # is large (the well-conditioned fixtures), and the measured number is printed and stored.
-FD_COUNT = {"lindblad_c4_full": 2, "lindblad_bench_c4": 2}
+FD_COUNT = {"lindblad_c4_full": 2, "lindblad_bench_c4": 2, "lindblad_wc_c4": 3}
 FD_STEP = {"lindblad_wc_n4": 4e-2, "lindblad_wc_n16": 4e-2, "lindblad_timedep_data": 4e-2,
-           "lindblad_bench_c4": 4e-2, "lindblad_opaque_wc": 1.5e-2}
+           "lindblad_bench_c4": 4e-2, "lindblad_opaque_wc": 1.5e-2, "lindblad_wc_c4": 4e-2}
 
 
 def main(only=None):

@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 PHASES = ["generator, norm, staging", "products", "barrier waits", "P / Q images",
-          "factorisation", "-", "-", "realtime"]
+          "factorisation (MFMA form: stores, fragments, MFMA issue)", "factorisation: panels through LDS",
+          "factorisation: four pivots per block", "realtime"]
 
 
 def main():
@@ -52,7 +53,7 @@ def main():
         life = cyc.sum()
         ghz = st[w, :7].sum() / (st[w, 7] * 10.0) if st[w, 7] > 0 else 0.0
         out["wave%d" % w] = {"cycles_per_matrix": life, "clock_GHz": ghz,
-                             "phases": {PHASES[k]: cyc[k] for k in range(5)}}
+                             "phases": {PHASES[k]: cyc[k] for k in range(7)}}
     print(json.dumps(out, indent=1))
     engine.close()
 
