@@ -215,6 +215,7 @@ struct qocx_ctx {
     DevBuf<double2> final_out, step_states;
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
     DevBuf<int> perm, iperm, s_arr, offs, status;
+    DevBuf<int> lu_redo;  // 33 <= n <= 64: matrices the MFMA factorisation hands to the general one (LuArgs::redo)
     // ---- Lindblad problem / evaluation state ----
     // ---- Magnus M4/M6 ----
     int nodes = 1;
@@ -547,7 +548,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->offs_x.release();
     ctx->ge_cimg.release(); ctx->ge_rimg.release(); ctx->ge_timg.release();
     ctx->interp_id.release(); ctx->veff.release(); ctx->gnode.release();
-    ctx->ustep.release(); ctx->g_norm_dev.release();
+    ctx->ustep.release(); ctx->g_norm_dev.release(); ctx->lu_redo.release();
     ctx->opt_m.release(); ctx->opt_v.release(); ctx->opt_best_controls.release();
     ctx->opt_max_norms.release(); ctx->opt_best_final.release(); ctx->opt_flags.release();
     ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
@@ -1249,6 +1250,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
         la.dbg = (dbg_skip_early & 16) ? 1 : 0;
         la.inverse = (dense || inverse_sweep) ? 1 : 0;
+        la.redo = nullptr;
+        if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
+            if (ctx->lu_redo.ensure((size_t)bc * nsteps)) return QOCX_ERR_HIP;
+            la.redo = ctx->lu_redo.p;
+        }
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
@@ -2778,6 +2784,11 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     la.status = ctx->status.p;
     la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
     la.inverse = inverse ? 1 : 0;
+    DevBuf<int> redo_d;
+    if (nb == 4 && ctx->knob("lu_mfma", 1) != 0) {
+        if (redo_d.ensure((size_t)count)) return QOCX_ERR_HIP;
+        la.redo = redo_d.p;
+    }
     if (!fused_lu) qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2796,7 +2807,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
             HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
             memcpy(s_out, sv.data(), count * sizeof(int));
         }
-        a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release();
+        a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); redo_d.release(); redo_d.release();
         iperm_d.release(); s_d.release();
         int st_inv = 0;
         HIP_TRY(hipMemcpy(&st_inv, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
@@ -2833,7 +2844,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
             }
         }
     if (s_out) memcpy(s_out, sv.data(), count * sizeof(int));
-    a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release();
+    a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); redo_d.release();
     iperm_d.release(); s_d.release();
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));

@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
     __shared__ __attribute__((aligned(16))) LuLds lds;
     const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
                      blockIdx.x % args.seg_len;
+    // behind the MFMA factorisation (qocx_lu4m.hip): only the matrices whose pivots left the diagonal
+    if (args.redo != nullptr && args.redo[m] == 0) return;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2* img = args.lu_img + m * MAT;

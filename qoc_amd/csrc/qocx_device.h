@@ -95,6 +95,10 @@ struct LuArgs {
     int n;                       // Hilbert size (sixteen-tile K1b: <= 48 -> 48 elimination steps); 0: unknown
     int dbg = 0;                 // timing experiment (dbg_skip bit 4): loads and stores only
     int inverse = 0;             // lu_img receives P^-1 instead of the factors (n <= 32; qocx_lu.h inv_body)
+    // 33 <= n <= 64, round 4: [matrices] flags of the MFMA factorisation (qocx_lu4m.hip) - 1: its
+    // diagonal-pivot attempt was abandoned, lu4_kernel factors the matrix; nullptr: lu4_kernel factors
+    // every matrix
+    int* redo = nullptr;
 };
 
 struct SweepArgs {
@@ -315,6 +319,7 @@ void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
 // ... and the four-wave K1b / K3 of qocx_big.hip
 void launch_lu4(const LuArgs& a, size_t count, hipStream_t st);
+void launch_lu4m(const LuArgs& a, size_t count, int* redo, hipStream_t st);  // qocx_lu4m.hip
 void launch_krylov4(const KrylovArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st);
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st);

@@ -2037,7 +2037,10 @@ void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     else if (a.inverse && nb == 2) hipLaunchKernelGGL(inv_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 2) hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
-    else launch_lu4(a, count, st);  // qocx_big.hip
+    else {
+        if (a.redo != nullptr) launch_lu4m(a, count, a.redo, st);  // qocx_lu4m.hip: diagonal pivots, MFMA updates
+        launch_lu4(a, count, st);                                  // qocx_big.hip: the general elimination
+    }
 }
 void launch_sweep(int nb, const SweepArgs& a, int batch, hipStream_t st) {
     if (nb == 1) launch_sweep_t<1>(a, batch, st);

@@ -57,7 +57,7 @@ def test_pade_factor_kernel(engine, n):
         # 17 <= n <= 32: the fused factorisation with its Schur updates on the matrix cores
         # (qocx_lu4.h: diagonal pivots, checked; the large-norm cases here leave the diagonal and
         # take the general elimination) and the one-wave elimination alone
-        for lu_mfma in ((1, 0) if 16 < n <= 32 else (default_mfma,)):
+        for lu_mfma in ((1, 0) if n > 16 else (default_mfma,)):  # (n > 32: qocx_lu4m.hip in front of lu4_kernel)
             engine.set_knob("pade_order", policy)
             engine.set_knob("lu_mfma", lu_mfma)
             try:

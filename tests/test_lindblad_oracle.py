@@ -151,6 +151,9 @@ def test_device_model_matches_fixtures(name):
         assert np.max(np.abs(dens - g["final_densities"][b])) < 1e-8
         ref = real_form(case, g["grads_ad"][b])
         assert lindblad_grad_close(grads, ref, case)
+        if "grads_ad_tight" in g:  # the reference's integrator at a tighter local tolerance
+            tight = real_form(case, g["grads_ad_tight"][b])
+            assert np.max(np.abs(grads - tight)) < case.grad_rtol_tight * np.max(np.abs(tight))
 
 
 def test_device_model_gradient_vs_own_finite_differences():
