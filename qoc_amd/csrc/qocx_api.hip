@@ -1248,7 +1248,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         qocx::LuArgs la;
         la.lu_img = fa.lu_img; la.dinv = ctx->dinv.p; la.perm = ctx->perm.p;
         la.iperm = ctx->iperm.p; la.status = ctx->status.p; la.nsteps = nsteps; la.n = ctx->n;
-        la.dbg = (dbg_skip_early & 16) ? 1 : 0;
+        la.dbg = ((dbg_skip_early & 16) ? 1 : 0) | ((ctx->knob("k1a_dbg", 0) & 8) ? 2 : 0) |
+                 ((ctx->knob("k1a_dbg", 0) & 16) ? 4 : 0) | ((ctx->knob("k1a_dbg", 0) & 32) ? 8 : 0);
         la.inverse = (dense || inverse_sweep) ? 1 : 0;
         la.redo = nullptr;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel

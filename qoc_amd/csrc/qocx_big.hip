@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void lu4_kernel(LuArgs args) {
     const size_t m = (size_t)(blockIdx.x / args.seg_len) * args.nsteps + args.step0 +
                      blockIdx.x % args.seg_len;
     // behind the MFMA factorisation (qocx_lu4m.hip): only the matrices whose pivots left the diagonal
-    if (args.redo != nullptr && args.redo[m] == 0) return;
+    if (args.redo != nullptr && (args.redo[m] == 0 || (QOCX_DBG_BITS(args.dbg) & 2))) return;  // (dbg: timing experiment)
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2* img = args.lu_img + m * MAT;
