@@ -329,6 +329,11 @@ int qocx_debug_read_stamps(qocx_ctx* ctx, uint64_t* out, int64_t count);
  * reference itself always evaluates [13/13] (expm.py:230-233: its selection loop has no break),
  * which the knob "pade_order" = 13 reproduces. Same matrix and same derivative to rounding. */
 int qocx_pade_orders(qocx_ctx* ctx, int64_t* counts);
+/* Matrices of the last Schroedinger evaluation (or qocx_debug_pade_factor call) whose LU factorisation
+ * left the diagonal-pivot form with MFMA Schur updates (knob "lu_mfma"; qoc_amd/csrc/qocx_lu4.h,
+ * qocx_lu4m.hip) for the general partial-pivoting elimination: LAPACK's pivot rule asked for a row
+ * interchange somewhere. 0 for the Pade denominators of well-scaled generators. */
+int qocx_lu_fallbacks(qocx_ctx* ctx, int64_t* count);
 /* With qocx_set_timing on: the kernel launches of the LAST evaluation as (which, start_ms, end_ms)
  * triples relative to its first launch (HIP events on the launch streams; which = the index of
  * qocx_get_timing: 0 K1a, 1 sweep, 2 K3, 3 scatter, 4 K1b, 5 Lindblad, 6 its combine kernel). out

@@ -215,6 +215,7 @@ struct qocx_ctx {
     DevBuf<double2> final_out, step_states;
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
     DevBuf<int> perm, iperm, s_arr, offs, status;
+    DevBuf<int> lu_fallbacks;  // [1] matrices that left the diagonal-pivot MFMA factorisation (qocx_lu_fallbacks)
     DevBuf<int> lu_redo;  // 33 <= n <= 64: matrices the MFMA factorisation hands to the general one (LuArgs::redo)
     // ---- Lindblad problem / evaluation state ----
     // ---- Magnus M4/M6 ----
@@ -548,7 +549,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->offs_x.release();
     ctx->ge_cimg.release(); ctx->ge_rimg.release(); ctx->ge_timg.release();
     ctx->interp_id.release(); ctx->veff.release(); ctx->gnode.release();
-    ctx->ustep.release(); ctx->g_norm_dev.release(); ctx->lu_redo.release();
+    ctx->ustep.release(); ctx->g_norm_dev.release(); ctx->lu_redo.release(); ctx->lu_fallbacks.release();
     ctx->opt_m.release(); ctx->opt_v.release(); ctx->opt_best_controls.release();
     ctx->opt_max_norms.release(); ctx->opt_best_final.release(); ctx->opt_flags.release();
     ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
@@ -1219,6 +1220,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             fa.stamps = ctx->stamps.p;
         }
         fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
+        if (ctx->lu_fallbacks.ensure(1)) return QOCX_ERR_HIP;
+        if (b0 == 0) HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), cs));
+        fa.lu_fallbacks = ctx->lu_fallbacks.p;
         fa.pade_policy = (int)ctx->knob("pade_order", 0);  // 0: by norm (qocx_wave.h), 13: always 13
         fa.prefer_low = ctx->norm_bound < 2.097847961257068 ? 1 : 0;  // theta_9
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
@@ -1252,6 +1256,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                  ((ctx->knob("k1a_dbg", 0) & 16) ? 4 : 0) | ((ctx->knob("k1a_dbg", 0) & 32) ? 8 : 0);
         la.inverse = (dense || inverse_sweep) ? 1 : 0;
         la.redo = nullptr;
+        la.fallbacks = ctx->lu_fallbacks.p;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
             if (ctx->lu_redo.ensure((size_t)bc * nsteps)) return QOCX_ERR_HIP;
             la.redo = ctx->lu_redo.p;
@@ -2438,6 +2443,17 @@ int qocx_debug_set_knob(qocx_ctx* ctx, const char* name, int64_t value) {
     return fail(QOCX_ERR_ARG, std::string("unknown knob: ") + name);
 }
 
+int qocx_lu_fallbacks(qocx_ctx* ctx, int64_t* count) {
+    if (!ctx || !count) return fail(QOCX_ERR_ARG, "NULL argument");
+    *count = 0;
+    if (ctx->lu_fallbacks.p == nullptr) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int v = 0;
+    HIP_TRY(hipMemcpy(&v, ctx->lu_fallbacks.p, sizeof(int), hipMemcpyDeviceToHost));
+    *count = v;
+    return 0;
+}
+
 int qocx_lindblad_last_subintervals(qocx_ctx* ctx, int64_t* total) {
     if (!ctx || !total) return fail(QOCX_ERR_ARG, "NULL argument");
     *total = ctx->lb.last_subintervals;
@@ -2778,6 +2794,9 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     const bool fused_lu = nb == 2 && !inverse && qocx::diag_getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
     fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
+    if (ctx->lu_fallbacks.ensure(1)) return QOCX_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), ctx->stream));
+    fa.lu_fallbacks = ctx->lu_fallbacks.p;
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
     qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
@@ -2785,6 +2804,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     la.status = ctx->status.p;
     la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
     la.inverse = inverse ? 1 : 0;
+    la.fallbacks = ctx->lu_fallbacks.p;
     DevBuf<int> redo_d;
     if (nb == 4 && ctx->knob("lu_mfma", 1) != 0) {
         if (redo_d.ensure((size_t)count)) return QOCX_ERR_HIP;

@@ -55,6 +55,7 @@ struct FactorArgs {
     // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel
     // neither interpolates nor forms a norm.
     int direct = 0;
+    int* lu_fallbacks = nullptr;  // LuArgs::fallbacks of the fused factorisation
     // two-wave K1a (17 <= n <= 32) with K1b fused in: P stays in LDS, wave 0 factors it, only the
     // factors (and 1/U_kk, the permutation) go to HBM; launch_lu is then not called
     int fuse_lu = 0;
@@ -99,6 +100,9 @@ struct LuArgs {
     // diagonal-pivot attempt was abandoned, lu4_kernel factors the matrix; nullptr: lu4_kernel factors
     // every matrix
     int* redo = nullptr;
+    // how many matrices left the diagonal-pivot MFMA factorisation for the general one (qocx_lu4.h,
+    // qocx_lu4m.hip); a device counter the host zeroes per evaluation (qocx_lu_fallbacks), or nullptr
+    int* fallbacks = nullptr;
 };
 
 struct SweepArgs {

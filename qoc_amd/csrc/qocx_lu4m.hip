@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void lu4m_kernel(LuArgs args, int* redo) {
     }
     const bool ok = all_blocks<NT>(T, lds, w, std::make_integer_sequence<int, 4 * NT>{});
     if (!ok) {  // workgroup-uniform: P is untouched, the general elimination takes this matrix
-        if (threadIdx.x == 0) redo[m] = 1;
+        if (threadIdx.x == 0) {
+            redo[m] = 1;
+            if (args.fallbacks != nullptr) atomicAdd(args.fallbacks, 1);
+        }
         return;
     }
     if (threadIdx.x == 0) redo[m] = 0;
@@ -423,7 +426,10 @@ __global__ __launch_bounds__(64, OCC) void lu9_kernel(LuArgs args, int* redo) {
             }
     const bool ok = all_blocks(T, lds, std::make_integer_sequence<int, 4 * NT>{});
     if (!ok) {  // wave-uniform: P is untouched, lu4_kernel takes this matrix
-        if (lane == 0) redo[m] = 1;
+        if (lane == 0) {
+            redo[m] = 1;
+            if (args.fallbacks != nullptr) atomicAdd(args.fallbacks, 1);
+        }
         return;
     }
     if (lane == 0) redo[m] = 0;

@@ -506,7 +506,10 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             // whose pivots leave the diagonal takes the general elimination, from the same image
             bool done = false;
             if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt), clk);
-            if (!done) lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+            if (!done) {
+                if (out.lu_mfma && out.lu.fallbacks != nullptr && lane_id() == 0) atomicAdd(out.lu.fallbacks, 1);
+                lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
+            }
         }
         clk.lap(4);
     } else {
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
     out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;
     out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
+    out.lu.fallbacks = args.lu_fallbacks;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
     out.dbg = args.dbg; out.stamps = args.stamps; out.lu_mfma = args.lu_mfma != 0;
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
     out.lu.lu_img = args.lu_img; out.lu.dinv = args.dinv; out.lu.perm = args.perm;
     out.lu.iperm = args.iperm; out.lu.status = args.status; out.lu.nsteps = args.nsteps;
     out.lu.step0 = args.step0; out.lu.seg_len = args.seg_len; out.lu.n = args.n; out.lu.dbg = 0;
+    out.lu.fallbacks = args.lu_fallbacks;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
     out.dbg = 0; out.stamps = nullptr; out.lu_mfma = args.lu_mfma != 0;

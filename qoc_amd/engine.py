@@ -152,6 +152,7 @@ SIGNATURES = {
     "qocx_debug_read_stamps": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64]),
     "qocx_debug_timeline": (ctypes.c_int, [_VP, _c_double_p, _I64, ctypes.POINTER(_I64)]),
     "qocx_pade_orders": (ctypes.c_int, [_VP, ctypes.POINTER(_I64)]),
+    "qocx_lu_fallbacks": (ctypes.c_int, [_VP, ctypes.POINTER(_I64)]),
     "qocx_debug_mfma_peak": (ctypes.c_int, [_VP, _I32, _I32, _c_double_p]),
     "qocx_opt_begin": (ctypes.c_int, [_VP]),
     "qocx_opt_clip": (ctypes.c_int, [_VP, _c_double_p]),
@@ -489,6 +490,13 @@ class Engine(object):
         counts = (_I64 * 5)()
         self._check(self._lib.qocx_pade_orders(self._ctx, counts))
         return {order: int(counts[i]) for i, order in enumerate((3, 5, 7, 9, 13))}
+
+    def lu_fallbacks(self):
+        """Matrices of the last evaluation / debug_pade_factor call whose factorisation left the
+        diagonal-pivot MFMA form for the general elimination (include/qocx.h: qocx_lu_fallbacks)."""
+        count = _I64(0)
+        self._check(self._lib.qocx_lu_fallbacks(self._ctx, ctypes.byref(count)))
+        return int(count.value)
 
     def timeline(self, capacity=4096):
         """(which, start_ms, end_ms) of the last evaluation's kernel launches (timing on)."""

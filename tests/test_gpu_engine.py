@@ -92,7 +92,7 @@ def test_pade_inverse_kernel(engine, n):
         assert rel_err(out["lu"][m] @ p_mat, np.eye(n)) < 1e-12 * np.linalg.cond(p_mat)
 
 
-def check_pade_factor(out, mats, policy):
+def check_pade_factor(out, mats, policy, expect_lower=True):
     lower = 0
     for m, a in enumerate(mats):
         # the kernel decides from an upper bound of the norm: never a lower order than the norm
@@ -119,7 +119,7 @@ def check_pade_factor(out, mats, policy):
         for _ in range(int(out["s"][m])):
             u = u @ u
         assert rel_err(u, onp.expm_pade(a)) < (1e-10 if order == 13 else 1e-13)
-    if policy == 0:
+    if policy == 0 and expect_lower:
         assert lower >= 12
 
 
@@ -609,3 +609,51 @@ def test_product_library_rejects_diagnostic_knobs(engine):
         with pytest.raises(QocxError):
             engine.set_knob(name, 1)
     engine.set_knob("pade_order", 0)  # a variant knob is accepted
+
+
+@pytest.mark.parametrize("n", [20, 32, 40, 48, 64])
+def test_mfma_factorisation_is_the_path_taken(engine, n):
+    """The LU with its Schur updates on the matrix cores (qocx_lu4.h inside the two-wave K1a, lu9 /
+    lu4m kernels for n > 32) takes its pivots on the diagonal speculatively and hands a matrix whose
+    pivots leave it to the general elimination - a silent net under a broken fast path. So: on the Pade
+    denominators of well-scaled generators NO matrix may fall back (qocx_lu_fallbacks), on generators
+    scaled to the edge of the squaring threshold some must, and both give the model's factors."""
+    rng = np.random.default_rng(500 + n)
+
+    def batch(scale, count=24, skew=True):
+        out = []
+        for _ in range(count):
+            g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            a = -1j * (g + g.conj().T) / 2 if skew else g
+            out.append(a * (scale / onp.one_norm(a)))
+        return np.stack(out)
+
+    small = batch(0.2)
+    out = engine.debug_pade_factor(small)
+    assert engine.lu_fallbacks() == 0
+    check_pade_factor(out, small, 0, expect_lower=False)
+    # generators with a few dominant sub-diagonal entries: P = b0 (I - a / 2 + ...) then has columns
+    # whose largest entry sits below the diagonal, and LAPACK's rule interchanges rows
+    large = 0.01 * batch(1.0, skew=False)
+    for m in range(len(large)):
+        for i in (0, n // 2, n - 2):
+            large[m, i + 1, i] += 4.8 * np.exp(1j * rng.uniform(0, 2 * np.pi))
+    out = engine.debug_pade_factor(large)
+    assert engine.lu_fallbacks() > 0
+    check_pade_factor(out, large, 0, expect_lower=False)
+
+
+def test_headline_evaluation_takes_no_fallback(engine):
+    """bench.py's workload at a reduced seed count: every one of the factorisations stays on the
+    diagonal-pivot MFMA path."""
+    import bench
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    h0, g, psi0, target = bench.make_problem()
+    engine.set_schroedinger_problem(
+        bench.DIM, 1, bench.K_CTRL, bench.N_EVAL, bench.N_EVAL, bench.DT * (bench.N_EVAL - 1),
+        h0[None], np.stack(g)[None], psi0,
+        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+    engine.evaluate(bench.make_controls(0, 8), want_grad=True)
+    assert engine.lu_fallbacks() == 0
+    orders = engine.pade_orders()
+    assert orders[5] == 8 * (bench.N_EVAL - 1)
