@@ -124,14 +124,31 @@ def _cpu_worker(seed_ids):
 
 
 def host_cores():
-    """(cores this process may run on, cores of the machine). The GPU box gives a one-GPU job a
-    CPU share (16 of its cores): the scheduler affinity, not os.cpu_count(), is what can be used."""
+    """(cores this process may use, cores of the machine, how the first number was found). The GPU
+    box gives a one-GPU job a CPU share - a cgroup quota of 16 CPUs on a 256-core host whose scheduler
+    affinity still lists every core - so the quota, not os.cpu_count(), is what can be used."""
     total = os.cpu_count() or 1
+    usable, how = total, "os.cpu_count()"
     try:
-        usable = len(os.sched_getaffinity(0))
+        usable, how = len(os.sched_getaffinity(0)), "scheduler affinity"
     except (AttributeError, OSError):  # pragma: no cover
-        usable = total
-    return max(1, usable), total
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1") and float(period) > 0:
+                share = max(1, int(float(quota) / float(period) + 0.5))
+                if share < usable:
+                    usable, how = share, "cgroup CPU quota ({})".format(path)
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, usable), total, how
 
 
 def cpu_baseline(budget_seconds=12.0):
@@ -140,7 +157,7 @@ def cpu_baseline(budget_seconds=12.0):
     probe so that the sample takes about `budget_seconds`; plus the single-core figure (one seed
     at a time, the reference's execution model)."""
     import multiprocessing as mp
-    cores, total = host_cores()
+    cores, total, how = host_cores()
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [[0]] * cores)  # process start, imports, BLAS warm-up: not timed
@@ -153,8 +170,8 @@ def cpu_baseline(budget_seconds=12.0):
         single_seconds = pool.apply(_cpu_worker, (list(range(1000, 1012)),))  # others idle
     steps = cores * seeds_per_worker * (N_EVAL - 1)
     return dict(value=steps / wall, unit="propagator-steps/s", cores=cores, cores_available=total,
-                cores_note="cores = the scheduler affinity of this process (the CPU share the box "
-                           "gives a one-GPU job), all of them used; cores_available = os.cpu_count()",
+                cores_note="cores = every CPU this job may use ({}), one worker process each; "
+                           "cores_available = os.cpu_count() of the host".format(how),
                 kind="port",
                 sample="{} seeds x {} steps (oracle/qoc_numpy.py fwd+grad, {} processes, "
                        "1 BLAS thread each, {:.1f}s wall, warm processes)".format(
@@ -290,6 +307,9 @@ def main():
                          "kernel statistics then hold the timed configuration only)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[3] Lindblad measurement")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the one-control-set latency block (profiling runs: its 400 small "
+                         "evaluations would swamp the per-kernel averages)")
     ap.add_argument("--time-segments", type=int, default=0,
                     help="tuning knob: time segments of the pipeline (0 = the engine's choice)")
     args = ap.parse_args()
@@ -398,7 +418,7 @@ def main():
     if world == 1 and not args.no_secondary and not standin:
         engine.set_timing(True)
         secondary = lindblad_secondary(engine)
-        latency = latency_secondary(engine)
+        latency = None if args.no_latency else latency_secondary(engine)
     engine.set_timing(False)
 
     units_per_step = world * seeds * (N_EVAL - 1)

@@ -36,7 +36,10 @@ struct Tiles {  // 32 x 32 complex, tile (ti, tj) in C-layout: lane (q, c), regi
     d4 re[2][2], im[2][2];
 };
 
-constexpr int XB_COMPLEX = 2 * 4 * 32;  // panel buffer [half][kk][index]: 4 KiB
+// panel buffer [half][kk][index]; pitch 36 complex per kk so that the 16 lanes of a column-panel
+// dump (four columns x four rows, 16 bytes each) fall into 16 different bank groups
+constexpr int XP = 36;
+constexpr int XB_COMPLEX = 2 * 4 * XP;
 
 struct Cx {
     double re, im;
@@ -64,11 +67,11 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
         for (int ti = t0; ti < 2; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                xb[(c - c0) * 32 + 16 * ti + 4 * r + q] = make_double2(T.re[ti][t0][r], T.im[ti][t0][r]);
+                xb[(c - c0) * XP + 16 * ti + 4 * r + q] = make_double2(T.re[ti][t0][r], T.im[ti][t0][r]);
     }
 #pragma unroll
     for (int tj = t0; tj < 2; ++tj)
-        xb[(4 + q) * 32 + 16 * tj + c] = make_double2(T.re[t0][tj][r0], T.im[t0][tj][r0]);
+        xb[(4 + q) * XP + 16 * tj + c] = make_double2(T.re[t0][tj][r0], T.im[t0][tj][r0]);
     wave_sync();
 
     // ---- this lane's four panel entries and the pivot block (upper half: its transpose - the
@@ -76,14 +79,14 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
     Cx x[4], dd[4][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        const double2 e = xb[(half * 4 + kk) * 32 + idx];
+        const double2 e = xb[(half * 4 + kk) * XP + idx];
         x[kk] = Cx{e.x, e.y};
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const double2 e = xb[(half * 4 + cc) * 32 + k0 + r];
+            const double2 e = xb[(half * 4 + cc) * XP + k0 + r];
             dd[r][cc] = Cx{e.x, e.y};
         }
 
@@ -139,18 +142,18 @@ __device__ __forceinline__ bool block_step(Tiles& T, double2* xb, double2* img, 
         // half), B fragment = U12 (4 x columns, the upper half's entries BEFORE their scaling).
         if (half == 0) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xb[kk * 32 + idx] = make_double2(f[kk].re, f[kk].im);
+            for (int kk = 0; kk < 4; ++kk) xb[kk * XP + idx] = make_double2(f[kk].re, f[kk].im);
         } else {
 #pragma unroll
-            for (int kk = 1; kk < 4; ++kk) xb[(4 + kk) * 32 + idx] = make_double2(x[kk].re, x[kk].im);
+            for (int kk = 1; kk < 4; ++kk) xb[(4 + kk) * XP + idx] = make_double2(x[kk].re, x[kk].im);
         }
         wave_sync();
         constexpr int ta = (k0 + 4) >> 4;  // first tile with rows / columns beyond the block
         double are[2], aim[2], nre[2], nim[2], bre[2], bim[2];
 #pragma unroll
         for (int t = ta; t < 2; ++t) {
-            double2 a = xb[q * 32 + 16 * t + c];
-            double2 b = xb[(4 + q) * 32 + 16 * t + c];
+            double2 a = xb[q * XP + 16 * t + c];
+            double2 b = xb[(4 + q) * XP + 16 * t + c];
             if (t == t0 && c <= c0 + 3) {  // rows / columns of this block and of earlier ones
                 a = make_double2(0.0, 0.0);
                 b = make_double2(0.0, 0.0);

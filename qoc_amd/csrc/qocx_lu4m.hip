@@ -272,7 +272,8 @@ struct Tiles {
 // each in LDS) a CU has 29 KiB left, and what decides this kernel's rate is how many of its waves
 // fit there (13 KiB per wave: 1.65 ms per 32 000 matrices; 7 KiB: see profiles/r04_sizes.jsonl)
 struct Lds {
-    double2 pan[2][4][NR];  // [0: column panel by row | 1: row panel by column][kk][index]: raw in, final out
+    double2 pan[2][4][NR + 4];  // [0: column panel by row | 1: row panel by column][kk][index (pitch 52:
+                                // the 16 lanes of a column-panel dump in 16 bank groups)]: raw in, final out
     double2 dinv[NR];
 };
 

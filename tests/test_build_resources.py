@@ -51,10 +51,11 @@ def test_headline_kernels_share_a_simd():
     sweep = find(kernels, "sweep_kernelILi2ELi1ELb0ELb0E")
     sweep1 = find(kernels, "sweep_kernelILi2ELi1ELb0ELb1E")  # one operand set in LDS (round 3)
     sweep4 = find(kernels, "sweep_kernelILi2ELi4ELb0ELb0E")
-    k1a = find(pade2, "pade_pq2_kernelILb1E")
+    k1a = find(pade2, "pade_pq2_kernelILb1ELb0ELb1E")   # Hermitian, product build, step table (the headline's)
+    k1a_norm = find(pade2, "pade_pq2_kernelILb1ELb0ELb0E")  # ... deciding order / squarings from the matrix norm
     k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0E")
     lu = find(kernels, "lu_kernelILi2E")
-    for entry in (sweep, sweep1, sweep4, k1a, k3, lu):
+    for entry in (sweep, sweep1, sweep4, k1a, k1a_norm, k3, lu):
         assert entry["VGPRs Spill"] == 0 and entry["ScratchSize"] == 0
     granule = lambda r: (r + 7) // 8 * 8  # noqa: E731  (allocation granularity)
     assert granule(total_registers(k1a)) * 2 <= 512          # two K1a waves per SIMD

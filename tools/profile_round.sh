@@ -4,11 +4,11 @@
 # writes gpurun_out/prof_<tag>/ (raw) and gpurun_out/<tag>_*.{csv,json} (summaries to copy into
 # profiles/). Counter passes are separate runs with --pmc only (no trace domains beside them).
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-order"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-order --no-latency"
 # 1. kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 STATS=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
