@@ -1272,6 +1272,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
         sa.psi0 = ctx->psi0.p;
         sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
+        sa.n = ctx->knob("sweep_nine", 1) ? ctx->n : 0;
         sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
         sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p;
         sa.cost_vectors = ctx->cost_vectors.p; sa.cost_counts = ctx->cost_counts.p;
@@ -2415,7 +2416,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

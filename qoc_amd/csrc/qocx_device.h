@@ -114,6 +114,7 @@ struct SweepArgs {
     const int* s_arr;
     const double2* psi0;  // [S][NP]
     int S, nsteps, cost_eval_step, want_grad, has_step_costs;
+    int n = 0;  // Hilbert size (sixteen-tile sweep: <= 48 -> nine-tile images in LDS); 0: unknown
     // Time segmentation: one launch runs the forward sweep over steps [j_begin, j_end) (phase
     // bit 0) and / or the adjoint sweep from j_end back to j_begin (phase bit 1); state is carried
     // between launches in states/offs/cost_out (forward) and lam_buf (adjoint).

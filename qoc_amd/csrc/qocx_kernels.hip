@@ -707,16 +707,16 @@ __device__ __forceinline__ double2 lds_coef(const double2* lb, int pm, int i, in
     }
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK, class Hook>
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK, int NA, class Hook>
 __device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, int permv,
                                              double2 (&ring)[8], double& zre, double& zim,
                                              Hook& hook) {
-    constexpr int NP = Geo<NB>::NP, D = 8;
-    constexpr int k = LOWER ? KK : (NP - 1 - KK);
+    constexpr int D = 8;
+    constexpr int k = LOWER ? KK : (NA - 1 - KK);
     constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
     const double2 c = ring[KK % D];
-    if constexpr (KK + D < NP - 1) {
-        constexpr int kn = LOWER ? (KK + D) : (NP - 1 - (KK + D));
+    if constexpr (KK + D < NA - 1) {
+        constexpr int kn = LOWER ? (KK + D) : (NA - 1 - (KK + D));
         ring[KK % D] = lds_coef<NB, ADJ>(lb, pm, i, permv, kn);
     }
     const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
@@ -725,23 +725,25 @@ __device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, i
         zre, zim, c.x, c.y, kre, kim);
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ, class Hook, int... KK>
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int NA, class Hook, int... KK>
 __device__ __forceinline__ void tri_solve_lds_seq(const double2* lb, int pm, int i, int permv,
                                                   double2 (&ring)[8], double& zre, double& zim,
                                                   Hook& hook, std::integer_sequence<int, KK...>) {
-    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK>(lb, pm, i, permv, ring, zre, zim, hook), ...);
+    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK, NA>(lb, pm, i, permv, ring, zre, zim, hook), ...);
 }
 
-template <int NB, bool LOWER, bool CONJ, bool ADJ, class Hook>
+// NA < NP (n <= 48 in a 64 x 64 image): rows and columns NA .. NP - 1 are the pad block - unit
+// columns, zero multipliers - so the stages of those columns do nothing and are left out.
+template <int NB, bool LOWER, bool CONJ, bool ADJ, int NA = Geo<NB>::NP, class Hook>
 __device__ __forceinline__ void tri_solve_lds(const double2* lb, int pm, int i, int permv,
                                               double& zre, double& zim, Hook& hook) {
-    constexpr int NP = Geo<NB>::NP, D = 8;
+    constexpr int D = 8;
     double2 ring[D];
 #pragma unroll
     for (int j = 0; j < D; ++j)
-        ring[j] = lds_coef<NB, ADJ>(lb, pm, i, permv, LOWER ? j : (NP - 1 - j));
-    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ>(lb, pm, i, permv, ring, zre, zim, hook,
-                                            std::make_integer_sequence<int, NP - 1>{});
+        ring[j] = lds_coef<NB, ADJ>(lb, pm, i, permv, LOWER ? j : (NA - 1 - j));
+    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ, NA>(lb, pm, i, permv, ring, zre, zim, hook,
+                                                std::make_integer_sequence<int, NA - 1>{});
 }
 
 template <int NB>
@@ -761,10 +763,13 @@ struct SweepLdsCoef {
     static constexpr bool value = NB >= QOCX_LDSCOEF_MIN_NB;
 };
 
-template <int NB, int NBUF = (SweepPrefetch<NB>::value ? 2 : 1)>
+// NA: columns of an image that are fetched into LDS (NB = 4, n <= 48: the 48 columns that are not
+// the pad block - 48 KiB per image instead of 64, so that a K1a workgroup fits on the CU beside the
+// sweep's; everywhere else the whole image)
+template <int NB, int NBUF = (SweepPrefetch<NB>::value ? 2 : 1), int NA = Geo<NB>::NP>
 struct SweepLds {
     typedef Geo<NB> G;
-    static constexpr int BUF_BYTES = G::MAT * 16;              // one matrix image
+    static constexpr int BUF_BYTES = NA * G::NP * 16;          // one matrix image (NA columns)
     static constexpr int Q_OFF = 0;                            // NBUF x Q image (ring)
     static constexpr int L_OFF = Q_OFF + NBUF * BUF_BYTES;      // NBUF x LU image
     static constexpr int D_OFF = L_OFF + NBUF * BUF_BYTES;      // NBUF x 64 complex: 1/U_kk
@@ -827,11 +832,11 @@ __device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb
 // Partial row sums of a matvec whose matrix sits in LDS as an R-layout image (`qlane` = the image
 // lane this lane takes: its own, or the one of a permuted row) and whose vector is broadcast from
 // LDS; BATCH (matrix, vector) pairs of LDS reads are in flight ahead of their FMAs.
-template <int NB, bool CONJ, int BATCH>
+template <int NB, bool CONJ, int BATCH, int NA = Geo<NB>::NP>
 __device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec, int qlane, int h,
                                            double& yre, double& yim) {
     typedef Geo<NB> G;
-    constexpr int CPL = G::CPL, H = G::H;
+    constexpr int CPL = NA / G::H, H = G::H;  // (NA < NP: the pad columns carry nothing)
     double ar = 0, ai = 0;
 #pragma unroll
     for (int c0 = 0; c0 < CPL; c0 += BATCH) {
@@ -908,9 +913,10 @@ __device__ __forceinline__ void lds_matvec2(const double2* qb, const double2* ve
 // share a CU, which halves the CUs on which the sweep displaces a K1a workgroup (a 221-register
 // sweep wave leaves room for three two-wave K1a workgroups instead of four - whether the CU hosts
 // one sweep wave or two).
-template <int NB, int W, bool LOADER, bool ONEBUF = false>
+template <int NB, int W, bool LOADER, bool ONEBUF = false, int NA = Geo<NB>::NP>
 __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sweep_kernel(SweepArgs args) {
     typedef Geo<NB> G;
+    static_assert(NA == G::NP || (NB == 4 && NA == 48), "NA < NP: the nine-tile images of 33 <= n <= 48");
     static_assert(!ONEBUF || (W == 1 && !LOADER && SweepPrefetch<NB>::value), "ONEBUF: one wave per seed");
     // With a loader wave the operands of TWO steps travel at once (ring of three buffers): the
     // fetch of step t+2 is issued while step t computes and has until the start of step t+2 to land.
@@ -923,8 +929,9 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     constexpr bool PAIRS = !ONEBUF && !LDSCOEF && !LOADER && W > 1;
     static_assert(PREFETCH || !LOADER, "the loader variant needs a ring of buffers");
     constexpr int NBUF = LOADER ? 3 : ((PREFETCH && !ONEBUF) ? 2 : 1);
-    typedef SweepLds<NB, NBUF> L;
+    typedef SweepLds<NB, NBUF, NA> L;
     constexpr int NP = G::NP, H = G::H, MAT = G::MAT;
+    constexpr int LMAT = NA * NP;  // complex per image in LDS (NA of its NP columns)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // ONEBUF: wave v of the workgroup is seed 2 * blockIdx.x + v, with LDS of its own
     const int pack_wave = ONEBUF ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     // gathers the transposed images), 1/U_kk, perm | iperm: 2*MAT/64 + 2 pieces. They are issued
     // one per column of the current step's triangular solves, into the bubbles of the
     // dependent readlane -> fma chain (an in-order wave cannot fill them otherwise).
-    constexpr int IMG_PIECES = MAT / 64, PIECES = 2 * IMG_PIECES + 2 + (NP > 32 ? 1 : 0);
+    constexpr int IMG_PIECES = LMAT / 64, PIECES = 2 * IMG_PIECES + 2 + (NP > 32 ? 1 : 0);
     constexpr int PINTS = L::PINTS;
     // Per-lane global base addresses of the step being fetched; the pieces of an image are
     // reached through the instruction offset (dma16_imm), so a step needs six addresses, not one
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
     };
     auto dma_image = [&](auto J, const char* const (&base)[NGROUP], double2* buf) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
-        char* dst = reinterpret_cast<char*>(buf + pf_par * MAT + j * 64);
+        char* dst = reinterpret_cast<char*>(buf + pf_par * LMAT + j * 64);
         if (pf_adjoint) dma16_imm<j * H * 16>(base[0], dst);
         else dma16_imm<(j - ((j / GROUP) * GROUP + CENTER)) * 1024>(base[j / GROUP], dst);
     };
@@ -1169,14 +1176,14 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 pf_fire_q = pf_fire_l = pf_due && (!ONEBUF || sub == nsub - 1);
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
-                lds_matvec<NB, false, MVB>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
+                lds_matvec<NB, false, MVB, NA>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
                 if constexpr (!LDSCOEF) tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
-                else tri_solve_lds<NB, true, false, false>(lcur, sc.pm, i, permv, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, false, false, NA>(lcur, sc.pm, i, permv, zre, zim, hook_a);
                 const double t = zre * sc.dv.x - zim * sc.dv.y;
                 zim = zre * sc.dv.y + zim * sc.dv.x;
                 zre = t;
                 if constexpr (!LDSCOEF) tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
-                else tri_solve_lds<NB, false, false, false>(lcur, sc.pm, i, permv, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, false, false, NA>(lcur, sc.pm, i, permv, zre, zim, hook_b);
                 finish_prefetch();
                 wave_sync();
                 {   // every lane group holds the same z: all of them store (no exec-mask branch
@@ -1224,12 +1231,12 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
             const StepScalars sc = scalars(par, false);
             if constexpr (!LDSCOEF) {
                 if (computes)
-                    lds_to_regs<NB, false>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
+                    lds_to_regs<NB, false>(qbuf + par * LMAT, lbuf + par * LMAT, pbuf + par * PINTS, r,
                                            sc.pm, lane, i);
             } else {
-                lcur = lbuf + par * MAT;
+                lcur = lbuf + par * LMAT;
             }
-            qcur = qbuf + par * MAT;
+            qcur = qbuf + par * LMAT;
             wave_sync();
             if constexpr (LOADER) {
                 pf_due = fetcher && (step + 2 < je);
@@ -1364,12 +1371,12 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
                 if constexpr (!LDSCOEF) tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
-                else tri_solve_lds<NB, true, true, true>(lcur, sc.pm, i, permv, zre, zim, hook_a);
+                else tri_solve_lds<NB, true, true, true, NA>(lcur, sc.pm, i, permv, zre, zim, hook_a);
                 const double t = zre * sc.dv.x + zim * sc.dv.y;
                 zim = zim * sc.dv.x - zre * sc.dv.y;
                 zre = t;
                 if constexpr (!LDSCOEF) tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
-                else tri_solve_lds<NB, false, true, true>(lcur, sc.pm, i, permv, zre, zim, hook_b);
+                else tri_solve_lds<NB, false, true, true, NA>(lcur, sc.pm, i, permv, zre, zim, hook_b);
                 finish_prefetch();
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
@@ -1390,7 +1397,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 }
                 // lambda = Q^H x ; the LDS image is that of Q^T (lane (h,i): Q[cc*H+h][i])
                 double yre, yim;
-                lds_matvec<NB, true, MVB>(qcur, tmp, lane, h, yre, yim);
+                lds_matvec<NB, true, MVB, NA>(qcur, tmp, lane, h, yre, yim);
                 wave_sync();
                 lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
@@ -1428,13 +1435,13 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
             const StepScalars sc = scalars(par, true);
             if constexpr (!LDSCOEF) {
                 if (computes)
-                    lds_to_regs<NB, true>(qbuf + par * MAT, lbuf + par * MAT, pbuf + par * PINTS, r,
+                    lds_to_regs<NB, true>(qbuf + par * LMAT, lbuf + par * LMAT, pbuf + par * PINTS, r,
                                           sc.pm, lane, i);
             } else {
-                lcur = lbuf + par * MAT;
+                lcur = lbuf + par * LMAT;
                 permv = pbuf[par * PINTS + lane % NP];
             }
-            qcur = qbuf + par * MAT;
+            qcur = qbuf + par * LMAT;
             wave_sync();
             if constexpr (LOADER) {
                 pf_due = fetcher && (step - 2 >= jb);
@@ -1946,6 +1953,15 @@ static void launch_pq_explicit_t(const double2* a_in, int n, const FactorArgs& a
 }
 template <int NB, int W, bool LOADER>
 static void launch_sweep_wl(const SweepArgs& a, int batch, hipStream_t st) {
+    if constexpr (NB == 4 && !LOADER) {
+        if (a.n > 0 && a.n <= 48) {  // nine-tile images: 48 of the 64 columns in LDS, 47 stages per solve
+            const int bytes9 = SweepLds<4, 1, 48>::bytes(a.S);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<4, W, false, false, 48>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes9);
+            hipLaunchKernelGGL((sweep_kernel<4, W, false, false, 48>), dim3(batch), dim3(64 * W), bytes9, st, a);
+            return;
+        }
+    }
     const int bytes = LOADER ? SweepLds<NB, 3>::bytes(a.S) : SweepLds<NB>::bytes(a.S);
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel<NB, W, LOADER>),

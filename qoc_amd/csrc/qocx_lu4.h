@@ -24,6 +24,13 @@
 //
 // Same factorisation, different summation order in the updates: factors agree with lu_body to
 // rounding, not bit for bit (tests/test_gpu_engine.py::test_pade_factor_kernel runs both).
+//
+// Measured and not kept (round 4): the factors held in the tiles until the
+// last block has passed the check and stored once in 64-byte runs (as lu9_kernel of qocx_lu4m.hip
+// does, where a failed check must leave the HBM image of P intact) - the same K1a time, 0.729 ms per
+// launch either way; and the products of the pivot-block update formed before the reciprocal they are
+// scaled with (two levels off every pivot's dependent chain, twelve more multiplications per
+// pivot) - 9 000 cycles MORE per matrix.
 #ifndef QOCX_LU4_H
 #define QOCX_LU4_H
 
@@ -212,6 +219,7 @@ __device__ __forceinline__ bool lu_mfma_body(const LuArgs& args, size_t m, const
     }
     return true;
 }
+
 
 }  // namespace lu4
 }  // namespace qocx

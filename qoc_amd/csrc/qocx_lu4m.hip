@@ -456,12 +456,20 @@ __global__ __launch_bounds__(64, OCC) void lu9_kernel(LuArgs args, int* redo) {
 }  // namespace lu9
 
 void launch_lu4m(const LuArgs& a, size_t count, int* redo, hipStream_t st) {
-    if (a.n > 0 && a.n <= 48 && !(a.dbg & 12))
-        hipLaunchKernelGGL(lu9::lu9_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a, redo);
-    else if (a.n > 0 && a.n <= 48 && (a.dbg & 8))  // (dbg bit 3: one wave per SIMD, no spills)
-        hipLaunchKernelGGL(lu9::lu9_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a, redo);
-    else if (a.n > 0 && a.n <= 48)  // (dbg bit 2: the four-wave form, for comparison)
+#ifdef QOCX_DIAG
+    // (measurement build: the forms lu9_kernel was chosen against - dbg bit 2 the four-wave form at
+    // n <= 48, bit 3 lu9_kernel at one wave per SIMD without spills)
+    if (a.n > 0 && a.n <= 48 && (a.dbg & 4)) {
         hipLaunchKernelGGL(lu4m::lu4m_kernel<3>, dim3((unsigned)count), dim3(256), 0, st, a, redo);
+        return;
+    }
+    if (a.n > 0 && a.n <= 48 && (a.dbg & 8)) {
+        hipLaunchKernelGGL(lu9::lu9_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a, redo);
+        return;
+    }
+#endif
+    if (a.n > 0 && a.n <= 48)
+        hipLaunchKernelGGL(lu9::lu9_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a, redo);
     else
         hipLaunchKernelGGL(lu4m::lu4m_kernel<4>, dim3((unsigned)count), dim3(256), 0, st, a, redo);
 }
