@@ -1260,6 +1260,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
             if (ctx->lu_redo.ensure((size_t)bc * nsteps)) return QOCX_ERR_HIP;
             la.redo = ctx->lu_redo.p;
+            // (Measured and not kept: the nine-tile factorisation INSIDE the nine-tile K1a, P through an
+            // LDS image as at n <= 32 - 3.81 ms per launch against 2.48 + 0.78 apart: wave 0 factors for
+            // 60 000 cycles while the workgroup's 46 KiB of LDS stay allocated.)
         }
         qocx::MagnusArgs ma;
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
@@ -2799,7 +2802,6 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), ctx->stream));
     fa.lu_fallbacks = ctx->lu_fallbacks.p;
     fa.dinv = dinv_d.p; fa.perm = perm_d.p; fa.iperm = iperm_d.p;
-    qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     qocx::LuArgs la;
     la.lu_img = lu_d.p; la.dinv = dinv_d.p; la.perm = perm_d.p; la.iperm = iperm_d.p;
     la.status = ctx->status.p;
@@ -2811,6 +2813,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
         if (redo_d.ensure((size_t)count)) return QOCX_ERR_HIP;
         la.redo = redo_d.p;
     }
+    qocx::launch_pq_explicit(nb, a_d.p, n, fa, count, ctx->stream);
     if (!fused_lu) qocx::launch_lu(nb, la, (size_t)count, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2829,7 +2832,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
             HIP_TRY(hipMemcpy(sv.data(), s_d.p, sv.size() * 4, hipMemcpyDeviceToHost));
             memcpy(s_out, sv.data(), count * sizeof(int));
         }
-        a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); redo_d.release(); redo_d.release();
+        a_d.release(); q_d.release(); lu_d.release(); dinv_d.release(); perm_d.release(); redo_d.release();
         iperm_d.release(); s_d.release();
         int st_inv = 0;
         HIP_TRY(hipMemcpy(&st_inv, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
