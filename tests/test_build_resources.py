@@ -123,3 +123,15 @@ def test_release_library_has_no_diagnostic_switches():
         assert env not in blob, env
     # the stamped kernel instantiations are not in the product library either
     assert b"pade_pq2_kernelILb1ELb1E" not in blob
+
+
+def test_mfma_factorisation_kernels_keep_their_budgets():
+    """Round 4 (qocx_lu4m.hip): the nine-tile one-wave factorisation must reach two waves per SIMD
+    (at one it was measured 12 % slower) with at most a handful of spilled registers, and the
+    four-wave form must not touch scratch (a lane-indexed register array in it once became a scratch
+    array: a trip to memory in every block of four pivots)."""
+    table = resources("qocx_lu4m.hip")
+    lu9 = find(table, "lu9_kernelILi2E")
+    assert lu9["Occupancy"] == 2 and lu9["VGPRs Spill"] <= 32, lu9
+    lu4m = find(table, "lu4m_kernelILi4E")
+    assert lu4m["ScratchSize"] == 0 and lu4m["VGPRs Spill"] == 0 and lu4m["Occupancy"] >= 2, lu4m
