@@ -2319,8 +2319,9 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                                     ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
             la.stamps = nullptr;
             if (ctx->knob("lindblad_stamps", 0)) {
-                if (ctx->stamps.ensure((size_t)B * 48)) return QOCX_ERR_HIP;
-                HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, (size_t)B * 48 * sizeof(unsigned long long),
+                // ([B] sets of the forward pass / classic launch, then [B] of the unit adjoint)
+                if (ctx->stamps.ensure((size_t)B * 96)) return QOCX_ERR_HIP;
+                HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, (size_t)B * 96 * sizeof(unsigned long long),
                                        ctx->stream));
                 la.stamps = ctx->stamps.p + pos0 * 48;
             }
@@ -2331,7 +2332,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             // the whole chip. While both launches find CUs of their own they run on two streams
             // (2 Bp CUs busy instead of Bp); a bigger piece runs them one after the other - the
             // same three kernels, so a seed's result does not depend on the batch it is part of.
-            const bool two_sided = two_sided_ok && keep_stages && multi && la.stamps == nullptr;
+            const bool two_sided = two_sided_ok && keep_stages && multi;
             if (two_sided) {
                 const int side_limit = (int)ctx->knob("lindblad_side_limit", ctx->cu_count / 2);
                 hipStream_t side = Bp <= side_limit ? ctx->sweep_streams[0] : ctx->stream;
@@ -2345,6 +2346,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 qocx::LindbladArgs fwd = la, adj = la;
                 fwd.phase = 1;
                 adj.phase = 2;
+                fwd.q2 = adj.q2 = ctx->knob("lindblad_q2", 1) != 0 ? 1 : 0;
+                if (la.stamps != nullptr) adj.stamps = la.stamps + (size_t)B * 48;
                 time_begin(ctx, 5, ctx->stream);
                 qocx::launch_lindblad(fwd, Bp, ctx->stream);
                 time_end(ctx, ctx->stream);
@@ -2419,7 +2422,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -286,6 +286,7 @@ struct LindbladArgs {
     // (lindblad_combine) contracts them with the forward stage values and the scalars into the
     // control cotangents. phase 0: the classic forward-then-adjoint launch.
     int phase = 0;
+    int q2 = 0;                    // phases 1 / 2, four waves: the stage loop with 18 MFMAs per wave (substep_q2)
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out
 };

@@ -16,6 +16,7 @@
 //
 // One wavefront per seed; the S densities of a seed advance together, sub-interval by
 // sub-interval (the recursion in time is serial).
+#include <cstddef>
 #include "dop853_tableau.h"
 #include "qocx_wave.h"
 
@@ -53,7 +54,7 @@ struct Slot {
 // MW: several wavefronts work on one seed - wave 0 the generator terms A_L y + y A_R, wave 1 + i
 // the term of Lindblad operator i, the last wave the control cotangents of the adjoint - and
 // exchange their partial right-hand sides through LDS (two workgroup barriers per stage).
-template <int LNB, bool GS, bool MW, bool RG = false, bool STAMP = false, bool QP = false>
+template <int LNB, bool GS, bool MW, bool RG = false, bool STAMP = false, bool QP = false, bool Q2 = false>
 struct LB {
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                               // C-layout register tiles
@@ -425,21 +426,50 @@ struct Wave {
     struct GenLin {
         double2* d;  // la | ld | ra : left(c) = la + c ld, right(c) = ra - c ld
     };
-    __device__ __forceinline__ void build_linear(const SubStep& ss, bool adjoint, GenLin& out) const {
+    // u_k at the two ends of a sub-interval (linear interpolation between control knots)
+    __device__ __forceinline__ void end_controls(const SubStep& ss, const double* ctl, int k, double& ua,
+                                                 double& ub) const {
+        const int K = a.K;
+        ua = ss.wa1 * ctl[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl[(size_t)ss.ia2 * K + k];
+        ub = ss.wb1 * ctl[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl[(size_t)ss.ib2 * K + k];
+    }
+    // `ua`, `ub` (substep_q2): the end-point controls, fetched one sub-interval ahead by run()
+    __device__ __forceinline__ void build_linear(const SubStep& ss, bool adjoint, GenLin& out,
+                                                 const double* ua_pre = nullptr,
+                                                 const double* ub_pre = nullptr) const {
         struct { Mat la, ld, ra; } g;
         out.d = kdump;
-        dump_load(g.la, adjoint ? c_a0ld : c_a0l);
-        dump_load(g.ra, adjoint ? c_a0rd : c_a0r);
+        if (ua_pre == nullptr) {
+            dump_load(g.la, adjoint ? c_a0ld : c_a0l);
+            dump_load(g.ra, adjoint ? c_a0rd : c_a0r);
+        }
         mat_zero(g.ld);
         const int K = a.K;
-        for (int k = 0; k < K; ++k) {
-            const double ua = ss.wa1 * ctl_b[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl_b[(size_t)ss.ia2 * K + k];
-            const double ub = ss.wb1 * ctl_b[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl_b[(size_t)ss.ib2 * K + k];
-            Mat gk;
-            dump_load(gk, (adjoint ? c_gpd : c_gp) + (size_t)k * MAT);
-            mat_axpy(g.la, ua, gk);
-            mat_axpy(g.ra, -ua, gk);
-            mat_axpy(g.ld, ub - ua, gk);
+        if (ua_pre != nullptr) {
+            // (Q2: the pass's constant dumps sit in kdump[6 ..], see run() - named here so that the
+            // reads are LDS instructions, not flat ones that would wait for the loads in flight)
+            const double2* cache = kdump + 6 * (size_t)MAT;
+            dump_load(g.la, cache);
+            dump_load(g.ra, cache + MAT);
+#pragma unroll
+            for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)  // (unrolled: the arrays stay in registers)
+                if (k < K) {
+                    Mat gk;
+                    dump_load(gk, cache + (size_t)(2 + k) * MAT);
+                    mat_axpy(g.la, ua_pre[k], gk);
+                    mat_axpy(g.ra, -ua_pre[k], gk);
+                    mat_axpy(g.ld, ub_pre[k] - ua_pre[k], gk);
+                }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                double ua, ub;
+                end_controls(ss, ctl_b, k, ua, ub);
+                Mat gk;
+                dump_load(gk, (adjoint ? c_gpd : c_gp) + (size_t)k * MAT);
+                mat_axpy(g.la, ua, gk);
+                mat_axpy(g.ra, -ua, gk);
+                mat_axpy(g.ld, ub - ua, gk);
+            }
         }
         wave_sync();
         dump_store(g.la, out.d);
@@ -722,6 +752,225 @@ struct Wave {
         __syncthreads();
     }
 
+    // ---- four waves, the two-sided evaluation's stage loop (round 4) ---------------------------
+    // In the two launches of the two-sided evaluation the fourth wave has no control cotangents to
+    // form, and the stamps (tools/lindblad_stamps.py) show the generator wave as the critical one:
+    // 700 cycles of generator build-up, then 24 MFMAs, while the operator waves wait 600 cycles and
+    // the fourth 3 200. Here every wave owns 18 of the 72 MFMAs of a right-hand side:
+    //   round 1   wave 0: A_L(c) y | wave 1: t_1 = gamma_1 L_1 y | wave 2: t_2 | wave 3: y A_R(c)
+    //   barrier M (t_1, t_2 are in their slots)
+    //   round 2   t_i L_i^H split along K: k-steps 0, 1 on the wave that formed t_i, 2, 3 on wave 0
+    //             (operator 1) and wave 3 (operator 2)
+    //   barrier E (the four partial sums are in `parts`)
+    // and the Runge-Kutta combination needs NO barrier of its own: before E every wave writes its
+    // quarter of the part of the next argument that is known already (y0 + h sum_{j<i} a_{i+1,j} k_j),
+    // behind E every wave reads that dump and the four partial sums whole and finishes y_{i+1} = pre
+    // + h a_{i+1,i} k_i itself. The generator image of the next stage (wave 0) and its right factor
+    // (wave 3) are prepared while the products of this one are in the pipe.
+    // ADJ: the same loop on kbar_i = h (b_i lambda + sum_{j>i} a_ji Ybar_j), stages 11 .. 0.
+    template <int HALF>
+    static __device__ __forceinline__ void gemm_half(Mat& acc, const Slot& left, const Mat& right) {
+        const int q = lane_id() >> 4, c = lane_id() & 15;
+        d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+        double are[2], aim[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int off = c * LG::PITCH + 4 * (2 * HALF + k2) + q;
+            are[k2] = left.re[off];
+            aim[k2] = left.im[off];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kk = 2 * HALF + k2;
+            t1 = mfma_f64(are[k2], right.re[0][0][kk], t1);
+            t2 = mfma_f64(aim[k2], right.im[0][0][kk], t2);
+            t3 = mfma_f64(are[k2] + aim[k2], right.re[0][0][kk] + right.im[0][0][kk], t3);
+        }
+        acc.re[0][0] += t1 - t2;
+        acc.im[0][0] += t3 - t1 - t2;
+    }
+    // coefficient of the stage processed t-th in the argument of the stage processed s-th (t < s)
+    static constexpr double q2_coef(bool adj, int s, int t) {
+        return adj ? QOCX_RK_A[STAGES - 1 - t][STAGES - 1 - s] : QOCX_RK_A[s][t];
+    }
+    // `ua`, `ub`: the controls at the two ends of the sub-interval (run() takes them from the mail box);
+    // `post`: what wave 0 does before the last barrier of the sub-interval (the next one's mail).
+    // Returns with `result` whole in every wave and NO barrier behind it: the new density (cotangent)
+    // is finished like a thirteenth argument, from the dump of its known part and the last k_i.
+    template <bool ADJ, class Post>
+    __device__ __forceinline__ void substep_q2(const SubStep& ss, const double (&ua)[QOCX_LINDBLAD_MAX_K],
+                                               const double (&ub)[QOCX_LINDBLAD_MAX_K], const Mat& base_in,
+                                               Mat& result, double2* store, Post post) const {
+        constexpr int LAST = STAGES - 1;
+        const int lane = lane_id();
+        const Mat base = base_in;
+        double2* pre = kdump + 4 * (size_t)MAT;   // two dumps, by the parity of the stage
+        const Slot gen_slot[2] = {slot_gen, slot_zk};
+        const int myop = (wv == 0 || wv == 1) ? 0 : 1;
+        const Slot tmp = slot_at(reinterpret_cast<char*>(slot_gen.re) + (size_t)(2 + myop) * SLOT_BYTES);
+        const Slot op = slot_at(op_planar + (size_t)myop * SLOT_BYTES);
+        const double gamma = a.gammas[myop];
+        double hr[STAGES], hi[STAGES];  // this wave's component of h k_j (ADJ: h Ybar_j), by order of processing
+        // the generators of the sub-interval, left(c) = la + c ld, right(c) = ra - c ld: kdump[0..2],
+        // one dump per wave, from the pass's constant dumps in kdump[6 ..] (run())
+        GenLin gen{kdump};
+        {
+            const double2* cache = kdump + 6 * (size_t)MAT;
+            const int K = a.K;
+            Mat m;
+            mat_zero(m);
+            if (wv == 0) dump_load(m, cache);
+            if (wv == 3) dump_load(m, cache + MAT);
+            if (wv != 2) {
+#pragma unroll
+                for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+                    if (k < K) {
+                        Mat gk;
+                        dump_load(gk, cache + (size_t)(2 + k) * MAT);
+                        mat_axpy(m, wv == 0 ? ua[k] : wv == 1 ? ub[k] - ua[k] : -ua[k], gk);
+                    }
+                dump_store(m, gen.d + (size_t)(wv == 0 ? 0 : wv == 1 ? 1 : 2) * MAT);
+            }
+        }
+        Mat opr;
+        if (ADJ) load_plain(opr, op);
+        else load_adjoint(opr, op);
+        double br, bi;
+        quarter_of(base, wv, br, bi);
+        double nr = br, ni = bi;  // ADJ: lambda_new = lambda + sum_i Ybar_i
+        Mat arg, gr;
+        mat_zero(gr);
+        if (ADJ) {
+            mat_zero(arg);
+            if (QOCX_RK_B[LAST] != 0.0) mat_axpy(arg, ss.h * QOCX_RK_B[LAST], base);
+        } else {
+            arg = base;
+        }
+        __syncthreads();  // the three generator dumps are there
+        // generator factors of a stage: left -> the slot (wave 0), right in registers (wave 3)
+        auto left_to_slot = [&](double c, const Slot& dst) {
+            Mat gl, gd;
+            dump_load(gl, gen.d);
+            dump_load(gd, gen.d + MAT);
+            mat_axpy(gl, c, gd);
+            cmat_to_lds<LNB>(gl, dst.re, dst.im);
+        };
+        auto right_of = [&](double c, Mat& gr_) {
+            Mat gd;
+            dump_load(gr_, gen.d + 2 * (size_t)MAT);
+            dump_load(gd, gen.d + MAT);
+            mat_axpy(gr_, -c, gd);
+        };
+        if (wv == 0) left_to_slot(QOCX_RK_C[ADJ ? LAST : 0], gen_slot[0]);
+        if (wv == 3) right_of(QOCX_RK_C[ADJ ? LAST : 0], gr);
+        wave_sync();
+        clk->lap(6);  // (stamped build: between the last stage of a sub-interval and the first of the next)
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            const int i = ADJ ? LAST - s : s;  // the stage of the tableau
+            const int sn = s < LAST ? s + 1 : s;  // (keeps the tableau subscripts below in range)
+            if (wv == 3 && store != nullptr) dump_store(arg, store + (size_t)i * MAT);
+            Mat acc;
+            mat_zero(acc);
+            // ---- round 1
+            if (wv == 0) {
+                clk->lap(0);
+                gemm<false>(acc, gen_slot[s & 1], arg);
+            } else if (wv == 3) {
+                cmat_to_lds<LNB>(arg, slot_y.re, slot_y.im);
+                wave_sync();
+                clk->lap(1);
+                gemm<false>(acc, slot_y, gr);
+            } else {
+                clk->lap(0);
+                Mat t;
+                mat_zero(t);
+                gemm<ADJ>(t, op, arg);
+                cmat_scale<LNB>(t, gamma);
+                cmat_to_lds<LNB>(t, tmp.re, tmp.im);
+            }
+            // this wave's quarter of what is known of the next argument (after the last stage: of the
+            // new density / cotangent)
+            {
+                double pr, pi;
+                if (s == LAST) {
+                    pr = nr;
+                    pi = ni;
+                    if (!ADJ) {
+#pragma unroll
+                        for (int t = 0; t < LAST; ++t)
+                            if (QOCX_RK_B[t] != 0.0) {
+                                pr = fma(QOCX_RK_B[t], hr[t], pr);
+                                pi = fma(QOCX_RK_B[t], hi[t], pi);
+                            }
+                    }
+                } else {
+                    if (ADJ) {
+                        pr = 0;
+                        pi = 0;
+                        if (QOCX_RK_B[LAST - sn] != 0.0) {
+                            pr = (ss.h * QOCX_RK_B[LAST - sn]) * br;
+                            pi = (ss.h * QOCX_RK_B[LAST - sn]) * bi;
+                        }
+                    } else {
+                        pr = br;
+                        pi = bi;
+                    }
+#pragma unroll
+                    for (int t = 0; t < s; ++t)
+                        if (q2_coef(ADJ, sn, t) != 0.0) {
+                            pr = fma(q2_coef(ADJ, sn, t), hr[t], pr);
+                            pi = fma(q2_coef(ADJ, sn, t), hi[t], pi);
+                        }
+                }
+                pre[(size_t)((s + 1) & 1) * MAT + wv * 64 + lane] = make_double2(pr, pi);
+            }
+            // the next stage's generator factors, beside the products
+            if (s < LAST) {
+                const double cn = QOCX_RK_C[ADJ ? LAST - sn : sn];
+                if (wv == 0) left_to_slot(cn, gen_slot[(s + 1) & 1]);
+                if (wv == 3) right_of(cn, gr);
+            }
+            clk->lap(2);
+            __syncthreads();  // M
+            clk->lap(4);
+            // ---- round 2: t_i Op_i^H along K
+            if (wv == 1 || wv == 2) gemm_half<0>(acc, tmp, opr);
+            else gemm_half<1>(acc, tmp, opr);
+            dump_store(acc, parts + (size_t)wv * MAT);
+            if (s == LAST && wv == 0) post();
+            clk->lap(3);
+            __syncthreads();  // E
+            clk->lap(4);
+            // ---- k_i whole, this wave's quarter of it, the next argument
+            Mat k;
+            dump_load(k, parts);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                Mat pw;
+                dump_load(pw, parts + (size_t)w * MAT);
+                mat_axpy(k, 1.0, pw);
+            }
+            double kr_, ki_;
+            quarter_of(k, wv, kr_, ki_);
+            if (ADJ) {
+                nr += kr_;
+                ni += ki_;
+            }
+            hr[s] = ss.h * kr_;
+            hi[s] = ss.h * ki_;
+            if (s < LAST) {
+                dump_load(arg, pre + (size_t)((s + 1) & 1) * MAT);
+                if (q2_coef(ADJ, sn, s) != 0.0) mat_axpy(arg, ss.h * q2_coef(ADJ, sn, s), k);
+            } else {
+                dump_load(result, pre + (size_t)((s + 1) & 1) * MAT);
+                if (ADJ) mat_axpy(result, 1.0, k);
+                else if (QOCX_RK_B[LAST] != 0.0) mat_axpy(result, ss.h * QOCX_RK_B[LAST], k);
+            }
+            clk->lap(5);
+        }
+    }
+
     // forward sub-interval, the 12 stage derivatives in registers (192 of them at n <= 16); the
     // stage loop is unrolled and the zeros of the tableau vanish at compile time
     __device__ __forceinline__ void substep_reg(const SubStep& ss, Mat& y0, double2* ystore) const {
@@ -938,7 +1187,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     const int lane = lane_id();
     const int S = a.S, K = a.K, nops = a.nops, nsub = a.nsub;
     const int b = blockIdx.x;
-    const int wv = MW ? (int)(threadIdx.x >> 6) : 0, nwaves = waves(nops);
+    // (Q2: the wave index as a scalar the compiler knows to be uniform)
+    const int wv = Q2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : MW ? (int)(threadIdx.x >> 6) : 0,
+              nwaves = waves(nops);
     const bool lead = !MW || wv == 0;  // the wave that owns the shared bookkeeping
     char* p = smem;
     const Slot slot_gen = slot_at(p); p += SLOT_BYTES;
@@ -1015,6 +1266,25 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         c_gp = cache + 4 * (size_t)MAT; c_gpd = c_gp + (size_t)K * MAT; c_gpt = c_gpd + (size_t)K * MAT;
         block_sync();
     }
+    if constexpr (Q2) {
+        // substep_q2 leaves kdump[6 ..] unused: the constant dumps THIS pass builds its generators
+        // from (forward: A0L A0R Gp_k, unit adjoint: their conjugate transposes; K <= 4,
+        // launch_lindblad) go there - a trip to L2 per sub-interval otherwise
+        const bool adj = a.phase == 2;
+        double2* cache = kdump + 6 * (size_t)MAT;
+        if (lead) {
+            Mat t;
+            dump_load(t, adj ? a.a0ld_cimg : a.a0l_cimg);
+            dump_store(t, cache);
+            dump_load(t, adj ? a.a0rd_cimg : a.a0r_cimg);
+            dump_store(t, cache + MAT);
+            for (int k = 0; k < K; ++k) {
+                dump_load(t, (adj ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
+                dump_store(t, cache + (size_t)(2 + k) * MAT);
+            }
+        }
+        block_sync();
+    }
     StampClock<STAMP> clock;
     clock.start();
     const Wave w{a, wv, nwaves, slot_gen, slot_y, slot_tmp, slot_zk, slot_zy, op_planar, parts,
@@ -1026,10 +1296,124 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     double cost = 0;
     // 1 / 2: the two launches of the two-sided evaluation (several waves per seed, n <= 16)
     const int phase = (MW && LNB == 1 && !GS) ? a.phase : 0;
+    // (Q2) the descriptor of a sub-interval and the control knots at its ends arrive one sub-interval
+    // ahead: two dependent trips to L2 per sub-interval leave the critical path. WAVE 0 fetches
+    // them - lane l holds dword l of the descriptor and control value l of the 4 K in flight (three
+    // registers across the stage loop), by VECTOR loads (a scalar load shares its counter with the
+    // LDS traffic of the stages) - and hands the descriptor to the others through sixteen words of
+    // LDS behind the barriers the sub-interval ends with anyway. Only wave 0: the wait for a load
+    // issued before the loop's back edge is a wait for everything the wave has in flight, and the
+    // fourth wave has 48 stores to HBM (stage values / cotangents) in flight at that point.
+    static_assert(sizeof(SubStep) == 64, "sixteen dwords");
+    const double* ctl_v = a.controls + (size_t)b * a.nc * K;
+    auto issue_ss = [&](int q) {  // this lane's dword of substeps[q]
+        const int* ptr = reinterpret_cast<const int*>(a.substeps + min(max(q, 0), nsub - 1)) + (lane & 15);
+        return *ptr;
+    };
+    auto take_ss = [&](int dword) {  // (field by field: a copy through an array would go through scratch)
+        auto i32 = [&](int l) { return __builtin_amdgcn_readlane(dword, l); };
+        auto f64 = [&](int l) { return __hiloint2double(i32(l + 1), i32(l)); };
+        static_assert(offsetof(SubStep, ia1) == 8 && offsetof(SubStep, ib2) == 20 && offsetof(SubStep, wa1) == 24 &&
+                          offsetof(SubStep, step) == 56, "dword indices below and in issue_u");
+        SubStep sd;
+        sd.h = f64(0);
+        sd.ia1 = i32(2); sd.ia2 = i32(3); sd.ib1 = i32(4); sd.ib2 = i32(5);
+        sd.wa1 = f64(6); sd.wa2 = f64(8); sd.wb1 = f64(10); sd.wb2 = f64(12);
+        sd.step = i32(14); sd.first_of_step = i32(15);
+        return sd;
+    };
+    auto issue_u = [&](int dword) {  // lane l < 4 K: knot (l / K) of a1 a2 b1 b2, control l % K
+        const int which = min(lane / K, 3), k = lane - which * K;
+        const int idx = __shfl(dword, 2 + which);  // ia1 ia2 ib1 ib2 are dwords 2 .. 5 of the descriptor
+        return lane < 4 * K ? ctl_v[(size_t)idx * K + k] : 0.0;
+    };
+    auto take_u = [&](const SubStep& sd, double cv, double (&ua)[QOCX_LINDBLAD_MAX_K],
+                      double (&ub)[QOCX_LINDBLAD_MAX_K]) {
+        const int lo = __double2loint(cv), hi = __double2hiint(cv);
+        auto at = [&](int l) {
+            return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+        };
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
+            ua[k] = 0;
+            ub[k] = 0;
+            if (k < K) {
+                ua[k] = sd.wa1 * at(k) + sd.wa2 * at(K + k);
+                ub[k] = sd.wb1 * at(2 * K + k) + sd.wb2 * at(3 * K + k);
+            }
+        }
+    };
+    // the mail box (the second set of `parts`: unused by substep_q2): sixteen dwords of descriptor,
+    // then u_k at the two ends of the sub-interval
+    int* mail = reinterpret_cast<int*>(parts + 4 * (size_t)MAT);
+    double* mail_u = reinterpret_cast<double*>(mail + 16);
+    double cv_nxt = 0;  // wave 0: control knots of the NEXT sub-interval (in flight)
+    int sw_nxt = 0;     // wave 0: its descriptor, and `sw_after` the one after it (in flight)
+    int sw_after = 0;
+    // wave 0 posts the next sub-interval: descriptor and end-point controls
+    auto post_mail = [&](int dword, double cv) {
+        if (lane < 16) mail[lane] = dword;
+        const SubStep sd = take_ss(dword);
+        double ua1[QOCX_LINDBLAD_MAX_K], ub1[QOCX_LINDBLAD_MAX_K];
+        take_u(sd, cv, ua1, ub1);
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+            if (k < K && lane == 0) {
+                mail_u[k] = ua1[k];
+                mail_u[QOCX_LINDBLAD_MAX_K + k] = ub1[k];
+            }
+    };
+    // the top of a sub-interval: every wave reads the mail; wave 0 sends out the next fetches
+    auto read_mail = [&](double (&ua)[QOCX_LINDBLAD_MAX_K], double (&ub)[QOCX_LINDBLAD_MAX_K]) {
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
+            ua[k] = 0;
+            ub[k] = 0;
+            if (k < K) {
+                ua[k] = mail_u[k];
+                ub[k] = mail_u[QOCX_LINDBLAD_MAX_K + k];
+            }
+        }
+    };
+    const int q2_dir = phase == 2 ? -1 : 1;
+    if constexpr (Q2) {
+        const int q0 = phase == 2 ? nsub - 1 : 0;
+        if (wv == 0) {
+            const int sw0 = issue_ss(q0);
+            post_mail(sw0, issue_u(sw0));
+            sw_nxt = issue_ss(q0 + q2_dir);
+        }
+        block_sync();
+    }
+    // (Q2) one density, no step costs, no densities or cotangents per step asked for: the density
+    // (cotangent) stays in every wave's registers from sub-interval to sub-interval - no trip
+    // through `dens` / `lam`, none of the three barriers that went with it
+    const bool q2_fast = Q2 && S == 1 && !a.has_step_costs && a.step_densities == nullptr &&
+                         a.inj_index == nullptr;
+    Mat carried;
+    mat_zero(carried);
+    if (q2_fast && phase != 2) dump_load(carried, dens);
     for (int q = 0; q < (phase == 2 ? 0 : nsub); ++q) {
-        const SubStep ss = a.substeps[q];
+        SubStep ss;
+        double ua[QOCX_LINDBLAD_MAX_K], ub[QOCX_LINDBLAD_MAX_K];
+        if constexpr (Q2) {
+            ss = take_ss(mail[lane & 15]);
+            read_mail(ua, ub);
+            if (wv == 0) {  // the controls of the next sub-interval and the descriptor after it set out
+                cv_nxt = issue_u(sw_nxt);
+                sw_after = issue_ss(q + 2);
+            }
+        } else {
+            ss = a.substeps[q];
+        }
+        auto post = [&]() {
+            post_mail(sw_nxt, cv_nxt);
+            sw_nxt = sw_after;
+        };
+        (void)post;
         if (ss.first_of_step && lead) {
-            if (ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
+            // (without step costs the walk over the cost list is two dependent trips to L2 for nothing)
+            if (a.has_step_costs && ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
                 cost += density_costs(a, true, false, dens, nullptr);
             if (a.step_densities != nullptr)
                 for (int s = 0; s < S; ++s) {
@@ -1039,6 +1423,14 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
                                         (((size_t)b * (a.nsteps + 1) + ss.step) * S + s) * MAT);
                 }
         }
+        if (q2_fast) {
+            if constexpr (Q2) {
+                if (lead) dump_store(carried, ckpt_b + (size_t)q * MAT);
+                w.template substep_q2<false>(ss, ua, ub, carried, carried,
+                                             a.ystages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+            }
+            continue;
+        }
         for (int s = 0; s < S; ++s) {
             Mat y0;
             dump_load(y0, dens + (size_t)s * MAT);
@@ -1046,7 +1438,9 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             double2* ys = a.ystages != nullptr
                               ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                               : nullptr;
-            if (QUARTER && a.a0_tab == nullptr && a.gp_tab == nullptr)
+            if constexpr (Q2)  // (launch_lindblad: phases 1 / 2, constant H0 / G_k, stage values kept)
+                w.template substep_q2<false>(ss, ua, ub, y0, y0, ys, [&]() { if (s == S - 1) post(); });
+            else if (QUARTER && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.substep_q(ss, y0, ys);
             else if (REG && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.substep_reg(ss, y0, ys);  // (ys == nullptr: forward only, or the adjoint recomputes)
@@ -1057,8 +1451,13 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             block_sync();
         }
     }
+    if (q2_fast && phase != 2) {
+        if (lead) dump_store(carried, dens);
+        block_sync();
+    }
     if (lead && phase != 2) {
-        if ((a.nsteps % a.cost_eval_step) == 0) cost += density_costs(a, true, false, dens, nullptr);
+        if (a.has_step_costs && (a.nsteps % a.cost_eval_step) == 0)
+            cost += density_costs(a, true, false, dens, nullptr);
         cost += density_costs(a, false, true, dens, nullptr);
         if (lane == 0) a.cost_out[b] = cost;
         if (phase == 1) {
@@ -1122,8 +1521,33 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     }
     block_sync();
 
+    if (q2_fast && phase == 2) dump_load(carried, lam);
     for (int q = nsub - 1; q >= 0; --q) {
-        const SubStep ss = a.substeps[q];
+        SubStep ss;
+        double ua[QOCX_LINDBLAD_MAX_K], ub[QOCX_LINDBLAD_MAX_K];
+        if constexpr (Q2) {
+            ss = take_ss(mail[lane & 15]);
+            read_mail(ua, ub);
+            if (wv == 0) {  // the controls of the next sub-interval and the descriptor after it set out
+                cv_nxt = issue_u(sw_nxt);
+                sw_after = issue_ss(q - 2);
+            }
+        } else {
+            ss = a.substeps[q];
+        }
+        auto post = [&]() {
+            post_mail(sw_nxt, cv_nxt);
+            sw_nxt = sw_after;
+        };
+        (void)post;
+        if (q2_fast) {
+            if constexpr (Q2) {
+                const Mat lambda = carried;
+                w.template substep_q2<true>(ss, ua, ub, lambda, carried,
+                                            a.kbstages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+            }
+            continue;
+        }
         double ga[QOCX_LINDBLAD_MAX_K], gb[QOCX_LINDBLAD_MAX_K];
 #pragma unroll
         for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
@@ -1131,16 +1555,23 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             gb[k] = 0;
         }
         for (int s = 0; s < S; ++s) {
-            Mat y0;
-            dump_load(y0, ckpt_b + ((size_t)q * S + s) * MAT);
             const double2* ys = a.ystages != nullptr
                                     ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                                     : nullptr;
-            if (ys == nullptr) w.substep(ss, q, y0, false);  // recompute the stage derivatives
+            Mat y0;
+            mat_zero(y0);
+            if (ys == nullptr) {  // recompute the stage derivatives from the checkpoint
+                dump_load(y0, ckpt_b + ((size_t)q * S + s) * MAT);
+                w.substep(ss, q, y0, false);
+            }
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
-            if (QUARTER && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
+            if constexpr (Q2)
+                w.template substep_q2<true>(ss, ua, ub, lambda, lambda_new,
+                                            a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT,
+                                            [&]() { if (s == S - 1) post(); });
+            else if (QUARTER && ys != nullptr && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.adjoint_substep_q(ss, lambda, lambda_new, ga, gb, ys,
                                     phase == 2 ? a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                                                : nullptr);
@@ -1181,20 +1612,20 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 };  // struct LB
 
 // MW4: the multi-wave form with exactly four wavefronts (nops = 2), one per SIMD: the
-// quarter-split stage loops
-template <int LNB, bool GS, bool MW, bool MW4, bool STAMP = false>
+// quarter-split stage loops. Q2: the launches of the two-sided evaluation (substep_q2).
+template <int LNB, bool GS, bool MW, bool MW4, bool STAMP = false, bool Q2 = false>
 __global__ __launch_bounds__(MW ? (MW4 ? 256 : 384) : 64) void lindblad_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LB<LNB, GS, MW, (LNB == 1 && !GS && !MW), STAMP, MW4>::run(a, smem);
+    LB<LNB, GS, MW, (LNB == 1 && !GS && !MW), STAMP, MW4, Q2>::run(a, smem);
 }
 
-template <int LNB, bool GS, bool MW, bool MW4 = false, bool STAMP = false>
+template <int LNB, bool GS, bool MW, bool MW4 = false, bool STAMP = false, bool Q2 = false>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
     typedef LB<LNB, GS, MW> I;
     const int bytes = I::lds_bytes(a.S, a.nops, (MW && a.cache_gen) ? a.K : -1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4, STAMP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4, STAMP>), dim3(batch),
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2>), dim3(batch),
                        dim3(64 * I::waves(a.nops)), bytes, st, a);
 }
 
@@ -1270,12 +1701,18 @@ void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st) {
 }
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
+    // the two-sided evaluation's stage loop: four waves, constant H0 / G_k, stage values kept
+    const bool q2 = a.q2 && a.phase != 0 && a.a0_tab == nullptr && a.gp_tab == nullptr && a.ystages != nullptr &&
+                    a.op_tab == nullptr && a.K <= 4;
     if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
 #ifdef QOCX_DIAG
+    else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr && q2)
+        launch_t<1, false, true, true, true, true>(a, batch, st);  // stamped builds (qocx_diag.h)
     else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr)
-        launch_t<1, false, true, true, true>(a, batch, st);  // stamped build (qocx_diag.h)
+        launch_t<1, false, true, true, true>(a, batch, st);
 #endif
+    else if (a.multi_wave && a.nops == 2 && q2) launch_t<1, false, true, true, false, true>(a, batch, st);
     else if (a.multi_wave && a.nops == 2) launch_t<1, false, true, true>(a, batch, st);
     else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
     else launch_t<1, false, false>(a, batch, st);

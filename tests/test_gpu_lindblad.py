@@ -295,6 +295,36 @@ def test_lindblad_launch_variants_agree(engine, name):
         engine.debug_lindblad_knobs(0, 256, 0)
 
 
+@pytest.mark.parametrize("name", ["lindblad_n4", "lindblad_c4_short", "lindblad_wc_n16"])
+def test_lindblad_two_sided_stage_loops_agree(engine, name):
+    """
+    Round 4: the launches of the two-sided evaluation run their own stage loop (substep_q2: 18 of the
+    72 MFMAs of a right-hand side on every wave, one barrier less per stage, generators and
+    descriptors prepared ahead; knob "lindblad_q2"). Against the quarter-split loops it replaces
+    (knob 0) and the golden vectors: one density (the register-resident sub-interval transition),
+    two densities (the path through LDS), a well-conditioned gradient.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.lindblad_case_by_name(name)
+    g = golden(name)
+    gh.setup_lindblad_engine(engine, case)
+    u = real_form(case, np.stack(case.controls))
+    try:
+        engine.set_knob("lindblad_q2", 0)
+        c0, g0, f0 = engine.evaluate_lindblad(u)
+        engine.set_knob("lindblad_q2", 1)
+        c1, g1, f1 = engine.evaluate_lindblad(u)
+    finally:
+        engine.set_knob("lindblad_q2", 1)
+    assert np.max(np.abs(c1 - c0)) < 1e-13
+    assert np.max(np.abs(f1 - f0)) < 1e-13
+    assert np.max(np.abs(g1 - g0)) < 1e-12 * max(1.0, np.max(np.abs(g0)))
+    for b in range(u.shape[0]):
+        assert abs(c1[b] - g["error"][b]) < 1e-9
+        assert np.max(np.abs(f1[b] - g["final_densities"][b])) < 1e-8
+        assert lindblad_grad_close(g1[b], real_form(case, g["grads_ad"][b]), case)
+
+
 def test_bench_lindblad_batch_is_pinned_on_itself(engine):
     """
     VERDICT r2 weak #1: BASELINE configs[3] is pinned on ITSELF. The whole 64-seed batch of

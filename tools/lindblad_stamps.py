@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 PHASES = ["stage value / kbar (axpys)", "generator + operands to LDS", "MFMA products",
-          "partial result to LDS", "barrier", "sum of partial results", "control cotangents"]
+          "partial result to LDS", "barrier", "sum of partial results",
+          "control cotangents (two-sided stage loop: between sub-intervals)"]
 WAVES = ["generator terms", "operator 1", "operator 2", "control cotangents"]
 
 
@@ -34,15 +35,21 @@ def main():
     engine.evaluate_lindblad(u)
     engine.set_knob("lindblad_stamps", 1)
     engine.evaluate_lindblad(u)
-    st = engine.read_stamps(seeds, roles=6).astype(np.float64)
-    stages = 24.0 * engine.lindblad_last_subintervals() / seeds  # forward + adjoint stage passes
+    raw = engine.read_stamps(2 * seeds, roles=6).astype(np.float64)
+    subs = engine.lindblad_last_subintervals() / seeds
     out = {}
-    for wv, name in enumerate(WAVES):
-        mean = st[:, wv, :].mean(axis=0)
-        cycles = mean[:7].sum()
-        out[name] = {"cycles_per_stage": cycles / stages,
-                     "clock_GHz": cycles / (mean[7] * 10.0) if mean[7] > 0 else 0.0,
-                     "phases": {PHASES[k]: round(mean[k] / stages, 1) for k in range(7)}}
+    # two-sided evaluation: the forward pass and the unit adjoint are launches of their own
+    passes = [("forward pass", raw[:seeds], 12.0 * subs), ("unit adjoint", raw[seeds:], 12.0 * subs)]
+    if raw[seeds:].sum() == 0:
+        passes = [("forward + adjoint (one launch)", raw[:seeds], 24.0 * subs)]
+    for title, st, stages in passes:
+        out[title] = {}
+        for wv, name in enumerate(WAVES):
+            mean = st[:, wv, :].mean(axis=0)
+            cycles = mean[:7].sum()
+            out[title][name] = {"cycles_per_stage": cycles / stages,
+                                "clock_GHz": cycles / (mean[7] * 10.0) if mean[7] > 0 else 0.0,
+                                "phases": {PHASES[k]: round(mean[k] / stages, 1) for k in range(7)}}
     print(json.dumps(out, indent=1))
     engine.close()
 
