@@ -305,6 +305,7 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *                   hoisted into constant matrices); "magnus_4w": four-wave LDS-resident Magnus
  *                   kernels at 17 <= n <= 32; "magnus_general": the general commutator forms.
  *   "lindblad_two_sided", "lindblad_side_limit": forward and unit-adjoint Lindblad passes side by side.
+ *   "lindblad_q2": their stage loop with 18 of the 72 MFMAs of a right-hand side per wave (0: the quarter-split loops).
  *   "sweep_onebuf", "k3_split": launch shapes of the sweep / of K3.
  * Diagnostic knobs - libqocx_diag.so only (make diag, -DQOCX_DIAG; the product library answers
  * QOCX_ERR_ARG): "dbg_skip", "sweep3_dbg", "k1a_dbg" switch parts of an evaluation off for timing

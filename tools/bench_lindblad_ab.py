@@ -25,8 +25,8 @@ def main():
     ap.add_argument("--seeds", type=int, default=bench.LB_SEEDS)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--diag", action="store_true",
-                    help="load libqocx_diag.so (diagnostic knobs such as lindblad_dbg; its kernels carry the "
-                         "experiments' tests and are slower than the product's)")
+                    help="load libqocx_diag.so (for a diagnostic knob; its kernels carry the experiments' tests "
+                         "and are slower than the product's)")
     args = ap.parse_args()
     if args.diag:
         from tools import diaglib
