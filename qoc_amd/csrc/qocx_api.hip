@@ -1220,6 +1220,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             fa.stamps = ctx->stamps.p;
         }
         fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
+        fa.herm_tiles = (int)ctx->knob("k1a_herm4", 1);
         if (ctx->lu_fallbacks.ensure(1)) return QOCX_ERR_HIP;
         if (b0 == 0) HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), cs));
         fa.lu_fallbacks = ctx->lu_fallbacks.p;
@@ -2422,7 +2423,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -44,6 +44,7 @@ struct FactorArgs {
     int prefer_low = 0;        // the host's bound of ||dt a||_1 is below theta_9 (four-wave K1a: which
                                // of its two paths is inlined, qocx_pade4.hip)
     int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
+    int herm_tiles = 1;        // four-wave K1a, Hermitian generators, orders 3 / 5: two thirds of the tiles (knob "k1a_herm4")
     // diagnostic build only (qocx_diag.h; knobs "k1a_dbg", "k1a_stamps"): bits 0-1 s_setprio level of
     // the fused factorisation, bit 2 no factorisation at all (garbage), and the cycle sums of the
     // stamped build, [2 waves][8]

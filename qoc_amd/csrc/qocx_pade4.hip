@@ -234,6 +234,247 @@ __device__ __attribute__((noinline)) void low_order_call(Gen gen, const Out& out
     low_order_impl<NT>(gen, out, smem, w, order, a);
 }
 
+// Orders 3 to 9 for HERMITIAN generators (a skew-Hermitian; x2, x4, wp, v Hermitian; u skew-Hermitian;
+// Q = P^H). Wave w computes only the row tiles w, w + 1 (, w + 2 for waves 0 and 1 of four) - cyclically -
+// of its column block: 6 of the 9 tiles (10 of 16), two per wave (3, 3, 2, 2), instead of three (four)
+// per wave; the other tiles of every matrix are their mirrors, written into the A-operand slot next to
+// the computed ones, and the B operand of x4 = x2 x2 is read from that slot like the A operand.
+template <int NT>
+struct Herm {
+    static constexpr int NR = NT == 3 ? 2 : 3;  // row tiles of a wave (the last one: waves 0, 1 of four)
+};
+template <int NT>
+struct HCol {  // tile d <-> row tile (w + d) % NT of column block w
+    d4 re[Herm<NT>::NR], im[Herm<NT>::NR];
+};
+template <int NT>
+struct HAcc {
+    d4 t1[Herm<NT>::NR], t2[Herm<NT>::NR], t3[Herm<NT>::NR];
+};
+template <int NT>
+__device__ __forceinline__ int herm_row(int w, int d) {
+    const int r = w + d;
+    return r >= NT ? r - NT : r;
+}
+template <int NT>
+__device__ __forceinline__ int herm_count(int w) {
+    return NT == 3 ? 2 : (w < 2 ? 3 : 2);
+}
+// acc(d) += A(row(d), :) B(:, w), d < nr
+template <int NT, class BFrag>
+__device__ __forceinline__ void gemm3h(HAcc<NT>& acc, const double* slot, int w, int nr, BFrag bf) {
+    constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE, NR = Herm<NT>::NR;
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+    int rowoff[NR];
+#pragma unroll
+    for (int d = 0; d < NR; ++d) rowoff[d] = (16 * herm_row<NT>(w, d) + c) * PITCH + q;
+#pragma unroll
+    for (int kk = 0; kk < 4 * NT; ++kk) {
+        double are[NR], aim[NR], asum[NR];
+#pragma unroll
+        for (int d = 0; d < NR; ++d)
+            if (d < 2 || nr == 3) {
+                are[d] = slot[rowoff[d] + 4 * kk];
+                aim[d] = slot[PLANE + rowoff[d] + 4 * kk];
+                asum[d] = are[d] + aim[d];
+            }
+        double bre, bim;
+        bf(kk, bre, bim);
+        const double bsum = bre + bim;
+#pragma unroll
+        for (int d = 0; d < NR; ++d)
+            if (d < 2 || nr == 3) {
+                acc.t1[d] = mfma_f64(are[d], bre, acc.t1[d]);
+                acc.t2[d] = mfma_f64(aim[d], bim, acc.t2[d]);
+                acc.t3[d] = mfma_f64(asum[d], bsum, acc.t3[d]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the wave's tiles and their mirrors (tile (w, row(d)) = sign conj(tile (row(d), w))^T, d >= 1) into the slot
+template <int NT>
+__device__ __forceinline__ void stage_herm(double* slot, int w, int nr, const HCol<NT>& m, double sign) {
+    constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE, NR = Herm<NT>::NR;
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+    for (int d = 0; d < NR; ++d)
+        if (d < 2 || nr == 3) {
+            const int row = herm_row<NT>(w, d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (16 * row + 4 * r + q) * PITCH + 16 * w + c;
+                slot[off] = m.re[d][r];
+                slot[PLANE + off] = m.im[d][r];
+                if (d > 0) {
+                    const int moff = (16 * w + c) * PITCH + 16 * row + 4 * r + q;
+                    slot[moff] = sign * m.re[d][r];
+                    slot[PLANE + moff] = -sign * m.im[d][r];
+                }
+            }
+        }
+}
+template <int NT, class Gen>
+__device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* smem, int w, int order,
+                                               Col<NT>& a) {
+    constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE, NR = Herm<NT>::NR;
+    typedef HCol<NT> HCol;
+    double* sl = smem;
+    const int lane = lane_id();
+    const int q = lane >> 4, c = lane & 15;
+    const int nr = herm_count<NT>(w);
+    const double* bt = pade_table(order);
+    const double b0 = bt[0];
+    HAcc<NT> acc;
+    auto zero = [&]() {
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+            acc.t1[d] = d4{0, 0, 0, 0};
+            acc.t2[d] = d4{0, 0, 0, 0};
+            acc.t3[d] = d4{0, 0, 0, 0};
+        }
+    };
+    auto finish = [&](HCol& m) {
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+            m.re[d] = acc.t1[d] - acc.t2[d];
+            m.im[d] = acc.t3[d] - acc.t1[d] - acc.t2[d];
+        }
+    };
+    // x2 = a a: A from the slot (the generator, staged by body()), B = this wave's column block of it
+    HCol x, wp, v, u;
+    zero();
+    gemm3h<NT>(acc, sl, w, nr, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    finish(x);
+#pragma unroll
+    for (int d = 0; d < NR; ++d) {
+        wp.re[d] = bt[3] * x.re[d];
+        wp.im[d] = bt[3] * x.im[d];
+        v.re[d] = bt[2] * x.re[d];
+        v.im[d] = bt[2] * x.im[d];
+    }
+    auto add_power = [&](const HCol& y, double bw, double bv) {
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+            wp.re[d] += bw * y.re[d];
+            wp.im[d] += bw * y.im[d];
+            v.re[d] += bv * y.re[d];
+            v.im[d] += bv * y.im[d];
+        }
+    };
+    auto slot_column = [&](int kk, double& bre, double& bim) {  // B = column block w of the staged matrix
+        const int off = (4 * kk + q) * PITCH + 16 * w + c;
+        bre = sl[off];
+        bim = sl[PLANE + off];
+    };
+    __syncthreads();  // H1: every read of a is done
+    if (order >= 5) {
+        stage_herm<NT>(sl, w, nr, x, 1.0);
+        __syncthreads();  // H2
+        // x4 = x2 x2, both operands from the slot
+        zero();
+        gemm3h<NT>(acc, sl, w, nr, slot_column);
+        HCol x4;
+        finish(x4);
+        add_power(x4, bt[5], bt[4]);
+        if (order >= 7) {
+            // x6 = x4 x2 (the powers commute): this wave's column block of x2 leaves the slot for the
+            // registers, x4 takes the slot; x8 = x4 x4 with both operands from the slot again
+            Col<NT> c2;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int off = (16 * ti + 4 * r + q) * PITCH + 16 * w + c;
+                    c2.re[ti][r] = sl[off];
+                    c2.im[ti][r] = sl[PLANE + off];
+                }
+            __syncthreads();  // every read of x2 is done
+            stage_herm<NT>(sl, w, nr, x4, 1.0);
+            __syncthreads();
+            zero();
+            gemm3h<NT>(acc, sl, w, nr, [&](int kk, double& bre, double& bim) {
+                bre = c2.re[kk >> 2][kk & 3];
+                bim = c2.im[kk >> 2][kk & 3];
+            });
+            HCol x6;
+            finish(x6);
+            add_power(x6, bt[7], bt[6]);
+            if (order == 9) {
+                zero();
+                gemm3h<NT>(acc, sl, w, nr, slot_column);
+                HCol x8;
+                finish(x8);
+                add_power(x8, bt[9], bt[8]);
+            }
+        }
+        __syncthreads();  // H3: every read of the slot is done
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)  // tile 0 is the diagonal tile (w, w)
+        if (4 * r + q == c) v.re[0][r] += b0;
+    stage_herm<NT>(sl, w, nr, wp, 1.0);
+    // u = wp a + b1 a, B = the generator's column block (rebuilt)
+    gen(a, w);
+#pragma unroll
+    for (int d = 0; d < NR; ++d) {
+        const int row = herm_row<NT>(w, d);
+        d4 are = a.re[0], aim = a.im[0];
+#pragma unroll
+        for (int t = 1; t < NT; ++t)
+            if (row == t) {
+                are = a.re[t];
+                aim = a.im[t];
+            }
+        acc.t1[d] = bt[1] * are;
+        acc.t2[d] = d4{0, 0, 0, 0};
+        acc.t3[d] = bt[1] * (are + aim);
+    }
+    __syncthreads();  // H4
+    gemm3h<NT>(acc, sl, w, nr, [&](int kk, double& bre, double& bim) {
+        bre = a.re[kk >> 2][kk & 3];
+        bim = a.im[kk >> 2][kk & 3];
+    });
+    finish(u);
+    // ---- P = v - u ; Q = v + u (expm.py:246): the wave's tiles, and their mirrors Q = P^H
+#pragma unroll
+    for (int d = 0; d < NR; ++d)
+        if (d < 2 || nr == 3) {
+            const int row = herm_row<NT>(w, d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = (16 * w + c) * NP + 16 * row + 4 * r + q;
+                const double qr = v.re[d][r] + u.re[d][r], qi = v.im[d][r] + u.im[d][r];
+                const double pr = v.re[d][r] - u.re[d][r], pi = v.im[d][r] - u.im[d][r];
+                out.q_img[idx] = make_double2(qr, qi);
+                out.p_img[idx] = make_double2(pr, pi);
+                if (d > 0) {  // element (16 w + c, 16 row + 4 r + q)
+                    const int midx = (16 * row + 4 * r + q) * NP + 16 * w + c;
+                    out.q_img[midx] = make_double2(pr, -pi);
+                    out.p_img[midx] = make_double2(qr, -qi);
+                }
+            }
+        }
+    if constexpr (NT < 4) {
+        // the pad block of the 64 x 64 images: v = b0 I and u = 0 there, so P = Q = b0 I
+        constexpr int NA = Cfg<NT>::NA;
+#pragma unroll
+        for (int r = 0; r < (NP - NA) / 4; ++r) {  // rows NA..63 of this wave's columns
+            const int idx = (16 * w + c) * NP + NA + 4 * r + q;
+            out.q_img[idx] = make_double2(0, 0);
+            out.p_img[idx] = make_double2(0, 0);
+        }
+        for (int e = w * 64 + lane; e < (NP - NA) * NP; e += 64 * NT) {  // columns NA..63
+            const int col = NA + e / NP, row = e % NP;
+            const double2 val = make_double2(row == col ? b0 : 0.0, 0.0);
+            out.q_img[col * NP + row] = val;
+            out.p_img[col * NP + row] = val;
+        }
+    }
+}
+
 // Order 13 (expm.py:153-159). The generator is staged in the slot (barrier 2 has passed); `a` is
 // this wave's column block of it, scaled by 2^-sq.
 template <int NT, class Gen>
@@ -356,7 +597,7 @@ __device__ __attribute__((noinline)) void high_order_call(Gen gen, const Out& ou
 }
 
 // Every wave executes the same barriers; w = the wave's column block (wave-uniform).
-template <int NT, bool LOWINL, class Gen>
+template <int NT, bool LOWINL, bool HERM = false, class Gen>
 __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
     typedef Col<NT> Col;
     double* sl = smem;
@@ -411,7 +652,13 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
     // (both inlined, the [13/13] path spilled 94 registers instead of 22 and ran 11 % slower). One
     // of them is a call; LOWINL - the host's choice from its bound of the norms, FactorArgs::
     // prefer_low - says which one is inlined. Same arithmetic either way.
-    if (order != 13) {
+    if constexpr (HERM) {
+        // Hermitian generators (FactorArgs::hermitian), the host's norm bound below theta_9: orders 3
+        // to 9 on two thirds of the tiles
+        // (the host's bound of the norms is below theta_9: order 13 here means a generator that is not
+        // finite - status bit 2 is set, what is computed does not matter)
+        low_order_herm<NT>(gen, out, smem, w, order == 13 ? 9 : order, a);
+    } else if (order != 13) {
         if constexpr (LOWINL) low_order_impl<NT>(gen, out, smem, w, order, a);
         else low_order_call<NT>(gen, out, smem, w, order);
     } else {
@@ -420,7 +667,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
     }
 }
 
-template <int NT, bool LOWINL>
+template <int NT, bool LOWINL, bool HERM = false>
 __global__ __launch_bounds__(64 * NT, LOWINL ? 2 : 1) void pade_pq4_kernel(FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -473,7 +720,7 @@ __global__ __launch_bounds__(64 * NT, LOWINL ? 2 : 1) void pade_pq4_kernel(Facto
             a.im[ti] = -dt * hre[ti];
         }
     };
-    body<NT, LOWINL>(gen, out, smem, w);
+    body<NT, LOWINL, HERM>(gen, out, smem, w);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
@@ -512,13 +759,13 @@ __global__ __launch_bounds__(64 * NT, (NT == 3 && LOWINL) ? 2 : 1) void pade_pq4
 
 }  // namespace pade4
 
-template <int NT, bool LOWINL>
+template <int NT, bool LOWINL, bool HERM = false>
 static void launch_pq4_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_kernel<NT, LOWINL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pade4::pade_pq4_kernel<NT, LOWINL, HERM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((pade4::pade_pq4_kernel<NT, LOWINL>), dim3(nsteps, batch), dim3(64 * NT), bytes,
+    hipLaunchKernelGGL((pade4::pade_pq4_kernel<NT, LOWINL, HERM>), dim3(nsteps, batch), dim3(64 * NT), bytes,
                        st, a);
 }
 template <int NT, bool LOWINL>
@@ -538,11 +785,14 @@ static void launch_pq4_explicit_t(const double2* a_in, int n, const FactorArgs& 
 // low Pade order - the variant with THAT path inlined runs (same results either way).
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     const bool low = a.prefer_low != 0 && a.pade_policy != 13;
+    const bool herm = low && a.hermitian != 0 && a.herm_tiles != 0;
     if (a.n > 0 && a.n <= 48) {
-        if (low) launch_pq4_t<3, true>(a, nsteps, batch, st);
+        if (herm) launch_pq4_t<3, true, true>(a, nsteps, batch, st);
+        else if (low) launch_pq4_t<3, true>(a, nsteps, batch, st);
         else launch_pq4_t<3, false>(a, nsteps, batch, st);
     } else {
-        if (low) launch_pq4_t<4, true>(a, nsteps, batch, st);
+        if (herm) launch_pq4_t<4, true, true>(a, nsteps, batch, st);
+        else if (low) launch_pq4_t<4, true>(a, nsteps, batch, st);
         else launch_pq4_t<4, false>(a, nsteps, batch, st);
     }
 }
