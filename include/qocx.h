@@ -305,6 +305,8 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *                   hoisted into constant matrices); "magnus_4w": four-wave LDS-resident Magnus
  *                   kernels at 17 <= n <= 32; "magnus_general": the general commutator forms.
  *   "lindblad_two_sided", "lindblad_side_limit": forward and unit-adjoint Lindblad passes side by side.
+ *   "k1a_herm4": four-wave K1a, Hermitian generators, orders 3..9: two thirds of the tiles (0: all tiles).
+ *   "lu_stream": n > 32, K1b of a time segment on a stream of its own beside K1a of the next (0: one stream).
  *   "lindblad_q2": their stage loop with 18 of the 72 MFMAs of a right-hand side per wave (0: the quarter-split loops).
  *   "sweep_onebuf", "k3_split": launch shapes of the sweep / of K3.
  * Diagnostic knobs - libqocx_diag.so only (make diag, -DQOCX_DIAG; the product library answers

@@ -198,6 +198,8 @@ struct qocx_ctx {
     int chunk_user = 0;
     int pipe_user = 0;
     std::vector<hipStream_t> sweep_streams;
+    hipStream_t lu_stream = nullptr;       // K1b of a segment beside K1a of the next one (n > 32)
+    std::vector<hipEvent_t> ev_pq;         // K1a of segment i has finished
     std::vector<hipEvent_t> ev_factored, ev_swept, ev_fwd;
     bool unit_ok = false;          // the only cost is one separable final cost (qocx_sweep_common.h)
     // multi-start driver on the device (qocx_opt_*)
@@ -508,6 +510,19 @@ int qocx_create(int device, qocx_ctx** out) {
     // waves are placed as soon as a SIMD frees up under the compute stream's big grids
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithFlags(&ctx->lu_stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx->lu_stream = nullptr;
+        qocx_destroy(ctx);
+        return fail(QOCX_ERR_HIP, "cannot create the pipeline streams");
+    }
+    for (int i = 0; i < 32; ++i) {
+        hipEvent_t e0;
+        if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess) {
+            qocx_destroy(ctx);
+            return fail(QOCX_ERR_HIP, "cannot create the pipeline streams");
+        }
+        ctx->ev_pq.push_back(e0);
+    }
     for (int i = 0; i < 32; ++i) {
         hipStream_t st;
         hipEvent_t e1, e2, e3;
@@ -593,6 +608,8 @@ int qocx_destroy(qocx_ctx* ctx) {
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto st : ctx->sweep_streams) (void)hipStreamDestroy(st);
+    if (ctx->lu_stream) (void)hipStreamDestroy(ctx->lu_stream);
+    for (auto e : ctx->ev_pq) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_factored) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_swept) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_fwd) (void)hipEventDestroy(e);
@@ -1361,6 +1378,21 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             // gain; with the two-wave K1a (240 registers) and K1b (160) sharing SIMDs 1 % - K1a
             // then takes 1.08 ms per launch beside K1b instead of 0.80 + 0.32 ms in sequence.
             // Not kept: one more stream and eight more events for 0.14 ms.)
+            // n > 32: K1b of this segment on a stream of its own, beside K1a of the next segment - the
+            // four-wave K1a is bound by the matrix pipe, the two-wave / one-wave MFMA factorisation by
+            // its pivot chains, and both fit a CU (knob "lu_stream"; n = 64: see DESIGN.md section 14).
+            // (Measured at n <= 32 with the round-2 kernels: no gain there - comment above.)
+            const bool lu_apart = !fused_lu && ctx->nb == 4 && nseg > 1 && ctx->lu_stream != nullptr &&
+                                  ctx->knob("lu_stream", 1) != 0;
+            if (lu_apart) {
+                HIP_TRY(hipEventRecord(ctx->ev_pq[i], cs));
+                HIP_TRY(hipStreamWaitEvent(ctx->lu_stream, ctx->ev_pq[i], 0));
+                time_begin(ctx, 4, ctx->lu_stream);
+                qocx::launch_lu(ctx->nb, la, (size_t)bc * len, ctx->lu_stream);
+                time_end(ctx, ctx->lu_stream);
+                HIP_TRY(hipEventRecord(ctx->ev_factored[i], ctx->lu_stream));
+                return 0;
+            }
             if (!fused_lu) {
                 time_begin(ctx, 4, cs);
                 qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
@@ -2423,7 +2455,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -348,13 +348,6 @@ __device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* 
         bim = a.im[kk >> 2][kk & 3];
     });
     finish(x);
-#pragma unroll
-    for (int d = 0; d < NR; ++d) {
-        wp.re[d] = bt[3] * x.re[d];
-        wp.im[d] = bt[3] * x.im[d];
-        v.re[d] = bt[2] * x.re[d];
-        v.im[d] = bt[2] * x.im[d];
-    }
     auto add_power = [&](const HCol& y, double bw, double bv) {
 #pragma unroll
         for (int d = 0; d < NR; ++d) {
@@ -378,7 +371,14 @@ __device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* 
         gemm3h<NT>(acc, sl, w, nr, slot_column);
         HCol x4;
         finish(x4);
-        add_power(x4, bt[5], bt[4]);
+        // (wp and v only now: x2 and the accumulators were all that lived through the product)
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+            wp.re[d] = bt[3] * x.re[d] + bt[5] * x4.re[d];
+            wp.im[d] = bt[3] * x.im[d] + bt[5] * x4.im[d];
+            v.re[d] = bt[2] * x.re[d] + bt[4] * x4.re[d];
+            v.im[d] = bt[2] * x.im[d] + bt[4] * x4.im[d];
+        }
         if (order >= 7) {
             // x6 = x4 x2 (the powers commute): this wave's column block of x2 leaves the slot for the
             // registers, x4 takes the slot; x8 = x4 x4 with both operands from the slot again
@@ -411,6 +411,14 @@ __device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* 
             }
         }
         __syncthreads();  // H3: every read of the slot is done
+    } else {
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+            wp.re[d] = bt[3] * x.re[d];
+            wp.im[d] = bt[3] * x.im[d];
+            v.re[d] = bt[2] * x.re[d];
+            v.im[d] = bt[2] * x.im[d];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)  // tile 0 is the diagonal tile (w, w)

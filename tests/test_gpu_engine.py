@@ -602,6 +602,52 @@ def test_random_shapes_fuzz_big(engine):
     assert checked > 15
 
 
+@pytest.mark.parametrize("n", [36, 48, 56, 64])
+def test_hermitian_tiles_of_the_four_wave_pade_kernel(engine, n):
+    """Round 4: for Hermitian generators whose norm bound is below theta_9 the four-wave K1a forms two
+    thirds of the tiles of every product and mirrors the rest (knob "k1a_herm4"). Every order the path
+    contains - 3, 5, 7, 9, chosen through the time step - against the kernel that forms all tiles (knob
+    0), at rounding level, and against the oracle at the parity gate."""
+    import bench
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    rng = np.random.default_rng(3600 + n)
+    h0 = bench.gue(rng, n)
+    g = [bench.gue(rng, n) for _ in range(2)]
+    psi0 = np.eye(n, dtype=np.complex128)[:1]
+    target = np.eye(n, dtype=np.complex128)[1:2]
+    N = 9
+    u = 0.2 * rng.standard_normal((3, N, 2))
+    # the host's bound of ||H||_1 (it picks the kernel: below theta_9 / dt the Hermitian-tile build runs)
+    h_bound = onp.one_norm(h0) + sum(np.max(np.abs(u[..., k])) * onp.one_norm(g[k]) for k in range(2))
+    seen = set()
+    for theta in (0.012, 0.2, 0.8, 2.0):  # bounds below theta_3, theta_5, theta_7, theta_9
+        dt = theta / h_bound
+        engine.set_schroedinger_problem(
+            n, 1, 2, N, N, dt * (N - 1), h0[None], np.stack(g)[None], psi0,
+            costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+        try:
+            engine.set_knob("k1a_herm4", 0)
+            c0, g0, f0 = engine.evaluate(u, True)
+            engine.set_knob("k1a_herm4", 1)
+            c1, g1, f1 = engine.evaluate(u, True)
+            orders = engine.pade_orders()
+        finally:
+            engine.set_knob("k1a_herm4", 1)
+        seen |= {o for o, cnt in orders.items() if cnt}
+        assert orders[13] == 0
+        assert np.max(np.abs(c1 - c0)) < 1e-13
+        assert np.max(np.abs(f1 - f0)) < 1e-13
+        assert np.max(np.abs(g1 - g0)) < 1e-12 * max(1.0, np.max(np.abs(g0)))
+        # the oracle's forward pass (expm of the same generators, the reference's order)
+        for b in range(u.shape[0]):
+            psi = psi0[0].copy()
+            for j in range(N - 1):
+                um = 0.5 * (u[b, j] + u[b, j + 1])  # (control knots at the system times: the mid point)
+                psi = onp.expm_pade(-1j * dt * (h0 + sum(c * gk for c, gk in zip(um, g)))) @ psi
+            assert np.max(np.abs(f1[b, 0] - psi)) < 1e-11
+    assert seen == {3, 5, 7, 9}, seen
+
+
 def test_product_library_rejects_diagnostic_knobs(engine):
     """The timing experiments whose results are garbage are not reachable through libqocx.so."""
     from qoc_amd.engine import QocxError
