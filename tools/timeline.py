@@ -22,9 +22,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--knob", action="append", default=[])
     ap.add_argument("--seeds", type=int, default=bench.SEEDS_PER_GPU)
+    ap.add_argument("--dim", type=int, default=bench.DIM, help="Hilbert size (GUE problem of bench.py)")
+    ap.add_argument("--diag", action="store_true", help="load libqocx_diag.so (for a diagnostic knob)")
     args = ap.parse_args()
-    from tools import diaglib
-    diaglib.load()  # the measurement build: diagnostic knobs (qocx_diag.h)
+    bench.DIM = args.dim
+    if args.diag:
+        from tools import diaglib
+        diaglib.load()  # the measurement build: diagnostic knobs (qocx_diag.h)
     from qoc_amd.engine import Engine, COST_TARGET_COHERENT
     engine = Engine(0)
     h0, g, psi0, target = bench.make_problem()
