@@ -1242,7 +1242,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         if (b0 == 0) HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), cs));
         fa.lu_fallbacks = ctx->lu_fallbacks.p;
         fa.pade_policy = (int)ctx->knob("pade_order", 0);  // 0: by norm (qocx_wave.h), 13: always 13
-        fa.prefer_low = ctx->norm_bound < 2.097847961257068 ? 1 : 0;  // theta_9
+        fa.prefer_low = ctx->norm_bound < 2.539398330063230e-01 ? 2 : ctx->norm_bound < 2.097847961257068 ? 1 : 0;  // theta_5, theta_9
         fa.q_img = ctx->q_img.p; fa.lu_img = ctx->lu_img.p;
         fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         // K1b fused into the two-wave K1a (17 <= n <= 32; knob "fuse_lu" 0 restores the two kernels)

@@ -41,8 +41,8 @@ struct FactorArgs {
     int hermitian;             // every h0[t], g[t][k] is exactly Hermitian
     int n;                     // Hilbert size (used by the sixteen-tile K1a: <= 48 -> nine tiles); 0: unknown
     int pade_policy = 0;       // 0: Pade order by norm (qocx_wave.h), 13: always [13/13]
-    int prefer_low = 0;        // the host's bound of ||dt a||_1 is below theta_9 (four-wave K1a: which
-                               // of its two paths is inlined, qocx_pade4.hip)
+    int prefer_low = 0;        // the host's bound of ||dt a||_1 is below theta_9 (1) or theta_5 (2): which
+                               // paths the four-wave K1a inlines (qocx_pade4.hip)
     int skip_q = 0;            // timing experiment: the two-wave K1a does not store Q
     int herm_tiles = 1;        // four-wave K1a, Hermitian generators, orders 3 / 5: two thirds of the tiles (knob "k1a_herm4")
     // diagnostic build only (qocx_diag.h; knobs "k1a_dbg", "k1a_stamps"): bits 0-1 s_setprio level of

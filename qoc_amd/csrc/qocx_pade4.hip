@@ -313,7 +313,9 @@ __device__ __forceinline__ void stage_herm(double* slot, int w, int nr, const HC
             }
         }
 }
-template <int NT, class Gen>
+// MAXORD: the highest order the build contains - 5 when the host's norm bound is below theta_5 (the
+// sixteen-tile build then has no spills), else 9
+template <int NT, int MAXORD, class Gen>
 __device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* smem, int w, int order,
                                                Col<NT>& a) {
     constexpr int PITCH = Cfg<NT>::PITCH, PLANE = Cfg<NT>::PLANE, NR = Herm<NT>::NR;
@@ -379,7 +381,7 @@ __device__ __forceinline__ void low_order_herm(Gen gen, const Out& out, double* 
             v.re[d] = bt[2] * x.re[d] + bt[4] * x4.re[d];
             v.im[d] = bt[2] * x.im[d] + bt[4] * x4.im[d];
         }
-        if (order >= 7) {
+        if (MAXORD >= 7 && order >= 7) {
             // x6 = x4 x2 (the powers commute): this wave's column block of x2 leaves the slot for the
             // registers, x4 takes the slot; x8 = x4 x4 with both operands from the slot again
             Col<NT> c2;
@@ -605,7 +607,7 @@ __device__ __attribute__((noinline)) void high_order_call(Gen gen, const Out& ou
 }
 
 // Every wave executes the same barriers; w = the wave's column block (wave-uniform).
-template <int NT, bool LOWINL, bool HERM = false, class Gen>
+template <int NT, bool LOWINL, int HERM = 0, class Gen>  // HERM: 0, or the highest order of the Hermitian-tile build
 __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int w) {
     typedef Col<NT> Col;
     double* sl = smem;
@@ -660,12 +662,12 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
     // (both inlined, the [13/13] path spilled 94 registers instead of 22 and ran 11 % slower). One
     // of them is a call; LOWINL - the host's choice from its bound of the norms, FactorArgs::
     // prefer_low - says which one is inlined. Same arithmetic either way.
-    if constexpr (HERM) {
-        // Hermitian generators (FactorArgs::hermitian), the host's norm bound below theta_9: orders 3
-        // to 9 on two thirds of the tiles
-        // (the host's bound of the norms is below theta_9: order 13 here means a generator that is not
-        // finite - status bit 2 is set, what is computed does not matter)
-        low_order_herm<NT>(gen, out, smem, w, order == 13 ? 9 : order, a);
+    if constexpr (HERM != 0) {
+        // Hermitian generators (FactorArgs::hermitian), the host's norm bound below theta_9 (theta_5):
+        // orders 3 to 9 (5) on two thirds of the tiles
+        // (an order beyond the bound here means a generator that is not finite - status bit 2 is set,
+        // what is computed does not matter)
+        low_order_herm<NT, HERM>(gen, out, smem, w, order > HERM ? HERM : order, a);
     } else if (order != 13) {
         if constexpr (LOWINL) low_order_impl<NT>(gen, out, smem, w, order, a);
         else low_order_call<NT>(gen, out, smem, w, order);
@@ -675,7 +677,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem, int 
     }
 }
 
-template <int NT, bool LOWINL, bool HERM = false>
+template <int NT, bool LOWINL, int HERM = 0>
 __global__ __launch_bounds__(64 * NT, LOWINL ? 2 : 1) void pade_pq4_kernel(FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(64 * NT, (NT == 3 && LOWINL) ? 2 : 1) void pade_pq4
 
 }  // namespace pade4
 
-template <int NT, bool LOWINL, bool HERM = false>
+template <int NT, bool LOWINL, int HERM = 0>
 static void launch_pq4_t(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
     if (bytes > 48 * 1024)
@@ -794,12 +796,14 @@ static void launch_pq4_explicit_t(const double2* a_in, int n, const FactorArgs& 
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     const bool low = a.prefer_low != 0 && a.pade_policy != 13;
     const bool herm = low && a.hermitian != 0 && a.herm_tiles != 0;
+    const bool herm5 = herm && a.prefer_low == 2;  // the norm bound is below theta_5
     if (a.n > 0 && a.n <= 48) {
-        if (herm) launch_pq4_t<3, true, true>(a, nsteps, batch, st);
+        if (herm) launch_pq4_t<3, true, 9>(a, nsteps, batch, st);
         else if (low) launch_pq4_t<3, true>(a, nsteps, batch, st);
         else launch_pq4_t<3, false>(a, nsteps, batch, st);
     } else {
-        if (herm) launch_pq4_t<4, true, true>(a, nsteps, batch, st);
+        if (herm5) launch_pq4_t<4, true, 5>(a, nsteps, batch, st);
+        else if (herm) launch_pq4_t<4, true, 9>(a, nsteps, batch, st);
         else if (low) launch_pq4_t<4, true>(a, nsteps, batch, st);
         else launch_pq4_t<4, false>(a, nsteps, batch, st);
     }

@@ -87,26 +87,29 @@ def test_sixteen_tile_kernels_do_not_spill():
         assert total_registers(find(big, "krylov4_kernelILb0ELb1E" + cols)) <= 256   # two per SIMD (Hermitian H)
     # two variants of each (qocx_pade4.hip): the [13/13] path inlined and the low-order path a
     # call (Lb0), or the other way round (Lb1, chosen when the host's norm bound is below theta_9)
-    for frag in ("pade_pq4_kernelILi4ELb0ELb0E", "pade_pq4_explicit_kernelILi4ELb0E",
-                 "pade_pq4_kernelILi3ELb0ELb0E", "pade_pq4_explicit_kernelILi3ELb0E"):
+    for frag in ("pade_pq4_kernelILi4ELb0ELi0E", "pade_pq4_explicit_kernelILi4ELb0E",
+                 "pade_pq4_kernelILi3ELb0ELi0E", "pade_pq4_explicit_kernelILi3ELb0E"):
         k1a = find(pade4, frag)
         # (<= 22 spilled registers, plus the call frame of the outlined path)
         assert k1a["ScratchSize"] <= 160 and k1a["VGPRs Spill"] <= 22, (frag, k1a)
-    for frag in ("pade_pq4_kernelILi4ELb1ELb0E", "pade_pq4_explicit_kernelILi4ELb1E",
-                 "pade_pq4_kernelILi3ELb1ELb0E", "pade_pq4_explicit_kernelILi3ELb1E"):
+    for frag in ("pade_pq4_kernelILi4ELb1ELi0E", "pade_pq4_explicit_kernelILi4ELb1E",
+                 "pade_pq4_kernelILi3ELb1ELi0E", "pade_pq4_explicit_kernelILi3ELb1E"):
         k1a = find(pade4, frag)
         # (the structured kernels and the nine-tile explicit one are capped at 256 registers - two
         # waves per SIMD: K1a 3.42 -> 1.98 ms per launch at n = 48, 4.77 -> 3.95 at n = 64 - and
         # what they spill sits in the outlined [13/13] path, which these variants do not reach)
         assert k1a["ScratchSize"] <= 1600 and k1a["VGPRs Spill"] <= 300, (frag, k1a)
-    assert find(pade4, "pade_pq4_kernelILi3ELb1ELb0E")["Occupancy"] == 2
-    assert find(pade4, "pade_pq4_kernelILi3ELb1ELb0E")["VGPRs Spill"] <= 32
+    assert find(pade4, "pade_pq4_kernelILi3ELb1ELi0E")["Occupancy"] == 2
+    assert find(pade4, "pade_pq4_kernelILi3ELb1ELi0E")["VGPRs Spill"] <= 32
     # round 4, Hermitian generators (two thirds of the tiles, every order inline, no call): nine tiles
     # without scratch; sixteen tiles keep their few spills inside the orders 7 / 9
-    herm9 = find(pade4, "pade_pq4_kernelILi3ELb1ELb1E")
+    herm9 = find(pade4, "pade_pq4_kernelILi3ELb1ELi9E")
     assert herm9["Occupancy"] == 2 and herm9["ScratchSize"] == 0 and herm9["VGPRs Spill"] == 0
-    herm16 = find(pade4, "pade_pq4_kernelILi4ELb1ELb1E")
+    herm16 = find(pade4, "pade_pq4_kernelILi4ELb1ELi9E")
     assert herm16["Occupancy"] == 2 and herm16["VGPRs Spill"] <= 80
+    # ... and none in the build for norm bounds below theta_5 (orders 3 and 5 only)
+    herm16_5 = find(pade4, "pade_pq4_kernelILi4ELb1ELi5E")
+    assert herm16_5["Occupancy"] == 2 and herm16_5["ScratchSize"] == 0 and herm16_5["VGPRs Spill"] == 0
 
 
 def test_release_library_has_no_diagnostic_switches():
