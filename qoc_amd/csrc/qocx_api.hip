@@ -924,18 +924,23 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // nothing in flight still reads the staging buffer
         const int K = ctx->K;
-        std::vector<double> umax(K, 0.0);
+        // sum_k |u_k(t)| ||G_k||_1 is largest at a control knot (u is linear between knots, the sum
+        // convex): the largest knot sum bounds every step, every Magnus node, and the device's
+        // per-step bound (launch_step_table) - tighter than sum_k max_t |u_k(t)| ||G_k||_1
+        double smax = 0.0;
         double* stage = ctx->pin_controls;
         for (size_t row = 0; row < (size_t)batch * ctx->nc; ++row) {
             const double* src = controls + row * K;
             double* dst = stage + row * K;
+            double srow = 0.0;
             for (int k = 0; k < K; ++k) {
-                const double v = src[k], a = fabs(v);
+                const double v = src[k];
                 dst[k] = v;
-                if (!(a <= umax[k])) umax[k] = a;  // also catches NaN
+                srow += fabs(v) * ctx->g_norm_max[k];
             }
+            if (!(srow <= smax)) smax = srow;  // also catches NaN
         }
-        for (int k = 0; k < K; ++k) bound += umax[k] * ctx->g_norm_max[k];
+        bound += smax;
         if (ctx->controls.ensure(total)) return QOCX_ERR_HIP;
         HIP_TRY(hipMemcpyAsync(ctx->controls.p, stage, total * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
