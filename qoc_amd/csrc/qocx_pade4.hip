@@ -734,9 +734,9 @@ __global__ __launch_bounds__(64 * NT, LOWINL ? 2 : 1) void pade_pq4_kernel(Facto
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (opaque Hamiltonians, debug)
-template <int NT, bool LOWINL>
-__global__ __launch_bounds__(64 * NT, (NT == 3 && LOWINL) ? 2 : 1) void pade_pq4_explicit_kernel(const double2* a_in, int n,
-                                                                    FactorArgs args) {
+template <int NT, bool LOWINL, int HERM = 0>
+__global__ __launch_bounds__(64 * NT, ((NT == 3 || HERM != 0) && LOWINL) ? 2 : 1) void pade_pq4_explicit_kernel(
+    const double2* a_in, int n, FactorArgs args) {
     typedef Col<NT> Col;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64 * NT, (NT == 3 && LOWINL) ? 2 : 1) void pade_pq4
                 a.im[ti][r] = e.y;
             }
     };
-    body<NT, LOWINL>(gen, out, smem, w);
+    body<NT, LOWINL, HERM>(gen, out, smem, w);
 }
 
 }  // namespace pade4
@@ -778,15 +778,15 @@ static void launch_pq4_t(const FactorArgs& a, int nsteps, int batch, hipStream_t
     hipLaunchKernelGGL((pade4::pade_pq4_kernel<NT, LOWINL, HERM>), dim3(nsteps, batch), dim3(64 * NT), bytes,
                        st, a);
 }
-template <int NT, bool LOWINL>
+template <int NT, bool LOWINL, int HERM = 0>
 static void launch_pq4_explicit_t(const double2* a_in, int n, const FactorArgs& a, int count,
                                   hipStream_t st) {
     constexpr int bytes = pade4::Cfg<NT>::LDS_BYTES;
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel<NT, LOWINL>),
+            reinterpret_cast<const void*>(pade4::pade_pq4_explicit_kernel<NT, LOWINL, HERM>),
             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((pade4::pade_pq4_explicit_kernel<NT, LOWINL>), dim3(count), dim3(64 * NT), bytes,
+    hipLaunchKernelGGL((pade4::pade_pq4_explicit_kernel<NT, LOWINL, HERM>), dim3(count), dim3(64 * NT), bytes,
                        st, a_in, n, a);
 }
 
@@ -810,11 +810,16 @@ void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
 }
 void launch_pq4_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st) {
     const bool low = a.prefer_low != 0 && a.pade_policy != 13;
+    // (Hermitian tiles: generators given as matrices - Magnus M4 / M6, opaque Hamiltonians - that are
+    // skew-Hermitian, FactorArgs::hermitian)
+    const bool herm = low && a.hermitian != 0 && a.herm_tiles != 0;
     if (a.n > 0 && a.n <= 48) {
-        if (low) launch_pq4_explicit_t<3, true>(a_in, n, a, count, st);
+        if (herm) launch_pq4_explicit_t<3, true, 9>(a_in, n, a, count, st);
+        else if (low) launch_pq4_explicit_t<3, true>(a_in, n, a, count, st);
         else launch_pq4_explicit_t<3, false>(a_in, n, a, count, st);
     } else {
-        if (low) launch_pq4_explicit_t<4, true>(a_in, n, a, count, st);
+        if (herm) launch_pq4_explicit_t<4, true, 9>(a_in, n, a, count, st);
+        else if (low) launch_pq4_explicit_t<4, true>(a_in, n, a, count, st);
         else launch_pq4_explicit_t<4, false>(a_in, n, a, count, st);
     }
 }
