@@ -1123,7 +1123,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                             (ctx->nodes > 1 ? (size_t)nsteps * mat * 32 : 0);
     const int nodes = m4lin ? 1 : ctx->nodes;  // nodes of the generator kernels
     // Magnus kernels as four-wave workgroups with every matrix in LDS (qocx_magnus4w.hip)
-    const bool magnus4w = nodes > 1 && qocx::magnus4w_supports(ctx->nb, K) && ctx->knob("magnus_4w", 1) != 0;
+    const bool magnus4w = nodes > 1 && qocx::magnus4w_supports(ctx->nb, K, ctx->n) && ctx->knob("magnus_4w", 1) != 0;
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1291,7 +1291,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ma.controls = fa.controls; ma.interp = ctx->interp.p;
         ma.h0_cimg = ctx->h0_cimg.p; ma.g_cimg = ctx->g_cimg.p;
         ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
-        ma.dt = ctx->dt; ma.scratch = ctx->magnus_scratch.p;
+        ma.dt = ctx->dt; ma.scratch = ctx->magnus_scratch.p; ma.n = ctx->n;
         ma.skew = (ctx->hermitian && !ctx->knob("magnus_general", 0)) ? 1 : 0;
         qocx::SweepArgs sa;
         sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;

@@ -198,6 +198,7 @@ struct MagnusArgs {
     double* gstep;             // vjp out: [B][nsteps * nodes][K]
     double2* scratch;          // [blocks][11] lane-linear matrix dumps
     size_t total;              // B * seg_len work items
+    int n = 0;                 // Hilbert size (qocx_magnus4w.hip: 33..48 -> the three-wave form)
 };
 
 // Magnus M4 with time-independent H0, G_k ("commutator-free" form, qocx_magnus.hip): the step
@@ -353,8 +354,8 @@ void launch_pipe_mix(double* out, int blocks, int iters, int mode, hipStream_t s
 void launch_magnus_fwd(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 void launch_magnus_vjp(int nb, const MagnusArgs& a, int blocks, hipStream_t st);
 size_t magnus_scratch_elems(int nb, int blocks);
-// four-wave, LDS-resident forms for 17 <= n <= 32 (qocx_magnus4w.hip); grid = (a.seg_len, batch)
-bool magnus4w_supports(int nb, int K);
+// multi-wave, LDS-resident forms for 17 <= n <= 48 (qocx_magnus4w.hip); grid = (a.seg_len, batch)
+bool magnus4w_supports(int nb, int K, int n);
 void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st);
 void launch_magnus4w_vjp(const MagnusArgs& a, int batch, hipStream_t st);
 void launch_m4lin_controls(const M4LinArgs& a, hipStream_t st);
