@@ -34,13 +34,23 @@ struct G48 {
     static __device__ __forceinline__ int ti(int i, int w) { return i; }
     static __device__ __forceinline__ int tj(int w) { return w; }
 };
+// G64 (49 <= n <= 64, round 4): four waves, wave w the column block w (four tiles) of a 64 x 64 matrix.
+// Four such matrices are 266 KiB: only TWO live in LDS at a time - the operands of the product at
+// hand - and everything else waits as tiles in registers (the `_r` forms of the commutator rules
+// below take their operands from registers and put them into the two slots themselves).
+struct G64 {
+    static constexpr int NP = 64, IMG = 64, WAVES = 4, NTW = 4;
+    static __device__ __forceinline__ int ti(int i, int w) { return i; }
+    static __device__ __forceinline__ int tj(int w) { return w; }
+};
 template <class G>
 struct Dim {
     static constexpr int NP = G::NP, PM = NP + 1, MELEM = NP * PM, MBYTES = MELEM * 16, KS = NP / 4;
     static constexpr int IMG = G::IMG, IMAT = IMG * IMG, TPS = IMG / 16;  // HBM images: pitch, elements, tiles per side
-    static constexpr int RED_OFF = 4 * MBYTES;
+    static constexpr int SLOTS = NP > 48 ? 2 : 4;             // LDS-resident matrices
+    static constexpr int RED_OFF = SLOTS * MBYTES;
     static constexpr int LDS_BYTES = RED_OFF + 3 * 64 * 4 * 8;  // + partial sums [node][control][wave]
-    static constexpr int LDS_BYTES_FWD = 4 * MBYTES;
+    static constexpr int LDS_BYTES_FWD = SLOTS * MBYTES;
 };
 constexpr double M4_F0 = 0.14433756729740643;  // sqrt(3)/12
 constexpr double M6_F0 = 1.2909944487358056;   // sqrt(15)/3
@@ -220,6 +230,69 @@ struct Wave {
         ybar = tile_zero<G>();
         mm<true, false>(ybar, x, zb, 1.0);   //  X^H Zbar
         mm<false, true>(ybar, zb, x, -1.0);  // -Zbar X^H
+    }
+    // ---- the same two rules with the operands in REGISTERS and two LDS slots (0, 1) to work in:
+    // for geometries whose matrices do not fit LDS four at a time (G64). Both slots are free on
+    // entry and on return; barriers inside.
+    __device__ __forceinline__ T commutator_r(const T& x, const T& y) const {
+        store(x, 0);
+        store(y, 1);
+        __syncthreads();
+        T z = tile_zero<G>();
+        mm<false, false>(z, 0, 1, 1.0);
+        if (!skew) mm<false, false>(z, 1, 0, -1.0);
+        __syncthreads();  // the operands have been read
+        if (skew) {       // Y X = (X Y)^H
+            store(z, 0);
+            __syncthreads();
+            tile_axpy<G>(z, -1.0, load_adjoint(0));
+            __syncthreads();
+        }
+        return z;
+    }
+    __device__ __forceinline__ void commutator_vjp_r(T& xbar, T& ybar, const T& x, const T& y,
+                                                     const T& zbar) const {
+        if (skew) {
+            store(zbar, 0);
+            __syncthreads();
+            T zs = zbar;
+            tile_axpy<G>(zs, -1.0, load_adjoint(0));
+            tile_scale<G>(zs, 0.5);
+            __syncthreads();  // Zbar has been read
+            store(zs, 0);
+            store(y, 1);
+            __syncthreads();
+            T v = tile_zero<G>();
+            mm<false, false>(v, 1, 0, 1.0);  // V = Y Zs
+            __syncthreads();
+            store(x, 1);
+            __syncthreads();
+            T wq = tile_zero<G>();
+            mm<false, false>(wq, 0, 1, 1.0);  // W = Zs X
+            __syncthreads();
+            store(v, 0);
+            store(wq, 1);
+            __syncthreads();
+            xbar = v;
+            tile_axpy<G>(xbar, -1.0, load_adjoint(0));
+            ybar = wq;
+            tile_axpy<G>(ybar, -1.0, load_adjoint(1));
+            __syncthreads();
+            return;
+        }
+        store(zbar, 0);
+        store(y, 1);
+        __syncthreads();
+        xbar = tile_zero<G>();
+        mm<false, true>(xbar, 0, 1, 1.0);   //  Zbar Y^H
+        mm<true, false>(xbar, 1, 0, -1.0);  // -Y^H Zbar
+        __syncthreads();
+        store(x, 1);
+        __syncthreads();
+        ybar = tile_zero<G>();
+        mm<true, false>(ybar, 1, 0, 1.0);   //  X^H Zbar
+        mm<false, true>(ybar, 0, 1, -1.0);  // -Zbar X^H
+        __syncthreads();
     }
     // C-image index of component r of tile i: ((ti * TPS + tj) * 4 + r) * 64 + lane
     __device__ __forceinline__ int cimg(int i, int r) const {
@@ -514,10 +587,175 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
     }
 }
 
+// ---- two LDS slots, operands from registers (G64) ---------------------------------------------------
+template <class G>
+__device__ __forceinline__ void m6_nodes_r(const Wave<G>& wv, const MagnusArgs& args, int step,
+                                           const double* ctl_b, Tile<G>& b1, Tile<G>& b2, Tile<G>& b3) {
+    const double dt = args.dt;
+    b1 = tile_zero<G>();
+    b2 = tile_zero<G>();
+    b3 = tile_zero<G>();
+    {   // b1 = dt a2 ; b2 = F0 dt (a3 - a1) ; b3 = F1 dt (a3 - 2 a2 + a1)   (mathmethods.py:153-155)
+        const Tile<G> a1 = node_generator<G>(wv, args, step, 0, ctl_b);
+        tile_axpy<G>(b2, -M6_F0 * dt, a1);
+        tile_axpy<G>(b3, M6_F1 * dt, a1);
+    }
+    {
+        const Tile<G> a2 = node_generator<G>(wv, args, step, 1, ctl_b);
+        tile_axpy<G>(b1, dt, a2);
+        tile_axpy<G>(b3, -2.0 * M6_F1 * dt, a2);
+    }
+    {
+        const Tile<G> a3 = node_generator<G>(wv, args, step, 2, ctl_b);
+        tile_axpy<G>(b2, M6_F0 * dt, a3);
+        tile_axpy<G>(b3, M6_F1 * dt, a3);
+    }
+}
+
+template <class G, int NODES>
+__global__ __launch_bounds__(64 * G::WAVES) void magnus2s_fwd_kernel(MagnusArgs args) {
+    typedef Dim<G> D;
+    typedef Tile<G> T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Wave<G> wv = make_wave<G>(smem, args);
+    const int step = args.step0 + blockIdx.x;
+    const size_t b = blockIdx.y;
+    const size_t m = b * args.nsteps + step;
+    const double* ctl_b = args.controls + b * args.nc * args.K;
+    T mt;
+    if (NODES == 2) {
+        // m4 = dt/2 (a1 + a2) + F0 dt^2 [a2, a1]   (mathmethods.py:119-121)
+        const T a1 = node_generator<G>(wv, args, step, 0, ctl_b);
+        const T a2 = node_generator<G>(wv, args, step, 1, ctl_b);
+        mt = wv.commutator_r(a2, a1);
+        tile_scale<G>(mt, M4_F0 * args.dt * args.dt);
+        tile_axpy<G>(mt, 0.5 * args.dt, a1);
+        tile_axpy<G>(mt, 0.5 * args.dt, a2);
+    } else {
+        T b1, b2, b3;
+        m6_nodes_r<G>(wv, args, step, ctl_b, b1, b2, b3);
+        // c12 = [b1, b2] ; w = 2 b3 + c12 ; x = -20 b1 - b3 + c12 ; y = b2 - F4 [b1, w] ;
+        // m = b1 + F2 b3 + F3 [x, y]   (mathmethods.py:156-163)
+        const T c12 = wv.commutator_r(b1, b2);
+        T wt = c12, xt = c12;
+        tile_axpy<G>(wt, 2.0, b3);
+        tile_axpy<G>(xt, -1.0, b3);
+        tile_axpy<G>(xt, -20.0, b1);
+        T yt = wv.commutator_r(b1, wt);
+        tile_scale<G>(yt, -M6_F4);
+        tile_axpy<G>(yt, 1.0, b2);
+        mt = wv.commutator_r(xt, yt);
+        tile_scale<G>(mt, M6_F3);
+        tile_axpy<G>(mt, 1.0, b1);
+        tile_axpy<G>(mt, M6_F2, b3);
+    }
+    double2* out = args.m_rm + m * D::IMAT;  // row-major
+#pragma unroll
+    for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[(size_t)(16 * wv.ti(i) + 4 * r + wv.q) * D::IMG + 16 * wv.tj() + wv.c] =
+                make_double2(mt.re[i][r], mt.im[i][r]);
+}
+
+template <class G, int NODES>
+__global__ __launch_bounds__(64 * G::WAVES) void magnus2s_vjp_kernel(MagnusArgs args) {
+    typedef Dim<G> D;
+    typedef Tile<G> T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Wave<G> wv = make_wave<G>(smem, args);
+    double* red = reinterpret_cast<double*>(smem + D::RED_OFF);
+    const int step = args.step0 + blockIdx.x;
+    const size_t b = blockIdx.y;
+    const size_t m = b * args.nsteps + step;
+    const double* ctl_b = args.controls + b * args.nc * args.K;
+    const double dt = args.dt;
+    T mbar;
+    {
+        const double2* in = args.mbar_rm + m * D::IMAT;
+#pragma unroll
+        for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = in[(size_t)(16 * wv.ti(i) + 4 * r + wv.q) * D::IMG + 16 * wv.tj() + wv.c];
+                mbar.re[i][r] = e.x;
+                mbar.im[i][r] = e.y;
+            }
+    }
+    if (NODES == 2) {
+        const T a1 = node_generator<G>(wv, args, step, 0, ctl_b);
+        const T a2 = node_generator<G>(wv, args, step, 1, ctl_b);
+        T cbar = mbar;
+        tile_scale<G>(cbar, M4_F0 * dt * dt);
+        T a2bar, a1bar;
+        wv.commutator_vjp_r(a2bar, a1bar, a2, a1, cbar);
+        tile_axpy<G>(a1bar, 0.5 * dt, mbar);
+        tile_axpy<G>(a2bar, 0.5 * dt, mbar);
+        contract_node<G>(wv, a1bar, args, step, 0, red);
+        contract_node<G>(wv, a2bar, args, step, 1, red);
+    } else {
+        T b1, b2, b3;
+        m6_nodes_r<G>(wv, args, step, ctl_b, b1, b2, b3);
+        const T c12 = wv.commutator_r(b1, b2);
+        T wt = c12, xt = c12;
+        tile_axpy<G>(wt, 2.0, b3);
+        tile_axpy<G>(xt, -1.0, b3);
+        tile_axpy<G>(xt, -20.0, b1);
+        T yt = wv.commutator_r(b1, wt);
+        tile_scale<G>(yt, -M6_F4);
+        tile_axpy<G>(yt, 1.0, b2);
+        // (xbar, ybar) = vjp of [x, y] with F3 mbar
+        T zb = mbar;
+        tile_scale<G>(zb, M6_F3);
+        T xbar, ybar;
+        wv.commutator_vjp_r(xbar, ybar, xt, yt, zb);
+        // b1bar = mbar - 20 xbar ; b3bar = F2 mbar - xbar ; c12bar = xbar ; b2bar = ybar
+        T b1bar = mbar, b3bar = tile_zero<G>(), c12bar = xbar, b2bar = ybar;
+        tile_axpy<G>(b1bar, -20.0, xbar);
+        tile_axpy<G>(b3bar, M6_F2, mbar);
+        tile_axpy<G>(b3bar, -1.0, xbar);
+        // y = b2 - F4 [b1, w]: innerbar = -F4 ybar ; (d1, wbar) = vjp of [b1, w]
+        T inner = ybar;
+        tile_scale<G>(inner, -M6_F4);
+        T d1, wbar;
+        wv.commutator_vjp_r(d1, wbar, b1, wt, inner);
+        tile_axpy<G>(b1bar, 1.0, d1);
+        tile_axpy<G>(b3bar, 2.0, wbar);
+        tile_axpy<G>(c12bar, 1.0, wbar);
+        // c12 = [b1, b2]
+        T d2;
+        wv.commutator_vjp_r(d1, d2, b1, b2, c12bar);
+        tile_axpy<G>(b1bar, 1.0, d1);
+        tile_axpy<G>(b2bar, 1.0, d2);
+        // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
+        // a3bar = F0 dt b2bar + F1 dt b3bar
+        T abar = tile_zero<G>();
+        tile_axpy<G>(abar, -M6_F0 * dt, b2bar);
+        tile_axpy<G>(abar, M6_F1 * dt, b3bar);
+        contract_node<G>(wv, abar, args, step, 0, red);
+        abar = tile_zero<G>();
+        tile_axpy<G>(abar, dt, b1bar);
+        tile_axpy<G>(abar, -2.0 * M6_F1 * dt, b3bar);
+        contract_node<G>(wv, abar, args, step, 1, red);
+        abar = tile_zero<G>();
+        tile_axpy<G>(abar, M6_F0 * dt, b2bar);
+        tile_axpy<G>(abar, M6_F1 * dt, b3bar);
+        contract_node<G>(wv, abar, args, step, 2, red);
+    }
+    __syncthreads();
+    for (int e = wv.tid; e < NODES * args.K; e += 64 * G::WAVES) {
+        const int node = e / args.K, k = e % args.K;
+        const double* p = red + (node * 64 + k) * 4;
+        args.gstep[((b * (size_t)args.nsteps + step) * NODES + node) * args.K + k] =
+            (p[0] + p[1]) + (p[2] + p[3]);
+    }
+}
+
 }  // namespace magnus4w
 
-// n: the Hilbert size (17..32: four waves; 33..48: three waves with a column block each)
-bool magnus4w_supports(int nb, int K, int n) { return (nb == 2 || (nb == 4 && n > 0 && n <= 48)) && K <= 64; }
+// n: the Hilbert size (17..32: four waves, a tile each; 33..48: three waves, a column block each;
+// 49..64: four waves, a column block each, two matrices in LDS at a time)
+bool magnus4w_supports(int nb, int K, int n) { return (nb == 2 || (nb == 4 && n > 32 && n <= 64)) && K <= 64; }
 
 template <class Kern>
 static void magnus4w_attr(Kern k, int bytes) {
@@ -536,6 +774,10 @@ static void magnus4w_prepare() {
     magnus4w_attr(magnus4w_fwd_kernel<G48, 3>, Dim<G48>::LDS_BYTES);
     magnus4w_attr(magnus4w_vjp_kernel<G48, 2>, Dim<G48>::LDS_BYTES);
     magnus4w_attr(magnus4w_vjp_kernel<G48, 3>, Dim<G48>::LDS_BYTES);
+    magnus4w_attr(magnus2s_fwd_kernel<G64, 2>, Dim<G64>::LDS_BYTES);
+    magnus4w_attr(magnus2s_fwd_kernel<G64, 3>, Dim<G64>::LDS_BYTES);
+    magnus4w_attr(magnus2s_vjp_kernel<G64, 2>, Dim<G64>::LDS_BYTES);
+    magnus4w_attr(magnus2s_vjp_kernel<G64, 3>, Dim<G64>::LDS_BYTES);
     attr_set = true;
 }
 
@@ -543,6 +785,13 @@ void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st) {
     using namespace magnus4w;
     magnus4w_prepare();
     const dim3 grid(a.seg_len, batch);
+    if (a.n > 48) {
+        if (a.nodes == 2)
+            hipLaunchKernelGGL((magnus2s_fwd_kernel<G64, 2>), grid, dim3(256), Dim<G64>::LDS_BYTES_FWD, st, a);
+        else
+            hipLaunchKernelGGL((magnus2s_fwd_kernel<G64, 3>), grid, dim3(256), Dim<G64>::LDS_BYTES_FWD, st, a);
+        return;
+    }
     if (a.n > 32) {
         if (a.nodes == 2)
             hipLaunchKernelGGL((magnus4w_fwd_kernel<G48, 2>), grid, dim3(192), Dim<G48>::LDS_BYTES_FWD, st, a);
@@ -560,6 +809,13 @@ void launch_magnus4w_vjp(const MagnusArgs& a, int batch, hipStream_t st) {
     using namespace magnus4w;
     magnus4w_prepare();
     const dim3 grid(a.seg_len, batch);
+    if (a.n > 48) {
+        if (a.nodes == 2)
+            hipLaunchKernelGGL((magnus2s_vjp_kernel<G64, 2>), grid, dim3(256), Dim<G64>::LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL((magnus2s_vjp_kernel<G64, 3>), grid, dim3(256), Dim<G64>::LDS_BYTES, st, a);
+        return;
+    }
     if (a.n > 32) {
         if (a.nodes == 2)
             hipLaunchKernelGGL((magnus4w_vjp_kernel<G48, 2>), grid, dim3(192), Dim<G48>::LDS_BYTES, st, a);

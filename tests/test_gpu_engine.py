@@ -648,6 +648,45 @@ def test_hermitian_tiles_of_the_four_wave_pade_kernel(engine, n):
     assert seen == {3, 5, 7, 9}, seen
 
 
+def test_magnus_above_n32_on_the_lds_resident_kernels(engine):
+    """Round 4: MagnusPolicy.M4 / M6 above n = 32 run the LDS-resident multi-wave kernels
+    (qocx_magnus4w.hip: three waves and four matrices in LDS for n <= 48, four waves and two matrices
+    at a time for n <= 64) instead of the one-wave kernels, whose sixteen-tile matrices live in
+    scratch memory. Random problems of both size classes under M4 / M6 - Hermitian and not, with and
+    without a time-dependent H0 - against the oracle, and against the one-wave kernels (knob
+    "magnus_4w" 0) at rounding level."""
+    from tests import fuzz_parity
+    for nmin, nmax, seed in ((33, 48, 4801), (49, 64, 6401)):
+        rng = np.random.default_rng(seed)
+        seen = set()
+        for index in range(40):
+            results = []
+            state = rng.bit_generator.state
+            worst, tag = fuzz_parity.one(engine, rng, index, nmin=nmin, nmax=nmax, smin=1, smax=2, results=results)
+            policy = [tok for tok in tag.split() if tok in ("M2", "M4", "M6")][0]
+            if worst is None or policy == "M2":
+                continue
+            assert worst < 1.0, tag
+            # the same problem on the one-wave kernels
+            engine.set_knob("magnus_4w", 0)
+            try:
+                rng2 = np.random.default_rng(0)
+                rng2.bit_generator.state = state
+                results2 = []
+                worst2, tag2 = fuzz_parity.one(engine, rng2, index, nmin=nmin, nmax=nmax, smin=1, smax=2,
+                                               results=results2)
+            finally:
+                engine.set_knob("magnus_4w", 1)
+            assert tag2 == tag and worst2 < 1.0
+            for new, old in zip(results[0], results2[0]):
+                scale = max(1.0, float(np.max(np.abs(old))))
+                assert np.max(np.abs(np.asarray(new) - np.asarray(old))) < 1e-11 * scale, tag
+            seen.add(policy)
+            if seen == {"M4", "M6"} and index >= 8:
+                break
+        assert seen == {"M4", "M6"}, (nmin, seen)
+
+
 def test_product_library_rejects_diagnostic_knobs(engine):
     """The timing experiments whose results are garbage are not reachable through libqocx.so."""
     from qoc_amd.engine import QocxError
