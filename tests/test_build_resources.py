@@ -87,13 +87,13 @@ def test_sixteen_tile_kernels_do_not_spill():
         assert total_registers(find(big, "krylov4_kernelILb0ELb1E" + cols)) <= 256   # two per SIMD (Hermitian H)
     # two variants of each (qocx_pade4.hip): the [13/13] path inlined and the low-order path a
     # call (Lb0), or the other way round (Lb1, chosen when the host's norm bound is below theta_9)
-    for frag in ("pade_pq4_kernelILi4ELb0ELi0E", "pade_pq4_explicit_kernelILi4ELb0E",
-                 "pade_pq4_kernelILi3ELb0ELi0E", "pade_pq4_explicit_kernelILi3ELb0E"):
+    for frag in ("pade_pq4_kernelILi4ELb0ELi0E", "pade_pq4_explicit_kernelILi4ELb0ELi0E",
+                 "pade_pq4_kernelILi3ELb0ELi0E", "pade_pq4_explicit_kernelILi3ELb0ELi0E"):
         k1a = find(pade4, frag)
         # (<= 22 spilled registers, plus the call frame of the outlined path)
         assert k1a["ScratchSize"] <= 160 and k1a["VGPRs Spill"] <= 22, (frag, k1a)
-    for frag in ("pade_pq4_kernelILi4ELb1ELi0E", "pade_pq4_explicit_kernelILi4ELb1E",
-                 "pade_pq4_kernelILi3ELb1ELi0E", "pade_pq4_explicit_kernelILi3ELb1E"):
+    for frag in ("pade_pq4_kernelILi4ELb1ELi0E", "pade_pq4_explicit_kernelILi4ELb1ELi0E",
+                 "pade_pq4_kernelILi3ELb1ELi0E", "pade_pq4_explicit_kernelILi3ELb1ELi0E"):
         k1a = find(pade4, frag)
         # (the structured kernels and the nine-tile explicit one are capped at 256 registers - two
         # waves per SIMD: K1a 3.42 -> 1.98 ms per launch at n = 48, 4.77 -> 3.95 at n = 64 - and
