@@ -2355,6 +2355,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.final_out = lb.final_out.p + pos0 * S * md;
             la.step_densities = ctx->keep_step_states
                                     ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
+            la.tile4 = ctx->knob("lindblad_4t", 1) != 0 ? 1 : 0;
             la.stamps = nullptr;
             if (ctx->knob("lindblad_stamps", 0)) {
                 // ([B] sets of the forward pass / classic launch, then [B] of the unit adjoint)
@@ -2460,7 +2461,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -288,6 +288,7 @@ struct LindbladArgs {
     // (lindblad_combine) contracts them with the forward stage values and the scalars into the
     // control cotangents. phase 0: the classic forward-then-adjoint launch.
     int phase = 0;
+    int tile4 = 1;                 // 17 <= n <= 32: the tile-per-wave kernel (qocx_lindblad4t.hip) where it applies
     int q2 = 0;                    // phases 1 / 2, four waves: the stage loop with 18 MFMAs per wave (substep_q2)
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out
@@ -313,6 +314,8 @@ void launch_optimizer_update(const OptimArgs& a, int batch, hipStream_t st);
 
 void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
 void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st);
+bool lindblad4t_supports(const LindbladArgs& a);
+void launch_lindblad4t(const LindbladArgs& a, int batch, hipStream_t st);
 int lindblad_lds_size(int n, int S, int nops, int mode, int K);
 size_t lindblad_scratch_elems(int n, int S);
 

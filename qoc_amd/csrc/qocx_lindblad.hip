@@ -1705,7 +1705,8 @@ void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     // the two-sided evaluation's stage loop: four waves, constant H0 / G_k, stage values kept
     const bool q2 = a.q2 && a.phase != 0 && a.a0_tab == nullptr && a.gp_tab == nullptr && a.ystages != nullptr &&
                     a.op_tab == nullptr && a.K <= 4;
-    if (a.n > 16) launch_t<2, true, false>(a, batch, st);
+    if (lindblad4t_supports(a)) launch_lindblad4t(a, batch, st);
+    else if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
 #ifdef QOCX_DIAG
     else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr && q2)

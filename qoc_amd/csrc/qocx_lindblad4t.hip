@@ -1,0 +1,385 @@
+// qocx_lindblad4t.hip - the Lindblad engine at 17 <= n <= 32 with the density tile-wise on four waves.
+//
+// Replaces (reference): qoc/core/lindbladdiscrete.py:434-501 (_evaluate_lindblad_discrete),
+// qoc/core/mathmethods.py:14-67 (integrate_rkdp5 - here the fixed-step DOP853 of qocx_lindblad.hip),
+// qoc/standard/functions/convenience.py:96-170 (get_lindbladian); the gradient autograd takes through
+// them is the discrete adjoint of the scheme.
+//
+// One workgroup = one seed = four waves; wave w owns tile (w & 1, w >> 1) of every 32 x 32 matrix - of
+// the density, of the stage value, of every stage derivative k_j, of the cotangents. A stage
+//     k = A_L(c) Y + Y A_R(c) + sum_i gamma_i L_i Y L_i^H        (adjoint: A^H, L_i^H . L_i)
+// is three rounds of LDS-operand products with one workgroup barrier before each: the generator
+// products, t_i = gamma_i L_i Y (stored over the generators), t_i L_i^H. No partial sums are exchanged -
+// every wave computes ITS tile of every product - and the Runge-Kutta combinations are tile
+// arithmetic: a wave writes its tile of k_j to the seed's HBM scratch and reads only that tile back (L2
+// hits, no synchronisation; twelve 16 KB matrices fit neither LDS next to the operands nor - as the
+// compiler allocates them - the accumulation registers). The stage loops stay ROLLED: unrolled, the
+// kernel is 258 KB of straight-line code against 64 KB of instruction cache and runs at the pace of
+// the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>) carries four tiles per matrix
+// in one wave and keeps its k_j in HBM scratch; it stays as the general path (time-dependent tables,
+// more than two operators, recomputed stage values, injected cotangents).
+#include "qocx_device.h"
+#include "qocx_tilewave.h"
+#include "dop853_tableau.h"
+
+namespace qocx {
+
+namespace lindblad4t {
+
+using namespace tilewave;
+
+typedef G32 G;
+typedef Tile<G> T;
+typedef Wave<G> W;
+typedef Dim<G> D;
+
+constexpr int STAGES = QOCX_RK_STAGES;
+constexpr int MAT = D::IMAT;  // complex elements of a C-dump
+constexpr int MAX_OPS = 2;
+
+// LDS matrices (pitch 33): the argument of the right-hand side, the two generators at the stage's
+// time (then t_0, t_1), the operators, the stage value of the control-cotangent products; behind them
+// the partial sums of a reduction
+enum { M_ARG = 0, M_GL, M_GR, M_OP0, M_OP1, M_YS, M_COUNT, M_T0 = M_GL, M_T1 = M_GR };
+constexpr int RED_OFF = M_COUNT * D::MBYTES;
+constexpr int LDS_BYTES = RED_OFF + 2 * 4 * 16;  // [parity][wave] of a complex scalar
+
+// the Butcher tableau in constant memory (runtime-indexed by the rolled stage loops)
+struct TableauInit {
+    double a[STAGES * STAGES], b[STAGES], c[STAGES];
+    constexpr TableauInit() : a(), b(), c() {
+        for (int i = 0; i < STAGES; ++i) {
+            b[i] = QOCX_RK_B[i];
+            c[i] = QOCX_RK_C[i];
+            for (int j = 0; j < STAGES; ++j) a[i * STAGES + j] = QOCX_RK_A[i][j];
+        }
+    }
+};
+__device__ __constant__ const TableauInit RK = TableauInit{};
+
+struct Ctx {
+    const LindbladArgs& a;
+    W wv;
+    double2* red;
+    int parity;
+
+    __device__ __forceinline__ T load_dump(const double2* d) const {
+        T t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = d[wv.cimg(0, r)];
+            t.re[0][r] = e.x;
+            t.im[0][r] = e.y;
+        }
+        return t;
+    }
+    __device__ __forceinline__ void store_dump(const T& t, double2* d) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[wv.cimg(0, r)] = make_double2(t.re[0][r], t.im[0][r]);
+    }
+    // the sum over the workgroup of a complex scalar, in every lane (one barrier)
+    __device__ __forceinline__ void block_sum(double& re, double& im) {
+        re = wave_sum(re);
+        im = wave_sum(im);
+        double2* slot = red + parity * 4;
+        parity ^= 1;
+        if (wv.lane == 0) slot[wv.w] = make_double2(re, im);
+        __syncthreads();
+        const double2 s0 = slot[0], s1 = slot[1], s2 = slot[2], s3 = slot[3];
+        re = (s0.x + s1.x) + (s2.x + s3.x);
+        im = (s0.y + s1.y) + (s2.y + s3.y);
+    }
+    // tr(X^H Y): this wave's share
+    static __device__ __forceinline__ void frob_part(const T& x, const T& y, double& re, double& im) {
+        re = 0;
+        im = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            re += x.re[0][r] * y.re[0][r] + x.im[0][r] * y.im[0][r];
+            im += x.re[0][r] * y.im[0][r] - x.im[0][r] * y.re[0][r];
+        }
+    }
+    static __device__ __forceinline__ void add_scaled(T& l, double zr, double zi, const T& t) {
+        l.re[0] += zr * t.re[0] - zi * t.im[0];
+        l.im[0] += zr * t.im[0] + zi * t.re[0];
+    }
+
+    // Density costs on the S densities in `dens` (HBM dumps); optionally adds the cotangents into
+    // `lam` (qoc/standard/costs/targetdensityinfidelity.py:41-69, forbiddensities.py:53-85): as
+    // density_costs of qocx_lindblad.hip, the traces summed over the four tiles.
+    __device__ __forceinline__ double costs(bool step_pass, bool final_pass, const double2* dens, double2* lam) {
+        const int S = a.S, n = a.n;
+        double total = 0;
+        for (int ci = 0; ci < a.cost_count; ++ci) {
+            const DevCost c = a.costs[ci];
+            const bool on = c.step_cost ? step_pass : final_pass;
+            if (!on) continue;
+            const double2* pool = a.cost_matrices + (size_t)c.vec_offset * MAT;
+            if (c.kind == QOCX_DEV_COST_TARGET_DENSITY) {
+                double fid = 0;
+                for (int s = 0; s < S; ++s) {
+                    const T t = load_dump(pool + (size_t)s * MAT);
+                    const T rho = load_dump(dens + (size_t)s * MAT);
+                    double zr, zi;
+                    frob_part(t, rho, zr, zi);
+                    block_sum(zr, zi);
+                    const double mag = sqrt(zr * zr + zi * zi);
+                    fid += mag;
+                    if (lam != nullptr && mag > 0) {
+                        const double f = -c.scale / ((double)S * n * mag);
+                        T l = load_dump(lam + (size_t)s * MAT);
+                        add_scaled(l, f * zr, f * zi, t);
+                        store_dump(l, lam + (size_t)s * MAT);
+                    }
+                }
+                total += c.scale * (1.0 - fid / ((double)S * n));
+            } else {  // QOCX_DEV_COST_FORBID_DENSITY
+                int base = 0;
+                double acc = 0;
+                for (int s = 0; s < S; ++s) {
+                    const int fs = a.cost_counts[c.cnt_offset + s];
+                    const T rho = load_dump(dens + (size_t)s * MAT);
+                    T l = tile_zero<G>();
+                    if (lam != nullptr) l = load_dump(lam + (size_t)s * MAT);
+                    for (int f = 0; f < fs; ++f) {
+                        const T t = load_dump(pool + (size_t)(base + f) * MAT);
+                        double zr, zi;
+                        frob_part(t, rho, zr, zi);
+                        block_sum(zr, zi);
+                        zr /= n;
+                        zi /= n;
+                        acc += (zr * zr + zi * zi) / fs;
+                        if (lam != nullptr) {
+                            const double g = 2.0 * c.scale / ((double)fs * n);
+                            add_scaled(l, g * zr, g * zi, t);
+                        }
+                    }
+                    if (lam != nullptr) store_dump(l, lam + (size_t)s * MAT);
+                    base += fs;
+                }
+                total += c.scale * acc;
+            }
+        }
+        return total;
+    }
+
+    // the generators of a sub-interval, linear in the stage's position c (the controls are linear in
+    // time between knots): left(c) = la + c ld, right(c) = ra - c ld
+    struct Gen {
+        T la, ld, ra;
+    };
+    __device__ __forceinline__ Gen generators(const SubStep& ss, const double* ctl, bool adjoint) const {
+        Gen g;
+        g.la = load_dump(adjoint ? a.a0ld_cimg : a.a0l_cimg);
+        g.ra = load_dump(adjoint ? a.a0rd_cimg : a.a0r_cimg);
+        g.ld = tile_zero<G>();
+        const int K = a.K;
+        for (int k = 0; k < K; ++k) {
+            const double ua = ss.wa1 * ctl[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl[(size_t)ss.ia2 * K + k];
+            const double ub = ss.wb1 * ctl[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl[(size_t)ss.ib2 * K + k];
+            const T gk = load_dump((adjoint ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
+            tile_axpy<G>(g.la, ua, gk);
+            tile_axpy<G>(g.ra, -ua, gk);
+            tile_axpy<G>(g.ld, ub - ua, gk);
+        }
+        return g;
+    }
+
+    // out = left(c) y + y right(c) + sum_i gamma_i L_i y L_i^H (ADJ: L_i^H y L_i; the generators are
+    // then the conjugate transposes already). Three workgroup barriers; y stays in M_ARG afterwards.
+    template <bool ADJ>
+    __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c, double gamma0, double gamma1) const {
+        T gl = g.la, gr = g.ra;
+        tile_axpy<G>(gl, c, g.ld);
+        tile_axpy<G>(gr, -c, g.ld);
+        wv.store(y, M_ARG);
+        wv.store(gl, M_GL);
+        wv.store(gr, M_GR);
+        __syncthreads();
+        T acc = tile_zero<G>();
+        wv.template mm<false, false>(acc, M_GL, M_ARG, 1.0);
+        wv.template mm<false, false>(acc, M_ARG, M_GR, 1.0);
+        const int nops = a.nops;
+        if (nops == 0) return acc;
+        __syncthreads();  // the generators have been read: t_i take their place
+        {
+            T t = tile_zero<G>();
+            wv.template mm<ADJ, false>(t, M_OP0, M_ARG, gamma0);
+            wv.store(t, M_T0);
+        }
+        if (nops > 1) {
+            T t = tile_zero<G>();
+            wv.template mm<ADJ, false>(t, M_OP1, M_ARG, gamma1);
+            wv.store(t, M_T1);
+        }
+        __syncthreads();
+        wv.template mm<false, !ADJ>(acc, M_T0, M_OP0, 1.0);
+        if (nops > 1) wv.template mm<false, !ADJ>(acc, M_T1, M_OP1, 1.0);
+        return acc;
+    }
+};
+
+__global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx{a, make_wave<G>(smem, false), reinterpret_cast<double2*>(smem + RED_OFF), 0};
+    const W& wv = cx.wv;
+    const int S = a.S, K = a.K, nsub = a.nsub, nops = a.nops;
+    const int b = blockIdx.x;
+    double2* dens = a.scratch + (size_t)b * (2 * S + STAGES) * MAT;
+    double2* lam = dens + (size_t)S * MAT;
+    double2* kdump = lam + (size_t)S * MAT;  // k_j / Ybar_j: [STAGES] dumps
+    double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
+    const double* ctl = a.controls + (size_t)b * a.nc * K;
+    const double gamma0 = nops > 0 ? a.gammas[0] : 0.0, gamma1 = nops > 1 ? a.gammas[1] : 0.0;
+
+    if (nops > 0) wv.store(cx.load_dump(a.op_cimg), M_OP0);
+    if (nops > 1) wv.store(cx.load_dump(a.op_cimg + MAT), M_OP1);
+    for (int s = 0; s < S; ++s) cx.store_dump(cx.load_dump(a.rho0_cimg + (size_t)s * MAT), dens + (size_t)s * MAT);
+    __syncthreads();
+
+    // ---- forward ----------------------------------------------------------------------------------
+    // (a wave reads back from `dens`, `lam`, `ckpt` only the tile it wrote itself: no fences needed)
+    double cost = 0;
+    for (int q = 0; q < nsub; ++q) {
+        const SubStep ss = a.substeps[q];
+        if (ss.first_of_step) {
+            if (a.has_step_costs && ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
+                cost += cx.costs(true, false, dens, nullptr);
+            if (a.step_densities != nullptr)
+                for (int s = 0; s < S; ++s)
+                    cx.store_dump(cx.load_dump(dens + (size_t)s * MAT),
+                                  a.step_densities + (((size_t)b * (a.nsteps + 1) + ss.step) * S + s) * MAT);
+        }
+        const Ctx::Gen g = cx.generators(ss, ctl, false);
+        for (int s = 0; s < S; ++s) {
+            T y0 = cx.load_dump(dens + (size_t)s * MAT);
+            cx.store_dump(y0, ckpt_b + ((size_t)q * S + s) * MAT);
+            double2* ys = a.ystages != nullptr ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT : nullptr;
+            const double h = ss.h;
+            T klast = tile_zero<G>();
+#pragma unroll 1
+            for (int i = 0; i < STAGES; ++i) {
+                T y = y0;
+#pragma unroll 1
+                for (int j = 0; j + 1 < i; ++j) {
+                    const double aij = RK.a[i * STAGES + j];
+                    if (aij != 0.0) tile_axpy<G>(y, h * aij, cx.load_dump(kdump + (size_t)j * MAT));
+                }
+                if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
+                if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
+                klast = cx.rhs<false>(y, g, RK.c[i], gamma0, gamma1);
+                cx.store_dump(klast, kdump + (size_t)i * MAT);
+            }
+#pragma unroll 1
+            for (int i = 0; i < STAGES; ++i) {
+                const double bi = RK.b[i];
+                if (bi != 0.0) tile_axpy<G>(y0, h * bi, cx.load_dump(kdump + (size_t)i * MAT));
+            }
+            cx.store_dump(y0, dens + (size_t)s * MAT);
+        }
+    }
+    if (a.has_step_costs && (a.nsteps % a.cost_eval_step) == 0) cost += cx.costs(true, false, dens, nullptr);
+    cost += cx.costs(false, true, dens, nullptr);
+    if (wv.tid == 0) a.cost_out[b] = cost;
+    for (int s = 0; s < S; ++s) {
+        const T rho = cx.load_dump(dens + (size_t)s * MAT);
+        cx.store_dump(rho, a.final_out + ((size_t)b * S + s) * MAT);
+        if (a.step_densities != nullptr)
+            cx.store_dump(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
+    }
+    if (!a.want_grad) return;
+
+    // ---- discrete adjoint -------------------------------------------------------------------------
+    for (int s = 0; s < S; ++s) cx.store_dump(tile_zero<G>(), lam + (size_t)s * MAT);
+    (void)cx.costs((a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+    for (int q = nsub - 1; q >= 0; --q) {
+        const SubStep ss = a.substeps[q];
+        const Ctx::Gen g = cx.generators(ss, ctl, true);
+        // control cotangents at the two ends of the sub-interval: per-lane partial sums
+        double ga[QOCX_LINDBLAD_MAX_K], gb[QOCX_LINDBLAD_MAX_K];
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
+            ga[k] = 0;
+            gb[k] = 0;
+        }
+        for (int s = 0; s < S; ++s) {
+            const double2* ys = a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT;
+            const T lambda = cx.load_dump(lam + (size_t)s * MAT);
+            T lambda_new = lambda;
+            const double h = ss.h;
+            T yblast = tile_zero<G>();
+#pragma unroll 1
+            for (int i = STAGES - 1; i >= 0; --i) {
+                // kbar_i = h (b_i lambda + sum_{j > i} a_ji Ybar_j)
+                const double ci = RK.c[i];
+                T kb = lambda;
+                tile_scale<G>(kb, h * RK.b[i]);
+#pragma unroll 1
+                for (int j = i + 2; j < STAGES; ++j) {
+                    const double aji = RK.a[j * STAGES + i];
+                    if (aji != 0.0) tile_axpy<G>(kb, h * aji, cx.load_dump(kdump + (size_t)j * MAT));
+                }
+                if (i + 1 < STAGES) tile_axpy<G>(kb, h * RK.a[(i + 1) * STAGES + i], yblast);
+                wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
+                yblast = cx.rhs<true>(kb, g, ci, gamma0, gamma1);
+                cx.store_dump(yblast, kdump + (size_t)i * MAT);
+                tile_axpy<G>(lambda_new, 1.0, yblast);
+                // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
+                // Z = Y kbar^H - kbar^H Y (kbar is still in M_ARG, Y_i in M_YS since before rhs's barriers)
+                T z = tile_zero<G>();
+                wv.template mm<false, true>(z, M_YS, M_ARG, 1.0);
+                wv.template mm<true, false>(z, M_ARG, M_YS, -1.0);
+#pragma unroll
+                for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+                    if (k < K) {
+                        const T gt = cx.load_dump(a.gpt_cimg + (size_t)k * MAT);
+                        double pr = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pr += z.re[0][r] * gt.re[0][r] - z.im[0][r] * gt.im[0][r];
+                        ga[k] += (1.0 - ci) * pr;
+                        gb[k] += ci * pr;
+                    }
+                __syncthreads();  // M_ARG, M_YS free for the next stage
+            }
+            cx.store_dump(lambda_new, lam + (size_t)s * MAT);
+        }
+#pragma unroll
+        for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+            if (k < K) {
+                double x = ga[k], y = gb[k];
+                cx.block_sum(x, y);
+                if (wv.tid == 0) {
+                    a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + k] = x;
+                    a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + k] = y;
+                }
+            }
+        // step costs are evaluated on the densities at the START of their system step
+        if (ss.first_of_step && ss.step != 0 && (ss.step % a.cost_eval_step) == 0 && a.has_step_costs) {
+            for (int s = 0; s < S; ++s)
+                cx.store_dump(cx.load_dump(ckpt_b + ((size_t)q * S + s) * MAT), dens + (size_t)s * MAT);
+            (void)cx.costs(true, false, dens, lam);
+        }
+    }
+}
+
+}  // namespace lindblad4t
+
+// the tile-per-wave kernel covers: constant H0 / G_k / lindblad_data, at most two operators, stage
+// values kept, no injected cotangents
+bool lindblad4t_supports(const LindbladArgs& a) {
+    return a.tile4 && a.n > 16 && a.n <= 32 && a.phase == 0 && a.a0_tab == nullptr && a.gp_tab == nullptr &&
+           a.op_tab == nullptr && a.nops <= lindblad4t::MAX_OPS && (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr &&
+           a.scratch != nullptr && a.K <= QOCX_LINDBLAD_MAX_K;
+}
+
+void launch_lindblad4t(const LindbladArgs& a, int batch, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad4t::lindblad4t_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lindblad4t::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lindblad4t::lindblad4t_kernel, dim3(batch), dim3(256), lindblad4t::LDS_BYTES, st, a);
+}
+
+}  // namespace qocx

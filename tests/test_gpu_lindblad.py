@@ -175,6 +175,9 @@ LINDBLAD_EDGES = [
     dict(n=3, S=12, K=1, L=4, N=3, Nc=3),   # one tile, but too many densities for LDS: HBM scratch
     dict(n=32, S=1, K=2, L=4, N=2, Nc=2),   # largest supported Hilbert space and operator count
     dict(n=17, S=2, K=1, L=1, N=3, Nc=4),   # two tiles with 15 padded rows
+    dict(n=32, S=2, K=3, L=2, N=4, Nc=3),   # the tile-per-wave kernel (qocx_lindblad4t.hip): full tiles
+    dict(n=24, S=1, K=2, L=0, N=3, Nc=3),   # ... without dissipation
+    dict(n=25, S=3, K=8, L=1, N=3, Nc=2),   # ... maximum controls
 ]
 
 
@@ -211,6 +214,40 @@ def test_lindblad_edge_shapes_against_model(engine, spec):
         assert np.max(np.abs(final[b] - m_final)) < 1e-12
         if K:
             assert np.max(np.abs(grads[b] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+
+
+def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
+    """17 <= n <= 32: the four-wave kernel that holds the density tile-wise (knob lindblad_4t, default)
+    against the one-wave form on the same problem - cost, gradient, final and per-step densities."""
+    from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY
+    n, S, K, L, N, Nc = 28, 2, 2, 2, 7, 4
+    rng = np.random.default_rng(4128)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 1.5
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)])
+    gam = rng.uniform(0.05, 0.3, L)
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    forb = np.stack([cases_mod.random_density(rng, n) for _ in range(3 * S)])
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ),
+             dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=0.1, vectors=forb, counts=[1, 5])]
+    controls = 0.7 * rng.standard_normal((3, Nc, K))
+    out = {}
+    try:
+        for knob in (1, 0):
+            engine.set_knob("lindblad_4t", knob)
+            engine.set_lindblad_problem(n, S, K, Nc, N, 0.3 * (N - 1), h0, g, gam, ops, rho0, costs=descs,
+                                        cost_eval_step=2)
+            out[knob] = engine.evaluate_lindblad(controls)
+            engine.set_keep_step_states(True)
+            out[knob] += (engine.evaluate_lindblad(controls, want_grad=False)[0], engine.download_step_densities())
+            engine.set_keep_step_states(False)
+    finally:
+        engine.set_knob("lindblad_4t", 1)
+        engine.set_keep_step_states(False)
+    for a, b in zip(out[1], out[0]):
+        assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-12 * max(1.0, np.max(np.abs(np.asarray(b))))
 
 
 def test_lindblad_random_shapes_fuzz(engine):
