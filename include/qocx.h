@@ -309,6 +309,7 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *   "lu_stream": n > 32, K1b of a time segment on a stream of its own beside K1a of the next (0: one stream).
  *   "lindblad_q2": their stage loop with 18 of the 72 MFMAs of a right-hand side per wave (0: the quarter-split loops).
  *   "lindblad_4t": Lindblad at 17 <= n <= 32 on the tile-per-wave kernel where it applies (0: one wave per seed).
+ *   "lindblad_hermitian": that kernel's shorter stages for Hermitian problems (Y A_R = (A_L Y)^H; 0: the general stages).
  *   "sweep_onebuf", "k3_split": launch shapes of the sweep / of K3.
  * Diagnostic knobs - libqocx_diag.so only (make diag, -DQOCX_DIAG; the product library answers
  * QOCX_ERR_ARG): "dbg_skip", "sweep3_dbg", "k1a_dbg" switch parts of an evaluation off for timing

@@ -270,6 +270,8 @@ struct qocx_ctx {
         DevBuf<double2> checkpoints, final_out, step_densities, ystages, scratch;
         DevBuf<double2> kbstages, lam_scale;  // two-sided evaluation (LindbladArgs::phase)
         bool unit_ok = false;                 // one final TargetDensityInfidelity, one density
+        bool hermitian = false;               // H0, G_k, sum gamma L^H L, initial densities and cost matrices
+                                              // are Hermitian: so is every density and every cotangent
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
         // qocx_debug_lindblad_knobs (tests force the kernel variants large batches / little HBM use)
@@ -1691,6 +1693,19 @@ cmat cm_zero(int n) { return cmat((size_t)2 * n * n, 0.0); }
 
 cmat cm_from(const double* p, int n) { return cmat(p, p + (size_t)2 * n * n); }
 
+// M = M^H to rounding: max |M - M^H| <= 64 eps max |M|
+bool cm_is_hermitian(const cmat& a, int n) {
+    double big = 0, diff = 0;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c <= r; ++c) {
+            const double xr = a[2 * ((size_t)r * n + c)], xi = a[2 * ((size_t)r * n + c) + 1];
+            const double yr = a[2 * ((size_t)c * n + r)], yi = a[2 * ((size_t)c * n + r) + 1];
+            big = std::max(big, std::max(fabs(xr), fabs(xi)));
+            diff = std::max(diff, std::max(fabs(xr - yr), fabs(xi + yi)));
+        }
+    return diff <= 1.5e-14 * big;
+}
+
 cmat cm_adjoint(const cmat& a, int n) {
     cmat o = cm_zero(n);
     for (int r = 0; r < n; ++r)
@@ -1895,6 +1910,8 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     cmat a0l = cm_scale(h0, 0.0, -1.0), a0r = cm_scale(h0, 0.0, 1.0);
     cm_axpy(a0l, -0.5, decay);
     cm_axpy(a0r, -0.5, decay);
+    lb.hermitian = p->h0_stages == nullptr && p->g_stages == nullptr && p->op_stages == nullptr &&
+                   cm_is_hermitian(h0, n) && cm_is_hermitian(decay, n);
     lb.h0_norm = two_norm(h0.data(), n);
     // static problem: the control-free Liouvillian as a whole (never above the sum of the parts)
     lb.l0_norm = std::min(liouvillian_norm(a0l, a0r, ops, gammas, n),
@@ -1905,6 +1922,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     for (int k = 0; k < K; ++k) {
         const cmat gk = cm_from(p->g + (size_t)k * n * n * 2, n);
         lb.g_norm[k] = two_norm(gk.data(), n);
+        lb.hermitian = lb.hermitian && cm_is_hermitian(gk, n);
         gp.push_back(cm_scale(gk, 0.0, -1.0));  // Gp = -i G
         gpd.push_back(cm_adjoint(gp.back(), n));
         gpt.push_back(cm_transpose(gp.back(), n));
@@ -1996,6 +2014,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     std::vector<cmat> rho0;
     for (int s = 0; s < S; ++s) rho0.push_back(cm_from(p->initial_densities + (size_t)s * n * n * 2, n));
     if (upload_dumps(lb.rho0, rho0, n, ctx->stream)) return QOCX_ERR_HIP;
+    for (const cmat& r : rho0) lb.hermitian = lb.hermitian && cm_is_hermitian(r, n);
 
     std::vector<qocx::DevCost> dcosts;
     std::vector<cmat> pool;
@@ -2028,6 +2047,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         if (d.step_cost) lb.has_step_costs = 1;
         dcosts.push_back(d);
     }
+    for (const cmat& m : pool) lb.hermitian = lb.hermitian && cm_is_hermitian(m, n);
     lb.cost_count = (int)dcosts.size();
     lb.unit_ok = dcosts.size() == 1 && !dcosts[0].step_cost &&
                  dcosts[0].kind == QOCX_DEV_COST_TARGET_DENSITY;
@@ -2356,6 +2376,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.step_densities = ctx->keep_step_states
                                     ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
             la.tile4 = ctx->knob("lindblad_4t", 1) != 0 ? 1 : 0;
+            la.hermitian = (lb.hermitian && ctx->knob("lindblad_hermitian", 1) != 0) ? 1 : 0;
             la.stamps = nullptr;
             if (ctx->knob("lindblad_stamps", 0)) {
                 // ([B] sets of the forward pass / classic launch, then [B] of the unit adjoint)
@@ -2461,7 +2482,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -288,6 +288,7 @@ struct LindbladArgs {
     // (lindblad_combine) contracts them with the forward stage values and the scalars into the
     // control cotangents. phase 0: the classic forward-then-adjoint launch.
     int phase = 0;
+    int hermitian = 0;             // every density and cotangent is Hermitian, A_R = A_L^H, Gp_k^H = -Gp_k (host-checked)
     int tile4 = 1;                 // 17 <= n <= 32: the tile-per-wave kernel (qocx_lindblad4t.hip) where it applies
     int q2 = 0;                    // phases 1 / 2, four waves: the stage loop with 18 MFMAs per wave (substep_q2)
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)

@@ -40,7 +40,8 @@ constexpr int MAX_OPS = 2;
 // LDS matrices (pitch 33): the argument of the right-hand side, the two generators at the stage's
 // time (then t_0, t_1), the operators, the stage value of the control-cotangent products; behind them
 // the partial sums of a reduction
-enum { M_ARG = 0, M_GL, M_GR, M_OP0, M_OP1, M_YS, M_COUNT, M_T0 = M_GL, M_T1 = M_GR };
+// (Hermitian problems: M_GR carries X = A_L Y to the wave that needs its mirror tile, t_1 has M_T1H)
+enum { M_ARG = 0, M_GL, M_GR, M_OP0, M_OP1, M_YS, M_T1H, M_COUNT, M_T0 = M_GL, M_T1 = M_GR, M_XS = M_GR };
 constexpr int RED_OFF = M_COUNT * D::MBYTES;
 constexpr int LDS_BYTES = RED_OFF + 2 * 4 * 16;  // [parity][wave] of a complex scalar
 
@@ -187,19 +188,42 @@ struct Ctx {
 
     // out = left(c) y + y right(c) + sum_i gamma_i L_i y L_i^H (ADJ: L_i^H y L_i; the generators are
     // then the conjugate transposes already). Three workgroup barriers; y stays in M_ARG afterwards.
-    template <bool ADJ>
+    // HERM (host-checked: y Hermitian, right = left^H): y right = (left y)^H - one product less, the
+    // mirror tile of X = left y comes from its owner through LDS.
+    template <bool ADJ, bool HERM>
     __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c, double gamma0, double gamma1) const {
-        T gl = g.la, gr = g.ra;
+        const int nops = a.nops;
+        T gl = g.la;
         tile_axpy<G>(gl, c, g.ld);
-        tile_axpy<G>(gr, -c, g.ld);
         wv.store(y, M_ARG);
         wv.store(gl, M_GL);
-        wv.store(gr, M_GR);
+        if (!HERM) {
+            T gr = g.ra;
+            tile_axpy<G>(gr, -c, g.ld);
+            wv.store(gr, M_GR);
+        }
         __syncthreads();
         T acc = tile_zero<G>();
         wv.template mm<false, false>(acc, M_GL, M_ARG, 1.0);
+        if (HERM) {
+            wv.store(acc, M_XS);
+            T t0 = tile_zero<G>();
+            if (nops > 0) wv.template mm<ADJ, false>(t0, M_OP0, M_ARG, gamma0);
+            if (nops > 1) {
+                T t1 = tile_zero<G>();
+                wv.template mm<ADJ, false>(t1, M_OP1, M_ARG, gamma1);
+                wv.store(t1, M_T1H);
+            }
+            __syncthreads();  // X complete; the generator has been read: t_0 takes its place
+            tile_axpy<G>(acc, 1.0, wv.load_adjoint(M_XS));
+            if (nops == 0) return acc;
+            wv.store(t0, M_T0);
+            __syncthreads();
+            wv.template mm<false, !ADJ>(acc, M_T0, M_OP0, 1.0);
+            if (nops > 1) wv.template mm<false, !ADJ>(acc, M_T1H, M_OP1, 1.0);
+            return acc;
+        }
         wv.template mm<false, false>(acc, M_ARG, M_GR, 1.0);
-        const int nops = a.nops;
         if (nops == 0) return acc;
         __syncthreads();  // the generators have been read: t_i take their place
         {
@@ -219,6 +243,7 @@ struct Ctx {
     }
 };
 
+template <bool HERM>
 __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx{a, make_wave<G>(smem, false), reinterpret_cast<double2*>(smem + RED_OFF), 0};
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
                 if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
                 if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
-                klast = cx.rhs<false>(y, g, RK.c[i], gamma0, gamma1);
+                klast = cx.template rhs<false, HERM>(y, g, RK.c[i], gamma0, gamma1);
                 cx.store_dump(klast, kdump + (size_t)i * MAT);
             }
 #pragma unroll 1
@@ -321,14 +346,19 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
                 if (i + 1 < STAGES) tile_axpy<G>(kb, h * RK.a[(i + 1) * STAGES + i], yblast);
                 wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
-                yblast = cx.rhs<true>(kb, g, ci, gamma0, gamma1);
+                yblast = cx.template rhs<true, HERM>(kb, g, ci, gamma0, gamma1);
                 cx.store_dump(yblast, kdump + (size_t)i * MAT);
                 tile_axpy<G>(lambda_new, 1.0, yblast);
                 // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
-                // Z = Y kbar^H - kbar^H Y (kbar is still in M_ARG, Y_i in M_YS since before rhs's barriers)
+                // Z = Y kbar^H - kbar^H Y (kbar is still in M_ARG, Y_i in M_YS since before rhs's barriers).
+                // HERM: Z = W - W^H with W = Y kbar, and Re tr(W^H Gp_k) = -Re tr(W Gp_k) as Gp_k^H = -Gp_k
                 T z = tile_zero<G>();
-                wv.template mm<false, true>(z, M_YS, M_ARG, 1.0);
-                wv.template mm<true, false>(z, M_ARG, M_YS, -1.0);
+                if (HERM) {
+                    wv.template mm<false, false>(z, M_YS, M_ARG, 2.0);
+                } else {
+                    wv.template mm<false, true>(z, M_YS, M_ARG, 1.0);
+                    wv.template mm<true, false>(z, M_ARG, M_YS, -1.0);
+                }
 #pragma unroll
                 for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
                     if (k < K) {
@@ -375,11 +405,16 @@ bool lindblad4t_supports(const LindbladArgs& a) {
 void launch_lindblad4t(const LindbladArgs& a, int batch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad4t::lindblad4t_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad4t::lindblad4t_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lindblad4t::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad4t::lindblad4t_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lindblad4t::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(lindblad4t::lindblad4t_kernel, dim3(batch), dim3(256), lindblad4t::LDS_BYTES, st, a);
+    if (a.hermitian)
+        hipLaunchKernelGGL(lindblad4t::lindblad4t_kernel<true>, dim3(batch), dim3(256), lindblad4t::LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(lindblad4t::lindblad4t_kernel<false>, dim3(batch), dim3(256), lindblad4t::LDS_BYTES, st, a);
 }
 
 }  // namespace qocx

@@ -217,7 +217,8 @@ def test_lindblad_edge_shapes_against_model(engine, spec):
 
 
 def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
-    """17 <= n <= 32: the four-wave kernel that holds the density tile-wise (knob lindblad_4t, default)
+    """17 <= n <= 32: the four-wave kernel that holds the density tile-wise (knob lindblad_4t, default),
+    with its shorter stages for Hermitian problems and with the general ones (knob lindblad_hermitian),
     against the one-wave form on the same problem - cost, gradient, final and per-step densities."""
     from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY
     n, S, K, L, N, Nc = 28, 2, 2, 2, 7, 4
@@ -235,8 +236,9 @@ def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
     controls = 0.7 * rng.standard_normal((3, Nc, K))
     out = {}
     try:
-        for knob in (1, 0):
-            engine.set_knob("lindblad_4t", knob)
+        for knob in (2, 1, 0):
+            engine.set_knob("lindblad_4t", min(knob, 1))
+            engine.set_knob("lindblad_hermitian", 1 if knob == 2 else 0)
             engine.set_lindblad_problem(n, S, K, Nc, N, 0.3 * (N - 1), h0, g, gam, ops, rho0, costs=descs,
                                         cost_eval_step=2)
             out[knob] = engine.evaluate_lindblad(controls)
@@ -245,9 +247,25 @@ def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
             engine.set_keep_step_states(False)
     finally:
         engine.set_knob("lindblad_4t", 1)
+        engine.set_knob("lindblad_hermitian", 1)
         engine.set_keep_step_states(False)
-    for a, b in zip(out[1], out[0]):
-        assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-12 * max(1.0, np.max(np.abs(np.asarray(b))))
+    for variant in (2, 1):
+        for a, b in zip(out[variant], out[0]):
+            assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-12 * max(1.0, np.max(np.abs(np.asarray(b))))
+    # a problem that is NOT Hermitian (an effective Hamiltonian with a loss term) takes the general stages
+    engine.set_lindblad_problem(n, S, K, Nc, N, 0.3 * (N - 1), h0 - 0.05j * np.diag(np.arange(n) / n), g, gam, ops,
+                                rho0, costs=descs, cost_eval_step=2)
+    lossy = engine.evaluate_lindblad(controls)
+    engine.set_knob("lindblad_4t", 0)
+    try:
+        engine.set_lindblad_problem(n, S, K, Nc, N, 0.3 * (N - 1), h0 - 0.05j * np.diag(np.arange(n) / n), g, gam,
+                                    ops, rho0, costs=descs, cost_eval_step=2)
+        ref = engine.evaluate_lindblad(controls)
+    finally:
+        engine.set_knob("lindblad_4t", 1)
+    for a, b in zip(lossy, ref):
+        assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))
+    assert np.max(np.abs(lossy[0] - out[0][0])) > 1e-10
 
 
 def test_lindblad_random_shapes_fuzz(engine):
