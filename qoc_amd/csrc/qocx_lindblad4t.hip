@@ -9,7 +9,8 @@
 // the density, of the stage value, of every stage derivative k_j, of the cotangents. A stage
 //     k = A_L(c) Y + Y A_R(c) + sum_i gamma_i L_i Y L_i^H        (adjoint: A^H, L_i^H . L_i)
 // is three rounds of LDS-operand products with one workgroup barrier before each: the generator
-// products, t_i = gamma_i L_i Y (stored over the generators), t_i L_i^H. No partial sums are exchanged -
+// products, t_i = gamma_i L_i Y (stored over the generators), t_i L_i^H (the operators two at a time: the
+// last two rounds again for a third and fourth). No partial sums are exchanged -
 // every wave computes ITS tile of every product - and the Runge-Kutta combinations are tile
 // arithmetic: a wave writes its tile of k_j to the seed's HBM scratch and reads only that tile back (L2
 // hits, no synchronisation; twelve 16 KB matrices fit neither LDS next to the operands nor - as the
@@ -17,7 +18,7 @@
 // kernel is 258 KB of straight-line code against 64 KB of instruction cache and runs at the pace of
 // the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>) carries four tiles per matrix
 // in one wave and keeps its k_j in HBM scratch; it stays as the general path (time-dependent tables,
-// more than two operators, recomputed stage values, injected cotangents).
+// recomputed stage values, injected cotangents).
 #include "qocx_device.h"
 #include "qocx_tilewave.h"
 #include "dop853_tableau.h"
@@ -35,15 +36,16 @@ typedef Dim<G> D;
 
 constexpr int STAGES = QOCX_RK_STAGES;
 constexpr int MAT = D::IMAT;  // complex elements of a C-dump
-constexpr int MAX_OPS = 2;
+constexpr int MAX_OPS = 4;
 
 // LDS matrices (pitch 33): the argument of the right-hand side, the two generators at the stage's
 // time (then t_0, t_1), the operators, the stage value of the control-cotangent products; behind them
 // the partial sums of a reduction
 // (Hermitian problems: M_GR carries X = A_L Y to the wave that needs its mirror tile, t_1 has M_T1H)
-enum { M_ARG = 0, M_GL, M_GR, M_OP0, M_OP1, M_YS, M_T1H, M_COUNT, M_T0 = M_GL, M_T1 = M_GR, M_XS = M_GR };
+enum { M_ARG = 0, M_GL, M_GR, M_YS, M_T1H, M_OP0, M_COUNT = M_OP0 + MAX_OPS, M_T0 = M_GL, M_T1 = M_GR, M_XS = M_GR };
 constexpr int RED_OFF = M_COUNT * D::MBYTES;
 constexpr int LDS_BYTES = RED_OFF + 2 * 4 * 16;  // [parity][wave] of a complex scalar
+static_assert(LDS_BYTES <= 160 * 1024, "one seed per CU");
 
 // the Butcher tableau in constant memory (runtime-indexed by the rolled stage loops)
 struct TableauInit {
@@ -187,14 +189,19 @@ struct Ctx {
     }
 
     // out = left(c) y + y right(c) + sum_i gamma_i L_i y L_i^H (ADJ: L_i^H y L_i; the generators are
-    // then the conjugate transposes already). Three workgroup barriers; y stays in M_ARG afterwards.
+    // then the conjugate transposes already). The operators go in pairs: t_i = gamma_i L_i y into the
+    // slots of the generators, a barrier, t_i L_i^H - three workgroup barriers for up to two operators,
+    // five for up to four (one more in the forward stage); y stays in M_ARG afterwards.
     // HERM (host-checked: y Hermitian, right = left^H): y right = (left y)^H - one product less, the
     // mirror tile of X = left y comes from its owner through LDS.
     template <bool ADJ, bool HERM>
-    __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c, double gamma0, double gamma1) const {
+    __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c) const {
         const int nops = a.nops;
         T gl = g.la;
         tile_axpy<G>(gl, c, g.ld);
+        // (the last products of the previous stage read t_i from the generators' slots; the adjoint
+        // stage ends with a barrier of its own)
+        if (!ADJ) __syncthreads();
         wv.store(y, M_ARG);
         wv.store(gl, M_GL);
         if (!HERM) {
@@ -205,13 +212,14 @@ struct Ctx {
         __syncthreads();
         T acc = tile_zero<G>();
         wv.template mm<false, false>(acc, M_GL, M_ARG, 1.0);
+        int first = 0;  // the first operator of the pair loop below
         if (HERM) {
             wv.store(acc, M_XS);
             T t0 = tile_zero<G>();
-            if (nops > 0) wv.template mm<ADJ, false>(t0, M_OP0, M_ARG, gamma0);
+            if (nops > 0) wv.template mm<ADJ, false>(t0, M_OP0, M_ARG, a.gammas[0]);
             if (nops > 1) {
                 T t1 = tile_zero<G>();
-                wv.template mm<ADJ, false>(t1, M_OP1, M_ARG, gamma1);
+                wv.template mm<ADJ, false>(t1, M_OP0 + 1, M_ARG, a.gammas[1]);
                 wv.store(t1, M_T1H);
             }
             __syncthreads();  // X complete; the generator has been read: t_0 takes its place
@@ -220,25 +228,29 @@ struct Ctx {
             wv.store(t0, M_T0);
             __syncthreads();
             wv.template mm<false, !ADJ>(acc, M_T0, M_OP0, 1.0);
-            if (nops > 1) wv.template mm<false, !ADJ>(acc, M_T1H, M_OP1, 1.0);
-            return acc;
+            if (nops > 1) wv.template mm<false, !ADJ>(acc, M_T1H, M_OP0 + 1, 1.0);
+            first = 2;
+        } else {
+            wv.template mm<false, false>(acc, M_ARG, M_GR, 1.0);
         }
-        wv.template mm<false, false>(acc, M_ARG, M_GR, 1.0);
-        if (nops == 0) return acc;
-        __syncthreads();  // the generators have been read: t_i take their place
-        {
-            T t = tile_zero<G>();
-            wv.template mm<ADJ, false>(t, M_OP0, M_ARG, gamma0);
-            wv.store(t, M_T0);
+        const int second_slot = HERM ? M_T1H : M_T1;
+#pragma unroll 1
+        for (int i = first; i < nops; i += 2) {
+            __syncthreads();  // the generators (the previous pair's t_i) have been read
+            {
+                T t = tile_zero<G>();
+                wv.template mm<ADJ, false>(t, M_OP0 + i, M_ARG, a.gammas[i]);
+                wv.store(t, M_T0);
+            }
+            if (i + 1 < nops) {
+                T t = tile_zero<G>();
+                wv.template mm<ADJ, false>(t, M_OP0 + i + 1, M_ARG, a.gammas[i + 1]);
+                wv.store(t, second_slot);
+            }
+            __syncthreads();
+            wv.template mm<false, !ADJ>(acc, M_T0, M_OP0 + i, 1.0);
+            if (i + 1 < nops) wv.template mm<false, !ADJ>(acc, second_slot, M_OP0 + i + 1, 1.0);
         }
-        if (nops > 1) {
-            T t = tile_zero<G>();
-            wv.template mm<ADJ, false>(t, M_OP1, M_ARG, gamma1);
-            wv.store(t, M_T1);
-        }
-        __syncthreads();
-        wv.template mm<false, !ADJ>(acc, M_T0, M_OP0, 1.0);
-        if (nops > 1) wv.template mm<false, !ADJ>(acc, M_T1, M_OP1, 1.0);
         return acc;
     }
 };
@@ -255,10 +267,8 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     double2* kdump = lam + (size_t)S * MAT;  // k_j / Ybar_j: [STAGES] dumps
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
     const double* ctl = a.controls + (size_t)b * a.nc * K;
-    const double gamma0 = nops > 0 ? a.gammas[0] : 0.0, gamma1 = nops > 1 ? a.gammas[1] : 0.0;
 
-    if (nops > 0) wv.store(cx.load_dump(a.op_cimg), M_OP0);
-    if (nops > 1) wv.store(cx.load_dump(a.op_cimg + MAT), M_OP1);
+    for (int i = 0; i < nops; ++i) wv.store(cx.load_dump(a.op_cimg + (size_t)i * MAT), M_OP0 + i);
     for (int s = 0; s < S; ++s) cx.store_dump(cx.load_dump(a.rho0_cimg + (size_t)s * MAT), dens + (size_t)s * MAT);
     __syncthreads();
 
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
                 if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
                 if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
-                klast = cx.template rhs<false, HERM>(y, g, RK.c[i], gamma0, gamma1);
+                klast = cx.template rhs<false, HERM>(y, g, RK.c[i]);
                 cx.store_dump(klast, kdump + (size_t)i * MAT);
             }
 #pragma unroll 1
@@ -315,6 +325,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     if (!a.want_grad) return;
 
     // ---- discrete adjoint -------------------------------------------------------------------------
+    __syncthreads();  // (the forward's last products are done with the slots)
     for (int s = 0; s < S; ++s) cx.store_dump(tile_zero<G>(), lam + (size_t)s * MAT);
     (void)cx.costs((a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
     for (int q = nsub - 1; q >= 0; --q) {
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
                 if (i + 1 < STAGES) tile_axpy<G>(kb, h * RK.a[(i + 1) * STAGES + i], yblast);
                 wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
-                yblast = cx.template rhs<true, HERM>(kb, g, ci, gamma0, gamma1);
+                yblast = cx.template rhs<true, HERM>(kb, g, ci);
                 cx.store_dump(yblast, kdump + (size_t)i * MAT);
                 tile_axpy<G>(lambda_new, 1.0, yblast);
                 // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
@@ -394,8 +405,8 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
 
 }  // namespace lindblad4t
 
-// the tile-per-wave kernel covers: constant H0 / G_k / lindblad_data, at most two operators, stage
-// values kept, no injected cotangents
+// the tile-per-wave kernel covers: constant H0 / G_k / lindblad_data, stage values kept (or no gradient
+// wanted), no injected cotangents
 bool lindblad4t_supports(const LindbladArgs& a) {
     return a.tile4 && a.n > 16 && a.n <= 32 && a.phase == 0 && a.a0_tab == nullptr && a.gp_tab == nullptr &&
            a.op_tab == nullptr && a.nops <= lindblad4t::MAX_OPS && (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr &&

@@ -178,6 +178,7 @@ LINDBLAD_EDGES = [
     dict(n=32, S=2, K=3, L=2, N=4, Nc=3),   # the tile-per-wave kernel (qocx_lindblad4t.hip): full tiles
     dict(n=24, S=1, K=2, L=0, N=3, Nc=3),   # ... without dissipation
     dict(n=25, S=3, K=8, L=1, N=3, Nc=2),   # ... maximum controls
+    dict(n=20, S=2, K=2, L=3, N=3, Nc=3),   # ... an odd operator count above two (second operator pair)
 ]
 
 
