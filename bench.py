@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 DIM, N_EVAL, SEEDS_PER_GPU, K_CTRL, DT = 32, 1001, 256, 2, 0.05
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (spec; SURVEY.md 8d / BASELINE.md 3)
 # The rate a register-only loop of v_mfma_f64_16x16x4_f64 sustains on the box is measured live
-# (qocx_debug_mfma_peak) and reported as roofline.peak_sustained_measured: ~48 TFLOP/s.
+# (qocx_debug_mfma_peak) and reported as roofline.peak_sustained_measured: ~68 TFLOP/s on one accumulation chain (48 on eight).
 
 
 def gue(rng, n):

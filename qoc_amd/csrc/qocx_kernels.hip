@@ -1854,23 +1854,19 @@ __global__ __launch_bounds__(64) void selftest_kernel(double* out) {
     out[448 + lane] = dpp_f64<0x140>(v);
 }
 
-// Sustained FP64 MFMA rate: every wave issues `iters` rounds of 8 independent
-// v_mfma_f64_16x16x4_f64 chains from registers, nothing else. Calibrates the roofline peak.
+// Sustained FP64 MFMA rate: every wave issues `iters` rounds of 8 v_mfma_f64_16x16x4_f64 from registers,
+// nothing else, all on ONE accumulator - the fastest pattern the pipe has: an MFMA that accumulates
+// onto the result of the one issued just before it costs 73 cycles (two waves per SIMD; 68.5 TFLOP/s
+// over the chip), three alternating accumulators 83 (61.0), eight 105 (48.2 - the figure of rounds
+// 1-3, whose kernel used eight): profiles/r04_mfma_chains.jsonl. Calibrates the roofline peak.
 __global__ __launch_bounds__(64) void mfma_peak_kernel(double* out, int iters) {
     const double a = 1.0 + 1e-9 * lane_id(), b = 1.0 - 1e-9 * lane_id();
-    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    d4 c = {0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
-        c0 = mfma_f64(a, b, c0);
-        c1 = mfma_f64(a, b, c1);
-        c2 = mfma_f64(a, b, c2);
-        c3 = mfma_f64(a, b, c3);
-        c4 = mfma_f64(a, b, c4);
-        c5 = mfma_f64(a, b, c5);
-        c6 = mfma_f64(a, b, c6);
-        c7 = mfma_f64(a, b, c7);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) c = mfma_f64(a, b, c);
     }
-    const d4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
-    if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = 1.0;  // keeps the chains alive
+    if (c[0] + c[1] + c[2] + c[3] == -1.0) out[0] = 1.0;  // keeps the chain alive
 }
 
 #ifdef QOCX_DIAG
@@ -1885,7 +1881,30 @@ __global__ __launch_bounds__(64) void pipe_mix_kernel(double* out, int iters, in
     const bool vec = (mode == 1 || mode == 3) || ((mode == 2 || mode == 4) && (slot & 1));
     const bool f32 = mode >= 3;
     const double a = 1.0 + 1e-9 * lane_id(), b = 1.0 - 1e-9 * lane_id();
-    if (!vec) {
+    if (mode >= 11 && mode <= 18) {
+        // 8 MFMAs per round on mode - 10 accumulation chains (1: every MFMA accumulates onto the one
+        // before it ... 8: the peak kernel's form): what a dependent FP64 MFMA costs
+        const int chains = mode - 10;
+        d4 c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = d4{0, 0, 0, 0};
+        auto rounds = [&](auto tag) {
+            constexpr int CH = decltype(tag)::value;
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) c[m % CH] = mfma_f64(a, b, c[m % CH]);
+        };
+        if (chains == 1) rounds(std::integral_constant<int, 1>{});
+        else if (chains == 2) rounds(std::integral_constant<int, 2>{});
+        else if (chains == 3) rounds(std::integral_constant<int, 3>{});
+        else if (chains == 4) rounds(std::integral_constant<int, 4>{});
+        else if (chains == 6) rounds(std::integral_constant<int, 6>{});
+        else rounds(std::integral_constant<int, 8>{});
+        d4 s = c[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += c[k];
+        if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = 1.0;
+    } else if (!vec) {
         d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
         for (int it = 0; it < iters; ++it) {
             c0 = mfma_f64(a, b, c0); c1 = mfma_f64(a, b, c1); c2 = mfma_f64(a, b, c2); c3 = mfma_f64(a, b, c3);
