@@ -2256,9 +2256,12 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
     // only if a piece would fall below 256 seeds does the adjoint recompute the stages instead.
     // Two-sided evaluation (LindbladArgs::phase): where it applies the adjoint's stage cotangents
     // need a buffer like the forward's stage values, and gsub holds complex numbers
-    const bool two_sided_ok = want_grad && lb.unit_ok && lb.inj_count == 0 && n <= 16 &&
-                              lb.nops >= 1 && lb.multi_wave && !lb.global_scratch &&
-                              lb.fixed_ksub == 0 && lb.dbg_wave_mode != 1 &&
+    // (n > 16: the tile-per-wave kernel of qocx_lindblad4t.hip in its phases, constant tables only)
+    const bool two_sided_small = n <= 16 && lb.nops >= 1 && lb.multi_wave && !lb.global_scratch &&
+                                 lb.dbg_wave_mode != 1;
+    const bool two_sided_tiles = n > 16 && ctx->knob("lindblad_4t", 1) != 0 && lb.nops <= 4;
+    const bool two_sided_ok = want_grad && lb.unit_ok && lb.inj_count == 0 &&
+                              (two_sided_small || two_sided_tiles) && lb.fixed_ksub == 0 &&
                               (int)ctx->sweep_streams.size() >= 1 &&
                               ctx->knob("lindblad_two_sided", 1) != 0;
     if (two_sided_ok)
@@ -2392,7 +2395,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             // the whole chip. While both launches find CUs of their own they run on two streams
             // (2 Bp CUs busy instead of Bp); a bigger piece runs them one after the other - the
             // same three kernels, so a seed's result does not depend on the batch it is part of.
-            const bool two_sided = two_sided_ok && keep_stages && multi;
+            const bool two_sided = two_sided_ok && keep_stages && (multi || two_sided_tiles);
             if (two_sided) {
                 const int side_limit = (int)ctx->knob("lindblad_side_limit", ctx->cu_count / 2);
                 hipStream_t side = Bp <= side_limit ? ctx->sweep_streams[0] : ctx->stream;

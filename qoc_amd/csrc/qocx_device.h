@@ -269,7 +269,7 @@ struct LindbladArgs {
     double2* checkpoints;      // [B][nsub][S] C-dumps: densities at the start of each sub-interval
     int multi_wave;            // 1: nops + 2 wavefronts per seed (n <= 16, everything in LDS)
     int cache_gen;             // multi_wave: constant generator dumps copied to LDS
-    double2* scratch;          // [B][2 S + 12] dumps when densities / cotangents / stage
+    double2* scratch;          // [B][2 S + 12] (n > 16: [B][2 S + 24]) dumps when densities / cotangents / stage
                                // derivatives do not live in LDS (always for n > 16), else nullptr
     double2* ystages;          // [B][nsub][S][12] C-dumps of the stage values, or nullptr: the
                                // adjoint then recomputes them from the checkpoints
@@ -317,6 +317,7 @@ void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st);
 void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st);
 bool lindblad4t_supports(const LindbladArgs& a);
 void launch_lindblad4t(const LindbladArgs& a, int batch, hipStream_t st);
+void launch_lindblad4t_combine(const LindbladArgs& a, int batch, hipStream_t st);
 int lindblad_lds_size(int n, int S, int nops, int mode, int K);
 size_t lindblad_scratch_elems(int n, int S);
 

@@ -1698,6 +1698,10 @@ __global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
 
 void launch_lindblad_combine(const LindbladArgs& a, int batch, hipStream_t st) {
     if (batch <= 0 || a.nsub <= 0) return;
+    if (a.n > 16) {
+        launch_lindblad4t_combine(a, batch, st);
+        return;
+    }
     hipLaunchKernelGGL(lindblad_combine_kernel, dim3(a.nsub, batch), dim3(64), 0, st, a);
 }
 
@@ -1732,8 +1736,9 @@ int lindblad_lds_size(int n, int S, int nops, int mode, int K) {
 }
 
 // complex elements of per-seed HBM scratch when it is used
+// (n > 16: a second set of stage dumps - the two passes of the two-sided evaluation run side by side)
 size_t lindblad_scratch_elems(int n, int S) {
-    return (size_t)(2 * S + STAGES) * (n > 16 ? 1024 : 256);
+    return n > 16 ? (size_t)(2 * S + 2 * STAGES) * 1024 : (size_t)(2 * S + STAGES) * 256;
 }
 
 }  // namespace qocx

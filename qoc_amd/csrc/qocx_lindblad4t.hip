@@ -262,20 +262,27 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     const W& wv = cx.wv;
     const int S = a.S, K = a.K, nsub = a.nsub, nops = a.nops;
     const int b = blockIdx.x;
-    double2* dens = a.scratch + (size_t)b * (2 * S + STAGES) * MAT;
+    // Two-sided evaluation (LindbladArgs::phase; one final TargetDensityInfidelity): phase 1 is the
+    // forward pass alone and leaves the scalars of the final cotangents, phase 2 the adjoint of the
+    // TARGETS - beside it, on other CUs - which stores its stage cotangents kbar_i instead of
+    // contracting them; lindblad4t_combine_kernel does that afterwards over the whole chip.
+    const int phase = a.phase;
+    double2* dens = a.scratch + (size_t)b * (2 * S + 2 * STAGES) * MAT;
     double2* lam = dens + (size_t)S * MAT;
-    double2* kdump = lam + (size_t)S * MAT;  // k_j / Ybar_j: [STAGES] dumps
+    // k_j / Ybar_j: [STAGES] dumps, a set of its own for the pass that runs beside the forward
+    double2* kdump = lam + (size_t)S * MAT + (phase == 2 ? (size_t)STAGES * MAT : 0);
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
     const double* ctl = a.controls + (size_t)b * a.nc * K;
 
     for (int i = 0; i < nops; ++i) wv.store(cx.load_dump(a.op_cimg + (size_t)i * MAT), M_OP0 + i);
-    for (int s = 0; s < S; ++s) cx.store_dump(cx.load_dump(a.rho0_cimg + (size_t)s * MAT), dens + (size_t)s * MAT);
+    if (phase != 2)
+        for (int s = 0; s < S; ++s) cx.store_dump(cx.load_dump(a.rho0_cimg + (size_t)s * MAT), dens + (size_t)s * MAT);
     __syncthreads();
 
     // ---- forward ----------------------------------------------------------------------------------
     // (a wave reads back from `dens`, `lam`, `ckpt` only the tile it wrote itself: no fences needed)
     double cost = 0;
-    for (int q = 0; q < nsub; ++q) {
+    for (int q = 0; q < (phase == 2 ? 0 : nsub); ++q) {
         const SubStep ss = a.substeps[q];
         if (ss.first_of_step) {
             if (a.has_step_costs && ss.step != 0 && (ss.step % a.cost_eval_step) == 0)
@@ -313,21 +320,39 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
             cx.store_dump(y0, dens + (size_t)s * MAT);
         }
     }
-    if (a.has_step_costs && (a.nsteps % a.cost_eval_step) == 0) cost += cx.costs(true, false, dens, nullptr);
-    cost += cx.costs(false, true, dens, nullptr);
-    if (wv.tid == 0) a.cost_out[b] = cost;
-    for (int s = 0; s < S; ++s) {
-        const T rho = cx.load_dump(dens + (size_t)s * MAT);
-        cx.store_dump(rho, a.final_out + ((size_t)b * S + s) * MAT);
-        if (a.step_densities != nullptr)
-            cx.store_dump(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
+    if (phase != 2) {
+        if (a.has_step_costs && (a.nsteps % a.cost_eval_step) == 0) cost += cx.costs(true, false, dens, nullptr);
+        cost += cx.costs(false, true, dens, nullptr);
+        if (wv.tid == 0) a.cost_out[b] = cost;
+        for (int s = 0; s < S; ++s) {
+            const T rho = cx.load_dump(dens + (size_t)s * MAT);
+            cx.store_dump(rho, a.final_out + ((size_t)b * S + s) * MAT);
+            if (a.step_densities != nullptr)
+                cx.store_dump(rho, a.step_densities + (((size_t)b * (a.nsteps + 1) + a.nsteps) * S + s) * MAT);
+            if (phase == 1) {
+                // cotangent of final density s = (f zr + i f zi) T_s, f = -scale / (S n |z|), z = tr(T_s^H rho_s)
+                // (costs()): the scalars the combine kernel applies
+                const DevCost c = a.costs[0];
+                double zr, zi;
+                Ctx::frob_part(cx.load_dump(a.cost_matrices + ((size_t)c.vec_offset + s) * MAT), rho, zr, zi);
+                cx.block_sum(zr, zi);
+                const double mag = sqrt(zr * zr + zi * zi);
+                const double f = mag > 0 ? -c.scale / ((double)S * a.n * mag) : 0.0;
+                if (wv.tid == 0) a.lam_scale[(size_t)b * S + s] = make_double2(f * zr, f * zi);
+            }
+        }
     }
-    if (!a.want_grad) return;
+    if (!a.want_grad || phase == 1) return;
 
     // ---- discrete adjoint -------------------------------------------------------------------------
     __syncthreads();  // (the forward's last products are done with the slots)
-    for (int s = 0; s < S; ++s) cx.store_dump(tile_zero<G>(), lam + (size_t)s * MAT);
-    (void)cx.costs((a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+    if (phase == 2) {  // lambda_s = the target of density s
+        for (int s = 0; s < S; ++s)
+            cx.store_dump(cx.load_dump(a.cost_matrices + ((size_t)a.costs[0].vec_offset + s) * MAT), lam + (size_t)s * MAT);
+    } else {
+        for (int s = 0; s < S; ++s) cx.store_dump(tile_zero<G>(), lam + (size_t)s * MAT);
+        (void)cx.costs((a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+    }
     for (int q = nsub - 1; q >= 0; --q) {
         const SubStep ss = a.substeps[q];
         const Ctx::Gen g = cx.generators(ss, ctl, true);
@@ -339,7 +364,8 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
             gb[k] = 0;
         }
         for (int s = 0; s < S; ++s) {
-            const double2* ys = a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT;
+            const size_t stage0 = ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT;
+            const double2* ys = a.ystages + stage0;
             const T lambda = cx.load_dump(lam + (size_t)s * MAT);
             T lambda_new = lambda;
             const double h = ss.h;
@@ -356,10 +382,15 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                     if (aji != 0.0) tile_axpy<G>(kb, h * aji, cx.load_dump(kdump + (size_t)j * MAT));
                 }
                 if (i + 1 < STAGES) tile_axpy<G>(kb, h * RK.a[(i + 1) * STAGES + i], yblast);
-                wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
+                if (phase == 2) cx.store_dump(kb, a.kbstages + stage0 + (size_t)i * MAT);
+                else wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
                 yblast = cx.template rhs<true, HERM>(kb, g, ci);
                 cx.store_dump(yblast, kdump + (size_t)i * MAT);
                 tile_axpy<G>(lambda_new, 1.0, yblast);
+                if (phase == 2) {
+                    __syncthreads();  // M_ARG free for the next stage
+                    continue;
+                }
                 // control cotangent of this stage: Re <kbar, Gp_k Y - Y Gp_k> = Re tr(Z Gp_k),
                 // Z = Y kbar^H - kbar^H Y (kbar is still in M_ARG, Y_i in M_YS since before rhs's barriers).
                 // HERM: Z = W - W^H with W = Y kbar, and Re tr(W^H Gp_k) = -Re tr(W Gp_k) as Gp_k^H = -Gp_k
@@ -384,6 +415,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
             }
             cx.store_dump(lambda_new, lam + (size_t)s * MAT);
         }
+        if (phase == 2) continue;
 #pragma unroll
         for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
             if (k < K) {
@@ -403,14 +435,85 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     }
 }
 
+// Two-sided evaluation, third kernel: the control cotangents of sub-interval q of seed b from the stage
+// values Y_i (phase 1) and the stage cotangents kbar_i of the unit adjoint (phase 2),
+//     g_k += Re( conj(c_s) tr(Z_i Gp_k) ),  Z_i = Y_i kbar_i^H - kbar_i^H Y_i,  c_s = lam_scale[b][s],
+// with the weights (1 - c_i, c_i) of the sub-interval's end points: gsub[B][nsub][2][K] as the classic
+// launch writes it. HERM: Z = W - W^H, W = Y kbar, and tr(Z Gp_k) = 2 Re tr(W Gp_k). Throughput work on
+// the whole chip: nsub x B workgroups of four waves, two LDS matrices each.
+template <bool HERM>
+__global__ __launch_bounds__(256) void lindblad4t_combine_kernel(LindbladArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * D::MBYTES + 2 * 4 * 16];
+    Ctx cx{a, make_wave<G>(smem, false), reinterpret_cast<double2*>(smem + 2 * D::MBYTES), 0};
+    const W& wv = cx.wv;
+    const int q = blockIdx.x, b = blockIdx.y, S = a.S, K = a.K, nsub = a.nsub;
+    double ga[QOCX_LINDBLAD_MAX_K], gb[QOCX_LINDBLAD_MAX_K];
+#pragma unroll
+    for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k) {
+        ga[k] = 0;
+        gb[k] = 0;
+    }
+    for (int s = 0; s < S; ++s) {
+        const double2 cs = a.lam_scale[(size_t)b * S + s];
+        const size_t base = ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT;
+#pragma unroll 1
+        for (int i = 0; i < STAGES; ++i) {
+            wv.store(cx.load_dump(a.ystages + base + (size_t)i * MAT), 0);
+            wv.store(cx.load_dump(a.kbstages + base + (size_t)i * MAT), 1);
+            __syncthreads();
+            T z = tile_zero<G>();
+            if (HERM) {
+                wv.template mm<false, false>(z, 0, 1, 2.0);
+            } else {
+                wv.template mm<false, true>(z, 0, 1, 1.0);
+                wv.template mm<true, false>(z, 1, 0, -1.0);
+            }
+            const double ci = RK.c[i];
+#pragma unroll
+            for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+                if (k < K) {
+                    const T gt = cx.load_dump(a.gpt_cimg + (size_t)k * MAT);
+                    double pr = 0, pi = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pr += z.re[0][r] * gt.re[0][r] - z.im[0][r] * gt.im[0][r];
+                        pi += z.re[0][r] * gt.im[0][r] + z.im[0][r] * gt.re[0][r];
+                    }
+                    // Re(conj(c) gamma); HERM: gamma = 2 Re tr(W Gp_k) is real
+                    const double gk = HERM ? cs.x * pr : fma(cs.y, pi, cs.x * pr);
+                    ga[k] += (1.0 - ci) * gk;
+                    gb[k] += ci * gk;
+                }
+            __syncthreads();  // the two matrices are free again
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+        if (k < K) {
+            double x = ga[k], y = gb[k];
+            cx.block_sum(x, y);
+            if (wv.tid == 0) {
+                a.gsub[(((size_t)b * nsub + q) * 2 + 0) * K + k] = x;
+                a.gsub[(((size_t)b * nsub + q) * 2 + 1) * K + k] = y;
+            }
+        }
+}
+
 }  // namespace lindblad4t
 
 // the tile-per-wave kernel covers: constant H0 / G_k / lindblad_data, stage values kept (or no gradient
 // wanted), no injected cotangents
 bool lindblad4t_supports(const LindbladArgs& a) {
-    return a.tile4 && a.n > 16 && a.n <= 32 && a.phase == 0 && a.a0_tab == nullptr && a.gp_tab == nullptr &&
+    return a.tile4 && a.n > 16 && a.n <= 32 && (a.phase == 0 || a.ystages != nullptr) && a.a0_tab == nullptr && a.gp_tab == nullptr &&
            a.op_tab == nullptr && a.nops <= lindblad4t::MAX_OPS && (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr &&
            a.scratch != nullptr && a.K <= QOCX_LINDBLAD_MAX_K;
+}
+
+void launch_lindblad4t_combine(const LindbladArgs& a, int batch, hipStream_t st) {
+    if (a.hermitian)
+        hipLaunchKernelGGL(lindblad4t::lindblad4t_combine_kernel<true>, dim3(a.nsub, batch), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(lindblad4t::lindblad4t_combine_kernel<false>, dim3(a.nsub, batch), dim3(256), 0, st, a);
 }
 
 void launch_lindblad4t(const LindbladArgs& a, int batch, hipStream_t st) {

@@ -269,6 +269,51 @@ def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
     assert np.max(np.abs(lossy[0] - out[0][0])) > 1e-10
 
 
+@pytest.mark.parametrize("spec", [dict(n=24, S=1, K=2, L=2, N=6, Nc=4), dict(n=32, S=3, K=3, L=1, N=4, Nc=3),
+                                  dict(n=18, S=2, K=1, L=4, N=3, Nc=2)],
+                         ids=lambda s: "n{n}_S{S}_K{K}_L{L}".format(**s))
+def test_lindblad_two_sided_above_one_tile(engine, spec):
+    """17 <= n <= 32, ONE final TargetDensityInfidelity: forward pass and unit adjoint of the tile-per-wave
+    kernel side by side, contracted by lindblad4t_combine_kernel (the default), against the classic
+    forward-then-adjoint launch (knob lindblad_two_sided = 0) - with the Hermitian stages and the general
+    ones - and against the NumPy model of the device algorithm."""
+    from qoc_amd.engine import COST_TARGET_DENSITY
+    n, S, K, L, N, Nc = (spec[k] for k in ("n", "S", "K", "L", "N", "Nc"))
+    rng = np.random.default_rng(911 * n + S)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 1.5
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)])
+    gam = rng.uniform(0.05, 0.3, L)
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    T = 0.3 * (N - 1)
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ)]
+    controls = 0.7 * rng.standard_normal((3, Nc, K))
+    out = {}
+    try:
+        for two_sided, herm in ((1, 1), (1, 0), (0, 1)):
+            engine.set_knob("lindblad_two_sided", two_sided)
+            engine.set_knob("lindblad_hermitian", herm)
+            engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs)
+            out[(two_sided, herm)] = engine.evaluate_lindblad(controls)
+    finally:
+        engine.set_knob("lindblad_two_sided", 1)
+        engine.set_knob("lindblad_hermitian", 1)
+    ref = out[(0, 1)]
+    for key in ((1, 1), (1, 0)):
+        for a, b in zip(out[key], ref):
+            assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))
+    costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8)]
+    system = lm.StructuredLindblad(h0, g, gam, ops)
+    cost, grads, final = out[(1, 1)]
+    for b in range(3):
+        m_err, m_grads, m_final = lm.evaluate_with_grad(system, controls[b], rho0, T, N, costs, 1, want_grad=True)
+        assert abs(cost[b] - m_err) < 1e-12
+        assert np.max(np.abs(final[b] - m_final)) < 1e-12
+        assert np.max(np.abs(grads[b] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+
+
 def test_lindblad_random_shapes_fuzz(engine):
     """tests/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
     several densities, batches that mix sub-division counts) against the device model."""
