@@ -17,8 +17,8 @@
 // compiler allocates them - the accumulation registers). The stage loops stay ROLLED: unrolled, the
 // kernel is 258 KB of straight-line code against 64 KB of instruction cache and runs at the pace of
 // the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>) carries four tiles per matrix
-// in one wave and keeps its k_j in HBM scratch; it stays as the general path (time-dependent tables,
-// recomputed stage values, injected cotangents).
+// in one wave and keeps its k_j in HBM scratch; it stays as the general path (recomputed stage values,
+// injected cotangents).
 #include "qocx_device.h"
 #include "qocx_tilewave.h"
 #include "dop853_tableau.h"
@@ -194,21 +194,48 @@ struct Ctx {
     // five for up to four (one more in the forward stage); y stays in M_ARG afterwards.
     // HERM (host-checked: y Hermitian, right = left^H): y right = (left y)^H - one product less, the
     // mirror tile of X = left y comes from its owner through LDS.
+    // `stage` = sub-interval index * STAGES + stage index: selects the time samples of a time-dependent
+    // Hamiltonian (a0_tab: A0L, A0R, A0L^H, A0R^H per stage; gp_tab: Gp, Gp^H, Gp^T per stage and
+    // control) and of time-dependent lindblad_data (op_tab, gamma_tab) when the host supplied them
+    // (qocx_lindblad.hip: build_generator, rhs_split); such problems take the general stages.
     template <bool ADJ, bool HERM>
-    __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c) const {
+    __device__ __forceinline__ T rhs(const T& y, const Gen& g, double c, const SubStep& ss, const double* ctl,
+                                     size_t stage) const {
         const int nops = a.nops;
-        T gl = g.la;
-        tile_axpy<G>(gl, c, g.ld);
-        // (the last products of the previous stage read t_i from the generators' slots; the adjoint
-        // stage ends with a barrier of its own)
+        const double* gam = a.gammas;
+        T gl, gr;
+        if (!HERM && a.a0_tab != nullptr) {
+            const double2* t = a.a0_tab + stage * 4 * MAT;
+            gl = load_dump(t + (ADJ ? 2 : 0) * (size_t)MAT);
+            gr = load_dump(t + (ADJ ? 3 : 1) * (size_t)MAT);
+            const int K = a.K;
+            for (int k = 0; k < K; ++k) {
+                const double ua = ss.wa1 * ctl[(size_t)ss.ia1 * K + k] + ss.wa2 * ctl[(size_t)ss.ia2 * K + k];
+                const double ub = ss.wb1 * ctl[(size_t)ss.ib1 * K + k] + ss.wb2 * ctl[(size_t)ss.ib2 * K + k];
+                const double u = (1.0 - c) * ua + c * ub;  // u(t) is linear inside a sub-interval
+                const T gk = a.gp_tab != nullptr ? load_dump(a.gp_tab + ((stage * K + k) * 3 + (ADJ ? 1 : 0)) * MAT)
+                                                 : load_dump((ADJ ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
+                tile_axpy<G>(gl, u, gk);
+                tile_axpy<G>(gr, -u, gk);
+            }
+        } else {
+            gl = g.la;
+            tile_axpy<G>(gl, c, g.ld);
+            if (!HERM) {
+                gr = g.ra;
+                tile_axpy<G>(gr, -c, g.ld);
+            }
+        }
+        // (the last products of the previous stage read t_i from the generators' slots - and the
+        // operators; the adjoint stage ends with a barrier of its own)
         if (!ADJ) __syncthreads();
+        if (!HERM && a.op_tab != nullptr) {  // this stage's L_i(t), gamma_i(t)
+            for (int i = 0; i < nops; ++i) wv.store(load_dump(a.op_tab + (stage * nops + i) * MAT), M_OP0 + i);
+            gam = a.gamma_tab + stage * nops;
+        }
         wv.store(y, M_ARG);
         wv.store(gl, M_GL);
-        if (!HERM) {
-            T gr = g.ra;
-            tile_axpy<G>(gr, -c, g.ld);
-            wv.store(gr, M_GR);
-        }
+        if (!HERM) wv.store(gr, M_GR);
         __syncthreads();
         T acc = tile_zero<G>();
         wv.template mm<false, false>(acc, M_GL, M_ARG, 1.0);
@@ -216,10 +243,10 @@ struct Ctx {
         if (HERM) {
             wv.store(acc, M_XS);
             T t0 = tile_zero<G>();
-            if (nops > 0) wv.template mm<ADJ, false>(t0, M_OP0, M_ARG, a.gammas[0]);
+            if (nops > 0) wv.template mm<ADJ, false>(t0, M_OP0, M_ARG, gam[0]);
             if (nops > 1) {
                 T t1 = tile_zero<G>();
-                wv.template mm<ADJ, false>(t1, M_OP0 + 1, M_ARG, a.gammas[1]);
+                wv.template mm<ADJ, false>(t1, M_OP0 + 1, M_ARG, gam[1]);
                 wv.store(t1, M_T1H);
             }
             __syncthreads();  // X complete; the generator has been read: t_0 takes its place
@@ -239,12 +266,12 @@ struct Ctx {
             __syncthreads();  // the generators (the previous pair's t_i) have been read
             {
                 T t = tile_zero<G>();
-                wv.template mm<ADJ, false>(t, M_OP0 + i, M_ARG, a.gammas[i]);
+                wv.template mm<ADJ, false>(t, M_OP0 + i, M_ARG, gam[i]);
                 wv.store(t, M_T0);
             }
             if (i + 1 < nops) {
                 T t = tile_zero<G>();
-                wv.template mm<ADJ, false>(t, M_OP0 + i + 1, M_ARG, a.gammas[i + 1]);
+                wv.template mm<ADJ, false>(t, M_OP0 + i + 1, M_ARG, gam[i + 1]);
                 wv.store(t, second_slot);
             }
             __syncthreads();
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
                 if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
                 if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
-                klast = cx.template rhs<false, HERM>(y, g, RK.c[i]);
+                klast = cx.template rhs<false, HERM>(y, g, RK.c[i], ss, ctl, (size_t)q * STAGES + i);
                 cx.store_dump(klast, kdump + (size_t)i * MAT);
             }
 #pragma unroll 1
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 if (i + 1 < STAGES) tile_axpy<G>(kb, h * RK.a[(i + 1) * STAGES + i], yblast);
                 if (phase == 2) cx.store_dump(kb, a.kbstages + stage0 + (size_t)i * MAT);
                 else wv.store(cx.load_dump(ys + (size_t)i * MAT), M_YS);
-                yblast = cx.template rhs<true, HERM>(kb, g, ci);
+                yblast = cx.template rhs<true, HERM>(kb, g, ci, ss, ctl, (size_t)q * STAGES + i);
                 cx.store_dump(yblast, kdump + (size_t)i * MAT);
                 tile_axpy<G>(lambda_new, 1.0, yblast);
                 if (phase == 2) {
@@ -404,7 +431,9 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
 #pragma unroll
                 for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
                     if (k < K) {
-                        const T gt = cx.load_dump(a.gpt_cimg + (size_t)k * MAT);
+                        const T gt = (!HERM && a.gp_tab != nullptr)
+                                         ? cx.load_dump(a.gp_tab + ((((size_t)q * STAGES + i) * K + k) * 3 + 2) * MAT)
+                                         : cx.load_dump(a.gpt_cimg + (size_t)k * MAT);
                         double pr = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pr += z.re[0][r] * gt.re[0][r] - z.im[0][r] * gt.im[0][r];
@@ -501,12 +530,12 @@ __global__ __launch_bounds__(256) void lindblad4t_combine_kernel(LindbladArgs a)
 
 }  // namespace lindblad4t
 
-// the tile-per-wave kernel covers: constant H0 / G_k / lindblad_data, stage values kept (or no gradient
-// wanted), no injected cotangents
+// the tile-per-wave kernel covers: stage values kept (or no gradient wanted), no injected cotangents
 bool lindblad4t_supports(const LindbladArgs& a) {
-    return a.tile4 && a.n > 16 && a.n <= 32 && (a.phase == 0 || a.ystages != nullptr) && a.a0_tab == nullptr && a.gp_tab == nullptr &&
-           a.op_tab == nullptr && a.nops <= lindblad4t::MAX_OPS && (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr &&
-           a.scratch != nullptr && a.K <= QOCX_LINDBLAD_MAX_K;
+    return a.tile4 && a.n > 16 && a.n <= 32 && (a.phase == 0 || a.ystages != nullptr) &&
+           (!a.hermitian || a.a0_tab == nullptr) && a.nops <= lindblad4t::MAX_OPS &&
+           (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr && a.scratch != nullptr &&
+           a.K <= QOCX_LINDBLAD_MAX_K;
 }
 
 void launch_lindblad4t_combine(const LindbladArgs& a, int batch, hipStream_t st) {

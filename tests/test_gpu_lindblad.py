@@ -253,6 +253,7 @@ def test_lindblad_tile_kernel_agrees_with_one_wave_form(engine):
     for variant in (2, 1):
         for a, b in zip(out[variant], out[0]):
             assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-12 * max(1.0, np.max(np.abs(np.asarray(b))))
+        assert np.max(np.abs(out[variant][1] - out[0][1])) < 1e-9 * np.max(np.abs(out[0][1]))
     # a problem that is NOT Hermitian (an effective Hamiltonian with a loss term) takes the general stages
     engine.set_lindblad_problem(n, S, K, Nc, N, 0.3 * (N - 1), h0 - 0.05j * np.diag(np.arange(n) / n), g, gam, ops,
                                 rho0, costs=descs, cost_eval_step=2)
@@ -304,6 +305,7 @@ def test_lindblad_two_sided_above_one_tile(engine, spec):
     for key in ((1, 1), (1, 0)):
         for a, b in zip(out[key], ref):
             assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))
+        assert np.max(np.abs(out[key][1] - ref[1])) < 1e-9 * np.max(np.abs(ref[1]))
     costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8)]
     system = lm.StructuredLindblad(h0, g, gam, ops)
     cost, grads, final = out[(1, 1)]
@@ -312,6 +314,47 @@ def test_lindblad_two_sided_above_one_tile(engine, spec):
         assert abs(cost[b] - m_err) < 1e-12
         assert np.max(np.abs(final[b] - m_final)) < 1e-12
         assert np.max(np.abs(grads[b] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+
+
+def test_lindblad_tile_kernel_time_dependent_tables(engine):
+    """17 <= n <= 32 with a time-dependent Hamiltonian, control operators and lindblad_data (the host's
+    samples at the integrator's stage times): the tile-per-wave kernel against the one-wave form."""
+    from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY, Engine
+    n, S, K, L, N, Nc, ksub = 21, 2, 2, 3, 4, 3, 4
+    rng = np.random.default_rng(5150)
+    gue = cases_mod.gue
+    T = 0.1 * (N - 1)
+    times = Engine.lindblad_stage_times(T, N, Nc, K, ksub)
+    h_a, h_b = gue(rng, n) * 1.5, gue(rng, n) * 0.4
+    g_a = [gue(rng, n) for _ in range(K)]
+    g_b = [gue(rng, n) * 0.3 for _ in range(K)]
+    o_a = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)])
+    o_b = np.stack([gue(rng, n) * 0.2 for _ in range(L)])
+    gam = rng.uniform(0.05, 0.3, L)
+    h0_st = np.stack([h_a + np.cos(1.3 * t) * h_b for t in times])
+    g_st = np.stack([np.stack([g_a[k] + np.sin(0.7 * t + k) * g_b[k] for k in range(K)]) for t in times])
+    op_st = np.stack([o_a + np.sin(0.9 * t) * o_b for t in times])
+    diss_st = np.stack([gam * (1.0 + 0.3 * np.cos(t)) for t in times])
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    forb = np.stack([cases_mod.random_density(rng, n) for _ in range(2 * S)])
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ),
+             dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=0.1, vectors=forb, counts=[2, 2])]
+    controls = 0.7 * rng.standard_normal((3, Nc, K))
+    out = {}
+    try:
+        for knob in (1, 0):
+            engine.set_knob("lindblad_4t", knob)
+            engine.set_lindblad_problem(n, S, K, Nc, N, T, h_a, g_a, gam, o_a, rho0, costs=descs,
+                                        fixed_subdivision=ksub, h0_stages=h0_st, g_stages=g_st,
+                                        diss_stages=diss_st, op_stages=op_st)
+            out[knob] = engine.evaluate_lindblad(controls)
+    finally:
+        engine.set_knob("lindblad_4t", 1)
+    for a, b in zip(out[1], out[0]):
+        assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))
+    assert np.max(np.abs(out[0][1])) > 1e-7
+    assert np.max(np.abs(out[1][1] - out[0][1])) < 1e-9 * np.max(np.abs(out[0][1]))
 
 
 def test_lindblad_random_shapes_fuzz(engine):
