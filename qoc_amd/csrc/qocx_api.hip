@@ -2379,7 +2379,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.step_densities = ctx->keep_step_states
                                     ? lb.step_densities.p + pos0 * (nsteps + 1) * S * md : nullptr;
             la.tile4 = ctx->knob("lindblad_4t", 1) != 0 ? 1 : 0;
-            la.hermitian = (lb.hermitian && ctx->knob("lindblad_hermitian", 1) != 0) ? 1 : 0;
+            la.hermitian = (lb.hermitian && lb.inj_count == 0 && ctx->knob("lindblad_hermitian", 1) != 0) ? 1 : 0;
             la.stamps = nullptr;
             if (ctx->knob("lindblad_stamps", 0)) {
                 // ([B] sets of the forward pass / classic launch, then [B] of the unit adjoint)

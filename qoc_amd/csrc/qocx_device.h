@@ -269,7 +269,7 @@ struct LindbladArgs {
     double2* checkpoints;      // [B][nsub][S] C-dumps: densities at the start of each sub-interval
     int multi_wave;            // 1: nops + 2 wavefronts per seed (n <= 16, everything in LDS)
     int cache_gen;             // multi_wave: constant generator dumps copied to LDS
-    double2* scratch;          // [B][2 S + 12] (n > 16: [B][2 S + 24]) dumps when densities / cotangents / stage
+    double2* scratch;          // [B][2 S + 12] (n > 16: [B][2 S + 36]) dumps when densities / cotangents / stage
                                // derivatives do not live in LDS (always for n > 16), else nullptr
     double2* ystages;          // [B][nsub][S][12] C-dumps of the stage values, or nullptr: the
                                // adjoint then recomputes them from the checkpoints

@@ -1736,9 +1736,10 @@ int lindblad_lds_size(int n, int S, int nops, int mode, int K) {
 }
 
 // complex elements of per-seed HBM scratch when it is used
-// (n > 16: a second set of stage dumps - the two passes of the two-sided evaluation run side by side)
+// (n > 16: a second set of stage dumps - the two passes of the two-sided evaluation run side by side -
+// and a third for stage values recomputed from a checkpoint)
 size_t lindblad_scratch_elems(int n, int S) {
-    return n > 16 ? (size_t)(2 * S + 2 * STAGES) * 1024 : (size_t)(2 * S + STAGES) * 256;
+    return n > 16 ? (size_t)(2 * S + 3 * STAGES) * 1024 : (size_t)(2 * S + STAGES) * 256;
 }
 
 }  // namespace qocx

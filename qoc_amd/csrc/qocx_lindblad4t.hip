@@ -17,8 +17,8 @@
 // compiler allocates them - the accumulation registers). The stage loops stay ROLLED: unrolled, the
 // kernel is 258 KB of straight-line code against 64 KB of instruction cache and runs at the pace of
 // the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>) carries four tiles per matrix
-// in one wave and keeps its k_j in HBM scratch; it stays as the general path (recomputed stage values,
-// injected cotangents).
+// in one wave and keeps its k_j in HBM scratch; it stays behind the knob lindblad_4t = 0 as the form the
+// tests hold this one against.
 #include "qocx_device.h"
 #include "qocx_tilewave.h"
 #include "dop853_tableau.h"
@@ -294,10 +294,12 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     // TARGETS - beside it, on other CUs - which stores its stage cotangents kbar_i instead of
     // contracting them; lindblad4t_combine_kernel does that afterwards over the whole chip.
     const int phase = a.phase;
-    double2* dens = a.scratch + (size_t)b * (2 * S + 2 * STAGES) * MAT;
+    double2* dens = a.scratch + (size_t)b * (2 * S + 3 * STAGES) * MAT;
     double2* lam = dens + (size_t)S * MAT;
     // k_j / Ybar_j: [STAGES] dumps, a set of its own for the pass that runs beside the forward
     double2* kdump = lam + (size_t)S * MAT + (phase == 2 ? (size_t)STAGES * MAT : 0);
+    // stage values recomputed from a checkpoint when the batch's did not fit into HBM (ystages == nullptr)
+    double2* ysdump = lam + (size_t)S * MAT + 2 * (size_t)STAGES * MAT;
     double2* ckpt_b = a.checkpoints + (size_t)b * nsub * S * MAT;
     const double* ctl = a.controls + (size_t)b * a.nc * K;
 
@@ -308,6 +310,41 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
 
     // ---- forward ----------------------------------------------------------------------------------
     // (a wave reads back from `dens`, `lam`, `ckpt` only the tile it wrote itself: no fences needed)
+    // the twelve stages of sub-interval q on y0 (in: the density at its start, out: at its end); the
+    // stage values go to `ys` if that is not null
+    auto forward_stages = [&](const SubStep& ss, const Ctx::Gen& g, int q, T& y0, double2* ys) {
+        const double h = ss.h;
+        T klast = tile_zero<G>();
+#pragma unroll 1
+        for (int i = 0; i < STAGES; ++i) {
+            T y = y0;
+#pragma unroll 1
+            for (int j = 0; j + 1 < i; ++j) {
+                const double aij = RK.a[i * STAGES + j];
+                if (aij != 0.0) tile_axpy<G>(y, h * aij, cx.load_dump(kdump + (size_t)j * MAT));
+            }
+            if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
+            if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
+            klast = cx.template rhs<false, HERM>(y, g, RK.c[i], ss, ctl, (size_t)q * STAGES + i);
+            cx.store_dump(klast, kdump + (size_t)i * MAT);
+        }
+#pragma unroll 1
+        for (int i = 0; i < STAGES; ++i) {
+            const double bi = RK.b[i];
+            if (bi != 0.0) tile_axpy<G>(y0, h * bi, cx.load_dump(kdump + (size_t)i * MAT));
+        }
+    };
+    // lambda += host-supplied cotangent of the densities at system step `step`, if there is one
+    auto inject = [&](int step) {
+        if (a.inj_index == nullptr) return;
+        const int row = a.inj_index[step];
+        if (row < 0) return;
+        for (int s = 0; s < S; ++s) {
+            T l = cx.load_dump(lam + (size_t)s * MAT);
+            tile_axpy<G>(l, 1.0, cx.load_dump(a.inj_bars + (((size_t)b * a.inj_count + row) * S + s) * MAT));
+            cx.store_dump(l, lam + (size_t)s * MAT);
+        }
+    };
     double cost = 0;
     for (int q = 0; q < (phase == 2 ? 0 : nsub); ++q) {
         const SubStep ss = a.substeps[q];
@@ -324,26 +361,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
             T y0 = cx.load_dump(dens + (size_t)s * MAT);
             cx.store_dump(y0, ckpt_b + ((size_t)q * S + s) * MAT);
             double2* ys = a.ystages != nullptr ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT : nullptr;
-            const double h = ss.h;
-            T klast = tile_zero<G>();
-#pragma unroll 1
-            for (int i = 0; i < STAGES; ++i) {
-                T y = y0;
-#pragma unroll 1
-                for (int j = 0; j + 1 < i; ++j) {
-                    const double aij = RK.a[i * STAGES + j];
-                    if (aij != 0.0) tile_axpy<G>(y, h * aij, cx.load_dump(kdump + (size_t)j * MAT));
-                }
-                if (i > 0) tile_axpy<G>(y, h * RK.a[i * STAGES + i - 1], klast);
-                if (ys != nullptr) cx.store_dump(y, ys + (size_t)i * MAT);
-                klast = cx.template rhs<false, HERM>(y, g, RK.c[i], ss, ctl, (size_t)q * STAGES + i);
-                cx.store_dump(klast, kdump + (size_t)i * MAT);
-            }
-#pragma unroll 1
-            for (int i = 0; i < STAGES; ++i) {
-                const double bi = RK.b[i];
-                if (bi != 0.0) tile_axpy<G>(y0, h * bi, cx.load_dump(kdump + (size_t)i * MAT));
-            }
+            forward_stages(ss, g, q, y0, ys);
             cx.store_dump(y0, dens + (size_t)s * MAT);
         }
     }
@@ -379,6 +397,7 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
     } else {
         for (int s = 0; s < S; ++s) cx.store_dump(tile_zero<G>(), lam + (size_t)s * MAT);
         (void)cx.costs((a.nsteps % a.cost_eval_step) == 0, true, dens, lam);
+        inject(a.nsteps);
     }
     for (int q = nsub - 1; q >= 0; --q) {
         const SubStep ss = a.substeps[q];
@@ -393,6 +412,13 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
         for (int s = 0; s < S; ++s) {
             const size_t stage0 = ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT;
             const double2* ys = a.ystages + stage0;
+            if (a.ystages == nullptr) {  // the stage values again, from the checkpoint
+                const Ctx::Gen gf = cx.generators(ss, ctl, false);
+                T y0 = cx.load_dump(ckpt_b + ((size_t)q * S + s) * MAT);
+                forward_stages(ss, gf, q, y0, ysdump);
+                ys = ysdump;
+                __syncthreads();  // (the forward's last products are done with the slots)
+            }
             const T lambda = cx.load_dump(lam + (size_t)s * MAT);
             T lambda_new = lambda;
             const double h = ss.h;
@@ -456,10 +482,13 @@ __global__ __launch_bounds__(256) void lindblad4t_kernel(LindbladArgs a) {
                 }
             }
         // step costs are evaluated on the densities at the START of their system step
-        if (ss.first_of_step && ss.step != 0 && (ss.step % a.cost_eval_step) == 0 && a.has_step_costs) {
-            for (int s = 0; s < S; ++s)
-                cx.store_dump(cx.load_dump(ckpt_b + ((size_t)q * S + s) * MAT), dens + (size_t)s * MAT);
-            (void)cx.costs(true, false, dens, lam);
+        if (ss.first_of_step && ss.step != 0) {
+            if ((ss.step % a.cost_eval_step) == 0 && a.has_step_costs) {
+                for (int s = 0; s < S; ++s)
+                    cx.store_dump(cx.load_dump(ckpt_b + ((size_t)q * S + s) * MAT), dens + (size_t)s * MAT);
+                (void)cx.costs(true, false, dens, lam);
+            }
+            inject(ss.step);
         }
     }
 }
@@ -530,12 +559,10 @@ __global__ __launch_bounds__(256) void lindblad4t_combine_kernel(LindbladArgs a)
 
 }  // namespace lindblad4t
 
-// the tile-per-wave kernel covers: stage values kept (or no gradient wanted), no injected cotangents
 bool lindblad4t_supports(const LindbladArgs& a) {
     return a.tile4 && a.n > 16 && a.n <= 32 && (a.phase == 0 || a.ystages != nullptr) &&
-           (!a.hermitian || a.a0_tab == nullptr) && a.nops <= lindblad4t::MAX_OPS &&
-           (a.ystages != nullptr || !a.want_grad) && a.inj_index == nullptr && a.scratch != nullptr &&
-           a.K <= QOCX_LINDBLAD_MAX_K;
+           (!a.hermitian || (a.a0_tab == nullptr && a.inj_index == nullptr)) && a.nops <= lindblad4t::MAX_OPS &&
+           a.scratch != nullptr && a.K <= QOCX_LINDBLAD_MAX_K;
 }
 
 void launch_lindblad4t_combine(const LindbladArgs& a, int batch, hipStream_t st) {

@@ -357,6 +357,53 @@ def test_lindblad_tile_kernel_time_dependent_tables(engine):
     assert np.max(np.abs(out[1][1] - out[0][1])) < 1e-9 * np.max(np.abs(out[0][1]))
 
 
+def test_lindblad_tile_kernel_recompute_and_host_cotangents(engine):
+    """17 <= n <= 32: the tile-per-wave kernel's adjoint with the stage values recomputed from the
+    checkpoints (a batch whose stage values do not fit: forced through qocx_debug_lindblad_knobs) and
+    with host-supplied density cotangents (qocx_set_density_cotangents: how user cost plugins are
+    differentiated), against the same kernel with kept stage values and against the one-wave form."""
+    from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY
+    n, S, K, L, N, Nc = 19, 2, 2, 2, 6, 4
+    rng = np.random.default_rng(2718)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 1.5
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(L)])
+    gam = rng.uniform(0.05, 0.3, L)
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    forb = np.stack([cases_mod.random_density(rng, n) for _ in range(2 * S)])
+    descs = [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ),
+             dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=0.1, vectors=forb, counts=[2, 2])]
+    controls = 0.7 * rng.standard_normal((3, Nc, K))
+    steps = [2, N - 1]
+    bars = 0.05 * (rng.standard_normal((3, len(steps), S, n, n)) + 1j * rng.standard_normal((3, len(steps), S, n, n)))
+    T = 0.3 * (N - 1)
+    out = {}
+    try:
+        for tag, knob, budget in (("kept", 1, 0), ("recompute", 1, 1), ("one_wave", 0, 0)):
+            engine.set_knob("lindblad_4t", knob)
+            engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs)
+            engine.debug_lindblad_knobs(budget, 256, 0)   # budget 1 < min_piece: stage values not kept
+            plain = engine.evaluate_lindblad(controls)
+            engine.set_density_cotangents(steps, bars)
+            with_bars = engine.evaluate_lindblad(controls)
+            engine.set_density_cotangents(None, None)
+            out[tag] = (plain, with_bars)
+    finally:
+        engine.set_knob("lindblad_4t", 1)
+        engine.debug_lindblad_knobs(0, 256, 0)
+        engine.set_density_cotangents(None, None)
+    ref_plain, ref_bars = out["one_wave"]
+    scale = np.max(np.abs(ref_plain[1]))
+    assert np.max(np.abs(ref_bars[1] - ref_plain[1])) > 1e-3 * scale   # the cotangents reach the gradient
+    for tag in ("kept", "recompute"):
+        for mine, ref in zip(out[tag], (ref_plain, ref_bars)):
+            assert np.max(np.abs(mine[0] - ref[0])) < 1e-12
+            assert np.max(np.abs(mine[2] - ref[2])) < 1e-12
+            assert np.max(np.abs(mine[1] - ref[1])) < 1e-9 * np.max(np.abs(ref[1]))
+
+
 def test_lindblad_random_shapes_fuzz(engine):
     """tests/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
     several densities, batches that mix sub-division counts) against the device model."""
