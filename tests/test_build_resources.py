@@ -144,3 +144,17 @@ def test_mfma_factorisation_kernels_keep_their_budgets():
     assert lu9["Occupancy"] == 2 and lu9["VGPRs Spill"] <= 32, lu9
     lu2w = find(table, "lu2w_kernel")  # 49 <= n <= 64: two waves, two tile columns each
     assert lu2w["ScratchSize"] == 0 and lu2w["VGPRs Spill"] == 0 and lu2w["Occupancy"] >= 2, lu2w
+
+
+def test_tile_per_wave_lindblad_kernels_stay_out_of_scratch():
+    """Round 4 (qocx_lindblad4t.hip, 17 <= n <= 32): the stage loops must stay rolled and scratch free.
+    Unrolled (to keep the twelve k_j tiles in registers) the kernel was 258 KB of code against 64 KB of
+    instruction cache and spilled 700-900 registers; the k_j tiles of a wave go through the seed's HBM
+    scratch instead. The combine kernel must fit several workgroups per CU (LDS, registers)."""
+    table = resources("qocx_lindblad4t.hip")
+    for herm in ("Lb0E", "Lb1E"):
+        kern = find(table, "lindblad4t_kernelI" + herm)
+        assert kern["ScratchSize"] == 0 and kern["VGPRs Spill"] == 0, kern
+        comb = find(table, "lindblad4t_combine_kernelI" + herm)
+        assert comb["ScratchSize"] == 0 and comb["VGPRs Spill"] == 0, comb
+        assert comb["LDS Size"] <= 40 * 1024 and comb["Occupancy"] >= 2, comb
