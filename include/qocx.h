@@ -310,6 +310,8 @@ int qocx_debug_selftest(qocx_ctx* ctx, int32_t* failures, char* report, int32_t 
  *   "lindblad_q2": their stage loop with 18 of the 72 MFMAs of a right-hand side per wave (0: the quarter-split loops).
  *   "lindblad_4t": Lindblad at 17 <= n <= 32 on the tile-per-wave kernel where it applies (0: one wave per seed).
  *   "lindblad_hermitian": that kernel's shorter stages for Hermitian problems (Y A_R = (A_L Y)^H; 0: the general stages).
+ *   "lindblad_pad_operator": Lindblad with ONE operator at n <= 16 on the four-wave launches of two (the second zero);
+ *                   read when the problem is set (0: the three-wave form).
  *   "sweep_onebuf", "k3_split": launch shapes of the sweep / of K3.
  * Diagnostic knobs - libqocx_diag.so only (make diag, -DQOCX_DIAG; the product library answers
  * QOCX_ERR_ARG): "dbg_skip", "sweep3_dbg", "k1a_dbg" switch parts of an evaluation off for timing

@@ -273,6 +273,7 @@ struct qocx_ctx {
         bool hermitian = false;               // H0, G_k, sum gamma L^H L, initial densities and cost matrices
                                               // are Hermitian: so is every density and every cotangent
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
+        int pad_op = 0;  // L = 1: a zero second operator behind the real one, for the four-wave launches
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
         // qocx_debug_lindblad_knobs (tests force the kernel variants large batches / little HBM use)
         int64_t last_subintervals = 0;   // sum over the seeds of the last evaluation
@@ -1882,11 +1883,16 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         return fail(QOCX_ERR_ARG, "too many operators for the kernel's LDS");
     // several waves per seed (generator terms | one per operator | control cotangents) whenever
     // that layout fits LDS: the recursion in time is serial, this shortens every stage
+    // (ONE operator - the T1 problem - runs the several-wave launches as two, the second one zero: the
+    // four-wave stage loops of section 14 exist for L = 2 only and are 1.5 times faster than the three-wave
+    // form of L = 1 although they multiply by that zero: 17.2 -> 11.5 ms on configs[3]'s sizes)
+    ctx->lb.pad_op = (L == 1 && n <= 16 && p->op_stages == nullptr && ctx->knob("lindblad_pad_operator", 1) != 0) ? 1 : 0;
+    const int Lmw = ctx->lb.pad_op ? 2 : L;
     ctx->lb.multi_wave = (!ctx->lb.global_scratch && L > 0 &&
-                          qocx::lindblad_lds_size(n, S, L, 2, K) <= 160 * 1024 &&
+                          qocx::lindblad_lds_size(n, S, Lmw, 2, K) <= 160 * 1024 &&
                           !qocx::diag_getenv("QOCX_LINDBLAD_SINGLE_WAVE")) ? 1 : 0;
     ctx->lb.cache_gen = (ctx->lb.multi_wave && p->fixed_subdivision <= 0 &&
-                         qocx::lindblad_lds_size(n, S, L, 3, K) <= 160 * 1024) ? 1 : 0;
+                         qocx::lindblad_lds_size(n, S, Lmw, 3, K) <= 160 * 1024) ? 1 : 0;
     auto& lb = ctx->lb;
     lb.has_problem = false;
     lb.n = n; lb.S = S; lb.K = K; lb.nc = nc; lb.N = N; lb.nsteps = N - 1; lb.ces = p->cost_eval_step;
@@ -1905,6 +1911,10 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         // applied where the bound is formed)
         const double opn = two_norm(ops[i].data(), n);
         lb.diss_norm += fabs(gammas[i]) * opn * opn;
+    }
+    if (lb.pad_op) {
+        ops.push_back(cm_zero(n));
+        gammas.push_back(0.0);
     }
     // A0L = -i H0 - decay/2 ; A0R = +i H0 - decay/2   (mathmethods.py:188, :200-203)
     cmat a0l = cm_scale(h0, 0.0, -1.0), a0r = cm_scale(h0, 0.0, 1.0);
@@ -2363,7 +2373,8 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             la.gp_tab = (lb.fixed_ksub > 0 && lb.gp_tab.p) ? lb.gp_tab.p : nullptr;
             la.op_tab = (lb.fixed_ksub > 0 && lb.op_tab.p) ? lb.op_tab.p : nullptr;
             la.gamma_tab = la.op_tab ? lb.gamma_tab.p : nullptr;
-            la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = lb.nops; la.nsub = nsub; la.nsteps = nsteps;
+            la.n = n; la.S = S; la.K = K; la.nc = nc; la.nops = (multi && lb.pad_op) ? 2 : lb.nops; la.nsub = nsub;
+            la.nsteps = nsteps;
             la.cost_eval_step = lb.ces; la.want_grad = want_grad; la.has_step_costs = lb.has_step_costs;
             la.cost_count = lb.cost_count; la.costs = lb.costs.p; la.cost_matrices = lb.cost_matrices.p;
             la.cost_counts = lb.cost_counts.p;
@@ -2485,7 +2496,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -404,6 +404,45 @@ def test_lindblad_tile_kernel_recompute_and_host_cotangents(engine):
             assert np.max(np.abs(mine[1] - ref[1])) < 1e-9 * np.max(np.abs(ref[1]))
 
 
+def test_lindblad_single_operator_on_the_four_wave_launches(engine):
+    """ONE Lindblad operator at n <= 16 (the T1 problem): the engine runs it as two operators, the second
+    zero, so that it takes the four-wave stage loops (knob lindblad_pad_operator, read when the problem is
+    set) - against the three-wave form and the device model, with one cost (two-sided launch) and two."""
+    from qoc_amd.engine import COST_FORBID_DENSITY, COST_TARGET_DENSITY
+    n, S, K, N, Nc = 12, 1, 2, 9, 5
+    rng = np.random.default_rng(1066)
+    gue = cases_mod.gue
+    h0 = gue(rng, n) * 1.5
+    g = [gue(rng, n) for _ in range(K)]
+    ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n)])
+    gam = np.array([0.21])
+    rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
+    forb = np.stack([cases_mod.random_density(rng, n) for _ in range(2 * S)])
+    T = 0.3 * (N - 1)
+    controls = 0.7 * rng.standard_normal((4, Nc, K))
+    for descs in ([dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ)],
+                  [dict(kind=COST_TARGET_DENSITY, step_cost=0, scale=0.8, vectors=targ),
+                   dict(kind=COST_FORBID_DENSITY, step_cost=1, scale=0.1, vectors=forb, counts=[2])]):
+        out = {}
+        try:
+            for pad in (1, 0):
+                engine.set_knob("lindblad_pad_operator", pad)
+                engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs)
+                out[pad] = engine.evaluate_lindblad(controls)
+        finally:
+            engine.set_knob("lindblad_pad_operator", 1)
+        for a, b in zip(out[1], out[0]):
+            assert np.max(np.abs(a - b)) < 1e-13 * max(1.0, np.max(np.abs(b)))
+        assert np.max(np.abs(out[1][1] - out[0][1])) < 1e-10 * np.max(np.abs(out[0][1]))
+    system = lm.StructuredLindblad(h0, g, gam, ops)
+    costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8),
+             ol.ForbidDensities(forb.reshape(S, 2, n, n), N, cost_multiplier=0.1 * (N - 1) * S)]
+    m_err, m_grads, m_final = lm.evaluate_with_grad(system, controls[0], rho0, T, N, costs, 1, want_grad=True)
+    assert abs(out[1][0][0] - m_err) < 1e-12
+    assert np.max(np.abs(out[1][1][0] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+
+
 def test_lindblad_random_shapes_fuzz(engine):
     """tests/fuzz_lindblad.py: 40 random problems (n up to 32, 0..3 controls and operators,
     several densities, batches that mix sub-division counts) against the device model."""
