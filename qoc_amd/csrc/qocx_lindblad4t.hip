@@ -1,9 +1,10 @@
 // qocx_lindblad4t.hip - the Lindblad engine at 17 <= n <= 32 with the density tile-wise on four waves.
 //
-// Replaces (reference): qoc/core/lindbladdiscrete.py:434-501 (_evaluate_lindblad_discrete),
-// qoc/core/mathmethods.py:14-67 (integrate_rkdp5 - here the fixed-step DOP853 of qocx_lindblad.hip),
-// qoc/standard/functions/convenience.py:96-170 (get_lindbladian); the gradient autograd takes through
-// them is the discrete adjoint of the scheme.
+// Replaces (reference): _evaluate_lindblad_discrete (qoc/core/lindbladdiscrete.py:357-441) with its
+// right-hand side _get_rhs_lindbladian (:444-495) / get_lindbladian (qoc/core/mathmethods.py:169-206) and
+// integrate_rkdp5 (mathmethods.py:352-480 - here the fixed-step DOP853 of qocx_lindblad.hip on
+// sub-intervals the host sizes); the gradient autograd takes through them is the discrete adjoint of the
+// scheme. Density costs: targetdensityinfidelity.py:41-69, forbiddensities.py:53-85.
 //
 // One workgroup = one seed = four waves; wave w owns tile (w & 1, w >> 1) of every 32 x 32 matrix - of
 // the density, of the stage value, of every stage derivative k_j, of the cotangents. A stage
@@ -16,8 +17,8 @@
 // hits, no synchronisation; twelve 16 KB matrices fit neither LDS next to the operands nor - as the
 // compiler allocates them - the accumulation registers). The stage loops stay ROLLED: unrolled, the
 // kernel is 258 KB of straight-line code against 64 KB of instruction cache and runs at the pace of
-// the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>) carries four tiles per matrix
-// in one wave and keeps its k_j in HBM scratch; it stays behind the knob lindblad_4t = 0 as the form the
+// the instruction fetch (11 us per stage). The one-wave form of qocx_lindblad.hip (LB<2, true, false>)
+// carries four tiles per matrix in one wave; it stays behind the knob lindblad_4t = 0 as the form the
 // tests hold this one against.
 #include "qocx_device.h"
 #include "qocx_tilewave.h"
