@@ -1317,6 +1317,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         sa.loader = (int)ctx->knob("sweep_loader", 0);
         sa.batch = bc;
         sa.onebuf = (int)ctx->knob("sweep_onebuf", 1);
+        sa.one_state = (int)ctx->knob("sweep_one", 1);
         sa.dbg = (int)ctx->knob("sweep3_dbg", 0);  // (bits 8, 9: the column-chain sweep fetches nothing)
         sa.stamps = nullptr;
         if (ctx->knob("sweep3_stamps", 0)) {
@@ -2494,7 +2495,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 // (qocx_diag.h): timing experiments that return garbage and the stamped kernel builds.
 static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
-    "sweep_onebuf", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
+    "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
     "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",

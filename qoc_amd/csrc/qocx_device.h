@@ -126,6 +126,7 @@ struct SweepArgs {
                           // sweep (it may run before the forward sweep has numbered the sub-steps)
     int batch = 0;        // seeds of the launch (set by the launcher of the two-seeds-per-workgroup form)
     int onebuf = 0;       // one state: one operand set in LDS; 1: one seed per workgroup, 2: two
+    int one_state = 0;    // one state, n <= 32: the dedicated kernel of qocx_sweep1.hip (knob "sweep_one")
     int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
     int dbg;              // sweep3 timing diagnostics (results are garbage): bit 0 no inversion,
                           // bit 1 no solves, bit 2 no LU fetch, bit 3 no Q fetch, bit 4 no Q touch
@@ -345,6 +346,8 @@ void launch_sweepd(const SweepArgs& a, int batch, hipStream_t st);
 void launch_krylovd(const KrylovArgs& a, int nsteps, int batch, hipStream_t st);  // K3 on the matrix cores
 // inverse-image sweep of latency mode (qocx_sweepi.hip): two matrix-vector products per sub-step
 bool sweepi_supports(int nb, int S);
+bool sweep1_supports(int nb, int S);
+void launch_sweep1(int nb, const SweepArgs& a, int batch, int pack, hipStream_t st);
 void launch_sweepi(int nb, const SweepArgs& a, int batch, hipStream_t st);
 int sweep3_max_states(int nb);
 void launch_krylov(int nb, const KrylovArgs& a, int nsteps, int batch, hipStream_t st);

@@ -535,361 +535,11 @@ __global__ __launch_bounds__(64) void pade_pq_explicit_kernel(const double2* a_i
     pade_pq_body<NB, HERM>(gen, out, smem);
 }
 
-// ------------------------------------------------------------------------------------------
-// K2: serial state sweep (forward), costs, adjoint sweep (backward)
-// ------------------------------------------------------------------------------------------
+}  // namespace qocx
 
-// Unit-diagonal triangular solves, axpy form, coefficient rows in F-layout (every lane group
-// holds the full row i = lane % NP, so all groups run the solve redundantly and z stays
-// replicated). Per column k: z_k is broadcast with v_readlane and the rows below (LOWER) or
-// above it take one complex FMA; the row predicate is a compile-time EXEC mask, so the update is
-// exactly four v_fma_f64. CONJ: use conj of the stored coefficients.
-template <int NB, bool LOWER>
-__device__ __forceinline__ constexpr unsigned long long row_mask(int k) {
-    constexpr int NP = Geo<NB>::NP;
-    unsigned long long m = 0;
-    for (int l = 0; l < 64; ++l) {
-        const int i = l % NP;
-        if (LOWER ? (i > k) : (i < k)) m |= (1ull << l);
-    }
-    return m;
-}
+#include "qocx_sweep_core.h"
 
-// z -= c * zk (or conj(c) * zk) on the lanes of a compile-time EXEC mask (two 32-bit literals:
-// no SGPRs are tied up); all 64 lanes are active on entry and on exit.
-template <bool CONJ, unsigned LO, unsigned HI>
-__device__ __forceinline__ void masked_cfma(double& zre, double& zim, double cre, double cim,
-                                            double kre, double kim) {
-    if (CONJ) {
-        asm volatile(
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
-            "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
-            "v_fma_f64 %[zr], -%[ci], %[ki], %[zr]\n\t"
-            "v_fma_f64 %[zi], %[ci], %[kr], %[zi]\n\t"
-            "s_mov_b64 exec, -1"
-            : [zr] "+v"(zre), [zi] "+v"(zim)
-            : [cr] "v"(cre), [ci] "v"(cim), [kr] "s"(kre), [ki] "s"(kim), [lo] "i"(LO), [hi] "i"(HI)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_fma_f64 %[zr], -%[cr], %[kr], %[zr]\n\t"
-            "v_fma_f64 %[zi], -%[cr], %[ki], %[zi]\n\t"
-            "v_fma_f64 %[zr], %[ci], %[ki], %[zr]\n\t"
-            "v_fma_f64 %[zi], -%[ci], %[kr], %[zi]\n\t"
-            "s_mov_b64 exec, -1"
-            : [zr] "+v"(zre), [zi] "+v"(zim)
-            : [cr] "v"(cre), [ci] "v"(cim), [kr] "s"(kre), [ki] "s"(kim), [lo] "i"(LO), [hi] "i"(HI)
-            : "memory");
-    }
-}
-
-template <int NB, bool LOWER, bool CONJ, int KK, class Hook>
-__device__ __forceinline__ void tri_step(const double (&tre)[Geo<NB>::NP],
-                                         const double (&tim)[Geo<NB>::NP], double& zre,
-                                         double& zim, Hook& hook) {
-    constexpr int NP = Geo<NB>::NP;
-    constexpr int k = LOWER ? KK : (NP - 1 - KK);
-    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
-    const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
-    hook(std::integral_constant<int, KK>());  // independent work for the chain's bubbles
-    masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
-        zre, zim, tre[k], tim[k], kre, kim);
-}
-
-template <int NB, bool LOWER, bool CONJ, class Hook, int... KK>
-__device__ __forceinline__ void tri_solve_seq(const double (&tre)[Geo<NB>::NP],
-                                              const double (&tim)[Geo<NB>::NP], double& zre,
-                                              double& zim, Hook& hook,
-                                              std::integer_sequence<int, KK...>) {
-    (tri_step<NB, LOWER, CONJ, KK>(tre, tim, zre, zim, hook), ...);
-}
-
-// hook(kk), kk = 0 .. NP-2, is called once per column between the broadcast and the update.
-template <int NB, bool LOWER, bool CONJ, class Hook>
-__device__ __forceinline__ void tri_solve(const double (&tre)[Geo<NB>::NP],
-                                          const double (&tim)[Geo<NB>::NP], double& zre,
-                                          double& zim, Hook& hook) {
-    tri_solve_seq<NB, LOWER, CONJ>(tre, tim, zre, zim, hook,
-                                   std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
-}
-
-// Two right-hand sides at once (two states of a seed on one wave): the two dependent chains are
-// independent of each other, so each fills the other's bubbles - the broadcasts of one pair of
-// z_k overlap the updates of the other - and the coefficient row is used twice.
-template <bool CONJ, unsigned LO, unsigned HI>
-__device__ __forceinline__ void masked_cfma2(double& are, double& aim, double& bre, double& bim,
-                                             double cre, double cim, double kar, double kai,
-                                             double kbr, double kbi) {
-    if (CONJ) {
-        asm volatile(
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_fma_f64 %[ar], -%[cr], %[kar], %[ar]\n\t"
-            "v_fma_f64 %[ai], -%[cr], %[kai], %[ai]\n\t"
-            "v_fma_f64 %[br], -%[cr], %[kbr], %[br]\n\t"
-            "v_fma_f64 %[bi], -%[cr], %[kbi], %[bi]\n\t"
-            "v_fma_f64 %[ar], -%[ci], %[kai], %[ar]\n\t"
-            "v_fma_f64 %[ai], %[ci], %[kar], %[ai]\n\t"
-            "v_fma_f64 %[br], -%[ci], %[kbi], %[br]\n\t"
-            "v_fma_f64 %[bi], %[ci], %[kbr], %[bi]\n\t"
-            "s_mov_b64 exec, -1"
-            : [ar] "+v"(are), [ai] "+v"(aim), [br] "+v"(bre), [bi] "+v"(bim)
-            : [cr] "v"(cre), [ci] "v"(cim), [kar] "s"(kar), [kai] "s"(kai), [kbr] "s"(kbr),
-              [kbi] "s"(kbi), [lo] "i"(LO), [hi] "i"(HI)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_fma_f64 %[ar], -%[cr], %[kar], %[ar]\n\t"
-            "v_fma_f64 %[ai], -%[cr], %[kai], %[ai]\n\t"
-            "v_fma_f64 %[br], -%[cr], %[kbr], %[br]\n\t"
-            "v_fma_f64 %[bi], -%[cr], %[kbi], %[bi]\n\t"
-            "v_fma_f64 %[ar], %[ci], %[kai], %[ar]\n\t"
-            "v_fma_f64 %[ai], -%[ci], %[kar], %[ai]\n\t"
-            "v_fma_f64 %[br], %[ci], %[kbi], %[br]\n\t"
-            "v_fma_f64 %[bi], -%[ci], %[kbr], %[bi]\n\t"
-            "s_mov_b64 exec, -1"
-            : [ar] "+v"(are), [ai] "+v"(aim), [br] "+v"(bre), [bi] "+v"(bim)
-            : [cr] "v"(cre), [ci] "v"(cim), [kar] "s"(kar), [kai] "s"(kai), [kbr] "s"(kbr),
-              [kbi] "s"(kbi), [lo] "i"(LO), [hi] "i"(HI)
-            : "memory");
-    }
-}
-
-template <int NB, bool LOWER, bool CONJ, int KK, class Hook>
-__device__ __forceinline__ void tri_step2(const double (&tre)[Geo<NB>::NP],
-                                          const double (&tim)[Geo<NB>::NP], double& are, double& aim,
-                                          double& bre, double& bim, Hook& hook) {
-    constexpr int NP = Geo<NB>::NP;
-    constexpr int k = LOWER ? KK : (NP - 1 - KK);
-    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
-    const double kar = readlane_f64(are, k), kai = readlane_f64(aim, k);
-    const double kbr = readlane_f64(bre, k), kbi = readlane_f64(bim, k);
-    hook(std::integral_constant<int, KK>());
-    masked_cfma2<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
-        are, aim, bre, bim, tre[k], tim[k], kar, kai, kbr, kbi);
-}
-template <int NB, bool LOWER, bool CONJ, class Hook, int... KK>
-__device__ __forceinline__ void tri_solve2_seq(const double (&tre)[Geo<NB>::NP],
-                                               const double (&tim)[Geo<NB>::NP], double& are,
-                                               double& aim, double& bre, double& bim, Hook& hook,
-                                               std::integer_sequence<int, KK...>) {
-    (tri_step2<NB, LOWER, CONJ, KK>(tre, tim, are, aim, bre, bim, hook), ...);
-}
-template <int NB, bool LOWER, bool CONJ, class Hook>
-__device__ __forceinline__ void tri_solve2(const double (&tre)[Geo<NB>::NP],
-                                           const double (&tim)[Geo<NB>::NP], double& are, double& aim,
-                                           double& bre, double& bim, Hook& hook) {
-    tri_solve2_seq<NB, LOWER, CONJ>(tre, tim, are, aim, bre, bim, hook,
-                                    std::make_integer_sequence<int, Geo<NB>::NP - 1>{});
-}
-
-// The same solves with the coefficients fetched from the LDS image stage by stage (NB = 4: a lane's
-// row of the LU image would be 256 registers; held there, the sweep wave owns a whole SIMD and only
-// one four-wave K3 workgroup fits on the other three). The coefficient of stage KK + 8 is requested
-// while stage KK runs (a ring of eight in registers); the asm statements of the chain carry memory
-// clobbers, so the requests stay where they are written. Forward: the lane at position i takes row
-// pm = perm[i], element (col k, row pm). Adjoint (the image in LDS is the transposed one): column
-// perm[k], element (col perm[k], row i), perm[k] by v_readlane from `permv` (lane l holds perm[l]).
-template <int NB, bool ADJ>
-__device__ __forceinline__ double2 lds_coef(const double2* lb, int pm, int i, int permv, int k) {
-    constexpr int NP = Geo<NB>::NP;
-    if constexpr (ADJ) {
-        const int pc = min(max(__builtin_amdgcn_readlane(permv, k), 0), NP - 1);
-        return lb[pc * NP + i];
-    } else {
-        return lb[k * NP + pm];
-    }
-}
-
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int KK, int NA, class Hook>
-__device__ __forceinline__ void tri_step_lds(const double2* lb, int pm, int i, int permv,
-                                             double2 (&ring)[8], double& zre, double& zim,
-                                             Hook& hook) {
-    constexpr int D = 8;
-    constexpr int k = LOWER ? KK : (NA - 1 - KK);
-    constexpr unsigned long long mask = row_mask<NB, LOWER>(k);
-    const double2 c = ring[KK % D];
-    if constexpr (KK + D < NA - 1) {
-        constexpr int kn = LOWER ? (KK + D) : (NA - 1 - (KK + D));
-        ring[KK % D] = lds_coef<NB, ADJ>(lb, pm, i, permv, kn);
-    }
-    const double kre = readlane_f64(zre, k), kim = readlane_f64(zim, k);
-    hook(std::integral_constant<int, KK>());  // independent work for the chain's bubbles
-    masked_cfma<CONJ, (unsigned)(mask & 0xffffffffull), (unsigned)(mask >> 32)>(
-        zre, zim, c.x, c.y, kre, kim);
-}
-
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int NA, class Hook, int... KK>
-__device__ __forceinline__ void tri_solve_lds_seq(const double2* lb, int pm, int i, int permv,
-                                                  double2 (&ring)[8], double& zre, double& zim,
-                                                  Hook& hook, std::integer_sequence<int, KK...>) {
-    (tri_step_lds<NB, LOWER, CONJ, ADJ, KK, NA>(lb, pm, i, permv, ring, zre, zim, hook), ...);
-}
-
-// NA < NP (n <= 48 in a 64 x 64 image): rows and columns NA .. NP - 1 are the pad block - unit
-// columns, zero multipliers - so the stages of those columns do nothing and are left out.
-template <int NB, bool LOWER, bool CONJ, bool ADJ, int NA = Geo<NB>::NP, class Hook>
-__device__ __forceinline__ void tri_solve_lds(const double2* lb, int pm, int i, int permv,
-                                              double& zre, double& zim, Hook& hook) {
-    constexpr int D = 8;
-    double2 ring[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j)
-        ring[j] = lds_coef<NB, ADJ>(lb, pm, i, permv, LOWER ? j : (NA - 1 - j));
-    tri_solve_lds_seq<NB, LOWER, CONJ, ADJ, NA>(lb, pm, i, permv, ring, zre, zim, hook,
-                                                std::make_integer_sequence<int, NA - 1>{});
-}
-
-template <int NB>
-struct SweepPrefetch {
-    static constexpr bool value = NB < 4;
-};
-// L / U coefficients from the LDS image stage by stage (tri_solve_lds) instead of a register row:
-// for sixteen tiles only. Measured at n = 32 and n = 16 (-DQOCX_LDSCOEF_MIN_NB=1, bit-identical
-// results): the sweep takes 1.57 instead of 0.525 ms per 125-step segment (0.54 instead of 0.27 at
-// n = 16) - the extra LDS round trip sits on the dependent chain there, while at NB = 4 the register
-// row costs a whole SIMD and scratch.
-#ifndef QOCX_LDSCOEF_MIN_NB
-#define QOCX_LDSCOEF_MIN_NB 4
-#endif
-template <int NB>
-struct SweepLdsCoef {
-    static constexpr bool value = NB >= QOCX_LDSCOEF_MIN_NB;
-};
-
-// NA: columns of an image that are fetched into LDS (NB = 4, n <= 48: the 48 columns that are not
-// the pad block - 48 KiB per image instead of 64, so that a K1a workgroup fits on the CU beside the
-// sweep's; everywhere else the whole image)
-template <int NB, int NBUF = (SweepPrefetch<NB>::value ? 2 : 1), int NA = Geo<NB>::NP>
-struct SweepLds {
-    typedef Geo<NB> G;
-    static constexpr int BUF_BYTES = NA * G::NP * 16;          // one matrix image (NA columns)
-    static constexpr int Q_OFF = 0;                            // NBUF x Q image (ring)
-    static constexpr int L_OFF = Q_OFF + NBUF * BUF_BYTES;      // NBUF x LU image
-    static constexpr int D_OFF = L_OFF + NBUF * BUF_BYTES;      // NBUF x 64 complex: 1/U_kk
-    static constexpr int P_OFF = D_OFF + NBUF * 64 * 16;        // NBUF x PINTS int: perm | iperm
-    static constexpr int PINTS = G::NP > 32 ? 128 : 64;        // iperm starts at PINTS / 2
-    static constexpr int MAX_WAVES = 4;                        // waves per seed (multi-state)
-    static constexpr int TMP_OFF = P_OFF + NBUF * PINTS * 4;    // TMPV x NP complex scratch per wave
-    static constexpr int TMPV = SweepLdsCoef<NB>::value ? 1 : 2;  // (two: the paired-state form)
-    static constexpr int VEC_OFF = TMP_OFF + MAX_WAVES * TMPV * G::NP * 16;  // [S][NP] states, [S][NP] lambda
-    static int bytes(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
-    __host__ __device__ static constexpr int bytes_static(int S) { return VEC_OFF + 2 * S * G::NP * 16; }
-};
-
-// Per-step operands of the sweep, in registers: Q in R-layout (matvec), LU in F-layout (solves).
-template <int NB>
-struct StepRegs {
-    double lre[Geo<NB>::NP], lim[Geo<NB>::NP];
-};
-
-struct StepScalars {
-    double2 dv;  // this lane's 1/U_ii (position i)
-    int pm;      // forward: perm[i] (row at position i); adjoint: iperm[i] (position of row i)
-};
-
-// The same with an instruction offset IMM (13 bits, signed): the 16 bytes at g + IMM land at
-// lds_dst + 16*l. The hardware adds the offset to the global AND to the LDS address, so M0 gets
-// lds_dst - IMM. One per-lane base address then serves many pieces of an image.
-template <int IMM>
-__device__ __forceinline__ void dma16_imm(const char* g, char* lds_dst) {
-    static_assert(IMM >= -4096 && IMM <= 4095, "instruction offset range");
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)g,
-        (__attribute__((address_space(3))) void*)(lds_dst - IMM), 16, IMM, 0);
-}
-
-// f(integral_constant<int, P>) for every P of the sequence
-template <class F, int... P>
-__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, P...>) {
-    (f(std::integral_constant<int, P>()), ...);
-}
-
-// LDS images -> registers. The LU image is stored in original row order, so the row at position
-// k is row perm[k]: the forward F-layout gathers row perm[i] per lane; the adjoint (transposed
-// image) reads column perm[k] for every k, with perm[k] fetched as an LDS broadcast.
-template <int NB, bool ADJOINT>
-__device__ __forceinline__ void lds_to_regs(const double2* qb, const double2* lb, const int* pb,
-                                            StepRegs<NB>& r, int pm, int lane, int i) {
-    typedef Geo<NB> G;
-#pragma unroll
-    for (int c = 0; c < G::NP; ++c) {
-        int src;
-        if (ADJOINT) src = min(max(pb[c], 0), G::NP - 1) * G::NP + i;
-        else src = c * G::NP + pm;
-        const double2 e = lb[src];
-        r.lre[c] = e.x;
-        r.lim[c] = e.y;
-    }
-}
-
-// Partial row sums of a matvec whose matrix sits in LDS as an R-layout image (`qlane` = the image
-// lane this lane takes: its own, or the one of a permuted row) and whose vector is broadcast from
-// LDS; BATCH (matrix, vector) pairs of LDS reads are in flight ahead of their FMAs.
-template <int NB, bool CONJ, int BATCH, int NA = Geo<NB>::NP>
-__device__ __forceinline__ void lds_matvec(const double2* qb, const double2* vec, int qlane, int h,
-                                           double& yre, double& yim) {
-    typedef Geo<NB> G;
-    constexpr int CPL = NA / G::H, H = G::H;  // (NA < NP: the pad columns carry nothing)
-    double ar = 0, ai = 0;
-#pragma unroll
-    for (int c0 = 0; c0 < CPL; c0 += BATCH) {
-        double2 qv[BATCH], xv[BATCH];
-#pragma unroll
-        for (int cc = 0; cc < BATCH; ++cc) {
-            qv[cc] = qb[(c0 + cc) * 64 + qlane];
-            xv[cc] = vec[(c0 + cc) * H + h];
-        }
-#pragma unroll
-        for (int cc = 0; cc < BATCH; ++cc) {
-            const double qi = CONJ ? -qv[cc].y : qv[cc].y;
-            ar = fma(-qi, xv[cc].y, fma(qv[cc].x, xv[cc].x, ar));
-            ai = fma(qi, xv[cc].x, fma(qv[cc].x, xv[cc].y, ai));
-        }
-        asm volatile("" ::: "memory");
-    }
-    yre = sum_groups<NB>(ar);
-    yim = sum_groups<NB>(ai);
-}
-
-// Two vectors against the same matrix: every matrix element is read from LDS once.
-template <int NB, bool CONJ, int BATCH>
-__device__ __forceinline__ void lds_matvec2(const double2* qb, const double2* veca, const double2* vecb,
-                                            int qlane, int h, double& yar, double& yai, double& ybr,
-                                            double& ybi) {
-    typedef Geo<NB> G;
-    constexpr int CPL = G::CPL, H = G::H;
-    double ar = 0, ai = 0, br = 0, bi = 0;
-#pragma unroll
-    for (int c0 = 0; c0 < CPL; c0 += BATCH) {
-        double2 qv[BATCH], xa[BATCH], xb[BATCH];
-#pragma unroll
-        for (int cc = 0; cc < BATCH; ++cc) {
-            qv[cc] = qb[(c0 + cc) * 64 + qlane];
-            xa[cc] = veca[(c0 + cc) * H + h];
-            xb[cc] = vecb[(c0 + cc) * H + h];
-        }
-#pragma unroll
-        for (int cc = 0; cc < BATCH; ++cc) {
-            const double qi = CONJ ? -qv[cc].y : qv[cc].y;
-            ar = fma(-qi, xa[cc].y, fma(qv[cc].x, xa[cc].x, ar));
-            ai = fma(qi, xa[cc].x, fma(qv[cc].x, xa[cc].y, ai));
-            br = fma(-qi, xb[cc].y, fma(qv[cc].x, xb[cc].x, br));
-            bi = fma(qi, xb[cc].x, fma(qv[cc].x, xb[cc].y, bi));
-        }
-        asm volatile("" ::: "memory");
-    }
-    yar = sum_groups<NB>(ar);
-    yai = sum_groups<NB>(ai);
-    ybr = sum_groups<NB>(br);
-    ybi = sum_groups<NB>(bi);
-}
+namespace qocx {
 
 // W waves per seed: the S states of a seed are dealt out to the waves of its workgroup (state s to
 // wave s % W). The operands of a step (Q, LU, 1/U_kk, perm) are fetched once, by wave 0, into LDS
@@ -1012,6 +662,10 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
         wave_sync();
     }
     StepRegs<NB> r;
+    if (QOCX_DBG_BITS(args.dbg) & 8192) {  // (timing experiment: the rows are never loaded)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) r.lre[c] = r.lim[c] = 0.0;
+    }
     const double2* qcur = qbuf;  // Q image of the step being computed
     const double2* lcur = lbuf;  // LU image of the step (read stage by stage when !PREFETCH)
     int permv = 0;               // perm[lane] of the step (adjoint, !PREFETCH)
@@ -1151,12 +805,8 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                     lds_matvec2<NB, false, MVB>(qcur, vecs + s * NP, vecs + (s + W) * NP,
                                                 h * NP + sc.pm, h, are, aim, bre, bim);
                     tri_solve2<NB, true, false>(r.lre, r.lim, are, aim, bre, bim, hook_a);
-                    const double ta = are * sc.dv.x - aim * sc.dv.y;
-                    aim = are * sc.dv.y + aim * sc.dv.x;
-                    are = ta;
-                    const double tb = bre * sc.dv.x - bim * sc.dv.y;
-                    bim = bre * sc.dv.y + bim * sc.dv.x;
-                    bre = tb;
+                    cscale(are, aim, sc.dv);
+                    cscale(bre, bim, sc.dv);
                     tri_solve2<NB, false, false>(r.lre, r.lim, are, aim, bre, bim, hook_b);
                     finish_prefetch();
                     wave_sync();
@@ -1176,14 +826,21 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 pf_fire_q = pf_fire_l = pf_due && (!ONEBUF || sub == nsub - 1);
                 // z = Pi (Q psi): the lane at position i takes row perm[i] of the Q image
                 double zre, zim;
+                if (QOCX_DBG_BITS(args.dbg) & 4096) {  // (timing experiment: no matrix-vector product)
+                    const double2 e = vecs[s * NP + i];
+                    zre = e.x; zim = e.y;
+                } else {
                 lds_matvec<NB, false, MVB, NA>(qcur, vecs + s * NP, h * NP + sc.pm, h, zre, zim);
+                }
+                if (!(QOCX_DBG_BITS(args.dbg) & 2048)) {  // (timing experiment: no solves)
                 if constexpr (!LDSCOEF) tri_solve<NB, true, false>(r.lre, r.lim, zre, zim, hook_a);
                 else tri_solve_lds<NB, true, false, false, NA>(lcur, sc.pm, i, permv, zre, zim, hook_a);
-                const double t = zre * sc.dv.x - zim * sc.dv.y;
-                zim = zre * sc.dv.y + zim * sc.dv.x;
-                zre = t;
+                }
+                cscale(zre, zim, sc.dv);
+                if (!(QOCX_DBG_BITS(args.dbg) & 2048)) {
                 if constexpr (!LDSCOEF) tri_solve<NB, false, false>(r.lre, r.lim, zre, zim, hook_b);
                 else tri_solve_lds<NB, false, false, false, NA>(lcur, sc.pm, i, permv, zre, zim, hook_b);
+                }
                 finish_prefetch();
                 wave_sync();
                 {   // every lane group holds the same z: all of them store (no exec-mask branch
@@ -1230,7 +887,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
             block_sync();
             const StepScalars sc = scalars(par, false);
             if constexpr (!LDSCOEF) {
-                if (computes)
+                if (computes && !(QOCX_DBG_BITS(args.dbg) & 8192))  // (timing experiment: stale rows)
                     lds_to_regs<NB, false>(qbuf + par * LMAT, lbuf + par * LMAT, pbuf + par * PINTS, r,
                                            sc.pm, lane, i);
             } else {
@@ -1334,12 +991,8 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                     const double2 la = lam[s * NP + i], lb = lam[(s + W) * NP + i];
                     double are = la.x, aim = la.y, bre = lb.x, bim = lb.y;
                     tri_solve2<NB, true, true>(r.lre, r.lim, are, aim, bre, bim, hook_a);
-                    const double ta = are * sc.dv.x + aim * sc.dv.y;
-                    aim = aim * sc.dv.x - are * sc.dv.y;
-                    are = ta;
-                    const double tb = bre * sc.dv.x + bim * sc.dv.y;
-                    bim = bim * sc.dv.x - bre * sc.dv.y;
-                    bre = tb;
+                    cscale_conj(are, aim, sc.dv);
+                    cscale_conj(bre, bim, sc.dv);
                     tri_solve2<NB, false, true>(r.lre, r.lim, are, aim, bre, bim, hook_b);
                     finish_prefetch();
                     const double xar = __shfl(are, sc.pm), xai = __shfl(aim, sc.pm);
@@ -1370,13 +1023,15 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 const double2 l0 = lam[s * NP + i];
                 double zre = l0.x, zim = l0.y;
                 // P^H = U'^H D^H L^H Pi : U'^H a = lambda ; b = a / conj(U_kk) ; L^H v = b
+                if (!(QOCX_DBG_BITS(args.dbg) & 2048)) {  // (timing experiment: no solves)
                 if constexpr (!LDSCOEF) tri_solve<NB, true, true>(r.lre, r.lim, zre, zim, hook_a);
                 else tri_solve_lds<NB, true, true, true, NA>(lcur, sc.pm, i, permv, zre, zim, hook_a);
-                const double t = zre * sc.dv.x + zim * sc.dv.y;
-                zim = zim * sc.dv.x - zre * sc.dv.y;
-                zre = t;
+                }
+                cscale_conj(zre, zim, sc.dv);
+                if (!(QOCX_DBG_BITS(args.dbg) & 2048)) {
                 if constexpr (!LDSCOEF) tri_solve<NB, false, true>(r.lre, r.lim, zre, zim, hook_b);
                 else tri_solve_lds<NB, false, true, true, NA>(lcur, sc.pm, i, permv, zre, zim, hook_b);
+                }
                 finish_prefetch();
                 // x = Pi^T v : x_i = v[position of row i]
                 const double xre = __shfl(zre, sc.pm), xim = __shfl(zim, sc.pm);
@@ -1397,7 +1052,11 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
                 }
                 // lambda = Q^H x ; the LDS image is that of Q^T (lane (h,i): Q[cc*H+h][i])
                 double yre, yim;
+                if (QOCX_DBG_BITS(args.dbg) & 4096) {  // (timing experiment: no matrix-vector product)
+                    yre = xre; yim = xim;
+                } else {
                 lds_matvec<NB, true, MVB, NA>(qcur, tmp, lane, h, yre, yim);
+                }
                 wave_sync();
                 lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();
@@ -1434,7 +1093,7 @@ __global__ __launch_bounds__(ONEBUF ? 128 : 64 * (W + (LOADER ? 1 : 0))) void sw
             block_sync();
             const StepScalars sc = scalars(par, true);
             if constexpr (!LDSCOEF) {
-                if (computes)
+                if (computes && !(QOCX_DBG_BITS(args.dbg) & 8192))
                     lds_to_regs<NB, true>(qbuf + par * LMAT, lbuf + par * LMAT, pbuf + par * PINTS, r,
                                           sc.pm, lane, i);
             } else {
@@ -2021,6 +1680,10 @@ template <int NB>
 static void launch_sweep_t(const SweepArgs& a, int batch, hipStream_t st) {
     if (SweepPrefetch<NB>::value && a.onebuf && a.S == 1 && !a.loader &&
         diag_getenv("QOCX_SWEEP_W") == nullptr) {
+        if (a.one_state && sweep1_supports(NB, a.S)) {  // qocx_sweep1.hip: the same step, bit for bit
+            launch_sweep1(NB, a, batch, a.onebuf, st);
+            return;
+        }
         launch_sweep_onebuf<NB>(a, batch, st);
         return;
     }

@@ -11,6 +11,7 @@ namespace qocx {
 // <t|psi> over lane group 0, result wave-uniform.
 __device__ __forceinline__ void inner(const double2 t, const double2 p, bool active, double& re,
                                       double& im) {
+#pragma clang fp contract(off)  // (the sweep kernels that share this code must round alike)
     double pr = active ? (t.x * p.x + t.y * p.y) : 0.0;  // conj(t) * p
     double pi = active ? (t.x * p.y - t.y * p.x) : 0.0;
     re = wave_sum(pr);
@@ -24,6 +25,7 @@ template <int NB>
 __device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pass,
                                              bool final_pass, const double2* vecs, double2* lam,
                                              int h, int i) {
+#pragma clang fp contract(off)
     constexpr int NP = Geo<NB>::NP;
     const int S = args.S;
     const bool act = (h == 0);
@@ -108,6 +110,7 @@ __device__ __forceinline__ double eval_costs(const SweepArgs& args, bool step_pa
 template <int NB>
 __device__ __forceinline__ void unit_adjoint_scales(const SweepArgs& args, const double2* vecs, int b,
                                                     int h, int i) {
+#pragma clang fp contract(off)
     constexpr int NP = Geo<NB>::NP;
     const int S = args.S;
     const DevCost c = args.costs[0];

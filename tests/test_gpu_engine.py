@@ -193,6 +193,56 @@ def test_chunked_equals_unchunked(engine):
     engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("n, dt, scale, non_herm", [(32, 0.05, 1.0, False), (20, 0.4, 6.0, False),
+                                                    (27, 0.3, 3.0, True), (8, 0.05, 1.0, False),
+                                                    (13, 1.0, 6.0, True)])
+def test_one_state_sweep_equals_general_sweep(engine, n, dt, scale, non_herm):
+    """
+    qocx_sweep1.hip (one state per seed, n <= 32; knob "sweep_one", on) against the general
+    column-chain sweep it replaces on that path: the same arithmetic in the same order, so cost,
+    gradient and final state are equal BIT FOR BIT - with the forward -> cost -> adjoint order and
+    with the unit adjoint, in one launch and in time segments (resumed sweeps), with squarings
+    (dt * scale large), with step costs every third step, with row exchanges in the factorisation
+    (non-Hermitian generators with large off-diagonal entries) and at one and two MFMA tiles.
+    Reference: qoc/core/schroedingerdiscrete.py:393-436.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_random("sweep1_n%d" % n, n=n, N=41, seeds=3, h_seed=7300 + n, S=1, K=2,
+                                 Nc=17, dt=dt, sigma=0.6)
+    case.h0 = case.h0 * scale
+    if non_herm:
+        rng = np.random.default_rng(7400 + n)
+        case.h0 = case.h0 - 0.3j * np.diag(rng.uniform(0, 1, n)) + 2.0 * np.roll(np.eye(n), 1, axis=0)
+    rng = np.random.default_rng(7500 + n)
+    forb = np.stack([cases_mod.column_states(cases_mod.random_unitary(rng, n)[:, 2:4])])
+    variants = [
+        (case.cost_specs, 1),
+        (case.cost_specs + [("ForbidStates", dict(forbidden_states=forb, system_eval_count=case.N,
+                                                  cost_eval_step=3, cost_multiplier=0.3))], 3),
+    ]
+    try:
+        engine.set_knob("sweep_inverse_small", 0)  # (n <= 16: keep the column-chain sweep)
+        for specs, ces in variants:
+            case.cost_specs, case.cost_eval_step = specs, ces
+            gh.setup_engine(engine, case)
+            u = np.concatenate([case.controls, -0.7 * case.controls])
+            for unit in (1, 0):
+                engine.set_knob("unit_adjoint", unit)
+                for pipe in (1, 4, 0):
+                    engine.set_pipeline(pipe)
+                    engine.set_knob("sweep_one", 0)
+                    general = engine.evaluate(u, True)
+                    engine.set_knob("sweep_one", 1)
+                    one = engine.evaluate(u, True)
+                    for a, b in zip(general, one):
+                        assert np.array_equal(a, b), (specs[-1][0], ces, unit, pipe)
+    finally:
+        engine.set_pipeline(0)
+        engine.set_knob("unit_adjoint", 1)
+        engine.set_knob("sweep_inverse_small", 1)
+        engine.set_knob("sweep_one", 1)
+
+
 @pytest.mark.parametrize("name", ["nc10_n101", "scaled_n8", "c3_fullU_short"])
 def test_unit_adjoint_and_two_sided_pipeline(engine, name):
     """
