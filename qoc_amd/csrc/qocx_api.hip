@@ -1245,6 +1245,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             fa.stamps = ctx->stamps.p;
         }
         fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
+        fa.lu_dpp = (int)ctx->knob("lu_dpp", 1);
         fa.herm_tiles = (int)ctx->knob("k1a_herm4", 1);
         if (ctx->lu_fallbacks.ensure(1)) return QOCX_ERR_HIP;
         if (b0 == 0) HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), cs));
@@ -1271,6 +1272,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             ta.controls = fa.controls; ta.interp = fa.interp; ta.K = K; ta.nc = ctx->nc;
             ta.nsteps = nsteps; ta.batch = bc; ta.dt = ctx->dt; ta.h0_norm = ctx->h0_norm_max;
             ta.g_norm = ctx->g_norm_dev.p; ta.pade_policy = fa.pade_policy;
+            ta.sq_max = std::min(30, ctx->sbound);
             ta.ustep = ctx->ustep.p; ta.s_arr = fa.s_arr; ta.status = fa.status;
             qocx::launch_step_table(ta, cs);
             fa.controls = ctx->ustep.p; fa.nc = nsteps; fa.direct = 1;
@@ -2497,7 +2499,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -51,6 +51,7 @@ struct FactorArgs {
     int dbg = 0;
     unsigned long long* stamps = nullptr;
     int lu_mfma = 0;           // fused K1b with its Schur updates on the matrix cores (qocx_lu4.h)
+    int lu_dpp = 0;            // fused K1b on the vector unit for provably diagonal pivots (qocx_lu5.h)
     // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
     // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
     // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel
@@ -81,6 +82,7 @@ struct StepTableArgs {
     double h0_norm;            // max over time of ||H0(t)||_1
     const double* g_norm;      // [K] max over time of ||G_k(t)||_1 (device memory)
     int pade_policy;           // 0: order by norm, 13: always [13/13]
+    int sq_max = 30;           // the squaring count the host sized the sub-step slots for
     double* ustep;             // out: [B][nsteps][K]
     int* s_arr;                // out: [B][nsteps]
     int* status;               // bit 1: non-finite controls

@@ -33,6 +33,7 @@
 #include "qocx_wave.h"
 #include "qocx_sweep_common.h"
 #include "qocx_lu.h"
+#include "qocx_lu5.h"
 
 namespace qocx {
 
@@ -1412,19 +1413,23 @@ __global__ __launch_bounds__(256) void step_table_kernel(StepTableArgs args) {
     }
     bound *= fabs(args.dt);
     int sq = 0, order = 13;
+    bool dominant = false;
     if (!(bound < 1e300)) {  // inf / nan
         atomicOr(args.status, 2);
     } else {
         order = pade_order_for(bound, args.pade_policy);
         if (order == 13) {
             double th = QOCX_THETA13;
-            while (bound > th && sq < 30) {
+            // (never more squarings than the host sized the sub-step slots for: its bound is this one
+            // up to the rounding of the interpolation)
+            while (bound > th && sq < args.sq_max) {
                 th *= 2.0;
                 ++sq;
             }
         }
+        dominant = pade_denominator_dominant(order, ldexp(bound, -sq));
     }
-    args.s_arr[idx] = step_entry(sq, order);
+    args.s_arr[idx] = step_entry(sq, order) | (dominant ? QOCX_STEP_DOMINANT : 0);
 }
 void launch_step_table(const StepTableArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.batch * a.nsteps;

@@ -19,6 +19,7 @@
 #include "qocx_wave.h"
 #include "qocx_lu.h"
 #include "qocx_lu4.h"
+#include "qocx_lu5.h"
 
 namespace qocx {
 
@@ -151,6 +152,7 @@ struct Out {
     bool fuse;
     size_t m;
     bool lu_mfma;                 // the factorisation's Schur updates on the matrix cores (qocx_lu4.h)
+    bool lu_dpp;                  // provably diagonal pivots: the factorisation of qocx_lu5.h
     int dbg;                      // FactorArgs::dbg (diagnostic build)
     unsigned long long* stamps;   // FactorArgs::stamps
 };
@@ -195,12 +197,14 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     // usually name the same interval (always when the norm is well below theta, the common
     // case); only if they disagree is the exact norm formed (16 FP64 square roots per lane).
     int sq = 0, order = 13;
+    bool dominant = false;  // LAPACK's pivots are provably the diagonal ones (qocx_lu5.h)
     if constexpr (PRESET) {
         // step table (launch_step_table): order and squaring count were decided from the bound
         // dt (||H0||_1 + sum |u_k| ||G_k||_1) when the controls of the step were interpolated
         const int entry = *out.s_out;
         sq = step_squarings(entry);
         order = step_order(entry);
+        dominant = step_dominant(entry);
         if (sq > 0) {
             const double scale = ldexp(1.0, -sq);
 #pragma unroll
@@ -272,6 +276,7 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
     }
     // Pade order from the upper bound of the norm (qocx_wave.h); both waves read the same numbers
     order = bad ? 13 : pade_order_for(fmax(nrm[0], nrm[1]), out.pade_policy);
+    dominant = !bad && pade_denominator_dominant(order, ldexp(fmax(nrm[0], nrm[1]), -sq));
     if (W == 0 && lane == 0) *out.s_out = step_entry(sq, order);
     }
     stage_tile(sl, 0, W, a.re[0], a.im[0]);
@@ -505,7 +510,10 @@ __device__ __forceinline__ void body(Gen gen, const Out& out, double* smem) {
             // diagonal pivots and rank-4 updates on the matrix cores first (qocx_lu4.h); a matrix
             // whose pivots leave the diagonal takes the general elimination, from the same image
             bool done = false;
-            if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt), clk);
+            if (out.lu_dpp && dominant) {
+                lu5::lu_dpp_body(out.lu, out.m, simg, LP);
+                done = true;
+            } else if (out.lu_mfma) done = lu4::lu_mfma_body(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt), clk);
             if (!done) {
                 if (out.lu_mfma && out.lu.fallbacks != nullptr && lane_id() == 0) atomicAdd(out.lu.fallbacks, 1);
                 lu_body<2>(out.lu, out.m, simg, LP, reinterpret_cast<double2*>(mt));
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     out.lu.fallbacks = args.lu_fallbacks;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
-    out.dbg = args.dbg; out.stamps = args.stamps; out.lu_mfma = args.lu_mfma != 0;
+    out.dbg = args.dbg; out.stamps = args.stamps; out.lu_mfma = args.lu_mfma != 0; out.lu_dpp = args.lu_dpp != 0;
     // (PRESET: the step table - controls is [B][nsteps][K], interpolated already)
     const StepInterp si = PRESET ? StepInterp{0, 0, 1.0, 0.0} : args.interp[step];
     const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_explicit_kernel(const double2
     out.lu.fallbacks = args.lu_fallbacks;
     out.fuse = args.fuse_lu != 0;
     out.m = m;
-    out.dbg = 0; out.stamps = nullptr; out.lu_mfma = args.lu_mfma != 0;
+    out.dbg = 0; out.stamps = nullptr; out.lu_mfma = args.lu_mfma != 0; out.lu_dpp = args.lu_dpp != 0;
     const double2* am = a_in + m * (size_t)n * n;
     auto gen = [&](Col& a, int wcol) {
 #pragma unroll

@@ -87,12 +87,6 @@ __device__ __forceinline__ void tri_solve_seq(const double (&tre)[Geo<NB>::NP],
     (tri_step<NB, LOWER, CONJ, KK>(tre, tim, zre, zim, hook), ...);
 }
 
-// f(integral_constant<int, P>) for every P of the sequence
-template <class F, int... P>
-__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, P...>) {
-    (f(std::integral_constant<int, P>()), ...);
-}
-
 // ---- the same solves with the broadcast INSIDE the multiply-add (round 5) ------------------------
 // v_fmac_f64_dpp row_newbcast:k reads its first factor from lane k of the reader's own row of 16
 // lanes, so a stage is four instructions and the value never travels through a scalar register

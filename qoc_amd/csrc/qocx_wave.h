@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "qocx_device.h"
@@ -71,6 +72,10 @@ __device__ __forceinline__ int step_entry(int squarings, int order) {
     return order == 13 ? squarings : (squarings | (order << 8));
 }
 __device__ __forceinline__ int step_squarings(int entry) { return min(max(entry & 0xff, 0), 30); }
+// bit 16: the Pade denominator of the step is diagonally dominant by a margin that makes LAPACK's
+// pivots the diagonal ones (qocx_lu5.h, pade_denominator_dominant)
+#define QOCX_STEP_DOMINANT 0x10000
+__device__ __forceinline__ bool step_dominant(int entry) { return (entry & QOCX_STEP_DOMINANT) != 0; }
 __device__ __forceinline__ int step_order(int entry) {
     const int o = (entry >> 8) & 0xff;
     return o == 0 ? 13 : o;
@@ -154,6 +159,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
     e = fma(-x, r, 1.0);
     r = fma(r, e, r);
     return r;
+}
+
+// f(integral_constant<int, P>) for every P of the sequence
+template <class F, int... P>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, P...>) {
+    (f(std::integral_constant<int, P>()), ...);
 }
 
 // ------------------------------------------------------------------------------------------
