@@ -1273,6 +1273,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             ta.nsteps = nsteps; ta.batch = bc; ta.dt = ctx->dt; ta.h0_norm = ctx->h0_norm_max;
             ta.g_norm = ctx->g_norm_dev.p; ta.pade_policy = fa.pade_policy;
             ta.sq_max = std::min(30, ctx->sbound);
+            // only the three-wave K1a (orders 3 and 5) will be launched: no step above order 5
+            qocx::FactorArgs probe = fa;
+            probe.direct = 1;
+            fa.three_wave = (int)ctx->knob("k1a_three", 1);
+            if (fa.three_wave && qocx::pq3_supports(probe) && fa.prefer_low == 2) ta.order_max = 5;
             ta.ustep = ctx->ustep.p; ta.s_arr = fa.s_arr; ta.status = fa.status;
             qocx::launch_step_table(ta, cs);
             fa.controls = ctx->ustep.p; fa.nc = nsteps; fa.direct = 1;
@@ -2499,7 +2504,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 
@@ -2878,6 +2883,7 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     const bool fused_lu = nb == 2 && !inverse && qocx::diag_getenv("QOCX_PQ1") == nullptr && ctx->knob("fuse_lu", 1) != 0;
     fa.fuse_lu = fused_lu ? 1 : 0;  // the same kernels the evaluation runs
     fa.lu_mfma = (int)ctx->knob("lu_mfma", 1);
+    fa.lu_dpp = (int)ctx->knob("lu_dpp", 1);
     if (ctx->lu_fallbacks.ensure(1)) return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->lu_fallbacks.p, 0, sizeof(int), ctx->stream));
     fa.lu_fallbacks = ctx->lu_fallbacks.p;

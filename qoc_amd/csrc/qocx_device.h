@@ -52,6 +52,7 @@ struct FactorArgs {
     unsigned long long* stamps = nullptr;
     int lu_mfma = 0;           // fused K1b with its Schur updates on the matrix cores (qocx_lu4.h)
     int lu_dpp = 0;            // fused K1b on the vector unit for provably diagonal pivots (qocx_lu5.h)
+    int three_wave = 0;        // orders 3 / 5, Hermitian, step table: one tile per wave on three waves (qocx_pade3.hip)
     // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
     // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
     // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel
@@ -83,6 +84,7 @@ struct StepTableArgs {
     const double* g_norm;      // [K] max over time of ||G_k(t)||_1 (device memory)
     int pade_policy;           // 0: order by norm, 13: always [13/13]
     int sq_max = 30;           // the squaring count the host sized the sub-step slots for
+    int order_max = 13;        // 5: the three-wave K1a of qocx_pade3.hip runs the evaluation (host bound below theta_5)
     double* ustep;             // out: [B][nsteps][K]
     int* s_arr;                // out: [B][nsteps]
     int* status;               // bit 1: non-finite controls
@@ -329,6 +331,8 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
                         hipStream_t st);
 // two-wave K1a for nb == 2 (qocx_pade2.hip)
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+bool pq3_supports(const FactorArgs& a);
+void launch_pq3(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
 // 33 <= n <= 64: four-wave workgroups (qocx_pade4.hip)
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st);

@@ -1418,6 +1418,9 @@ __global__ __launch_bounds__(256) void step_table_kernel(StepTableArgs args) {
         atomicOr(args.status, 2);
     } else {
         order = pade_order_for(bound, args.pade_policy);
+        // (the host skips the launch of the two-wave K1a when ITS bound is below theta_5; the two
+        // bounds differ by rounding at most)
+        if (order > args.order_max) order = args.order_max;
         if (order == 13) {
             double th = QOCX_THETA13;
             // (never more squarings than the host sized the sub-step slots for: its bound is this one
@@ -1726,7 +1729,17 @@ void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t s
     if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
     else if (nb == 4) launch_pq4(a, nsteps, batch, st);
     else if (one_wave_pq()) launch_pq_t<2>(a, nsteps, batch, st);
-    else launch_pq2(a, nsteps, batch, st);
+    else if (a.three_wave && pq3_supports(a)) {
+        // steps at order 3 / 5 on the three-wave kernel, the others on the two-wave one (each workgroup
+        // looks its step up in the step table); no step of the evaluation is above order 5 when the
+        // host's bound says so
+        launch_pq3(a, nsteps, batch, st);
+        if (a.prefer_low != 2) launch_pq2(a, nsteps, batch, st);
+    } else {
+        FactorArgs b = a;
+        b.three_wave = 0;
+        launch_pq2(b, nsteps, batch, st);
+    }
 }
 void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a, int count,
                         hipStream_t st) {

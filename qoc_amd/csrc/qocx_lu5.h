@@ -13,7 +13,7 @@
 // at every step, zgetrf never exchanges rows, and this kernel - which never looks - makes the same
 // choice. pade_denominator_dominant() grants that for eps(theta) <= 0.40 (the margin covers rounding
 // in P and in the bound); every other matrix takes the checked factorisations (qocx_lu4.h, qocx_lu.h).
-// On the headline workload theta < theta_5 = 0.254, eps <= 0.133: every step.
+// On the headline workload theta < theta_5 = 0.254, eps <= 0.135: every step.
 // tests/test_oracle.py::test_dominant_pade_denominators_pivot_on_the_diagonal holds the claim against
 // LAPACK on the CPU, tests/test_gpu_engine.py::test_pade_factor_kernel the factors on the GPU.
 //

@@ -541,6 +541,10 @@ __global__ __launch_bounds__(128, 2) void pade_pq2_kernel(FactorArgs args) {
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t m = (size_t)b * args.nsteps + step;
+    if constexpr (PRESET) {
+        // the steps at order 3 / 5 belong to the three-wave kernel (qocx_pade3.hip) when it runs too
+        if (args.three_wave && step_order(args.s_arr[m]) <= 5) return;
+    }
     Out out;
     out.q_img = QOCX_DBG_BITS(args.skip_q) ? nullptr : args.q_img + m * MAT;  // (skip_q: timing experiment)
     out.p_img = args.lu_img + m * MAT;

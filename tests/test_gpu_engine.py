@@ -243,6 +243,54 @@ def test_one_state_sweep_equals_general_sweep(engine, n, dt, scale, non_herm):
         engine.set_knob("sweep_one", 1)
 
 
+@pytest.mark.parametrize("n, dt, sigma", [(32, 0.05, 0.6), (17, 0.04, 0.3), (25, 0.004, 0.5)])
+def test_three_wave_pade_kernel_equals_two_wave_kernel(engine, n, dt, sigma):
+    """
+    qocx_pade3.hip (Hermitian generators, every step at Pade order 3 or 5: one tile per wave on three
+    waves, P factored by the vector-unit factorisation of qocx_lu5.h; knob "k1a_three", on) against the
+    two-wave kernel with the checked MFMA factorisation (knobs "k1a_three" 0, "lu_dpp" 0): the same
+    rational function, sums in another order - cost, gradient and final state equal to 1e-12 - and
+    both within the parity gates of the oracle. dt = 0.004 puts the steps on order 3; the first problem
+    has steps at order 7 among those at order 5 (they stay on the two-wave kernel).
+    Reference: qoc/standard/functions/expm.py:119-135, :246.
+    """
+    from tests import gpu_helpers as gh
+    from oracle import qoc_numpy as onp
+    case = cases_mod.case_random("pade3_n%d" % n, n=n, N=33, seeds=3, h_seed=7600 + n, S=1, K=2, Nc=9,
+                                 dt=dt, sigma=sigma)
+    gh.setup_engine(engine, case)
+    u = np.concatenate([case.controls, -0.5 * case.controls])
+    try:
+        engine.set_knob("k1a_three", 0)
+        engine.set_knob("lu_dpp", 0)
+        two = engine.evaluate(u, True)
+        orders_two = engine.pade_orders()
+        engine.set_knob("lu_dpp", 1)
+        two_dpp = engine.evaluate(u, True)
+        engine.set_knob("k1a_three", 1)
+        three = engine.evaluate(u, True)
+        # (the first problem mixes orders 5 and 7: both kernels run over the same grid and every
+        # workgroup takes or leaves its step by the order in the step table)
+        assert engine.pade_orders() == orders_two and orders_two[3] + orders_two[5] > 0
+    finally:
+        engine.set_knob("k1a_three", 1)
+        engine.set_knob("lu_dpp", 1)
+    for other in (two_dpp, three):
+        assert abs(other[0] - two[0]).max() <= 1e-12
+        assert np.abs(other[1] - two[1]).max() <= 1e-12 * max(1.0, np.abs(two[1]).max())
+        assert np.abs(other[2] - two[2]).max() <= 1e-12
+    h0, g = np.asarray(case.h0), [np.asarray(m) for m in case.g_re]
+    problem = onp.SchroedingerProblem(
+        case.T, lambda uu, t: h0 + uu[0] * g[0] + uu[1] * g[1], case.initial_states, case.N,
+        control_eval_count=case.Nc, control_count=2,
+        costs=[onp.TargetStateInfidelity(case.cost_specs[0][1]["target_states"])])
+    for b in (0, 4):
+        err, gr, fin = onp.evaluate_with_grad(problem, u[b])
+        assert abs(err - three[0][b]) <= 1e-10
+        assert rel_err(three[2][b], fin[:, :, 0]) <= 1e-10
+        assert np.abs(gr - three[1][b]).max() <= 1e-8 * max(1.0, np.abs(gr).max())
+
+
 @pytest.mark.parametrize("name", ["nc10_n101", "scaled_n8", "c3_fullU_short"])
 def test_unit_adjoint_and_two_sided_pipeline(engine, name):
     """

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import qoc_numpy as onp
 from tests import cases as cases_mod
+from tests import device_model as dm
 from tests.helpers import (CASE_NAMES, GRAD_CASE_NAMES, golden, oracle_problem, rel_err)
 
 
@@ -150,3 +151,74 @@ def test_gradient_matches_fixtures(name):
         scale = np.max(np.abs(g["grads_ad"][b]))
         fd_dev = np.max(np.abs(grads.flat[g["fd_index"][b]] - g["grads_fd"][b])) / scale
         assert fd_dev < 1e-7
+
+
+def _pade_denominator(a, order):
+    """P = v - u of the [order/order] approximant (expm.py:119-159, :246), from the power series."""
+    b = dm.PADE_COEFFS[order]
+    n = a.shape[0]
+    p, power = np.zeros((n, n), dtype=np.complex128), np.eye(n, dtype=np.complex128)
+    for j, bj in enumerate(b):
+        p += ((-1) ** j) * bj * power
+        power = power @ a
+    return p
+
+
+def _eps(order, theta):
+    b = dm.PADE_COEFFS[order]
+    return sum(b[j] / b[0] * theta ** j for j in range(1, order + 1))
+
+
+@pytest.mark.parametrize("order", [3, 5, 7, 9, 13])
+def test_dominant_pade_denominators_pivot_on_the_diagonal(order):
+    """
+    qoc_amd/csrc/qocx_lu5.h factors the Pade denominator WITHOUT looking for pivots when the bound
+    eps(theta) = sum_{j>=1} (b_j / b0) theta^j of ||P / b0 - I||_1 is at most 0.40 (theta: an upper
+    bound of the 1-norm of the scaled generator): below 1 / (1 + sqrt 2) LAPACK's zgetrf - what
+    numpy.linalg.solve runs at qoc/standard/functions/expm.py:246 - provably takes the diagonal entry at
+    every step. Checked here against LAPACK itself (scipy.linalg.lu_factor): generators whose norm sits
+    right at the threshold - Hermitian, general complex, and adversarial ones that concentrate a whole
+    column of P on one off-diagonal entry with |re| = |im| - never see a row exchange; and the
+    condition is not vacuous: far above the threshold LAPACK does exchange rows.
+    """
+    from scipy.linalg import lu_factor
+    rng = np.random.default_rng(500 + order)
+    # the largest theta the kernel accepts for this order
+    lo, hi = 0.0, 8.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if _eps(order, mid) <= 0.40 else (lo, mid)
+    theta = min(lo, dm.PADE_THETA[order])
+    assert _eps(order, theta) <= 0.40
+    if order == 5:  # every order-5 step qualifies: eps(theta_5) = 0.134
+        assert theta == dm.PADE_THETA[5] and _eps(5, theta) < 0.135
+    for n in (2, 7, 32):
+        for trial in range(40):
+            g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            kind = trial % 4
+            if kind == 0:
+                a = -1j * (g + g.conj().T)                      # skew-Hermitian (the headline's kind)
+            elif kind == 1:
+                a = g                                           # general complex
+            elif kind == 2:                                     # one entry carries a whole column
+                a = np.zeros((n, n), dtype=np.complex128)
+                a[(np.arange(n) + 1) % n, np.arange(n)] = (1 + 1j) * rng.choice([-1, 1], n)
+            else:                                               # nilpotent: the series does not cancel
+                a = np.triu(np.abs(g.real) + 1j * np.abs(g.imag), 1)
+            a = a * (theta / onp.one_norm(a))
+            p = _pade_denominator(a, order)
+            assert onp.one_norm(p / dm.PADE_COEFFS[order][0] - np.eye(n)) <= 0.40 * (1 + 1e-12)
+            _, piv = lu_factor(p)
+            assert np.array_equal(piv, np.arange(n)), (n, trial, kind)
+    # ... and above the threshold the rule matters (order 13, the only one whose theta reaches there):
+    # a rotation generator a = t [[0, 1], [-1, 0]] has P = v(t) I - w(t) a with v ~ cos-like and
+    # w ~ sin-like polynomials, and where |w t| > |v| LAPACK takes the second row first
+    if order == 13:
+        exchanged = 0
+        for t in np.linspace(0.5, 5.3, 49):
+            a = t * np.array([[0, 1], [-1, 0]], dtype=np.complex128)
+            _, piv = lu_factor(_pade_denominator(a, 13))
+            if not np.array_equal(piv, np.arange(2)):
+                exchanged += 1
+                assert not _eps(13, onp.one_norm(a)) <= 0.40
+        assert exchanged > 0
