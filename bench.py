@@ -63,43 +63,97 @@ def make_controls(first_seed, count):
     return out
 
 
-PMC_SUMMARY = "profiles/r04_pmc_hbm.json"
-PMC_SQ_SUMMARY = "profiles/r04_pmc_sq.json"  # SQ counters of the same command (tools/profile_round.sh)
+PMC_SUMMARY = "profiles/r05_pmc_hbm.json"
+PMC_SQ_SUMMARY = "profiles/r05_pmc_sq.json"  # SQ counters of the same command (tools/profile_round.sh)
+PMC_META = "profiles/r05_profile_meta.json"  # what the counter passes were taken from (kernel sources)
+K1A_KERNEL = "qocx::pade3::pade_pq3_kernel<false>"  # the roofline kernel of the headline workload
+# the kernel sources whose change makes the committed counters of K1A_KERNEL stale
+K1A_SOURCES = ("qoc_amd/csrc/qocx_pade3.hip", "qoc_amd/csrc/qocx_lu5.h", "qoc_amd/csrc/qocx_wave.h")
+
+
+def source_digest(paths=K1A_SOURCES):
+    import hashlib
+    h = hashlib.sha256()
+    for rel in paths:
+        try:
+            with open(os.path.join(ROOT, rel), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b"missing:" + rel.encode())
+    return h.hexdigest()[:16]
+
+
+def counters_current():
+    """True if the committed counter summaries were taken from the kernel sources of this tree
+    (tools/profile_round.sh records their digest in PMC_META)."""
+    try:
+        with open(os.path.join(ROOT, PMC_META)) as f:
+            return json.load(f).get("k1a_sources_sha16") == source_digest()
+    except (OSError, ValueError):
+        return False
 
 
 def pmc_executed_mfma_flops(kernel, units_per_dispatch=32000):
     """
-    Executed FP64 MFMA flops per propagator step of `kernel` from the committed SQ counter pass
-    (SQ_INSTS_VALU_MFMA_MOPS_F64 per dispatch; one v_mfma_f64_16x16x4_f64 = 2048 flop counts 4, i.e.
-    512 flop per counted operation - calibrated in round 2 against the instruction count of the
-    kernel). None if the summary is absent.
+    Executed FP64 MFMA flops per propagator step of `kernel` (exact name) from the committed SQ
+    counter pass (SQ_INSTS_VALU_MFMA_MOPS_F64 per dispatch; one v_mfma_f64_16x16x4_f64 = 2048 flop
+    counts 4, i.e. 512 flop per counted operation - calibrated in round 2 against the instruction
+    count of the kernel). None if the summary or the kernel is absent.
     """
     try:
         with open(os.path.join(ROOT, PMC_SQ_SUMMARY)) as f:
             summary = json.load(f)
-        entry = [v for k, v in summary.items() if k.startswith(kernel)][0]
-        return entry["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / units_per_dispatch
-    except (OSError, KeyError, ValueError, IndexError, TypeError):
+        return summary[kernel]["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / units_per_dispatch
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
 def pmc_traffic_bytes(kernel, units_per_launch):
     """
-    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (PMC_SUMMARY:
-    FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this bench command, gfx950 correction
-    applied; tools/profile_round.sh + tools/pmc_summary.py), rescaled to this run's units per
-    launch. PMC counters cannot be collected from inside the timed run; None if the
-    summary is absent.
+    HBM bytes per launch of `kernel` (exact name) from the committed rocprofv3 PMC summary
+    (PMC_SUMMARY: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this bench command, gfx950
+    correction applied; tools/profile_round.sh + tools/pmc_summary.py), rescaled to this run's
+    units per launch. PMC counters cannot be collected from inside the timed run; None if the
+    summary or the kernel is absent.
     """
     path = os.path.join(ROOT, PMC_SUMMARY)
     try:
         with open(path) as f:
             summary = json.load(f)
-        entry = [v for k, v in summary["kernels"].items() if k.startswith(kernel)][0]
+        entry = summary["kernels"][kernel]
         return (entry["hbm_bytes_per_dispatch_corrected"] * units_per_launch
                 / summary["units_per_dispatch"])
-    except (OSError, KeyError, ValueError, IndexError):
+    except (OSError, KeyError, ValueError):
         return None
+
+
+# kernels of one headline evaluation: timing class (qocx_set_timing) -> kernel names in the profiles
+EVAL_KERNELS = {
+    "pade_pq": (K1A_KERNEL,),
+    "sweep": ("qocx::sweep1::sweep1_kernel<2>",),
+    "krylov_grad": ("qocx::krylov_grad_skew_kernel<2, false>",),
+    "scatter": ("qocx::scatter_kernel",),
+}
+
+
+def pmc_evaluation_bytes(launches_per_evaluation):
+    """HBM bytes of ONE headline evaluation from the committed PMC summary: the average bytes per
+    dispatch of every kernel of the evaluation x its launches per evaluation (this run's count),
+    plus the step table and the reduction (one launch each). None if a kernel is missing."""
+    try:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+            kernels = json.load(f)["kernels"]
+        total, parts = 0.0, {}
+        for cls, names in EVAL_KERNELS.items():
+            per = sum(kernels[n]["hbm_bytes_per_dispatch_corrected"] for n in names)
+            parts[cls] = per * launches_per_evaluation[cls]
+            total += parts[cls]
+        for name in ("qocx::step_table_kernel", "qocx::reduce_results_kernel"):
+            parts[name] = kernels[name]["hbm_bytes_per_dispatch_corrected"]
+            total += parts[name]
+        return total, parts
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 # ---- CPU baseline: the oracle (NumPy restatement of the reference + hand adjoint) ----------
@@ -279,6 +333,10 @@ def lindblad_secondary(engine, reps=3):
         "metric": "propagator-steps/sec (fwd+grad), dim=16 Lindblad, 500 steps x 64 seeds",
         "value": LB_SEEDS * (LB_EVAL - 1) / wall, "unit": "propagator-steps/s",
         "ms_per_eval": wall * 1e3, "subintervals_per_step": subs / (LB_SEEDS * (LB_EVAL - 1.0)),
+        "cus_occupied": {"busy": 2 * LB_SEEDS, "of": 256,
+                         "note": "one workgroup (one CU) per seed and pass: forward pass and unit "
+                                 "adjoint side by side = 2 x 64 of the 256 CUs; the roofline fraction "
+                                 "below is against the whole chip"},
         "roofline": {"bound": "mfma",
                      "kernel": "qocx::lindblad_kernel (forward || unit adjoint) + lindblad_combine",
                      "achieved": achieved,
@@ -312,10 +370,13 @@ def main():
                          "evaluations would swamp the per-kernel averages)")
     ap.add_argument("--time-segments", type=int, default=0,
                     help="tuning knob: time segments of the pipeline (0 = the engine's choice)")
+    ap.add_argument("--standin-engine", default=None, metavar="MODULE",
+                    help="TESTS ONLY (tests/test_bench_main.py): a stand-in engine module in the "
+                         "place of libqocx, to rehearse the multi-rank control flow without a GPU")
     args = ap.parse_args()
 
     from qoc_amd import parallel
-    standin = os.environ.get("QOCX_BENCH_STANDIN")
+    standin = args.standin_engine
     if standin:
         # CPU rehearsal of the multi-rank control flow (tests/test_bench_main.py): a stand-in engine
         # module in the place of libqocx, gloo in the place of RCCL. The line says so in `data`;
@@ -434,33 +495,72 @@ def main():
     mean_products = sum(products[o] * c for o, c in orders.items()) / steps_counted
     k1_flops_per_unit = 8.0 * mean_products * DIM ** 3
     roofline = None
+    current = counters_current()
+    stale_note = ("" if current else " - STALE: the kernel sources have changed since those passes "
+                                     "(profiles/r05_profile_meta.json), re-run tools/profile_round.sh")
     if launches > 0 and total_ms > 0:
         avg_s = total_ms / launches * 1e-3
         units_per_launch = seeds * (N_EVAL - 1) * args.steps / launches
         achieved = k1_flops_per_unit * units_per_launch / avg_s / 1e12
-        roofline = dict(bound="mfma", kernel="qocx::pade2::pade_pq2_kernel<true>", achieved=achieved,
+        roofline = dict(bound="mfma", kernel=K1A_KERNEL, achieved=achieved,
                         peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS,
                         peak_sustained_measured=engine.mfma_peak(2, 20000),
-                        traffic=pmc_traffic_bytes("qocx::pade2::pade_pq2_kernel<true", units_per_launch),
+                        peak_sustained_chains=1,
+                        peak_sustained_note="register-only loop of v_mfma_f64_16x16x4_f64, ONE "
+                                            "accumulation chain per wave, two waves per SIMD "
+                                            "(qocx_debug_mfma_peak; eight chains sustain ~48)",
+                        traffic=pmc_traffic_bytes(K1A_KERNEL, units_per_launch),
                         traffic_source="committed rocprofv3 --pmc passes of this command "
                                        "({}; FETCH_SIZE x2 + WRITE_SIZE), not collected in "
-                                       "this run".format(PMC_SUMMARY),
+                                       "this run{}".format(PMC_SUMMARY, stale_note),
                         avg_launch_ms=total_ms / launches,
                         gemm_products_per_step=mean_products,
-                        flops_per_step=k1_flops_per_unit)
-        # what the matrix cores executed (3M scheme, Hermitian tiles, the factorisation's Schur
-        # updates), from the committed SQ counter pass: MFMA operations per step x 512 flop
-        executed = pmc_executed_mfma_flops("qocx::pade2::pade_pq2_kernel<true")
+                        flops_per_step=k1_flops_per_unit,
+                        note="FP64 MFMA and FP64 vector instructions share one pipe on this part "
+                             "(SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r05_pmc_k1a_two_vs_three.json): "
+                             "the kernel's 232 MFMA + ~3 900 vector instructions per step keep that "
+                             "pipe busy ~75 % of the launch")
+        # what the matrix cores executed (3M scheme, Hermitian tiles, the Schur update of the
+        # factorisation), from the committed SQ counter pass: MFMA operations per step x 512 flop
+        executed = pmc_executed_mfma_flops(K1A_KERNEL)
         if executed is not None:
             roofline["executed_mfma_flops_per_step"] = executed
             roofline["frac_executed"] = executed * units_per_launch / avg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS
             roofline["frac_executed_source"] = ("SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed rocprofv3 "
-                                                "--pmc pass ({}) over this run's launch time".format(PMC_SQ_SUMMARY))
+                                                "--pmc pass ({}) over this run's launch time{}".format(
+                                                    PMC_SQ_SUMMARY, stale_note))
+            roofline["frac_executed_current"] = current
     kernel_ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in warm_timing.items()}
     kernel_ms["pade_pq"] = total_ms / launches if launches else kernel_ms["pade_pq"]
-    path_flops_per_unit = 8.0 * ((64.0 / 3.0) * DIM ** 3 + 3 * DIM ** 2 + K_CTRL * DIM ** 2)
+    # The whole path under the BUILD'S OWN operation count (SURVEY.md 8d's
+    # 21.33 n^3 is the count of the reference's formulation - U_j formed and squared, the dense
+    # reverse rules of the tape - which this algorithm does not execute): per propagator step
+    #   K1a   m_p complex n^3 products of the Pade chain (m_p = 2 / 3 / 4 / 5 / 6 at order 3..13)
+    #   K1b   n^3 / 3 complex MACs (LU of P)
+    #   K2    forward + adjoint sweep: Q psi and two triangular solves each = 4 n^2 complex MACs
+    #   K3    2 (m - 1) matrix-vector products, m rank-1 updates, K contractions = (3 m - 2 + K) n^2
+    # at 8 real flops per complex MAC, m = the mean Pade order of the workload.
+    mean_order = sum(o * c for o, c in orders.items()) / steps_counted
+    path_flops_per_unit = 8.0 * (mean_products * DIM ** 3 + DIM ** 3 / 3.0 + 4 * DIM ** 2
+                                 + (3 * mean_order - 2 + K_CTRL) * DIM ** 2)
     path_tflops = path_flops_per_unit * units_per_step * args.steps / elapsed / 1e12 / world
+    # HBM traffic of one evaluation (committed PMC passes x this run's launch counts) over this
+    # run's time per evaluation
+    per_eval_launches = {k: (v[0] / max(1, args.warmup)) for k, v in warm_timing.items()}
+    hbm = None
+    eval_bytes, eval_parts = pmc_evaluation_bytes(per_eval_launches) if all(
+        k in per_eval_launches for k in EVAL_KERNELS) else (None, None)
+    if eval_bytes is not None:
+        tbs = eval_bytes / (elapsed / args.steps) / 1e12
+        hbm = dict(bytes_per_evaluation=eval_bytes, achieved=tbs, peak=8.0, unit="TB/s", frac=tbs / 8.0,
+                   algorithmic_bytes_per_evaluation=float(seeds) * (N_EVAL * K_CTRL * 8 * 2 + DIM * 16 + 8),
+                   by_kernel=eval_parts,
+                   note="Q and the LU factors of every step are written once (K1a) and read twice "
+                        "(forward and adjoint sweep): 33.8 KB per step and pass by design; the "
+                        "algorithmic bytes are controls in, gradients + final states + costs out",
+                   source="committed rocprofv3 --pmc passes ({}) x the launches per evaluation of "
+                          "this run{}".format(PMC_SUMMARY, stale_note))
 
     line = {
         "metric": "propagator-steps/sec (fwd+grad), dim=32 Schroedinger, 1000 steps x 256 seeds",
@@ -481,7 +581,13 @@ def main():
         "kernel_ms_source": "pade_pq: HIP events inside the timed region; the others: HIP events of "
                             "the warm-up steps (all launches timed there)",
         "step_ms": step_ms,
-        "path_algorithmic_tflops_per_gpu": path_tflops,
+        "flops_per_step_path": path_flops_per_unit,
+        "path_tflops_per_gpu": path_tflops,
+        "frac_path": path_tflops / FP64_MFMA_PEAK_TFLOPS,
+        "frac_path_note": "whole evaluation under the build's own operation count (K1a products + LU "
+                          "+ both sweeps + K3, bench.py) over the FP64 peak of the chip (78.6 TFLOP/s, "
+                          "vector and matrix alike)",
+        "hbm": hbm,
         "check": {"sum_cost": total_cost, "grad_l2": float(np.linalg.norm(total_grad))},
         "value_definition": "controls resident in HBM when the clock starts (bench contract), Pade "
                             "order by norm; value_host_to_host: fresh controls from host memory and "

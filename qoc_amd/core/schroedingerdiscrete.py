@@ -215,12 +215,14 @@ def _native_ok(*arrays):
     the NumPy block path below each call site does the same arithmetic."""
     global _NATIVE_HOST
     if _NATIVE_HOST is None:
+        from qoc_amd import engine
         try:
-            from qoc_amd import engine
             engine.load_library()
             _NATIVE_HOST = True
-        except (ImportError, OSError, AttributeError):
+        except ImportError:  # the library FILE is absent: a CPU box running the host logic only
             _NATIVE_HOST = False
+        # (a library that is present but does not load, or lacks a declared symbol, is a broken
+        # build: OSError / AttributeError propagate instead of silently taking the NumPy path)
     return _NATIVE_HOST and all(a.dtype == np.float64 and a.flags.c_contiguous for a in arrays)
 
 

@@ -2414,7 +2414,15 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
             // the whole chip. While both launches find CUs of their own they run on two streams
             // (2 Bp CUs busy instead of Bp); a bigger piece runs them one after the other - the
             // same three kernels, so a seed's result does not depend on the batch it is part of.
-            const bool two_sided = two_sided_ok && keep_stages && (multi || two_sided_tiles);
+            bool two_sided = two_sided_ok && keep_stages && (multi || two_sided_tiles);
+            if (two_sided && n > 16) {
+                // above one tile only the tile-per-wave kernel knows the phases: ask IT whether it
+                // takes these launches (the one-wave form would run the whole evaluation twice)
+                qocx::LindbladArgs probe = la;
+                probe.phase = 1;
+                probe.kbstages = lb.kbstages.p;
+                if (!qocx::lindblad4t_supports(probe)) two_sided = false;
+            }
             if (two_sided) {
                 const int side_limit = (int)ctx->knob("lindblad_side_limit", ctx->cu_count / 2);
                 hipStream_t side = Bp <= side_limit ? ctx->sweep_streams[0] : ctx->stream;

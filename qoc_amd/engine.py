@@ -183,9 +183,12 @@ def load_library(path=None):
             "qoc_amd: the HIP engine {} is missing. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback.".format(path))
-    # multi-process GPU work on this platform needs dmabuf IPC (RCCL between the ranks of a node
-    # fails with hipIpcGetMemHandle: invalid argument otherwise); the HSA runtime reads the variable
-    # when it initialises, which no call has triggered yet. A value the user has set is kept.
+    # Multi-process GPU work on this platform needs dmabuf IPC (RCCL between the ranks of a node
+    # fails with hipIpcGetMemHandle: invalid argument otherwise). The HSA runtime reads
+    # HSA_ENABLE_IPC_MODE_LEGACY when it initialises - which dlopen of libqocx does not trigger, the
+    # first qocx_create does - so it is defaulted here, before any context exists: a value the user
+    # (or the launcher, qoc_amd/parallel.py documents it) has set is kept, a process in which
+    # another library initialised HSA earlier is not affected, and child processes inherit it.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():

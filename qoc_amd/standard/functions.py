@@ -43,24 +43,31 @@ _EXPM_ENGINE = []
 
 def expm(a):
     """
-    Matrix exponential of one square complex matrix (n <= 32) by the engine's Pade-13 scaling
-    and squaring path - the same kernels the propagation uses: exp(a) is the one-step propagator
-    of H = i a over dt = 1 applied to the identity columns. There is no CPU implementation in
-    this package; without the HIP library / a GPU the call raises.
+    Matrix exponential of one square complex matrix (n <= 64, the engine's size limit) by the
+    engine's Pade scaling-and-squaring path - the same kernels the propagation uses: exp(a) is the
+    one-step propagator of H = i a over dt = 1 applied to the identity columns (the engine takes the
+    Pade order from the norm, [13/13] with squarings for large ones; qoc/standard/functions/expm.py:210-252).
+    Above n = 32 the engine propagates at most 13 states at a time, so the columns go in blocks.
+    There is no CPU implementation in this package; without the HIP library / a GPU the call raises.
     """
     from qoc_amd.core import device
     a = np.asarray(a, dtype=np.complex128)
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError("expm expects one square matrix, got shape {}".format(a.shape))
     n = a.shape[0]
-    if n > 32:
-        raise NotImplementedError("expm on the MI355X engine handles n <= 32 (got {})".format(n))
+    if n > 64:
+        raise NotImplementedError("expm on the MI355X engine handles n <= 64 (got {})".format(n))
     if not _EXPM_ENGINE:
         _EXPM_ENGINE.append(device.make_backend())
     engine = _EXPM_ENGINE[0]
-    engine.set_schroedinger_problem(n, n, 0, 0, 2, 1.0, (1j * a)[None], None,
-                                    np.eye(n, dtype=np.complex128), costs=())
-    engine.upload_controls(1)
-    engine.eval_resident(False)
-    _, _, final = engine.download_results(want_grad=False)
-    return np.ascontiguousarray(final[0].T)  # final[s] = U e_s is column s of U
+    block = n if n <= 32 else 13
+    out = np.empty((n, n), dtype=np.complex128)
+    eye = np.eye(n, dtype=np.complex128)
+    for c0 in range(0, n, block):
+        cols = eye[c0:c0 + block]
+        engine.set_schroedinger_problem(n, len(cols), 0, 0, 2, 1.0, (1j * a)[None], None, cols, costs=())
+        engine.upload_controls(1)
+        engine.eval_resident(False)
+        _, _, final = engine.download_results(want_grad=False)
+        out[:, c0:c0 + block] = final[0].T  # final[s] = U e_s is column s of U
+    return out

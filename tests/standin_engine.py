@@ -1,6 +1,6 @@
 """
 standin_engine.py - TEST INFRASTRUCTURE: a CPU stand-in for qoc_amd.engine.Engine that bench.py
-loads when QOCX_BENCH_STANDIN names this module (tests/test_bench_main.py). It rehearses the
+loads when its test-only flag --standin-engine names this module (tests/test_bench_main.py). It rehearses the
 multi-rank CONTROL FLOW of bench.py on a box without GPUs - torchrun environment, the real file
 rendezvous of qoc_amd.parallel.RcclComm, the --gpus / WORLD_SIZE check, the barrier + max-over-ranks
 timing, rank-0-only printing - with gloo in the place of RCCL. It computes nothing of the hot

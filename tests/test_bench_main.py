@@ -26,7 +26,6 @@ def _free_port():
 
 def _env(tmp_path):
     env = dict(os.environ)
-    env["QOCX_BENCH_STANDIN"] = "tests.standin_engine"
     env["QOCX_RDZV_DIR"] = str(tmp_path)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -45,7 +44,7 @@ def test_two_rank_launch_prints_one_line_with_whole_job_throughput(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1",
-           "--seeds-per-gpu", str(seeds)]
+           "--seeds-per-gpu", str(seeds), "--standin-engine", "tests.standin_engine"]
     run = subprocess.run(cmd, env=_env(tmp_path), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-4000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -66,17 +65,19 @@ def test_two_rank_launch_prints_one_line_with_whole_job_throughput(tmp_path):
 def test_single_process_default_and_gpus_mismatch(tmp_path):
     env = _env(tmp_path)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
-                          "--seeds-per-gpu", "2", "--no-cpu-baseline"],
+                          "--seeds-per-gpu", "2", "--no-cpu-baseline", "--standin-engine", "tests.standin_engine"],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     line = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and abs(line["check"]["sum_cost"] - _expected_sum_cost(1, 2)) < 1e-9
     # --gpus 2 without a launcher: refuses, names the command
-    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--standin-engine",
+                          "tests.standin_engine"], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
     # WORLD_SIZE that disagrees with --gpus
     env2 = dict(env, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
-    bad2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, cwd=ROOT,
+    bad2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--standin-engine",
+                           "tests.standin_engine"], env=env2, cwd=ROOT,
                           capture_output=True, text=True, timeout=300)
     assert bad2.returncode != 0 and "WORLD_SIZE=4" in (bad2.stderr + bad2.stdout)

@@ -159,7 +159,7 @@ def test_expm_and_example_on_gpu(capsys):
     from oracle import qoc_numpy as onp
     from qoc_amd.standard import expm
     rng = np.random.default_rng(9)
-    for n, scale in ((1, 0.3), (2, 0.5), (16, 4.0), (17, 9.0), (32, 40.0)):
+    for n, scale in ((1, 0.3), (2, 0.5), (16, 4.0), (17, 9.0), (32, 40.0), (40, 6.0), (64, 20.0)):
         a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * scale / n
         out = expm(a)
         assert rel_err(out, onp.expm_pade(a)) < 1e-11

@@ -183,14 +183,49 @@ def test_substeps_never_straddle_control_knots():
             assert not any(ta + 1e-12 < k < tb - 1e-12 for k in knots)
 
 
-def test_controller_traced_gradient_is_not_a_usable_oracle():
-    """For the record: AD that differentiates the step-size controller, as
-    autograd does in the reference, deviates from the gradient of the integrated quantity."""
-    worst = 0.0
-    for case in cases_mod.lindblad_cases():
-        g = golden(case.name)
-        for b in range(len(case.controls)):
-            ref = real_form(case, g["grads_ad"][b])
-            traced = real_form(case, g["grads_ad_traced_controller"][b])
-            worst = max(worst, np.max(np.abs(traced - ref)) / np.max(np.abs(ref)))
-    assert worst > 1e-4
+# Largest element-wise gap between the gradient the reference's tape produces - autograd through the
+# RKDP5 step-size controller, qoc/core/mathmethods.py:441-463: step_current is arithmetic on traced
+# values - and the gradient of the integrated quantity on the frozen mesh (what the engine computes
+# and what finite differences of the reference's own forward pass confirm), relative to the largest
+# entry of the latter, per fixture (both flavours stored by tools/gen_golden_lindblad.py). The
+# table INTEGRATION.md section 2 and README quote; the test keeps it tied to the data.
+CONTROLLER_GAP = {
+    "lindblad_bench_c4": 1.75,       # BASELINE configs[3]'s exact problem: 175 %
+    "lindblad_c4_full": 10.2,        # ten times the gradient itself
+    "lindblad_c4_short": 1.46e-2,
+    "lindblad_n20": 1.75e-3,
+    "lindblad_n4": 3.14e-2,
+    "lindblad_n4_complex": 6.55e-4,
+    "lindblad_opaque_wc": 1.21e-4,
+    "lindblad_timedep": 3.10e-6,
+    "lindblad_timedep_data": 3.53e-4,
+    "lindblad_wc_c4": 1.61e-6,
+    "lindblad_wc_n16": 4.53e-4,
+    "lindblad_wc_n4": 3.11e-5,
+}
+
+
+def test_controller_traced_gradient_is_not_a_usable_oracle(capsys):
+    """For the record (Lindblad section): AD that differentiates
+    the step-size controller, as autograd does in the reference, deviates from the gradient of the
+    integrated quantity - by the amounts of CONTROLLER_GAP, up to 175 % on configs[3]'s problem and
+    10x on lindblad_c4_full; the frozen-mesh gradient agrees with finite differences of the
+    reference forward on every fixture (the parity gates of test_device_model_matches_fixtures)."""
+    import glob
+    import os
+    seen = {}
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lindblad*.npz"))):
+        g = np.load(path)
+        if "grads_ad_traced_controller" not in g.files:
+            continue
+        frozen, traced = g["grads_ad"], g["grads_ad_traced_controller"]
+        seen[os.path.basename(path)[:-4]] = max(
+            np.max(np.abs(traced[b] - frozen[b])) / np.max(np.abs(frozen[b])) for b in range(len(frozen)))
+    with capsys.disabled():
+        print("\n  fixture                      max |traced - frozen| / max |frozen|")
+        for name, gap in sorted(seen.items()):
+            print("  {:28s} {:.3e}".format(name, gap))
+    assert set(seen) == set(CONTROLLER_GAP)
+    for name, gap in seen.items():
+        assert abs(gap - CONTROLLER_GAP[name]) <= 0.01 * CONTROLLER_GAP[name], (name, gap)
+    assert max(seen.values()) > 10.0 and seen["lindblad_bench_c4"] > 1.7

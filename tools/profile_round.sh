@@ -4,7 +4,7 @@
 # writes gpurun_out/prof_<tag>/ (raw) and gpurun_out/<tag>_*.{csv,json} (summaries to copy into
 # profiles/). Counter passes are separate runs with --pmc only (no trace domains beside them).
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -27,4 +27,6 @@ echo "sq1 done"
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -- $CMD > /dev/null 2> $OUT/sq2.err
 echo "sq2 done"
 python3 tools/pmc_counters.py $OUT/sq1 $OUT/sq2 > gpurun_out/${TAG}_pmc_sq.json
+# 4. what the passes were taken from: bench.py labels the committed counters stale once these change
+python3 -c "import bench, json; print(json.dumps({'k1a_sources': list(bench.K1A_SOURCES), 'k1a_sources_sha16': bench.source_digest(), 'command': '$CMD'}))" > gpurun_out/${TAG}_profile_meta.json
 ls -la gpurun_out/${TAG}_*
