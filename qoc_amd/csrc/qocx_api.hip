@@ -194,6 +194,10 @@ struct qocx_ctx {
     int sbound = 0;
     int last_chunk = 0;         // seeds of the last memory chunk of the last evaluation (its step table is in s_arr)
     double norm_bound = 1e300;  // host bound of ||step generator||_1 of the uploaded controls / generators
+    // M2, control knots at the system times (Nc = N): a bound of the step generators at their MIDPOINTS,
+    // where u is the mean of two knots - what the step table's per-step bound can reach at most; 1e300 when
+    // it does not apply. Decides only whether the two-wave K1a is launched beside the three-wave one.
+    double norm_bound_mid = 1e300;
     size_t slot_cap = 0;
     int chunk_user = 0;
     int pipe_user = 0;
@@ -930,7 +934,7 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
         // sum_k |u_k(t)| ||G_k||_1 is largest at a control knot (u is linear between knots, the sum
         // convex): the largest knot sum bounds every step, every Magnus node, and the device's
         // per-step bound (launch_step_table) - tighter than sum_k max_t |u_k(t)| ||G_k||_1
-        double smax = 0.0;
+        double smax = 0.0, smid = 0.0, sprev = 0.0;
         double* stage = ctx->pin_controls;
         for (size_t row = 0; row < (size_t)batch * ctx->nc; ++row) {
             const double* src = controls + row * K;
@@ -942,7 +946,17 @@ int qocx_upload_controls(qocx_ctx* ctx, int32_t batch, const double* controls) {
                 srow += fabs(v) * ctx->g_norm_max[k];
             }
             if (!(srow <= smax)) smax = srow;  // also catches NaN
+            // midpoint of two knots of the same seed: |u_mid| <= (|u_j| + |u_j+1|) / 2
+            if (row % (size_t)ctx->nc != 0) {
+                const double m = 0.5 * (sprev + srow);
+                if (!(m <= smid)) smid = m;
+            }
+            sprev = srow;
         }
+        if (ctx->nodes == 1 && ctx->nc == ctx->nsteps + 1)
+            ctx->norm_bound_mid = (bound + smid) * fabs(ctx->dt) * (1.0 + 1e-12);
+        else
+            ctx->norm_bound_mid = 1e300;
         bound += smax;
         if (ctx->controls.ensure(total)) return QOCX_ERR_HIP;
         HIP_TRY(hipMemcpyAsync(ctx->controls.p, stage, total * sizeof(double), hipMemcpyHostToDevice,
@@ -995,6 +1009,7 @@ int qocx_upload_generators(qocx_ctx* ctx, int32_t batch, const double* generator
     if (!(worst < 1e300)) return fail(QOCX_ERR_ARG, "non-finite generator");
     ctx->sbound = pade_scale_count(worst);
     ctx->norm_bound = worst;
+    ctx->norm_bound_mid = 1e300;
     if (ctx->sbound > 10)
         return fail(QOCX_ERR_CAPACITY,
                     "||dt H||_1 needs more than 2^10 squaring sub-steps per step; reduce dt");
@@ -1277,7 +1292,13 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             qocx::FactorArgs probe = fa;
             probe.direct = 1;
             fa.three_wave = (int)ctx->knob("k1a_three", 1);
-            if (fa.three_wave && qocx::pq3_supports(probe) && fa.prefer_low == 2) ta.order_max = 5;
+            // (the bound at the step midpoints, where it applies, speaks for the two-wave K1a only: the
+            // four-wave kernels and the slot capacity keep the bound over the knots)
+            if (fa.three_wave && qocx::pq3_supports(probe) &&
+                std::min(ctx->norm_bound, ctx->norm_bound_mid) < 2.539398330063230e-01) {
+                fa.prefer_low = 2;
+                ta.order_max = 5;
+            }
             ta.ustep = ctx->ustep.p; ta.s_arr = fa.s_arr; ta.status = fa.status;
             qocx::launch_step_table(ta, cs);
             fa.controls = ctx->ustep.p; fa.nc = nsteps; fa.direct = 1;
@@ -2740,6 +2761,7 @@ int qocx_opt_clip(qocx_ctx* ctx, const double* max_norms) {
                     "||dt H||_1 bound needs more than 2^10 squaring sub-steps per step; reduce dt");
     ctx->sbound = std::max(ctx->sbound, sb);
     ctx->norm_bound = std::max(ctx->norm_bound, bound);
+    ctx->norm_bound_mid = 1e300;  // (the controls move on the device from here on)
     ctx->slot_cap = ((size_t)ctx->nsteps << ctx->sbound) + 1;
     HIP_TRY(hipMemcpyAsync(ctx->opt_max_norms.p, max_norms, ctx->K * sizeof(double),
                            hipMemcpyHostToDevice, ctx->stream));

@@ -1,0 +1,32 @@
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import bench
+from qoc_amd.engine import Engine, COST_TARGET_COHERENT
+engine = Engine(0)
+h0, g, psi0, target = bench.make_problem()
+engine.set_schroedinger_problem(bench.DIM, 1, bench.K_CTRL, bench.N_EVAL, bench.N_EVAL, bench.DT * (bench.N_EVAL - 1),
+    h0[None], np.stack(g)[None], psi0, costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+engine.upload_controls(bench.make_controls(0, bench.SEEDS_PER_GPU))
+def run(label, nseg=0, **knobs):
+    for k, v in knobs.items(): engine.set_knob(k, v)
+    engine.set_pipeline(nseg)
+    for _ in range(3): engine.eval_resident(True)
+    engine.synchronize()
+    ts = []
+    for _ in range(4):
+        t = time.perf_counter()
+        for _ in range(5): engine.eval_resident(True)
+        engine.synchronize()
+        ts.append((time.perf_counter() - t) * 200)
+    print(json.dumps(dict(label=label, nseg=nseg, knobs=knobs, ms_median=sorted(ts)[len(ts)//2], ms_min=min(ts))), flush=True)
+run("default")
+run("k3_split=3", k3_split=3)
+run("k3_split=4", k3_split=4)
+run("k3_split=5", k3_split=5)
+run("k3_split=6", k3_split=6)
+run("nseg=6 split 4", 6, k3_split=4)
+run("nseg=4 split 6", 4, k3_split=6)
+run("nseg=10 split 3", 10, k3_split=3)
+run("nseg=8 split 3", 8, k3_split=3)
+engine.close()
