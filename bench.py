@@ -130,7 +130,7 @@ def pmc_traffic_bytes(kernel, units_per_launch):
 # kernels of one headline evaluation: timing class (qocx_set_timing) -> kernel names in the profiles
 EVAL_KERNELS = {
     "pade_pq": (K1A_KERNEL,),
-    "sweep": ("qocx::sweep1::sweep1_kernel<2>",),
+    "sweep": ("qocx::sweep1::sweep1_kernel<2, 1>",),
     "krylov_grad": ("qocx::krylov_grad_skew_kernel<2, false>",),
     "scatter": ("qocx::scatter_kernel",),
 }

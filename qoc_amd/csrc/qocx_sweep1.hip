@@ -87,27 +87,59 @@ __device__ __forceinline__ void burst_image(const double2* img, unsigned lds_dst
     }
 }
 
-template <int NB>
+// LDS of one seed: RING operand sets (Q image, LU image, 1 / U_kk, perm | iperm), then the vectors
+template <int NB, int RING>
+struct Lds1 {
+    typedef SweepLds<NB, 1> L;
+    static constexpr int SLOT = L::TMP_OFF;  // one operand set
+    static constexpr int SEED_BYTES = RING * SLOT + (L::bytes_static(1) - L::TMP_OFF);
+};
+
+// RING = 1: one operand set - the next step's LU image lands while this step's solves run, its Q
+// image once the matrix-vector product has read the old one (n = 17..32: 35 KiB per seed, so that K1a
+// workgroups fit beside two sweeps). RING > 1 (n <= 16: 9 KiB per set): the sets of the next RING - 1
+// steps are in flight - a step of a 16 x 16 problem is shorter than the trip to memory.
+template <int NB, int RING>
 __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
     typedef Geo<NB> G;
     typedef SweepLds<NB, 1> L;
     typedef Pieces<NB> P;
+    typedef Lds1<NB, RING> LR;
     constexpr int NP = G::NP, MAT = G::MAT;
     constexpr int PINTS = L::PINTS;
     constexpr int MVB = G::CPL < 4 ? G::CPL : 4;
+    constexpr int SET_PIECES = P::LU_SET + P::IMG;  // LDS-DMA instructions of one operand set
+    static_assert(RING >= 1 && (RING - 2) * SET_PIECES <= 63, "vmcnt is a 6-bit count");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // wave v of the workgroup is seed (waves per workgroup) * blockIdx.x + v, with LDS of its own
     const int pack_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* smem = smem_raw + pack_wave * L::bytes_static(1);
+    char* smem = smem_raw + pack_wave * LR::SEED_BYTES;
     __builtin_amdgcn_s_setprio(3);  // the serial chain of the evaluation goes first on its SIMD
-    double2* qbuf = reinterpret_cast<double2*>(smem + L::Q_OFF);
+    double2* qbuf = reinterpret_cast<double2*>(smem + L::Q_OFF);   // (set 0; set k: + k * SLOT bytes)
     double2* lbuf = reinterpret_cast<double2*>(smem + L::L_OFF);
     double2* dbuf = reinterpret_cast<double2*>(smem + L::D_OFF);
     int* pbuf = reinterpret_cast<int*>(smem + L::P_OFF);
-    double2* tmp = reinterpret_cast<double2*>(smem + L::TMP_OFF);
-    double2* vecs = reinterpret_cast<double2*>(smem + L::VEC_OFF);
+    double2* tmp = reinterpret_cast<double2*>(smem + RING * LR::SLOT);
+    double2* vecs = reinterpret_cast<double2*>(smem + RING * LR::SLOT + (L::VEC_OFF - L::TMP_OFF));
     double2* lam = vecs + NP;
     const unsigned q_lds = lds_addr(qbuf), l_lds = lds_addr(lbuf), d_lds = lds_addr(dbuf), p_lds = lds_addr(pbuf);
+    auto at_set = [&](auto* ptr, int set) __attribute__((always_inline)) {
+        return reinterpret_cast<decltype(ptr)>(reinterpret_cast<char*>(ptr) + set * LR::SLOT);
+    };
+    // everything but the `younger` youngest operand sets has landed
+    auto wait_sets = [&](int younger) __attribute__((always_inline)) {
+        if constexpr (RING > 2) {
+            if (younger >= RING - 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * SET_PIECES) : "memory"); return; }
+        }
+        if constexpr (RING > 3) {
+            if (younger == RING - 3) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * SET_PIECES) : "memory"); return; }
+        }
+        if constexpr (RING > 4) {
+            if (younger == RING - 4) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 4) * SET_PIECES) : "memory"); return; }
+        }
+        if (younger >= 1 && RING > 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SET_PIECES) : "memory"); return; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     const int b = (int)(blockDim.x >> 6) * blockIdx.x + pack_wave;
     if (b >= args.batch) return;  // odd batch: the last workgroup has one seed
     const int lane = lane_id(), i = lane % NP, h = lane / NP;
@@ -117,26 +149,28 @@ __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
     double2* xs_b = args.xs + (size_t)b * cap * NP;
     int* offs_b = args.offs + (size_t)b * (nsteps + 1);
     const bool g0 = (h == 0);
-    const size_t m0 = (size_t)b * nsteps;
+    // (timing experiment, diagnostic build: every seed fetches the images of seed 0 - cache hits)
+    const size_t m0 = (QOCX_DBG_BITS(args.dbg) & 16384) ? 0 : (size_t)b * nsteps;
     const int jb = args.j_begin, je = args.j_end;
     const bool do_fwd = (args.phase & 1) != 0, do_bwd = (args.phase & 2) != 0;
     if (jb > 0 || !do_fwd)
         if ((*(volatile int*)args.status) & 4) return;  // an earlier segment overflowed
 
     // the fetches of a step, as two bursts of LDS-DMA
-    auto burst_lu = [&](size_t m, auto ADJ) __attribute__((always_inline)) {
+    auto burst_lu = [&](size_t m, auto ADJ, int set = 0) __attribute__((always_inline)) {
         constexpr bool adj = decltype(ADJ)::value;
-        burst_image<NB, adj>(args.lu_img + m * MAT, l_lds, lane);
-        dma16<0>(reinterpret_cast<const char*>(args.dinv + m * NP + i), d_lds);
-        dma4((lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP, p_lds);
+        const unsigned off = (unsigned)(set * LR::SLOT);
+        burst_image<NB, adj>(args.lu_img + m * MAT, l_lds + off, lane);
+        dma16<0>(reinterpret_cast<const char*>(args.dinv + m * NP + i), d_lds + off);
+        dma4((lane < 32 ? args.perm : args.iperm) + m * NP + (lane & 31) % NP, p_lds + off);
     };
-    auto burst_q = [&](size_t m, auto ADJ) __attribute__((always_inline)) {
-        burst_image<NB, decltype(ADJ)::value>(args.q_img + m * MAT, q_lds, lane);
+    auto burst_q = [&](size_t m, auto ADJ, int set = 0) __attribute__((always_inline)) {
+        burst_image<NB, decltype(ADJ)::value>(args.q_img + m * MAT, q_lds + (unsigned)(set * LR::SLOT), lane);
     };
-    auto scalars = [&](bool adjoint) {
+    auto scalars = [&](bool adjoint, int set = 0) {
         StepScalars sc;
-        sc.dv = dbuf[i];
-        sc.pm = min(max(pbuf[(adjoint ? PINTS / 2 : 0) + i], 0), NP - 1);
+        sc.dv = at_set(dbuf, set)[i];
+        sc.pm = min(max(at_set(pbuf, set)[(adjoint ? PINTS / 2 : 0) + i], 0), NP - 1);
         return sc;
     };
     // squaring counts: lane l holds the entry of step sq_base + l
@@ -188,21 +222,34 @@ __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
         wave_sync();
         if (jb < je) {
             (void)substeps(jb, false);
-            burst_lu(m0 + jb, FWD_T);
-            burst_q(m0 + jb, FWD_T);
+            for (int k = 0; k < (RING > 1 ? RING - 1 : 1); ++k)
+                if (jb + k < je) {
+                    burst_lu(m0 + jb + k, FWD_T, k);
+                    burst_q(m0 + jb + k, FWD_T, k);
+                }
         }
         bool pend = false;
         double zre = 0, zim = 0;
         for (int step = jb; step < je; ++step) {
             const int nsub = substeps(step, false);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's operands have landed
+            const int set = RING > 1 ? (step - jb) % RING : 0;
+            wait_sets(RING > 1 ? min(RING - 2, je - 1 - step) : 0);  // this step's operands have landed
             if (pend) states_b[(size_t)slot * NP + i] = make_double2(zre, zim);
             pend = false;
             wave_sync();
-            const StepScalars sc = scalars(false);
-            if (!(QOCX_DBG_BITS(args.dbg) & 8192)) lds_to_regs<NB, false>(qbuf, lbuf, pbuf, r, sc.pm, lane, i);
+            if constexpr (RING > 1) {  // the set of step + RING - 1 into the buffers step - 1 has left
+                const int nxt = step + RING - 1;
+                if (nxt < je && !(QOCX_DBG_BITS(args.dbg) & 256)) {
+                    burst_lu(m0 + nxt, FWD_T, (nxt - jb) % RING);
+                    burst_q(m0 + nxt, FWD_T, (nxt - jb) % RING);
+                }
+            }
+            const StepScalars sc = scalars(false, set);
+            const double2* qset = at_set(qbuf, set);
+            if (!(QOCX_DBG_BITS(args.dbg) & 8192))
+                lds_to_regs<NB, false>(qset, at_set(lbuf, set), at_set(pbuf, set), r, sc.pm, lane, i);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are in registers: the buffer is free
-            const bool more = step + 1 < je && !(QOCX_DBG_BITS(args.dbg) & 256);
+            const bool more = RING == 1 && step + 1 < je && !(QOCX_DBG_BITS(args.dbg) & 256);
             if (more) burst_lu(m0 + step + 1, FWD_T);
             before_step(step);
             for (int sub = 0; sub < nsub; ++sub) {
@@ -215,7 +262,7 @@ __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
                     const double2 e = vecs[i];
                     zre = e.x; zim = e.y;
                 } else {
-                    lds_matvec<NB, false, MVB>(qbuf, vecs, h * NP + sc.pm, h, zre, zim);
+                    lds_matvec<NB, false, MVB>(qset, vecs, h * NP + sc.pm, h, zre, zim);
                 }
                 if (sub == nsub - 1 && more) {  // the Q image has been read for the last time
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,29 +344,47 @@ __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
         sq_valid = false;
         if (jb < je) {
             (void)substeps(je - 1, true);
-            burst_lu(m0 + je - 1, ADJ_T);
+            if constexpr (RING > 1) {
+                for (int k = 0; k < RING - 1; ++k)
+                    if (je - 1 - k >= jb) {
+                        burst_lu(m0 + je - 1 - k, ADJ_T, k);
+                        burst_q(m0 + je - 1 - k, ADJ_T, k);
+                    }
+            } else {
+                burst_lu(m0 + je - 1, ADJ_T);
+            }
         }
         bool pend = false;
         double pxre = 0, pxim = 0;
         int pslot = 0, pstep = -1;  // (pstep: the step whose first xs slot is still to be recorded)
         for (int step = je - 1; step >= jb; --step) {
             const int nsub = substeps(step, true);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's LU image, 1 / U_kk, permutation
+            const int it = je - 1 - step, set = RING > 1 ? it % RING : 0;
+            wait_sets(RING > 1 ? min(RING - 2, step - jb) : 0);  // this step's LU image, 1 / U_kk, permutation (RING > 1: Q too)
             if (pend) xs_b[(size_t)pslot * NP + i] = make_double2(pxre, pxim);
             pend = false;
             if (pstep >= 0 && lane == 0) offs_x[pstep] = slot;
             pstep = -1;
             wave_sync();
-            const StepScalars sc = scalars(true);
-            if (!(QOCX_DBG_BITS(args.dbg) & 8192)) lds_to_regs<NB, true>(qbuf, lbuf, pbuf, r, sc.pm, lane, i);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // the step's OWN Q image (read at the end of its first sub-step; the buffer has been free
-            // since the previous step's product), then the LU image of the next step
             const bool fetch = !(QOCX_DBG_BITS(args.dbg) & 512);
-            if (fetch) burst_q(m0 + step, ADJ_T);
-            const bool more = step - 1 >= jb && fetch;
+            if constexpr (RING > 1) {
+                const int nxt = step - (RING - 1);
+                if (nxt >= jb && fetch) {
+                    burst_lu(m0 + nxt, ADJ_T, (it + RING - 1) % RING);
+                    burst_q(m0 + nxt, ADJ_T, (it + RING - 1) % RING);
+                }
+            }
+            const StepScalars sc = scalars(true, set);
+            const double2* qset = at_set(qbuf, set);
+            if (!(QOCX_DBG_BITS(args.dbg) & 8192))
+                lds_to_regs<NB, true>(qset, at_set(lbuf, set), at_set(pbuf, set), r, sc.pm, lane, i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // RING = 1: the step's OWN Q image (read at the end of its first sub-step; the buffer has been
+            // free since the previous step's product), then the LU image of the next step
+            if (RING == 1 && fetch) burst_q(m0 + step, ADJ_T);
+            const bool more = RING == 1 && step - 1 >= jb && fetch;
             if (more) burst_lu(m0 + step - 1, ADJ_T);
-            bool first = true;
+            bool first = RING == 1;
             for (int sub = nsub - 1; sub >= 0; --sub) {
                 if (slot <= 0) {  // (unit adjoint: nobody has checked the capacity before)
                     overflow = true;
@@ -349,7 +414,7 @@ __global__ __launch_bounds__(128) void sweep1_kernel(SweepArgs args) {
                 if (QOCX_DBG_BITS(args.dbg) & 4096) {
                     yre = xre; yim = xim;
                 } else {
-                    lds_matvec<NB, true, MVB>(qbuf, tmp, lane, h, yre, yim);
+                    lds_matvec<NB, true, MVB>(qset, tmp, lane, h, yre, yim);
                 }
                 wave_sync();
                 lam[i] = make_double2(yre, yim);
@@ -389,17 +454,24 @@ void launch_sweep1(int nb, const SweepArgs& a, int batch, int pack, hipStream_t 
     b.batch = batch;
     pack = pack >= 2 ? 2 : 1;
     if (nb == 1) {
-        const int bytes = SweepLds<1, 1>::bytes_static(1) * pack;
-        hipLaunchKernelGGL(sweep1::sweep1_kernel<1>, dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
-    } else {
-        const int bytes = SweepLds<2, 1>::bytes_static(1) * pack;
+        constexpr int RING = 4;
+        const int bytes = sweep1::Lds1<1, RING>::SEED_BYTES * pack;
         static bool attr_set = false;
         if (bytes > 48 * 1024 && !attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep1::sweep1_kernel<2>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep1::sweep1_kernel<1, RING>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             attr_set = true;
         }
-        hipLaunchKernelGGL(sweep1::sweep1_kernel<2>, dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
+        hipLaunchKernelGGL((sweep1::sweep1_kernel<1, RING>), dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
+    } else {
+        const int bytes = sweep1::Lds1<2, 1>::SEED_BYTES * pack;
+        static bool attr_set = false;
+        if (bytes > 48 * 1024 && !attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep1::sweep1_kernel<2, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((sweep1::sweep1_kernel<2, 1>), dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
     }
 }
 
