@@ -894,6 +894,31 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
 
 // 1-norm bound of the step generator from the bound b >= ||dt a(t)|| of its node generators
 // (mathmethods.py:96-164: m2 = b; m4 = dt/2 (a1 + a2) + sqrt(3)/12 dt^2 [a2, a1]; m6)
+// max over the Pade orders of eps_m(theta) = sum_{j>=1} (b_j / b_0) theta^j (qocx_lu5.h)
+static double pade_eps_max(double theta) {
+    const double b3[] = {120.0, 60.0, 12.0, 1.0};
+    const double b5[] = {30240.0, 15120.0, 3360.0, 420.0, 30.0, 1.0};
+    const double b7[] = {17297280.0, 8648640.0, 1995840.0, 277200.0, 25200.0, 1512.0, 56.0, 1.0};
+    const double b9[] = {17643225600.0, 8821612800.0, 2075673600.0, 302702400.0, 30270240.0, 2162160.0,
+                         110880.0, 3960.0, 90.0, 1.0};
+    const double b13[] = {64764752532480000.0, 32382376266240000.0, 7771770303897600.0, 1187353796428800.0,
+                          129060195264000.0, 10559470521600.0, 670442572800.0, 33522128640.0, 1323241920.0,
+                          40840800.0, 960960.0, 16380.0, 182.0, 1.0};
+    const double* tabs[] = {b3, b5, b7, b9, b13};
+    const int orders[] = {3, 5, 7, 9, 13};
+    if (!(theta >= 0.0) || !(theta < 1e300)) return 1e300;
+    double worst = 0.0;
+    for (int t = 0; t < 5; ++t) {
+        double eps = 0.0, tp = 1.0;
+        for (int j = 1; j <= orders[t]; ++j) {
+            tp *= theta;
+            eps += tabs[t][j] / tabs[t][0] * tp;
+        }
+        worst = std::max(worst, eps);
+    }
+    return worst;
+}
+
 static double magnus_norm_bound(int nodes, double bound) {
     if (nodes == 2) return bound + (std::sqrt(3.0) / 12) * 2 * bound * bound;
     if (nodes == 3) {
@@ -1309,6 +1334,9 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         la.dbg = ((dbg_skip_early & 16) ? 1 : 0) | ((ctx->knob("k1a_dbg", 0) & 8) ? 2 : 0) |
                  ((ctx->knob("k1a_dbg", 0) & 16) ? 4 : 0) | ((ctx->knob("k1a_dbg", 0) & 32) ? 8 : 0);
         la.inverse = (dense || inverse_sweep) ? 1 : 0;
+        // every Pade denominator of the evaluation diagonally dominant by the margin of qocx_lu5.h
+        // (eps_m(theta) <= 0.40 for every order m at the host's bound theta of the step norm)
+        la.all_dominant = (pade_eps_max(ctx->norm_bound) <= 0.40 && ctx->knob("lu_dpp", 1) != 0) ? 1 : 0;
         la.redo = nullptr;
         la.fallbacks = ctx->lu_fallbacks.p;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
@@ -2923,6 +2951,11 @@ int qocx_debug_pade_factor(qocx_ctx* ctx, int32_t count, int32_t n, const double
     la.status = ctx->status.p;
     la.nsteps = count; la.step0 = 0; la.seg_len = count; la.n = n;
     la.inverse = inverse ? 1 : 0;
+    {   // the four-to-a-wave inverse of n <= 16 (qocx_lu5.h) where every matrix handed in qualifies
+        double theta = 0.0;
+        for (int c = 0; c < count; ++c) theta = std::max(theta, one_norm(a + (size_t)c * n * n * 2, n));
+        la.all_dominant = (pade_eps_max(theta) <= 0.40 && ctx->knob("lu_dpp", 1) != 0) ? 1 : 0;
+    }
     la.fallbacks = ctx->lu_fallbacks.p;
     DevBuf<int> redo_d;
     if (nb == 4 && ctx->knob("lu_mfma", 1) != 0) {

@@ -101,6 +101,8 @@ struct LuArgs {
     int n;                       // Hilbert size (sixteen-tile K1b: <= 48 -> 48 elimination steps); 0: unknown
     int dbg = 0;                 // timing experiment (dbg_skip bit 4): loads and stores only
     int inverse = 0;             // lu_img receives P^-1 instead of the factors (n <= 32; qocx_lu.h inv_body)
+    int all_dominant = 0;        // every matrix of the launch is diagonally dominant by the margin of qocx_lu5.h
+                                 // (the host's bound of the step norm says so): n <= 16 inverses four to a wave
     // 33 <= n <= 64, round 4: [matrices] flags of the MFMA factorisation (qocx_lu4m.hip) - 1: its
     // diagonal-pivot attempt was abandoned, lu4_kernel factors the matrix; nullptr: lu4_kernel factors
     // every matrix

@@ -1749,7 +1749,9 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
     else launch_pq2_explicit(a_in, n, a, count, st);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
-    if (a.inverse && nb == 1) hipLaunchKernelGGL(inv_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
+    if (a.inverse && nb == 1 && a.all_dominant)
+        hipLaunchKernelGGL(inv16::inv16_dpp_kernel<1>, dim3((unsigned)((count + 3) / 4)), dim3(64), 0, st, a, (unsigned)count);
+    else if (a.inverse && nb == 1) hipLaunchKernelGGL(inv_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (a.inverse && nb == 2) hipLaunchKernelGGL(inv_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 2) hipLaunchKernelGGL(lu_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);

@@ -266,6 +266,97 @@ __device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double
 }
 
 }  // namespace lu5
+
+// ---- n <= 16: P^-1 of FOUR matrices per wave (round 5) -----------------------------------------------
+// The batched evaluator applies P^-1 as a matrix at n <= 16 (qocx_sweepi.hip). inv_kernel (qocx_lu.h)
+// spends a wave on ONE 16 x 16 Gauss-Jordan elimination with the pivot row through LDS; here every row
+// of 16 lanes holds a different matrix, a matrix row per lane, and one stream of DPP multiply-adds
+// eliminates all four: per pivot the multipliers f_j = a_jK / a_KK of every row but the pivot's,
+// a_jc -= f_j a_Kc over the fifteen other columns (the pivot row is NOT scaled: it never leaves its
+// lane), column K takes the identity part of the augmented matrix ( -f_j, and 1 in the pivot row);
+// at the end row j is scaled by 1 / d_j. No pivot search: only for launches whose every matrix is
+// diagonally dominant by the margin of pade_denominator_dominant() (the host decides from its bound of
+// the step norm, LuArgs::all_dominant); others take inv_kernel.
+namespace inv16 {
+
+using lu5::Block;
+using lu5::Recip;
+
+// f = x * r on every lane of the rows but lane K of each (zero there); x := -f there, 1 on lane K
+template <int K>
+__device__ __forceinline__ void multiplier_gj(double& fr, double& fi, double& xr, double& xi, double rr, double ri) {
+    constexpr unsigned one = 1u << K, others = (0xffffu & ~one), m_others = others | (others << 16), m_one = one | (one << 16);
+    fr = 0.0;
+    fi = 0.0;
+    asm volatile(
+        "s_mov_b32 exec_lo, %6\n\t"
+        "s_mov_b32 exec_hi, %6\n\t"
+        "v_mul_f64 %0, %2, %4\n\t"
+        "v_mul_f64 %1, %2, %5\n\t"
+        "v_fma_f64 %0, -%3, %5, %0\n\t"
+        "v_fma_f64 %1, %3, %4, %1\n\t"
+        "v_mul_f64 %2, %0, -1.0\n\t"
+        "v_mul_f64 %3, %1, -1.0\n\t"
+        "s_mov_b32 exec_lo, %7\n\t"
+        "s_mov_b32 exec_hi, %7\n\t"
+        "v_mov_b64 %2, 1.0\n\t"
+        "v_mov_b64 %3, 0\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(fr), "+v"(fi), "+v"(xr), "+v"(xi)
+        : "v"(rr), "v"(ri), "i"(m_others), "i"(m_one));
+}
+
+template <int K>
+__device__ __forceinline__ void pivot(Block& x, double& myrr, double& myri, int j, Recip& s) {
+    const double rr = s.rr, ri = s.ri;
+    myrr = (j == K) ? rr : myrr;
+    myri = (j == K) ? ri : myri;
+    double fr, fi;
+    multiplier_gj<K>(fr, fi, x.re[K], x.im[K], rr, ri);
+    // the column right of the pivot first (the next pivot is its diagonal entry), the reciprocal of the
+    // next pivot between the others
+    for_each_const(
+        [&](auto C) __attribute__((always_inline)) {
+            constexpr int idx = decltype(C)::value, c = (K + 1 + idx) % 16;
+            if constexpr (idx >= 1 && idx - 1 < lu5::RECIP_STEPS && K + 1 < 16) lu5::recip_step<(K + 1) % 16, idx - 1>(s, x);
+            if constexpr (c != K) lu5::elim<K, 0xf>(x.re[c], x.im[c], fr, fi);
+        },
+        std::make_integer_sequence<int, 16>{});
+}
+template <int... K>
+__device__ __forceinline__ void pivots(Block& x, double& myrr, double& myri, int j, std::integer_sequence<int, K...>) {
+    Recip s;
+    lu5::recip_all<0>(s, x, std::make_integer_sequence<int, lu5::RECIP_STEPS>{});
+    (pivot<K>(x, myrr, myri, j, s), ...);
+}
+
+// work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len; the image (column-major 16 x 16)
+// is inverted in place
+template <int NB>  // (a template, NB = 1 only: the header goes into several translation units)
+__global__ __launch_bounds__(64) void inv16_dpp_kernel(LuArgs args, unsigned count) {
+    static_assert(NB == 1, "one MFMA tile");
+    const int lane = lane_id(), d = lane >> 4, j = lane & 15;
+    const unsigned w = min(4u * blockIdx.x + (unsigned)d, count - 1u);
+    const bool live = 4u * blockIdx.x + (unsigned)d < count;
+    const size_t m = (size_t)(w / args.seg_len) * args.nsteps + args.step0 + w % args.seg_len;
+    double2* img = args.lu_img + m * 256;
+    Block x;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double2 e = img[c * 16 + j];
+        x.re[c] = e.x;
+        x.im[c] = e.y;
+    }
+    double myrr = 0.0, myri = 0.0;
+    pivots(x, myrr, myri, j, std::make_integer_sequence<int, 16>{});
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            img[c * 16 + j] = make_double2(x.re[c] * myrr - x.im[c] * myri, x.re[c] * myri + x.im[c] * myrr);
+    }
+}
+
+}  // namespace inv16
 }  // namespace qocx
 
 #endif

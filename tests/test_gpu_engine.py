@@ -92,6 +92,36 @@ def test_pade_inverse_kernel(engine, n):
         assert rel_err(out["lu"][m] @ p_mat, np.eye(n)) < 1e-12 * np.linalg.cond(p_mat)
 
 
+@pytest.mark.parametrize("n, count", [(16, 9), (8, 4), (1, 3), (13, 6)])
+def test_pade_inverse_four_to_a_wave(engine, n, count):
+    """n <= 16, every matrix of the launch diagonally dominant (eps(theta) <= 0.40, qocx_lu5.h): P^-1
+    of four matrices per wave by DPP multiply-adds, no pivot search (inv16_dpp_kernel), against the
+    one-matrix-per-wave Gauss-Jordan kernel with LAPACK's pivot rule (knob "lu_dpp" 0) and against the
+    model; `count` not a multiple of four leaves rows of lanes without a matrix."""
+    rng = np.random.default_rng(900 + n)
+    mats = []
+    for c in range(count):
+        g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        a = -1j * (g + g.conj().T) / 2 if c % 2 == 0 else g
+        mats.append(a * (float(rng.uniform(0.01, 0.65)) / max(onp.one_norm(a), 1e-300)))
+    mats = np.stack(mats)
+    engine.set_knob("lu_inverse", 1)
+    try:
+        out = engine.debug_pade_factor(mats)
+        engine.set_knob("lu_dpp", 0)
+        ref = engine.debug_pade_factor(mats)
+    finally:
+        engine.set_knob("lu_dpp", 1)
+        engine.set_knob("lu_inverse", 0)
+    assert np.array_equal(out["q"], ref["q"]) and np.array_equal(out["order"], ref["order"])
+    for m, a in enumerate(mats):
+        f = dm.pade_factor(a, order=int(out["order"][m]))
+        p_mat = dm.pade_uv(f["a"], f["order"])
+        p_mat = p_mat[1] - p_mat[0]
+        assert rel_err(out["lu"][m], ref["lu"][m]) < 1e-13
+        assert rel_err(out["lu"][m] @ p_mat, np.eye(n)) < 1e-13 * np.linalg.cond(p_mat)
+
+
 def check_pade_factor(out, mats, policy, expect_lower=True):
     lower = 0
     for m, a in enumerate(mats):
