@@ -1557,14 +1557,25 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             // left of K3 once the sweeps have finished is a piece, not a segment.  Measured at
             // configs[1]: 1 piece 12.86 ms, 2 -> 13.00, 3 -> 13.19, 4 -> 13.55 (every launch
             // refills its pipeline), so the default is whole segments.
-            const int parts = (int)std::max<int64_t>(
-                1, std::min<int64_t>(ctx->knob("k3_split", 1), (int64_t)ctx->ev_fwd.size() / nseg));
-            const int P = nseg * parts;
-            auto piece_lo = [&](int p) {
-                const int i = p / parts, part = p % parts;
-                return lo[i] + (int)((int64_t)(lo[i + 1] - lo[i]) * part / parts);
-            };
-            auto piece_hi = [&](int p) { return (p % parts == parts - 1) ? lo[p / parts + 1] : piece_lo(p + 1); };
+            // "k3_split": pieces of every segment; "k3_split_outer": pieces of the FIRST and the LAST
+            // segment only - the two whose sweeps finish last: with them in pieces all that is left of
+            // K3 once the sweeps have ended is a piece of a segment.
+            const int max_pieces = (int)ctx->ev_fwd.size();
+            int parts_in = (int)std::max<int64_t>(1, ctx->knob("k3_split", 1));
+            int parts_out = (int)std::max<int64_t>(parts_in, ctx->knob("k3_split_outer", 3));
+            if ((nseg - 2) * parts_in + 2 * parts_out > max_pieces) parts_in = parts_out = 1;
+            struct Piece { int lo, hi; };
+            std::vector<Piece> piece;
+            std::vector<int> first(nseg + 1, 0);
+            for (int i = 0; i < nseg; ++i) {
+                const int np_i = (i == 0 || i == nseg - 1) ? parts_out : parts_in;
+                first[i] = (int)piece.size();
+                for (int part = 0; part < np_i; ++part)
+                    piece.push_back({lo[i] + (int)((int64_t)(lo[i + 1] - lo[i]) * part / np_i),
+                                     lo[i] + (int)((int64_t)(lo[i + 1] - lo[i]) * (part + 1) / np_i)});
+            }
+            first[nseg] = (int)piece.size();
+            const int P = (int)piece.size();
             std::vector<char> factored(nseg, 0);
             int next_f = 0, next_b = nseg - 1;
             for (int t = 0; t < nseg; ++t) {
@@ -1573,18 +1584,16 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 factored[i] = 1;
                 while (next_f < nseg && factored[next_f]) {
                     HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_factored[next_f], 0));
-                    for (int part = 0; part < parts; ++part) {
-                        const int p = next_f * parts + part;
-                        if (piece_hi(p) > piece_lo(p)) forward_range(piece_lo(p), piece_hi(p), sf);
+                    for (int p = first[next_f]; p < first[next_f + 1]; ++p) {
+                        if (piece[p].hi > piece[p].lo) forward_range(piece[p].lo, piece[p].hi, sf);
                         HIP_TRY(hipEventRecord(ctx->ev_fwd[p], sf));
                     }
                     ++next_f;
                 }
                 while (next_b >= 0 && factored[next_b]) {
                     HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_factored[next_b], 0));
-                    for (int part = parts - 1; part >= 0; --part) {
-                        const int p = next_b * parts + part;
-                        if (piece_hi(p) > piece_lo(p)) adjoint_range(piece_lo(p), piece_hi(p), sb);
+                    for (int p = first[next_b + 1] - 1; p >= first[next_b]; --p) {
+                        if (piece[p].hi > piece[p].lo) adjoint_range(piece[p].lo, piece[p].hi, sb);
                         HIP_TRY(hipEventRecord(ctx->ev_swept[p], sb));
                     }
                     --next_b;
@@ -1593,16 +1602,17 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             // K3 from the middle outwards: a piece is complete once the forward sweep (going up)
             // and the adjoint sweep (going down) have both crossed it
             std::vector<int> order;
+            const int mid = first[nseg / 2];
             for (int d = 0; d < P; ++d) {
-                const int up = P / 2 + d, down = P / 2 - 1 - d;
+                const int up = mid + d, down = mid - 1 - d;
                 if (up < P) order.push_back(up);
                 if (down >= 0) order.push_back(down);
             }
             for (int p : order) {
-                if (piece_hi(p) <= piece_lo(p)) continue;
+                if (piece[p].hi <= piece[p].lo) continue;
                 HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_fwd[p], 0));
                 HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_swept[p], 0));
-                QOCX_STEP(krylov_range(piece_lo(p), piece_hi(p)));
+                QOCX_STEP(krylov_range(piece[p].lo, piece[p].hi));
             }
         } else {
             // ---- factor + forward sweep, segment by segment --------------------------------
@@ -2559,7 +2569,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 // (qocx_diag.h): timing experiments that return garbage and the stamped kernel builds.
 static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
-    "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split",
+    "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
     "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",

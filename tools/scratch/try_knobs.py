@@ -21,12 +21,12 @@ def run(label, nseg=0, **knobs):
         ts.append((time.perf_counter() - t) * 200)
     print(json.dumps(dict(label=label, nseg=nseg, knobs=knobs, ms_median=sorted(ts)[len(ts)//2], ms_min=min(ts))), flush=True)
 run("default")
-run("k3_split=3", k3_split=3)
-run("k3_split=4", k3_split=4)
-run("k3_split=5", k3_split=5)
-run("k3_split=6", k3_split=6)
-run("nseg=6 split 4", 6, k3_split=4)
-run("nseg=4 split 6", 4, k3_split=6)
-run("nseg=10 split 3", 10, k3_split=3)
-run("nseg=8 split 3", 8, k3_split=3)
+run("outer=2", k3_split_outer=2)
+run("outer=3", k3_split_outer=3)
+run("outer=4", k3_split_outer=4)
+run("outer=1", k3_split_outer=1)
+run("outer=3 again", k3_split_outer=3)
+run("outer=1 again", k3_split_outer=1)
+run("outer=4, all=2", k3_split=2, k3_split_outer=4)
+run("default again", k3_split=1, k3_split_outer=1)
 engine.close()
