@@ -1416,28 +1416,32 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         sa.inj_bars = ctx->inj_count > 0
                           ? ctx->inj_bars.p + (size_t)b0 * ctx->inj_count * S * np : nullptr;
 
-        auto factor_segment = [&](int i) -> int {
+        // `fs`: the stream of this segment's factor kernels (the compute stream; in the two-sided
+        // pipeline every other segment goes to a second one, so that a K1a grid fills the CUs the
+        // previous one is draining from - knob "k1a_streams"; measured 8.08-8.15 ms against 8.06-8.07 ms
+        // with one stream, profiles/r05_k1a_streams.jsonl, so the default stays at one)
+        auto factor_segment = [&](int i, hipStream_t fs) -> int {
             // (Measured and dropped: K1a / K1b of a segment as 2, 4 or 8 pairs of sub-launches, so
             // that K1b might find P in the last-level cache: 13.1 / 13.8 / 15.5 ms against 12.7 -
             // the launch tails cost more than any cache hit returns.)
             const int plo = lo[i], len = lo[i + 1] - lo[i];
             fa.step0 = plo; fa.seg_len = len;
-            time_begin(ctx, 0, cs);
+            time_begin(ctx, 0, fs);
             if (explicit_gen) {
                 // generators sampled by the host (opaque Hamiltonian): [seed][step] row-major
                 qocx::FactorArgs fe = fa;
                 qocx::launch_pq_explicit(ctx->nb, ctx->gen_rm.p + (size_t)b0 * nsteps * mat, np, fe,
-                                         bc * len, cs);
+                                         bc * len, fs);
             } else if (nodes > 1) {
                 ma.step0 = plo; ma.seg_len = len; ma.total = (size_t)bc * len;
                 ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
-                if (magnus4w) qocx::launch_magnus4w_fwd(ma, bc, cs);
-                else qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), cs);
-                qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, bc * len, cs);
+                if (magnus4w) qocx::launch_magnus4w_fwd(ma, bc, fs);
+                else qocx::launch_magnus_fwd(ctx->nb, ma, (int)std::min<size_t>(ma.total, magnus_blocks), fs);
+                qocx::launch_pq_explicit(ctx->nb, ma.m_rm, np, fa, bc * len, fs);
             } else {
-                qocx::launch_pq(ctx->nb, fa, len, bc, cs);
+                qocx::launch_pq(ctx->nb, fa, len, bc, fs);
             }
-            time_end(ctx, cs);
+            time_end(ctx, fs);
             la.step0 = plo; la.seg_len = len;
             // (K1b on a stream of its own, beside the next segment's K1a: with the v5 kernels no
             // gain; with the two-wave K1a (240 registers) and K1b (160) sharing SIMDs 1 % - K1a
@@ -1450,7 +1454,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             const bool lu_apart = !fused_lu && ctx->nb == 4 && nseg > 1 && ctx->lu_stream != nullptr &&
                                   ctx->knob("lu_stream", 1) != 0;
             if (lu_apart) {
-                HIP_TRY(hipEventRecord(ctx->ev_pq[i], cs));
+                HIP_TRY(hipEventRecord(ctx->ev_pq[i], fs));
                 HIP_TRY(hipStreamWaitEvent(ctx->lu_stream, ctx->ev_pq[i], 0));
                 time_begin(ctx, 4, ctx->lu_stream);
                 qocx::launch_lu(ctx->nb, la, (size_t)bc * len, ctx->lu_stream);
@@ -1460,10 +1464,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             }
             if (!fused_lu) {
                 time_begin(ctx, 4, cs);
-                qocx::launch_lu(ctx->nb, la, (size_t)bc * len, cs);
+                qocx::launch_lu(ctx->nb, la, (size_t)bc * len, fs);
                 time_end(ctx, cs);
             }
-            if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], cs));
+            if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], fs));
             return 0;
         };
         // forward sweep over segment i on stream st (behind the segment's factorisation)
@@ -1578,9 +1582,16 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             const int P = (int)piece.size();
             std::vector<char> factored(nseg, 0);
             int next_f = 0, next_b = nseg - 1;
+            // two factor streams: the second one starts behind everything the compute stream has
+            // enqueued so far (the step table, the previous evaluation's tail)
+            const bool two_k1a = fused_lu && ctx->lu_stream != nullptr && ctx->knob("k1a_streams", 1) >= 2;
+            if (two_k1a) {
+                HIP_TRY(hipEventRecord(ctx->ev_pq[nseg], cs));
+                HIP_TRY(hipStreamWaitEvent(ctx->lu_stream, ctx->ev_pq[nseg], 0));
+            }
             for (int t = 0; t < nseg; ++t) {
                 const int i = (t % 2 == 0) ? t / 2 : nseg - 1 - t / 2;
-                QOCX_STEP(factor_segment(i));
+                QOCX_STEP(factor_segment(i, (two_k1a && (t % 2 == 1)) ? ctx->lu_stream : cs));
                 factored[i] = 1;
                 while (next_f < nseg && factored[next_f]) {
                     HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_factored[next_f], 0));
@@ -1617,7 +1628,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         } else {
             // ---- factor + forward sweep, segment by segment --------------------------------
             for (int i = 0; i < nseg; ++i) {
-                QOCX_STEP(factor_segment(i));
+                QOCX_STEP(factor_segment(i, cs));
                 QOCX_STEP(forward_segment(i, ss));
             }
             // ---- adjoint sweep walks back; K3 follows on the compute stream ------------------
@@ -2571,7 +2582,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

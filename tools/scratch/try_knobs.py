@@ -20,13 +20,10 @@ def run(label, nseg=0, **knobs):
         engine.synchronize()
         ts.append((time.perf_counter() - t) * 200)
     print(json.dumps(dict(label=label, nseg=nseg, knobs=knobs, ms_median=sorted(ts)[len(ts)//2], ms_min=min(ts))), flush=True)
-run("default")
-run("outer=2", k3_split_outer=2)
-run("outer=3", k3_split_outer=3)
-run("outer=4", k3_split_outer=4)
-run("outer=1", k3_split_outer=1)
-run("outer=3 again", k3_split_outer=3)
-run("outer=1 again", k3_split_outer=1)
-run("outer=4, all=2", k3_split=2, k3_split_outer=4)
-run("default again", k3_split=1, k3_split_outer=1)
+run("streams=2", k1a_streams=2)
+run("streams=1", k1a_streams=1)
+run("streams=2 again", k1a_streams=2)
+run("streams=1 again", k1a_streams=1)
+run("streams=2 third", k1a_streams=2)
+run("streams=1 third", k1a_streams=1)
 engine.close()
