@@ -2507,6 +2507,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 fwd.phase = 1;
                 adj.phase = 2;
                 fwd.q2 = adj.q2 = ctx->knob("lindblad_q2", 1) != 0 ? 1 : 0;
+                fwd.chain = adj.chain = ctx->knob("lindblad_chain", 1) != 0 ? 1 : 0;
                 if (la.stamps != nullptr) adj.stamps = la.stamps + (size_t)B * 48;
                 time_begin(ctx, 5, ctx->stream);
                 qocx::launch_lindblad(fwd, Bp, ctx->stream);
@@ -2582,7 +2583,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

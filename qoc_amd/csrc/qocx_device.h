@@ -298,6 +298,7 @@ struct LindbladArgs {
     int hermitian = 0;             // every density and cotangent is Hermitian, A_R = A_L^H, Gp_k^H = -Gp_k (host-checked)
     int tile4 = 1;                 // 17 <= n <= 32: the tile-per-wave kernel (qocx_lindblad4t.hip) where it applies
     int q2 = 0;                    // phases 1 / 2, four waves: the stage loop with 18 MFMAs per wave (substep_q2)
+    int chain = 0;                 // with q2, 2 <= nops <= 4: the stage loop with one barrier per stage (substep_chain)
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out
 };

@@ -54,7 +54,8 @@ struct Slot {
 // MW: several wavefronts work on one seed - wave 0 the generator terms A_L y + y A_R, wave 1 + i
 // the term of Lindblad operator i, the last wave the control cotangents of the adjoint - and
 // exchange their partial right-hand sides through LDS (two workgroup barriers per stage).
-template <int LNB, bool GS, bool MW, bool RG = false, bool STAMP = false, bool QP = false, bool Q2 = false>
+template <int LNB, bool GS, bool MW, bool RG = false, bool STAMP = false, bool QP = false, bool Q2 = false,
+          bool CH = false>
 struct LB {
 typedef Geo<LNB> LG;
 typedef CMat<LNB> Mat;                               // C-layout register tiles
@@ -292,6 +293,8 @@ static __device__ __forceinline__ double density_costs(const LindbladArgs& a, bo
 // dumps | S lambda dumps | STAGES stage-derivative dumps. 80 KB at LNB = 1, S = 1, L = 2: two
 // seeds per CU.
 static __host__ __device__ int waves(int nops) { return MW ? nops + 2 : 1; }
+// the chain form of the two-sided stage loop (substep_chain): waves per seed
+static __host__ __device__ int chain_waves(int) { return 4; }
 static __host__ __device__ int lds_bytes(int S, int nops, int cached_controls = -1) {
     // work slots: single wave gen | y | tmp; MW: gen | y | tmp per operator | zk | zy ; then the
     // operator images, MW: one partial-result dump per wave, the per-seed dumps, and (MW,
@@ -972,6 +975,258 @@ struct Wave {
         }
     }
 
+    // ---- the two-sided stage loop with ONE workgroup barrier per stage (chain form, CH) -------------
+    // gamma L y L^H = gamma L (y L^H): the wave that owns an operator forms u = y L^H and u comes out
+    // of the matrix pipe in the C layout, which IS the right-operand layout, so L u follows without a
+    // trip through LDS and without the barrier substep_q2 has between its two rounds (24 MFMAs in a
+    // row on the operator waves instead of 12 + 6 on every wave: a stage is bound by its barriers and
+    // LDS round trips, not by the matrix pipe). Every LEFT operand is held in registers (lane (q, c):
+    // element (c, 4 kk + q), i.e. the C layout of the transpose): L for the whole sub-interval, the
+    // generator as la + c ld (eight fma per stage), and the argument y itself - for a Hermitian problem
+    // (LindbladArgs::hermitian) its left-operand image is conj of its C-layout registers, so a stage
+    // touches LDS for the exchange of the partial sums only; otherwise through the wave's own planar
+    // slot. Jobs by wave:
+    //   nops = 2: A_L y | chain 1 | chain 2 | y A_R            (12 | 24 | 24 | 12 MFMAs)
+    //   nops = 3: A_L y + y A_R | chain 1 | chain 2 | chain 3  (24 each)
+    //   nops = 4: A_L y + chain 1 | y A_R + chain 2 | chain 3 | chain 4  (36 | 36 | 24 | 24)
+    // The Runge-Kutta bookkeeping is substep_q2's: every wave keeps a quarter of every h k_j.
+    // ADJ: Gen^H, GenRight^H, L^H (y L). Returns with `result` whole in every wave, no barrier behind it.
+    template <bool LEFT_ADJ>
+    static __device__ __forceinline__ void left_regs(const Slot& left, double (&are)[4], double (&aim)[4]) {
+        const int q = lane_id() >> 4, c = lane_id() & 15;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int off = LEFT_ADJ ? ((4 * kk + q) * LG::PITCH + c) : (c * LG::PITCH + 4 * kk + q);
+            are[kk] = left.re[off];
+            aim[kk] = LEFT_ADJ ? -left.im[off] : left.im[off];
+        }
+    }
+    // acc += Left right, Left in registers (the 3M scheme of gemm())
+    static __device__ __forceinline__ void gemm_r(Mat& acc, const double (&are)[4], const double (&aim)[4],
+                                                  const Mat& right) {
+        d4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+        double asum[4], bsum[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            asum[kk] = are[kk] + aim[kk];
+            bsum[kk] = right.re[0][0][kk] + right.im[0][0][kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            t1 = mfma_f64(are[kk], right.re[0][0][kk], t1);
+            t2 = mfma_f64(aim[kk], right.im[0][0][kk], t2);
+            t3 = mfma_f64(asum[kk], bsum[kk], t3);
+        }
+        acc.re[0][0] += t1 - t2;
+        acc.im[0][0] += t3 - t1 - t2;
+    }
+    // One straight-line copy of the stage loop per set of jobs (JOBS: 1 = A_L y, 2 = y A_R, 4 = an
+    // operator chain): a wave carries the registers of its own jobs only.
+    template <bool ADJ, class Post>
+    __device__ __forceinline__ void substep_chain(const SubStep& ss, const double (&ua)[QOCX_LINDBLAD_MAX_K],
+                                                  const double (&ub)[QOCX_LINDBLAD_MAX_K], const Mat& base_in,
+                                                  Mat& result, double2* store, Post& post) const {
+        const int nops = a.nops;
+        if (nops == 2) {
+            if (wv == 0) chain_jobs<ADJ, 1>(ss, ua, ub, base_in, result, store, post, 0);
+            else if (wv == 3) chain_jobs<ADJ, 2>(ss, ua, ub, base_in, result, store, post, 0);
+            else chain_jobs<ADJ, 4>(ss, ua, ub, base_in, result, store, post, wv - 1);
+        } else if (nops == 3) {
+            if (wv == 0) chain_jobs<ADJ, 3>(ss, ua, ub, base_in, result, store, post, 0);
+            else chain_jobs<ADJ, 4>(ss, ua, ub, base_in, result, store, post, wv - 1);
+        } else {
+            if (wv == 0) chain_jobs<ADJ, 5>(ss, ua, ub, base_in, result, store, post, 0);
+            else if (wv == 1) chain_jobs<ADJ, 6>(ss, ua, ub, base_in, result, store, post, 1);
+            else chain_jobs<ADJ, 4>(ss, ua, ub, base_in, result, store, post, wv);
+        }
+    }
+    template <bool ADJ, int JOBS, class Post>
+    __device__ __forceinline__ void chain_jobs(const SubStep& ss, const double (&ua)[QOCX_LINDBLAD_MAX_K],
+                                               const double (&ub)[QOCX_LINDBLAD_MAX_K], const Mat& base_in,
+                                               Mat& result, double2* store, Post& post, int chain_index) const {
+        static_assert(LNB == 1, "one tile per matrix");
+        constexpr int LAST = STAGES - 1;
+        constexpr bool has_gl = (JOBS & 1) != 0, has_gr = (JOBS & 2) != 0;
+        const int lane = lane_id();
+        const int nops = a.nops;
+        const bool herm = a.hermitian != 0;
+        const int chain = (JOBS & 4) ? chain_index : -1;
+        const Mat base = base_in;
+        double2* pre = kdump + 4 * (size_t)MAT;   // two dumps, by the parity of the stage
+        // this wave's planar slot (slot_tmp: one per operator, that of waves 1 and 2)
+        const Slot mine = wv == 0 ? slot_y : wv == 3 ? slot_zy : slot_tmp;
+        const Slot op = slot_at(op_planar + (size_t)(chain >= 0 ? chain : 0) * SLOT_BYTES);
+        const double gamma = a.gammas[chain >= 0 ? chain : 0];
+        double hr[STAGES], hi[STAGES];  // this wave's quarter of h k_j (ADJ: h Ybar_j), by order of processing
+        // the generators of the sub-interval, left(c) = la + c ld (their left-operand registers),
+        // right(c) = ra - c ld (C layout), from the pass's constant dumps in kdump[6 ..] (run())
+        double lar[4], lai[4], ldr[4], ldi[4];
+        Mat ra, rd;
+        mat_zero(ra);
+        mat_zero(rd);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lar[kk] = lai[kk] = ldr[kk] = ldi[kk] = 0;
+        if constexpr (has_gl || has_gr) {
+            const double2* cache = kdump + 6 * (size_t)MAT;
+            const int K = a.K;
+            Mat la;
+            dump_load(la, cache);
+            dump_load(ra, cache + MAT);
+#pragma unroll
+            for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+                if (k < K) {
+                    Mat gk;
+                    dump_load(gk, cache + (size_t)(2 + k) * MAT);
+                    mat_axpy(la, ua[k], gk);
+                    mat_axpy(ra, -ua[k], gk);
+                    mat_axpy(rd, ub[k] - ua[k], gk);
+                }
+            if constexpr (has_gl) {
+                cmat_to_lds<LNB>(la, slot_gen.re, slot_gen.im);
+                cmat_to_lds<LNB>(rd, slot_zk.re, slot_zk.im);
+                wave_sync();
+                left_regs<false>(slot_gen, lar, lai);
+                left_regs<false>(slot_zk, ldr, ldi);
+            }
+        }
+        Mat opr;
+        mat_zero(opr);
+        double lr[4], li[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lr[kk] = li[kk] = 0;
+        if constexpr ((JOBS & 4) != 0) {
+            if (ADJ) load_plain(opr, op);
+            else load_adjoint(opr, op);
+            left_regs<ADJ>(op, lr, li);
+        }
+        double br, bi;
+        quarter_of(base, wv, br, bi);
+        double nr = br, ni = bi;  // ADJ: lambda_new = lambda + sum_i Ybar_i
+        Mat arg;
+        if (ADJ) {
+            mat_zero(arg);
+            if (QOCX_RK_B[LAST] != 0.0) mat_axpy(arg, ss.h * QOCX_RK_B[LAST], base);
+        } else {
+            arg = base;
+        }
+        clk->lap(6);  // (stamped build: between the last stage of a sub-interval and the first of the next)
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            const int i = ADJ ? LAST - s : s;  // the stage of the tableau
+            const int sn = s < LAST ? s + 1 : s;  // (keeps the tableau subscripts below in range)
+            const double ci = QOCX_RK_C[i];
+            if (wv == (nops == 2 ? 3 : 2) && store != nullptr) dump_store(arg, store + (size_t)i * MAT);
+            Mat acc;
+            mat_zero(acc);
+            // the argument as a left operand
+            double yr[4], yi[4];
+            if constexpr ((JOBS & 6) != 0) {
+                if (herm) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        yr[kk] = arg.re[0][0][kk];
+                        yi[kk] = -arg.im[0][0][kk];
+                    }
+                } else {
+                    cmat_to_lds<LNB>(arg, mine.re, mine.im);
+                    wave_sync();
+                    left_regs<false>(mine, yr, yi);
+                }
+            }
+            clk->lap(1);
+            if constexpr (has_gl) {
+                double gr_[4], gi_[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    gr_[kk] = fma(ci, ldr[kk], lar[kk]);
+                    gi_[kk] = fma(ci, ldi[kk], lai[kk]);
+                }
+                gemm_r(acc, gr_, gi_, arg);
+            }
+            if constexpr (has_gr) {
+                Mat gr = ra;
+                mat_axpy(gr, -ci, rd);
+                gemm_r(acc, yr, yi, gr);
+            }
+            if constexpr ((JOBS & 4) != 0) {
+                Mat u;
+                mat_zero(u);
+                gemm_r(u, yr, yi, opr);
+                cmat_scale<LNB>(u, gamma);
+                gemm_r(acc, lr, li, u);
+            }
+            // this wave's quarter of what is known of the next argument (after the last stage: of the
+            // new density / cotangent)
+            {
+                double pr, pi;
+                if (s == LAST) {
+                    pr = nr;
+                    pi = ni;
+                    if (!ADJ) {
+#pragma unroll
+                        for (int t = 0; t < LAST; ++t)
+                            if (QOCX_RK_B[t] != 0.0) {
+                                pr = fma(QOCX_RK_B[t], hr[t], pr);
+                                pi = fma(QOCX_RK_B[t], hi[t], pi);
+                            }
+                    }
+                } else {
+                    if (ADJ) {
+                        pr = 0;
+                        pi = 0;
+                        if (QOCX_RK_B[LAST - sn] != 0.0) {
+                            pr = (ss.h * QOCX_RK_B[LAST - sn]) * br;
+                            pi = (ss.h * QOCX_RK_B[LAST - sn]) * bi;
+                        }
+                    } else {
+                        pr = br;
+                        pi = bi;
+                    }
+#pragma unroll
+                    for (int t = 0; t < s; ++t)
+                        if (q2_coef(ADJ, sn, t) != 0.0) {
+                            pr = fma(q2_coef(ADJ, sn, t), hr[t], pr);
+                            pi = fma(q2_coef(ADJ, sn, t), hi[t], pi);
+                        }
+                }
+                pre[(size_t)((s + 1) & 1) * MAT + wv * 64 + lane] = make_double2(pr, pi);
+            }
+            clk->lap(2);
+            const double2* set = parts + (size_t)(s & 1) * 4 * MAT;  // (read while the other set fills)
+            dump_store(acc, parts + ((size_t)(s & 1) * 4 + wv) * MAT);
+            if (s == LAST && has_gl) post();
+            clk->lap(3);
+            __syncthreads();
+            clk->lap(4);
+            // ---- k_i whole, this wave's quarter of it, the next argument
+            Mat k;
+            dump_load(k, set);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                Mat pw;
+                dump_load(pw, set + (size_t)w * MAT);
+                mat_axpy(k, 1.0, pw);
+            }
+            double kr_, ki_;
+            quarter_of(k, wv, kr_, ki_);
+            if (ADJ) {
+                nr += kr_;
+                ni += ki_;
+            }
+            hr[s] = ss.h * kr_;
+            hi[s] = ss.h * ki_;
+            if (s < LAST) {
+                dump_load(arg, pre + (size_t)((s + 1) & 1) * MAT);
+                if (q2_coef(ADJ, sn, s) != 0.0) mat_axpy(arg, ss.h * q2_coef(ADJ, sn, s), k);
+            } else {
+                dump_load(result, pre + (size_t)((s + 1) & 1) * MAT);
+                if (ADJ) mat_axpy(result, 1.0, k);
+                else if (QOCX_RK_B[LAST] != 0.0) mat_axpy(result, ss.h * QOCX_RK_B[LAST], k);
+            }
+            clk->lap(5);
+        }
+    }
+
     // forward sub-interval, the 12 stage derivatives in registers (192 of them at n <= 16); the
     // stage loop is unrolled and the zeros of the tableau vanish at compile time
     __device__ __forceinline__ void substep_reg(const SubStep& ss, Mat& y0, double2* ystore) const {
@@ -1190,7 +1445,7 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     const int b = blockIdx.x;
     // (Q2: the wave index as a scalar the compiler knows to be uniform)
     const int wv = Q2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : MW ? (int)(threadIdx.x >> 6) : 0,
-              nwaves = waves(nops);
+              nwaves = CH ? chain_waves(nops) : waves(nops);
     const bool lead = !MW || wv == 0;  // the wave that owns the shared bookkeeping
     char* p = smem;
     const Slot slot_gen = slot_at(p); p += SLOT_BYTES;
@@ -1346,7 +1601,8 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
     };
     // the mail box (the second set of `parts`: unused by substep_q2): sixteen dwords of descriptor,
     // then u_k at the two ends of the sub-interval
-    int* mail = reinterpret_cast<int*>(parts + 4 * (size_t)MAT);
+    // (chain form: both sets of `parts` are in use; kdump[3] is free)
+    int* mail = reinterpret_cast<int*>(CH ? kdump + 3 * (size_t)MAT : parts + 4 * (size_t)MAT);
     double* mail_u = reinterpret_cast<double*>(mail + 16);
     double cv_nxt = 0;  // wave 0: control knots of the NEXT sub-interval (in flight)
     int sw_nxt = 0;     // wave 0: its descriptor, and `sw_after` the one after it (in flight)
@@ -1427,8 +1683,12 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         if (q2_fast) {
             if constexpr (Q2) {
                 if (lead) dump_store(carried, ckpt_b + (size_t)q * MAT);
-                w.template substep_q2<false>(ss, ua, ub, carried, carried,
-                                             a.ystages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+                if constexpr (CH)
+                    w.template substep_chain<false>(ss, ua, ub, carried, carried,
+                                                    a.ystages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+                else
+                    w.template substep_q2<false>(ss, ua, ub, carried, carried,
+                                                 a.ystages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
             }
             continue;
         }
@@ -1439,7 +1699,12 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             double2* ys = a.ystages != nullptr
                               ? a.ystages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT
                               : nullptr;
-            if constexpr (Q2)  // (launch_lindblad: phases 1 / 2, constant H0 / G_k, stage values kept)
+            if constexpr (Q2 && CH)
+            {
+                auto post_s = [&]() { if (s == S - 1) post(); };
+                w.template substep_chain<false>(ss, ua, ub, y0, y0, ys, post_s);
+            }
+            else if constexpr (Q2)  // (launch_lindblad: phases 1 / 2, constant H0 / G_k, stage values kept)
                 w.template substep_q2<false>(ss, ua, ub, y0, y0, ys, [&]() { if (s == S - 1) post(); });
             else if (QUARTER && a.a0_tab == nullptr && a.gp_tab == nullptr)
                 w.substep_q(ss, y0, ys);
@@ -1544,8 +1809,12 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
         if (q2_fast) {
             if constexpr (Q2) {
                 const Mat lambda = carried;
-                w.template substep_q2<true>(ss, ua, ub, lambda, carried,
-                                            a.kbstages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+                if constexpr (CH)
+                    w.template substep_chain<true>(ss, ua, ub, lambda, carried,
+                                                   a.kbstages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
+                else
+                    w.template substep_q2<true>(ss, ua, ub, lambda, carried,
+                                                a.kbstages + (((size_t)b * nsub + q) * STAGES) * MAT, post);
             }
             continue;
         }
@@ -1568,7 +1837,13 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             Mat lambda, lambda_new;
             dump_load(lambda, lam + (size_t)s * MAT);
             lambda_new = lambda;
-            if constexpr (Q2)
+            if constexpr (Q2 && CH)
+            {
+                auto post_s = [&]() { if (s == S - 1) post(); };
+                w.template substep_chain<true>(ss, ua, ub, lambda, lambda_new,
+                                               a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT, post_s);
+            }
+            else if constexpr (Q2)
                 w.template substep_q2<true>(ss, ua, ub, lambda, lambda_new,
                                             a.kbstages + ((((size_t)b * nsub + q) * S + s) * STAGES) * MAT,
                                             [&]() { if (s == S - 1) post(); });
@@ -1614,20 +1889,21 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
 
 // MW4: the multi-wave form with exactly four wavefronts (nops = 2), one per SIMD: the
 // quarter-split stage loops. Q2: the launches of the two-sided evaluation (substep_q2).
-template <int LNB, bool GS, bool MW, bool MW4, bool STAMP = false, bool Q2 = false>
+// CH: the chain form of that stage loop (substep_chain), four waves for nops = 2, 3, 4.
+template <int LNB, bool GS, bool MW, bool MW4, bool STAMP = false, bool Q2 = false, bool CH = false>
 __global__ __launch_bounds__(MW ? (MW4 ? 256 : 384) : 64) void lindblad_kernel(LindbladArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LB<LNB, GS, MW, (LNB == 1 && !GS && !MW), STAMP, MW4, Q2>::run(a, smem);
+    LB<LNB, GS, MW, (LNB == 1 && !GS && !MW), STAMP, MW4, Q2, CH>::run(a, smem);
 }
 
-template <int LNB, bool GS, bool MW, bool MW4 = false, bool STAMP = false, bool Q2 = false>
+template <int LNB, bool GS, bool MW, bool MW4 = false, bool STAMP = false, bool Q2 = false, bool CH = false>
 void launch_t(const LindbladArgs& a, int batch, hipStream_t st) {
     typedef LB<LNB, GS, MW> I;
     const int bytes = I::lds_bytes(a.S, a.nops, (MW && a.cache_gen) ? a.K : -1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2, CH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2>), dim3(batch),
-                       dim3(64 * I::waves(a.nops)), bytes, st, a);
+    hipLaunchKernelGGL((lindblad_kernel<LNB, GS, MW, MW4, STAMP, Q2, CH>), dim3(batch),
+                       dim3(64 * (CH ? I::chain_waves(a.nops) : I::waves(a.nops))), bytes, st, a);
 }
 
 // Two-sided evaluation, third kernel: one wave per (sub-interval, seed) contracts the forward
@@ -1713,11 +1989,15 @@ void launch_lindblad(const LindbladArgs& a, int batch, hipStream_t st) {
     else if (a.n > 16) launch_t<2, true, false>(a, batch, st);
     else if (a.scratch != nullptr) launch_t<1, true, false>(a, batch, st);
 #ifdef QOCX_DIAG
+    else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr && q2 && a.chain)
+        launch_t<1, false, true, true, true, true, true>(a, batch, st);
     else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr && q2)
         launch_t<1, false, true, true, true, true>(a, batch, st);  // stamped builds (qocx_diag.h)
     else if (a.multi_wave && a.nops == 2 && a.stamps != nullptr)
         launch_t<1, false, true, true, true>(a, batch, st);
 #endif
+    else if (a.multi_wave && a.nops >= 2 && a.nops <= 4 && q2 && a.chain)
+        launch_t<1, false, true, true, false, true, true>(a, batch, st);
     else if (a.multi_wave && a.nops == 2 && q2) launch_t<1, false, true, true, false, true>(a, batch, st);
     else if (a.multi_wave && a.nops == 2) launch_t<1, false, true, true>(a, batch, st);
     else if (a.multi_wave) launch_t<1, false, true>(a, batch, st);
