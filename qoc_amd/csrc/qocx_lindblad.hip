@@ -1098,6 +1098,11 @@ struct Wave {
             if (ADJ) load_plain(opr, op);
             else load_adjoint(opr, op);
             left_regs<ADJ>(op, lr, li);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {  // gamma L (u) = (gamma L) u
+                lr[kk] *= gamma;
+                li[kk] *= gamma;
+            }
         }
         double br, bi;
         quarter_of(base, wv, br, bi);
@@ -1152,7 +1157,6 @@ struct Wave {
                 Mat u;
                 mat_zero(u);
                 gemm_r(u, yr, yi, opr);
-                cmat_scale<LNB>(u, gamma);
                 gemm_r(acc, lr, li, u);
             }
             // this wave's quarter of what is known of the next argument (after the last stage: of the

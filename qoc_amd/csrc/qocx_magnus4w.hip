@@ -13,6 +13,8 @@
 // magnus_m4 / magnus_m6, qoc/core/mathmethods.py:96-164; reverse rule of Z = XY - YX: Xbar = Zbar
 // Y^H - Y^H Zbar, Ybar = X^H Zbar - Zbar X^H), with the one-product commutators for skew-Hermitian
 // node generators.
+#include <cstdio>
+#include <cstdlib>
 #include "qocx_tilewave.h"
 
 namespace qocx {
@@ -99,24 +101,108 @@ __device__ __forceinline__ Wave<G> make_wave(char* smem, const MagnusArgs& args)
     return tilewave::make_wave<G>(smem, args.skew != 0);
 }
 
+// Constant H0, G_k (one table, args.nt == 1): b1, b2, b3 are linear in (H0, G_k) with the node controls as
+// coefficients - H0 drops out of the differences b2, b3 - so every image is read ONCE per step instead of
+// once per node: b1 = -i dt (H0 + sum u_k(t2) G_k), b2 = -i F0 dt sum (u_k(t3) - u_k(t1)) G_k,
+// b3 = -i F1 dt sum (u_k(t3) - 2 u_k(t2) + u_k(t1)) G_k.
+template <class G>
+__device__ __forceinline__ void m6_nodes_const(const Wave<G>& wv, const MagnusArgs& args, int step,
+                                               const double* ctl_b, Tile<G>& b1, Tile<G>& b2, Tile<G>& b3) {
+    typedef Dim<G> D;
+    const double dt = args.dt;
+    const size_t col = (size_t)step * args.nodes;
+    const StepInterp s0 = args.interp[col], s1 = args.interp[col + 1], s2 = args.interp[col + 2];
+    Tile<G> h1, h2 = tile_zero<G>(), h3 = tile_zero<G>();
+#pragma unroll
+    for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 e = args.h0_cimg[wv.cimg(i, r)];
+            h1.re[i][r] = e.x;
+            h1.im[i][r] = e.y;
+        }
+    for (int k = 0; k < args.K; ++k) {
+        const double u0 = control_at(ctl_b, s0, args.K, k), u1 = control_at(ctl_b, s1, args.K, k),
+                     u2 = control_at(ctl_b, s2, args.K, k);
+        const double d2 = u2 - u0, d3 = (u2 - 2.0 * u1) + u0;
+        const double2* gk = args.g_cimg + (size_t)k * D::IMAT;
+#pragma unroll
+        for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = gk[wv.cimg(i, r)];
+                h1.re[i][r] += u1 * e.x;
+                h1.im[i][r] += u1 * e.y;
+                h2.re[i][r] += d2 * e.x;
+                h2.im[i][r] += d2 * e.y;
+                h3.re[i][r] += d3 * e.x;
+                h3.im[i][r] += d3 * e.y;
+            }
+    }
+    // a = -i h: (re, im) = (h.im, -h.re)
+#pragma unroll
+    for (int i = 0; i < G::NTW; ++i) {
+        b1.re[i] = dt * h1.im[i];
+        b1.im[i] = -dt * h1.re[i];
+        b2.re[i] = (M6_F0 * dt) * h2.im[i];
+        b2.im[i] = -(M6_F0 * dt) * h2.re[i];
+        b3.re[i] = (M6_F1 * dt) * h3.im[i];
+        b3.im[i] = -(M6_F1 * dt) * h3.re[i];
+    }
+}
+
+// the control gradients of the three nodes from b1bar, b2bar, b3bar, constant G_k: d_j = Re <bjbar, -i G_k>
+// with every image read once; a1bar = -F0 dt b2bar + F1 dt b3bar, a2bar = dt b1bar - 2 F1 dt b3bar,
+// a3bar = F0 dt b2bar + F1 dt b3bar
+template <class G>
+__device__ __forceinline__ void contract_m6_const(const Wave<G>& wv, const Tile<G>& b1bar, const Tile<G>& b2bar,
+                                                  const Tile<G>& b3bar, const MagnusArgs& args, double* red) {
+    typedef Dim<G> D;
+    const double dt = args.dt;
+    for (int k = 0; k < args.K; ++k) {
+        double d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+        for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = args.g_cimg[(size_t)k * D::IMAT + wv.cimg(i, r)];
+                d1 += b1bar.re[i][r] * e.y - b1bar.im[i][r] * e.x;
+                d2 += b2bar.re[i][r] * e.y - b2bar.im[i][r] * e.x;
+                d3 += b3bar.re[i][r] * e.y - b3bar.im[i][r] * e.x;
+            }
+        d1 = wave_sum(d1);
+        d2 = wave_sum(d2);
+        d3 = wave_sum(d3);
+        if (wv.lane == 0) {
+            red[(0 * 64 + k) * 4 + wv.w] = -M6_F0 * dt * d2 + M6_F1 * dt * d3;
+            red[(1 * 64 + k) * 4 + wv.w] = dt * d1 - 2.0 * M6_F1 * dt * d3;
+            red[(2 * 64 + k) * 4 + wv.w] = M6_F0 * dt * d2 + M6_F1 * dt * d3;
+        }
+    }
+}
+
 // b1, b2 -> LDS (M6), b3 in registers; every wave writes its tiles
 template <class G>
 __device__ __forceinline__ void m6_nodes(const Wave<G>& wv, const MagnusArgs& args, int step,
                                          const double* ctl_b, Tile<G>& b1, Tile<G>& b2, Tile<G>& b3) {
     const double dt = args.dt;
-    const Tile<G> a1 = node_generator<G>(wv, args, step, 0, ctl_b);
-    const Tile<G> a2 = node_generator<G>(wv, args, step, 1, ctl_b);
-    const Tile<G> a3 = node_generator<G>(wv, args, step, 2, ctl_b);
-    b1 = tile_zero<G>();
-    b2 = tile_zero<G>();
-    b3 = tile_zero<G>();
-    // b1 = dt a2 ; b2 = F0 dt (a3 - a1) ; b3 = F1 dt (a3 - 2 a2 + a1)   (mathmethods.py:153-155)
-    tile_axpy<G>(b1, dt, a2);
-    tile_axpy<G>(b2, -M6_F0 * dt, a1);
-    tile_axpy<G>(b2, M6_F0 * dt, a3);
-    tile_axpy<G>(b3, M6_F1 * dt, a1);
-    tile_axpy<G>(b3, -2.0 * M6_F1 * dt, a2);
-    tile_axpy<G>(b3, M6_F1 * dt, a3);
+    if (args.nt == 1) {
+        m6_nodes_const<G>(wv, args, step, ctl_b, b1, b2, b3);
+    } else {
+        const Tile<G> a1 = node_generator<G>(wv, args, step, 0, ctl_b);
+        const Tile<G> a2 = node_generator<G>(wv, args, step, 1, ctl_b);
+        const Tile<G> a3 = node_generator<G>(wv, args, step, 2, ctl_b);
+        b1 = tile_zero<G>();
+        b2 = tile_zero<G>();
+        b3 = tile_zero<G>();
+        // b1 = dt a2 ; b2 = F0 dt (a3 - a1) ; b3 = F1 dt (a3 - 2 a2 + a1)   (mathmethods.py:153-155)
+        tile_axpy<G>(b1, dt, a2);
+        tile_axpy<G>(b2, -M6_F0 * dt, a1);
+        tile_axpy<G>(b2, M6_F0 * dt, a3);
+        tile_axpy<G>(b3, M6_F1 * dt, a1);
+        tile_axpy<G>(b3, -2.0 * M6_F1 * dt, a2);
+        tile_axpy<G>(b3, M6_F1 * dt, a3);
+    }
     wv.store(b1, L_B1);
     wv.store(b2, L_B2);
 }
@@ -192,8 +278,9 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_fwd_kernel(MagnusArgs 
     }
 }
 
+// (n <= 32: four matrices are 66 KB - two workgroups to a CU, which is what hides the barriers)
 template <class G, int NODES>
-__global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs args) {
+__global__ __launch_bounds__(64 * G::WAVES, G::NP <= 32 ? 2 : 1) void magnus4w_vjp_kernel(MagnusArgs args) {
     typedef Dim<G> D;
     typedef Tile<G> T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,7 +291,9 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
     const size_t m = b * args.nsteps + step;
     const double* ctl_b = args.controls + b * args.nc * args.K;
     const double dt = args.dt;
-    T mbar;
+    // mskew (skew-Hermitian generators): the skew-Hermitian part of mbar, its transposed tile straight from
+    // the HBM image - the cotangent the commutator rules start from needs no exchange through LDS then
+    T mbar, mskew;
     {
         const double2* in = args.mbar_rm + m * D::IMAT;
 #pragma unroll
@@ -215,19 +304,31 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
                 mbar.re[i][r] = e.x;
                 mbar.im[i][r] = e.y;
             }
+        mskew = mbar;
+        if (wv.skew) {
+#pragma unroll
+            for (int i = 0; i < G::NTW; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 e = in[(size_t)(16 * wv.tj() + wv.c) * D::IMG + 16 * wv.ti(i) + 4 * r + wv.q];
+                    mskew.re[i][r] = 0.5 * (mbar.re[i][r] - e.x);
+                    mskew.im[i][r] = 0.5 * (mbar.im[i][r] + e.y);
+                }
+        }
     }
     if (NODES == 2) {
         // a1bar = dt/2 mbar + d[a2, a1]/d a1 ; a2bar likewise (cbar = F0 dt^2 mbar)
         wv.store(node_generator<G>(wv, args, step, 0, ctl_b), L_B1);
         wv.store(node_generator<G>(wv, args, step, 1, ctl_b), L_B2);
-        T cbar = mbar;
+        T cbar = mskew;
         tile_scale<G>(cbar, M4_F0 * dt * dt);
         wv.store(cbar, L_W);
         __syncthreads();
         T a2bar, a1bar;
-        wv.commutator_vjp(a2bar, a1bar, L_B2, L_B1, L_W, L_X, L_B1);
+        wv.template commutator_vjp<true>(a2bar, a1bar, L_B2, L_B1, L_W, L_X, L_B1);
         tile_axpy<G>(a1bar, 0.5 * dt, mbar);
         tile_axpy<G>(a2bar, 0.5 * dt, mbar);
+        __syncthreads();  // `red` is matrix 0: every product has read it
         contract_node<G>(wv, a1bar, args, step, 0, red);
         contract_node<G>(wv, a2bar, args, step, 1, red);
     } else {
@@ -250,14 +351,14 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
         tile_scale<G>(yt, -M6_F4);
         tile_axpy<G>(yt, 1.0, b2);
         // (xbar, ybar) = vjp of [x, y] with F3 mbar: x in s3, y -> s1, Zbar -> s0
-        T zb = mbar;
+        T zb = mskew;
         tile_scale<G>(zb, M6_F3);
         __syncthreads();  // b1 (s0) and b2 (s1) have been read
         wv.store(yt, S1);
         wv.store(zb, S0);
         __syncthreads();
         T xbar, ybar;
-        wv.commutator_vjp(xbar, ybar, S3, S1, S0, S3, S1);
+        wv.template commutator_vjp<true>(xbar, ybar, S3, S1, S0, S3, S1);
         // b1bar = mbar - 20 xbar ; b3bar = F2 mbar - xbar ; c12bar = xbar ; b2bar = ybar
         T b1bar = mbar, b3bar = tile_zero<G>(), c12bar = xbar, b2bar = ybar;
         tile_axpy<G>(b1bar, -20.0, xbar);
@@ -270,8 +371,8 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
         wv.store(b1, S1);
         wv.store(inner, S0);
         __syncthreads();
-        T d1, wbar;
-        wv.commutator_vjp(d1, wbar, S1, S2, S0, S3, S2);
+        T d1, wbar;  // (skew: ybar = W - W^H is skew-Hermitian as it comes, and so are xbar, wbar below)
+        wv.template commutator_vjp<true>(d1, wbar, S1, S2, S0, S3, S2);
         tile_axpy<G>(b1bar, 1.0, d1);
         tile_axpy<G>(b3bar, 2.0, wbar);
         tile_axpy<G>(c12bar, 1.0, wbar);
@@ -281,23 +382,28 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus4w_vjp_kernel(MagnusArgs 
         wv.store(c12bar, S0);
         __syncthreads();
         T d2;
-        wv.commutator_vjp(d1, d2, S1, S2, S0, S3, S2);
+        wv.template commutator_vjp<true>(d1, d2, S1, S2, S0, S3, S2);
         tile_axpy<G>(b1bar, 1.0, d1);
         tile_axpy<G>(b2bar, 1.0, d2);
         // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
         // a3bar = F0 dt b2bar + F1 dt b3bar
-        T abar = tile_zero<G>();
-        tile_axpy<G>(abar, -M6_F0 * dt, b2bar);
-        tile_axpy<G>(abar, M6_F1 * dt, b3bar);
-        contract_node<G>(wv, abar, args, step, 0, red);
-        abar = tile_zero<G>();
-        tile_axpy<G>(abar, dt, b1bar);
-        tile_axpy<G>(abar, -2.0 * M6_F1 * dt, b3bar);
-        contract_node<G>(wv, abar, args, step, 1, red);
-        abar = tile_zero<G>();
-        tile_axpy<G>(abar, M6_F0 * dt, b2bar);
-        tile_axpy<G>(abar, M6_F1 * dt, b3bar);
-        contract_node<G>(wv, abar, args, step, 2, red);
+        __syncthreads();  // `red` is matrix 0: every product has read it
+        if (args.nt == 1) {
+            contract_m6_const<G>(wv, b1bar, b2bar, b3bar, args, red);
+        } else {
+            T abar = tile_zero<G>();
+            tile_axpy<G>(abar, -M6_F0 * dt, b2bar);
+            tile_axpy<G>(abar, M6_F1 * dt, b3bar);
+            contract_node<G>(wv, abar, args, step, 0, red);
+            abar = tile_zero<G>();
+            tile_axpy<G>(abar, dt, b1bar);
+            tile_axpy<G>(abar, -2.0 * M6_F1 * dt, b3bar);
+            contract_node<G>(wv, abar, args, step, 1, red);
+            abar = tile_zero<G>();
+            tile_axpy<G>(abar, M6_F0 * dt, b2bar);
+            tile_axpy<G>(abar, M6_F1 * dt, b3bar);
+            contract_node<G>(wv, abar, args, step, 2, red);
+        }
     }
     __syncthreads();
     for (int e = wv.tid; e < NODES * args.K; e += 64 * G::WAVES) {
@@ -415,6 +521,7 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus2s_vjp_kernel(MagnusArgs 
         wv.commutator_vjp_r(a2bar, a1bar, a2, a1, cbar);
         tile_axpy<G>(a1bar, 0.5 * dt, mbar);
         tile_axpy<G>(a2bar, 0.5 * dt, mbar);
+        __syncthreads();  // `red` is matrix 0: every product has read it
         contract_node<G>(wv, a1bar, args, step, 0, red);
         contract_node<G>(wv, a2bar, args, step, 1, red);
     } else {
@@ -453,6 +560,7 @@ __global__ __launch_bounds__(64 * G::WAVES) void magnus2s_vjp_kernel(MagnusArgs 
         tile_axpy<G>(b2bar, 1.0, d2);
         // a1bar = -F0 dt b2bar + F1 dt b3bar ; a2bar = dt b1bar - 2 F1 dt b3bar ;
         // a3bar = F0 dt b2bar + F1 dt b3bar
+        __syncthreads();  // `red` is matrix 0: every product has read it
         T abar = tile_zero<G>();
         tile_axpy<G>(abar, -M6_F0 * dt, b2bar);
         tile_axpy<G>(abar, M6_F1 * dt, b3bar);
@@ -503,6 +611,13 @@ static void magnus4w_prepare() {
     magnus4w_attr(magnus2s_vjp_kernel<G64, 2>, Dim<G64>::LDS_BYTES);
     magnus4w_attr(magnus2s_vjp_kernel<G64, 3>, Dim<G64>::LDS_BYTES);
     attr_set = true;
+    if (getenv("QOCX_PRINT_OCCUPANCY")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, magnus4w_vjp_kernel<G32, 3>, 256, Dim<G32>::LDS_BYTES);
+        fprintf(stderr, "magnus4w_vjp_kernel<G32, 3>: %d workgroups per CU (LDS %d)\n", nb, Dim<G32>::LDS_BYTES);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, magnus4w_fwd_kernel<G32, 3>, 256, Dim<G32>::LDS_BYTES_FWD);
+        fprintf(stderr, "magnus4w_fwd_kernel<G32, 3>: %d workgroups per CU (LDS %d)\n", nb, Dim<G32>::LDS_BYTES_FWD);
+    }
 }
 
 void launch_magnus4w_fwd(const MagnusArgs& a, int batch, hipStream_t st) {

@@ -40,8 +40,11 @@ struct Dim {
     static constexpr int NP = G::NP, PM = NP + 1, MELEM = NP * PM, MBYTES = MELEM * 16, KS = NP / 4;
     static constexpr int IMG = G::IMG, IMAT = IMG * IMG, TPS = IMG / 16;  // HBM images: pitch, elements, tiles per side
     static constexpr int SLOTS = NP > 48 ? 2 : 4;             // LDS-resident matrices
-    static constexpr int RED_OFF = SLOTS * MBYTES;
-    static constexpr int LDS_BYTES = RED_OFF + 3 * 64 * 4 * 8;  // + partial sums [node][control][wave]
+    // the partial sums [node][control][wave] of the control gradients (3 x 64 x 4 doubles) take the place of
+    // matrix 0 once the last product has read its operands (a barrier before the first of them is written):
+    // 66 KB instead of 72 at n <= 32, and the reverse kernels fit twice on a CU like the forward ones
+    static constexpr int RED_OFF = 0;
+    static constexpr int LDS_BYTES = SLOTS * MBYTES;
     static constexpr int LDS_BYTES_FWD = SLOTS * MBYTES;
 };
 template <class G>
@@ -183,15 +186,20 @@ struct Wave {
     // perturbations to skew ones, so with Zs = (Zbar - Zbar^H) / 2: Xbar = V - V^H, V = Y Zs;
     // Ybar = W - W^H, W = Zs X - two products instead of four. `sa`, `sb`: LDS matrices that are free
     // once the products have read their operands (they may be x's and y's own). Barriers inside.
+    // ZB_SKEW: the caller knows Zbar to be skew-Hermitian already (a cotangent that came out of this rule,
+    // V - V^H, or one it has projected itself): Zs = Zbar, two barriers and an exchange less.
+    template <bool ZB_SKEW = false>
     __device__ __forceinline__ void commutator_vjp(T& xbar, T& ybar, int x, int y, int zb, int sa,
                                                    int sb) const {
         if (skew) {
-            T zs = load(zb);
-            tile_axpy<G>(zs, -1.0, load_adjoint(zb));
-            tile_scale<G>(zs, 0.5);
-            __syncthreads();  // Zbar has been read
-            store(zs, zb);
-            __syncthreads();
+            if (!ZB_SKEW) {
+                T zs = load(zb);
+                tile_axpy<G>(zs, -1.0, load_adjoint(zb));
+                tile_scale<G>(zs, 0.5);
+                __syncthreads();  // Zbar has been read
+                store(zs, zb);
+                __syncthreads();
+            }
             xbar = tile_zero<G>();
             mm<false, false>(xbar, y, zb, 1.0);  // V = Y Zs
             ybar = tile_zero<G>();
