@@ -349,6 +349,11 @@ def lindblad_secondary(engine, reps=5):
                      "avg_launch_ms": {"lindblad_kernel": total_ms / max(launches, 1),
                                        "lindblad_combine": combine_ms / max(combine_launches, 1)},
                      "flops_per_subinterval": flops_per_sub,
+                     "note": "algorithmic flops: the complex count of the right-hand side. configs[3]'s "
+                             "Lindblad operators (a, a^dagger a) are REAL matrices: the kernel notices and "
+                             "spends two real products per complex one on them (16 MFMAs per operator and "
+                             "stage instead of 24); complex operators take the general path "
+                             "(knob lindblad_real_ops, tests/test_gpu_lindblad.py)",
                      "traffic": pmc_traffic_bytes(LB_KERNEL, 32000),
                      "traffic_source": "committed rocprofv3 --pmc passes ({}), per launch of this "
                                        "workload".format(PMC_SUMMARY)},
@@ -398,7 +403,9 @@ def main():
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     seeds = args.seeds_per_gpu
 
-    engine = Engine(local_rank)
+    # (a launcher that shows every rank one device only: local rank 3 still finds device 0)
+    visible = Engine.device_count() if hasattr(Engine, "device_count") else 0
+    engine = Engine(local_rank % visible if visible > 0 else local_rank)
     comm = parallel.RcclComm(engine, rank, world) if world > 1 else parallel.SingleComm()
     h0, g, psi0, target = make_problem()
     engine.set_schroedinger_problem(

@@ -276,6 +276,7 @@ struct qocx_ctx {
         bool unit_ok = false;                 // one final TargetDensityInfidelity, one density
         bool hermitian = false;               // H0, G_k, sum gamma L^H L, initial densities and cost matrices
                                               // are Hermitian: so is every density and every cotangent
+        bool ops_real = false;                // every Lindblad operator has a zero imaginary part
         int global_scratch = 0, multi_wave = 0, cache_gen = 0;
         int pad_op = 0;  // L = 1: a zero second operator behind the real one, for the four-wave launches
         int fixed_ksub = 0;              // > 0: time-dependent Hamiltonian sampled for this grid
@@ -1994,6 +1995,10 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         ops.push_back(cm_zero(n));
         gammas.push_back(0.0);
     }
+    lb.ops_real = p->op_stages == nullptr;
+    for (const cmat& op : ops)
+        for (size_t e = 0; e < (size_t)n * n; ++e)
+            if (op[2 * e + 1] != 0.0) lb.ops_real = false;
     // A0L = -i H0 - decay/2 ; A0R = +i H0 - decay/2   (mathmethods.py:188, :200-203)
     cmat a0l = cm_scale(h0, 0.0, -1.0), a0r = cm_scale(h0, 0.0, 1.0);
     cm_axpy(a0l, -0.5, decay);
@@ -2508,6 +2513,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
                 adj.phase = 2;
                 fwd.q2 = adj.q2 = ctx->knob("lindblad_q2", 1) != 0 ? 1 : 0;
                 fwd.chain = adj.chain = ctx->knob("lindblad_chain", 1) != 0 ? 1 : 0;
+                fwd.ops_real = adj.ops_real = (lb.ops_real && ctx->knob("lindblad_real_ops", 1) != 0) ? 1 : 0;
                 if (la.stamps != nullptr) adj.stamps = la.stamps + (size_t)B * 48;
                 time_begin(ctx, 5, ctx->stream);
                 qocx::launch_lindblad(fwd, Bp, ctx->stream);
@@ -2583,7 +2589,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

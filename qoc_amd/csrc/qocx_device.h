@@ -299,6 +299,7 @@ struct LindbladArgs {
     int tile4 = 1;                 // 17 <= n <= 32: the tile-per-wave kernel (qocx_lindblad4t.hip) where it applies
     int q2 = 0;                    // phases 1 / 2, four waves: the stage loop with 18 MFMAs per wave (substep_q2)
     int chain = 0;                 // with q2, 2 <= nops <= 4: the stage loop with one barrier per stage (substep_chain)
+    int ops_real = 0;              // every Lindblad operator has a zero imaginary part (host-checked): chain form only
     double2* kbstages = nullptr;   // [B][nsub][S][12] C-dumps of kbar_i (phase 2 out, combine in)
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out
 };

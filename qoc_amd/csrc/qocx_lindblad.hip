@@ -985,7 +985,7 @@ struct Wave {
     // generator as la + c ld (eight fma per stage), and the argument y itself - for a Hermitian problem
     // (LindbladArgs::hermitian) its left-operand image is conj of its C-layout registers, so a stage
     // touches LDS for the exchange of the partial sums only; otherwise through the wave's own planar
-    // slot. Jobs by wave:
+    // slot. Real Lindblad operators (LindbladArgs::ops_real): 16 MFMAs per chain instead of 24. Jobs by wave:
     //   nops = 2: A_L y | chain 1 | chain 2 | y A_R            (12 | 24 | 24 | 12 MFMAs)
     //   nops = 3: A_L y + y A_R | chain 1 | chain 2 | chain 3  (24 each)
     //   nops = 4: A_L y + chain 1 | y A_R + chain 2 | chain 3 | chain 4  (36 | 36 | 24 | 24)
@@ -1049,7 +1049,7 @@ struct Wave {
         constexpr bool has_gl = (JOBS & 1) != 0, has_gr = (JOBS & 2) != 0;
         const int lane = lane_id();
         const int nops = a.nops;
-        const bool herm = a.hermitian != 0;
+        const bool herm = a.hermitian != 0, real_ops = a.ops_real != 0;
         const int chain = (JOBS & 4) ? chain_index : -1;
         const Mat base = base_in;
         double2* pre = kdump + 4 * (size_t)MAT;   // two dumps, by the parity of the stage
@@ -1154,10 +1154,26 @@ struct Wave {
                 gemm_r(acc, yr, yi, gr);
             }
             if constexpr ((JOBS & 4) != 0) {
-                Mat u;
-                mat_zero(u);
-                gemm_r(u, yr, yi, opr);
-                gemm_r(acc, lr, li, u);
+                if (real_ops) {
+                    // real L (a, a^dagger a, sigma_-, ...; host-checked): two real products per complex
+                    // one instead of three, and the second one accumulates straight into acc
+                    d4 ur = {0, 0, 0, 0}, ui = {0, 0, 0, 0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        ur = mfma_f64(yr[kk], opr.re[0][0][kk], ur);
+                        ui = mfma_f64(yi[kk], opr.re[0][0][kk], ui);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        acc.re[0][0] = mfma_f64(lr[kk], ur[kk], acc.re[0][0]);
+                        acc.im[0][0] = mfma_f64(lr[kk], ui[kk], acc.im[0][0]);
+                    }
+                } else {
+                    Mat u;
+                    mat_zero(u);
+                    gemm_r(u, yr, yi, opr);
+                    gemm_r(acc, lr, li, u);
+                }
             }
             // this wave's quarter of what is known of the next argument (after the last stage: of the
             // new density / cotangent)

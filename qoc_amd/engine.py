@@ -213,6 +213,16 @@ def _as_complex(array, shape=None):
 class Engine(object):
     """One context on one MI355X."""
 
+    @staticmethod
+    def device_count():
+        """HIP devices visible to this process (qocx_device_count)."""
+        lib = load_library()
+        count = ctypes.c_int(0)
+        code = lib.qocx_device_count(ctypes.byref(count))
+        if code != 0:
+            raise QocxError(code, lib.qocx_last_error().decode("utf-8", "replace"))
+        return int(count.value)
+
     def __init__(self, device=-1):
         self._lib = load_library()
         self._ctx = _VP()

@@ -557,14 +557,17 @@ def test_lindblad_two_sided_stage_loops_agree(engine, name):
 
 @pytest.mark.parametrize("nops", [1, 2, 3, 4])
 @pytest.mark.parametrize("densities", [1, 2])
-def test_lindblad_chain_stage_loop_agrees(engine, nops, densities):
+@pytest.mark.parametrize("real_operators", [False, True])
+def test_lindblad_chain_stage_loop_agrees(engine, nops, densities, real_operators):
     """
     Round 5: the two-sided launches at n <= 16 run the chain form of the stage loop (substep_chain:
     gamma L (y L^H) on the wave that owns L, every left operand in registers, one barrier per stage;
     L = 2, 3, 4 operators in four waves, L = 1 padded to two; knob "lindblad_chain"). Against the loops it
     replaces (knob 0: substep_q2 at L <= 2, the L + 2 wave form above) and the device model; with the
     Hermitian shortcut (the argument's left-operand image is the conjugate of its own registers) and
-    without it (knob "lindblad_hermitian" 0: through the wave's planar slot).
+    without it (knob "lindblad_hermitian" 0: through the wave's planar slot); and with REAL Lindblad
+    operators (a, a^dagger a, sigma_-: the engine notices and spends two real products per complex one,
+    knob "lindblad_real_ops") against the same problem on the complex path.
     """
     from qoc_amd.engine import COST_TARGET_DENSITY
     n, S, K, N, Nc = 13, densities, 2, 9, 5
@@ -573,6 +576,8 @@ def test_lindblad_chain_stage_loop_agrees(engine, nops, densities):
     h0 = gue(rng, n) * 1.5
     g = [gue(rng, n) for _ in range(K)]
     ops = np.stack([gue(rng, n) + 0.5j * gue(rng, n) for _ in range(nops)])
+    if real_operators:
+        ops = np.stack([rng.standard_normal((n, n)) / np.sqrt(n) + 0j for _ in range(nops)])
     gam = 0.05 + 0.2 * rng.random(nops)
     rho0 = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
     targ = np.stack([cases_mod.random_density(rng, n) for _ in range(S)])
@@ -582,15 +587,17 @@ def test_lindblad_chain_stage_loop_agrees(engine, nops, densities):
     engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs)
     out = {}
     try:
-        for chain, herm in ((0, 1), (1, 1), (1, 0)):
+        for chain, herm, real in ((0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0)):
             engine.set_knob("lindblad_chain", chain)
             engine.set_knob("lindblad_hermitian", herm)
-            out[chain, herm] = engine.evaluate_lindblad(controls)
+            engine.set_knob("lindblad_real_ops", real)
+            out[chain, herm, real] = engine.evaluate_lindblad(controls)
     finally:
         engine.set_knob("lindblad_chain", 1)
         engine.set_knob("lindblad_hermitian", 1)
-    ref = out[0, 1]
-    for key in ((1, 1), (1, 0)):
+        engine.set_knob("lindblad_real_ops", 1)
+    ref = out[0, 1, 1]
+    for key in ((1, 1, 1), (1, 0, 1), (1, 1, 0)):
         c, gr, f = out[key]
         assert np.max(np.abs(c - ref[0])) < 1e-13
         assert np.max(np.abs(f - ref[2])) < 1e-13
@@ -598,8 +605,8 @@ def test_lindblad_chain_stage_loop_agrees(engine, nops, densities):
     system = lm.StructuredLindblad(h0, g, gam, ops)
     costs = [ol.TargetDensityInfidelity(targ, cost_multiplier=0.8)]
     m_err, m_grads, m_final = lm.evaluate_with_grad(system, controls[0], rho0, T, N, costs, 1, want_grad=True)
-    assert abs(out[1, 1][0][0] - m_err) < 1e-12
-    assert np.max(np.abs(out[1, 1][1][0] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
+    assert abs(out[1, 1, 1][0][0] - m_err) < 1e-12
+    assert np.max(np.abs(out[1, 1, 1][1][0] - m_grads)) < 1e-10 * max(np.max(np.abs(m_grads)), 1e-3)
 
 
 def test_bench_lindblad_batch_is_pinned_on_itself(engine):
