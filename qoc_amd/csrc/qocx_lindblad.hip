@@ -1066,28 +1066,50 @@ struct Wave {
         mat_zero(rd);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) lar[kk] = lai[kk] = ldr[kk] = ldi[kk] = 0;
-        if constexpr (has_gl || has_gr) {
+        if constexpr (has_gr) {
             const double2* cache = kdump + 6 * (size_t)MAT;
             const int K = a.K;
-            Mat la;
-            dump_load(la, cache);
             dump_load(ra, cache + MAT);
 #pragma unroll
             for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
                 if (k < K) {
                     Mat gk;
                     dump_load(gk, cache + (size_t)(2 + k) * MAT);
-                    mat_axpy(la, ua[k], gk);
                     mat_axpy(ra, -ua[k], gk);
                     mat_axpy(rd, ub[k] - ua[k], gk);
                 }
-            if constexpr (has_gl) {
-                cmat_to_lds<LNB>(la, slot_gen.re, slot_gen.im);
-                cmat_to_lds<LNB>(rd, slot_zk.re, slot_zk.im);
-                wave_sync();
-                left_regs<false>(slot_gen, lar, lai);
-                left_regs<false>(slot_zk, ldr, ldi);
+        }
+        if constexpr (has_gl) {
+            // The left-operand registers of M are the C-layout registers of M^T, and the transposes are
+            // (conjugates of) dumps that exist: forward A0L^T = conj(A0L^H), Gp_k^T; adjoint (A0L^H)^T =
+            // conj(A0L), (Gp_k^H)^T = conj(Gp_k) - run() keeps them in kdump[0 .. 2] (the first two
+            // controls; further ones come from their HBM images). Linear in the controls like la, ld.
+            const int K = a.K;
+            {
+                Mat t0;
+                dump_load(t0, kdump);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    lar[kk] = t0.re[0][0][kk];
+                    lai[kk] = -t0.im[0][0][kk];
+                }
             }
+#pragma unroll
+            for (int k = 0; k < QOCX_LINDBLAD_MAX_K; ++k)
+                if (k < K) {
+                    Mat tk;
+                    dump_load(tk, k < 2 ? kdump + (size_t)(1 + k) * MAT
+                                        : (ADJ ? a.gp_cimg : a.gpt_cimg) + (size_t)k * MAT);
+                    const double sg = ADJ ? -1.0 : 1.0, du = ub[k] - ua[k];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double tr = tk.re[0][0][kk], ti = sg * tk.im[0][0][kk];
+                        lar[kk] = fma(ua[k], tr, lar[kk]);
+                        lai[kk] = fma(ua[k], ti, lai[kk]);
+                        ldr[kk] = fma(du, tr, ldr[kk]);
+                        ldi[kk] = fma(du, ti, ldi[kk]);
+                    }
+                }
         }
         Mat opr;
         mat_zero(opr);
@@ -1557,6 +1579,14 @@ static __device__ __forceinline__ void run(const LindbladArgs& a, char* smem) {
             for (int k = 0; k < K; ++k) {
                 dump_load(t, (adj ? a.gpd_cimg : a.gp_cimg) + (size_t)k * MAT);
                 dump_store(t, cache + (size_t)(2 + k) * MAT);
+            }
+            if constexpr (CH) {  // the sources of the generator's left-operand registers (chain_jobs)
+                dump_load(t, adj ? a.a0l_cimg : a.a0ld_cimg);
+                dump_store(t, kdump);
+                for (int k = 0; k < K && k < 2; ++k) {
+                    dump_load(t, (adj ? a.gp_cimg : a.gpt_cimg) + (size_t)k * MAT);
+                    dump_store(t, kdump + (size_t)(1 + k) * MAT);
+                }
             }
         }
         block_sync();
