@@ -451,6 +451,10 @@ def test_lindblad_random_shapes_fuzz(engine):
     for index in range(40):
         worst, tag = fuzz_lindblad.one(engine, rng, index)
         assert worst < 1.0, tag
+    # the shapes of the two-sided evaluation (one final target cost; chain form of the stage loop at n <= 16)
+    for index in range(30):
+        worst, tag = fuzz_lindblad.one_two_sided(engine, rng, index)
+        assert worst < 1.0, tag
 
 
 @pytest.mark.parametrize("name", ["lindblad_n4", "lindblad_c4_short"])
