@@ -1485,17 +1485,25 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             time_end(ctx, st);
             return 0;
         };
+        // (tail_ring: bit 0 the forward, bit 1 the adjoint sweeps enqueued behind the LAST factor launch get
+        // two operand sets in LDS - nothing but K3 shares the CUs with them then; knob "sweep_tail_ring")
+        bool in_tail = false;
+        const int tail_ring = (int)ctx->knob("sweep_tail_ring", 0);
         auto forward_range = [&](int jb, int je, hipStream_t st) {  // steps [jb, je), no wait
             sa.j_begin = jb; sa.j_end = je; sa.phase = 1;
+            sa.ring2 = (in_tail && (tail_ring & 1)) ? 1 : 0;
             time_begin(ctx, 1, st);
             run_sweep(sa, bc, st);
             time_end(ctx, st);
+            sa.ring2 = 0;
         };
         auto adjoint_range = [&](int jb, int je, hipStream_t st) {
             sa.j_begin = jb; sa.j_end = je; sa.phase = 2;
+            sa.ring2 = (in_tail && (tail_ring & 2)) ? 1 : 0;
             time_begin(ctx, 1, st);
             run_sweep(sa, bc, st);
             time_end(ctx, st);
+            sa.ring2 = 0;
         };
         auto adjoint_segment = [&](int i, hipStream_t st) -> int {
             adjoint_range(lo[i], lo[i + 1], st);
@@ -1594,6 +1602,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 const int i = (t % 2 == 0) ? t / 2 : nseg - 1 - t / 2;
                 QOCX_STEP(factor_segment(i, (two_k1a && (t % 2 == 1)) ? ctx->lu_stream : cs));
                 factored[i] = 1;
+                in_tail = (t == nseg - 1);
                 while (next_f < nseg && factored[next_f]) {
                     HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_factored[next_f], 0));
                     for (int p = first[next_f]; p < first[next_f + 1]; ++p) {
@@ -2589,7 +2598,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "sweep_tail_ring", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -133,6 +133,7 @@ struct SweepArgs {
     int batch = 0;        // seeds of the launch (set by the launcher of the two-seeds-per-workgroup form)
     int onebuf = 0;       // one state: one operand set in LDS; 1: one seed per workgroup, 2: two
     int one_state = 0;    // one state, n <= 32: the dedicated kernel of qocx_sweep1.hip (knob "sweep_one")
+    int ring2 = 0;        // sweep1, n > 16: two operand sets in LDS, every fetch a whole step ahead (70 KiB per seed)
     int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
     int dbg;              // sweep3 timing diagnostics (results are garbage): bit 0 no inversion,
                           // bit 1 no solves, bit 2 no LU fetch, bit 3 no Q fetch, bit 4 no Q touch

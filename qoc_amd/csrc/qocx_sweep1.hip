@@ -463,6 +463,15 @@ void launch_sweep1(int nb, const SweepArgs& a, int batch, int pack, hipStream_t 
             attr_set = true;
         }
         hipLaunchKernelGGL((sweep1::sweep1_kernel<1, RING>), dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
+    } else if (a.ring2) {
+        const int bytes = sweep1::Lds1<2, 2>::SEED_BYTES * pack;
+        static bool attr_set = false;
+        if (bytes > 48 * 1024 && !attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep1::sweep1_kernel<2, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((sweep1::sweep1_kernel<2, 2>), dim3((batch + pack - 1) / pack), dim3(64 * pack), bytes, st, b);
     } else {
         const int bytes = sweep1::Lds1<2, 1>::SEED_BYTES * pack;
         static bool attr_set = false;

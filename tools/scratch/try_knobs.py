@@ -20,10 +20,10 @@ def run(label, nseg=0, **knobs):
         engine.synchronize()
         ts.append((time.perf_counter() - t) * 200)
     print(json.dumps(dict(label=label, nseg=nseg, knobs=knobs, ms_median=sorted(ts)[len(ts)//2], ms_min=min(ts))), flush=True)
-run("streams=2", k1a_streams=2)
-run("streams=1", k1a_streams=1)
-run("streams=2 again", k1a_streams=2)
-run("streams=1 again", k1a_streams=1)
-run("streams=2 third", k1a_streams=2)
-run("streams=1 third", k1a_streams=1)
+ref = None
+for label, v in (("ring=0", 0), ("ring=2 (adjoint)", 2), ("ring=1 (forward)", 1), ("ring=3 (both)", 3), ("ring=0 again", 0), ("ring=2 again", 2)):
+    run(label, sweep_tail_ring=v)
+    c, g, _ = engine.download_results(want_grad=True, want_final=False)
+    if ref is None: ref = (c.copy(), g.copy())
+    print("   identical to ring=0:", bool(np.array_equal(c, ref[0]) and np.array_equal(g, ref[1])), flush=True)
 engine.close()
