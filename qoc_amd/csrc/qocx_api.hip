@@ -1517,6 +1517,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ka.g_rimg = m4lin ? ctx->ge_rimg.p : ctx->g_rimg.p;
         ka.g_timg = m4lin ? ctx->ge_timg.p : ctx->g_timg.p;
         ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
+        ka.lds_pad = (int)ctx->knob("k3_lds_pad", 0);
         ka.direct = fa.direct;
         ka.n = ctx->n;
         ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
@@ -2598,7 +2599,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "sweep_tail_ring", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -162,6 +162,7 @@ struct SweepArgs {
 };
 
 struct KrylovArgs {
+    int lds_pad = 0;  // extra dynamic LDS per workgroup (bytes): fewer K3 waves per CU beside the tail sweeps (knob "k3_lds_pad")
     const double* controls;
     const StepInterp* interp;
     const double2* h0_rimg;  // column-major h0

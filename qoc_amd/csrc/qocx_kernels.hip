@@ -1715,7 +1715,7 @@ static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStrea
                            KrylovLds<NB>::BYTES, st, a);
     else if (a.skew)
         hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
-                           KrylovLds<NB>::BYTES, st, a);
+                           KrylovLds<NB>::BYTES + (a.lds_pad > 0 && a.lds_pad <= 40 * 1024 ? a.lds_pad : 0), st, a);
     else
         hipLaunchKernelGGL((krylov_grad_kernel<NB, false>), dim3(nsteps, batch), dim3(64),
                            KrylovLds<NB>::BYTES, st, a);

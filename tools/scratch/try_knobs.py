@@ -20,10 +20,6 @@ def run(label, nseg=0, **knobs):
         engine.synchronize()
         ts.append((time.perf_counter() - t) * 200)
     print(json.dumps(dict(label=label, nseg=nseg, knobs=knobs, ms_median=sorted(ts)[len(ts)//2], ms_min=min(ts))), flush=True)
-ref = None
-for label, v in (("ring=0", 0), ("ring=2 (adjoint)", 2), ("ring=1 (forward)", 1), ("ring=3 (both)", 3), ("ring=0 again", 0), ("ring=2 again", 2)):
-    run(label, sweep_tail_ring=v)
-    c, g, _ = engine.download_results(want_grad=True, want_final=False)
-    if ref is None: ref = (c.copy(), g.copy())
-    print("   identical to ring=0:", bool(np.array_equal(c, ref[0]) and np.array_equal(g, ref[1])), flush=True)
+for label, v in (("pad=0", 0), ("pad=8K", 8192), ("pad=16K", 16384), ("pad=24K", 24576), ("pad=36K", 36864), ("pad=0 again", 0), ("pad=16K again", 16384)):
+    run(label, k3_lds_pad=v)
 engine.close()
