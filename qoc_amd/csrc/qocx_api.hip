@@ -1318,6 +1318,13 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             qocx::FactorArgs probe = fa;
             probe.direct = 1;
             fa.three_wave = (int)ctx->knob("k1a_three", 1);
+            // (1: the second halves of the factorisations four to a wave in a kernel of their own behind K1a,
+            // 2: on the factor side stream, beside the next segment's K1a. Measured, profiles/r05_k1a_four.txt:
+            // K1a 0.650 -> 0.587 ms, the second kernel 0.061 ms - it moves 4 KB per step in and out, 262 MB
+            // per segment -, the evaluation 8.05 -> 8.05 (1) / 7.93 ms (2). Off: 1.3 % for a kernel and a
+            // stream more and 2 GB more traffic per evaluation.)
+            fa.four_steps = (int)ctx->knob("k1a_four", 0);
+            if (fa.four_steps == 2 && ctx->lu_stream == nullptr) fa.four_steps = 1;
             // (the bound at the step midpoints, where it applies, speaks for the two-wave K1a only: the
             // four-wave kernels and the slot capacity keep the bound over the knots)
             if (fa.three_wave && qocx::pq3_supports(probe) &&
@@ -1443,6 +1450,18 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 qocx::launch_pq(ctx->nb, fa, len, bc, fs);
             }
             time_end(ctx, fs);
+            if (!explicit_gen && nodes == 1 && qocx::pq_second_pending(ctx->nb, fa, len)) {
+                // the second halves of the segment's factorisations (memory-bound: 4 KB in and out per
+                // step) on the side stream, beside the K1a launch of the next segment
+                HIP_TRY(hipEventRecord(ctx->ev_pq[i], fs));
+                HIP_TRY(hipStreamWaitEvent(ctx->lu_stream, ctx->ev_pq[i], 0));
+                time_begin(ctx, 4, ctx->lu_stream);
+                qocx::launch_pq3_second(fa, len, bc, ctx->lu_stream);
+                time_end(ctx, ctx->lu_stream);
+                HIP_TRY(hipEventRecord(ctx->ev_factored[i], ctx->lu_stream));
+                if (nseg <= 1) HIP_TRY(hipStreamWaitEvent(fs, ctx->ev_factored[i], 0));
+                return 0;
+            }
             la.step0 = plo; la.seg_len = len;
             // (K1b on a stream of its own, beside the next segment's K1a: with the v5 kernels no
             // gain; with the two-wave K1a (240 registers) and K1b (160) sharing SIMDs 1 % - K1a
@@ -2599,7 +2618,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_four", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -53,6 +53,7 @@ struct FactorArgs {
     int lu_mfma = 0;           // fused K1b with its Schur updates on the matrix cores (qocx_lu4.h)
     int lu_dpp = 0;            // fused K1b on the vector unit for provably diagonal pivots (qocx_lu5.h)
     int three_wave = 0;        // orders 3 / 5, Hermitian, step table: one tile per wave on three waves (qocx_pade3.hip)
+    int four_steps = 0;     // three-wave K1a: the second halves of the factorisations four to a wave in a kernel of their own (knob "k1a_four"; 1: launch_pq launches it, 2: the caller)
     // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
     // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
     // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel
@@ -339,6 +340,10 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 bool pq3_supports(const FactorArgs& a);
 void launch_pq3(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+bool pq3_parks(const FactorArgs& a, int nsteps);
+void launch_pq3_second(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+// true: launch_pq left the second halves of the factorisations to launch_pq3_second (FactorArgs::four_steps == 2)
+bool pq_second_pending(int nb, const FactorArgs& a, int nsteps);
 void launch_pq2_explicit(const double2* a_in, int n, const FactorArgs& a, int count, hipStream_t st);
 // 33 <= n <= 64: four-wave workgroups (qocx_pade4.hip)
 void launch_pq4(const FactorArgs& a, int nsteps, int batch, hipStream_t st);

@@ -1725,6 +1725,9 @@ static bool one_wave_pq() {
     static const bool v = diag_getenv("QOCX_PQ1") != nullptr;
     return v;
 }
+bool pq_second_pending(int nb, const FactorArgs& a, int nsteps) {
+    return nb == 2 && !one_wave_pq() && a.three_wave && pq3_supports(a) && a.four_steps == 2 && pq3_parks(a, nsteps);
+}
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
     if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
     else if (nb == 4) launch_pq4(a, nsteps, batch, st);

@@ -173,7 +173,10 @@ __device__ __forceinline__ void pivots(Block& x, double& myrr, double& myri, int
 // One wave factors the 32 x 32 matrix whose column-major image (pitch `pitch` complex per column) sits
 // at `src` in LDS; the image is overwritten (it serves as the exchange buffer). Only for matrices
 // pade_denominator_dominant() has granted.
-__device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double2* src, int pitch) {
+// (first half: the four blocks, columns 0..15 and rows 0..15 of the factors, and the Schur complement S
+// as an accumulator tile - lane (q, c), register r: S[4 r + q][c])
+__device__ __forceinline__ void lu_dpp_first(const LuArgs& args, size_t m, double2* src, int pitch, d4& sre,
+                                             d4& sim) {
     const int lane = lane_id(), dr = lane >> 4, j = lane & 15, q = dr, c = j;
     double2* img = args.lu_img + m * 1024;
     double2* dinv = args.dinv + m * 32;
@@ -189,7 +192,6 @@ __device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double
             x.im[cc] = e.y;
         }
     }
-    d4 sre, sim;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double2 e = src[(16 + c) * pitch + 16 + 4 * r + q];
@@ -235,22 +237,22 @@ __device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double
         sim = mfma_f64(-a.x, b.y, sim);
         sim = mfma_f64(-a.y, b.x, sim);
     }
-    // ---- S, a row per lane (every row of 16 lanes a copy), and its elimination
-    wave_sync();
-    double2* lds_s = src + 32 * SP;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lds_s[(4 * r + q) * SP + c] = make_double2(sre[r], sim[r]);
-    wave_sync();
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-        const double2 e = lds_s[j * SP + cc];
-        x.re[cc] = e.x;
-        x.im[cc] = e.y;
+    if (lane < 32) {
+        args.perm[m * 32 + lane] = lane;
+        args.iperm[m * 32 + lane] = lane;
     }
-    myrr = 0.0;
-    myri = 0.0;
+}
+
+// (second half: S a row per lane - lane j of a row of 16 lanes holds row j - eliminated in every row of 16
+// lanes at once, by the same instructions; the rows of lanes that `store` switches on write their factors
+// to THEIR matrix `m`: one matrix in four copies (lu_dpp_body) or four matrices (qocx_pade3.hip))
+__device__ __forceinline__ void lu_dpp_second(const LuArgs& args, size_t m, Block& x, bool store) {
+    const int j = lane_id() & 15;
+    double2* img = args.lu_img + m * 1024;
+    double2* dinv = args.dinv + m * 32;
+    double myrr = 0.0, myri = 0.0;
     pivots<false>(x, myrr, myri, j, std::make_integer_sequence<int, 16>{});
-    if (dr == 0) {
+    if (store) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
             const double tr = x.re[cc] * myrr - x.im[cc] * myri, ti = x.re[cc] * myri + x.im[cc] * myrr;
@@ -259,10 +261,26 @@ __device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double
         }
         dinv[16 + j] = make_double2(myrr, myri);
     }
-    if (lane < 32) {
-        args.perm[m * 32 + lane] = lane;
-        args.iperm[m * 32 + lane] = lane;
+}
+
+__device__ __forceinline__ void lu_dpp_body(const LuArgs& args, size_t m, double2* src, int pitch) {
+    const int lane = lane_id(), dr = lane >> 4, j = lane & 15, q = dr, c = j;
+    d4 sre, sim;
+    lu_dpp_first(args, m, src, pitch, sre, sim);
+    // ---- S, a row per lane (every row of 16 lanes a copy), and its elimination
+    wave_sync();
+    double2* lds_s = src + 32 * SP;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_s[(4 * r + q) * SP + c] = make_double2(sre[r], sim[r]);
+    wave_sync();
+    Block x;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const double2 e = lds_s[j * SP + cc];
+        x.re[cc] = e.x;
+        x.im[cc] = e.y;
     }
+    lu_dpp_second(args, m, x, dr == 0);
 }
 
 }  // namespace lu5

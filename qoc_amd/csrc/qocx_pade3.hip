@@ -77,7 +77,15 @@ __device__ __forceinline__ void gemm3(d4& t1, d4& t2, d4& t3, const double* slot
     }
 }
 
-template <bool STAMP>
+// PARK: the second half of the factorisation is left to lu5_second_kernel. The Schur complement S of a
+// step is 16 x 16: lu5 eliminates it a row per lane in every row of 16 lanes at once, and with ONE matrix
+// in the wave the four rows of lanes hold four copies of it (800 of the factorisation's 2 760 vector
+// instructions at a quarter of the lanes). Wave 0 parks S in the (1, 1) block of the step's LU image
+// instead (4 KB through L2), and lu5_second_kernel gives every row of lanes the S of a DIFFERENT step:
+// the same instructions, four matrices. (Four steps per workgroup, the second halves at its end, was
+// tried first and is 50 % slower: the waves that wait for wave 0 keep their slots, whereas here - as
+// before - they leave and the next workgroup's products fill the matrix pipe beside the factorisation.)
+template <bool STAMP, bool PARK>
 __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sl = reinterpret_cast<double*>(smem_raw);
@@ -230,7 +238,15 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
         lu.lu_img = args.lu_img; lu.dinv = args.dinv; lu.perm = args.perm; lu.iperm = args.iperm;
         lu.status = args.status; lu.nsteps = args.nsteps; lu.step0 = args.step0; lu.seg_len = args.seg_len;
         lu.n = args.n; lu.dbg = 0; lu.fallbacks = nullptr;
-        if (!(QOCX_DBG_BITS(args.dbg) & 4)) lu5::lu_dpp_body(lu, m, simg, LP);
+        if constexpr (PARK) {
+            d4 sre, sim;
+            lu5::lu_dpp_first(lu, m, simg, LP, sre, sim);
+            double2* img = args.lu_img + m * 1024;  // S[4 r + q][c] -> column 16 + c, row 16 + 4 r + q
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 + c) * 32 + 16 + 4 * r + q] = make_double2(sre[r], sim[r]);
+        } else {
+            if (!(QOCX_DBG_BITS(args.dbg) & 4)) lu5::lu_dpp_body(lu, m, simg, LP);
+        }
         clk.lap(4);
     }
     if constexpr (STAMP) {
@@ -243,6 +259,30 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
     }
 }
 
+// the second halves of the factorisations pade_pq3_kernel<., true> parked: a wave per FOUR steps of the
+// launch (work item i -> seed i / seg_len, step step0 + i % seg_len), a row of 16 lanes each
+__global__ __launch_bounds__(64) void lu5_second_kernel(FactorArgs args, int total) {
+    const int lane = lane_id(), dr = lane >> 4, j = lane & 15;
+    const int item = 4 * (int)blockIdx.x + dr;
+    const int it = item < total ? item : total - 1;
+    const size_t m = (size_t)(it / args.seg_len) * args.nsteps + args.step0 + it % args.seg_len;
+    // (a step above order 5 was factored whole by the two-wave kernel)
+    const bool mine = item < total && step_order(args.s_arr[m]) <= 5;
+    const double2* img = args.lu_img + m * 1024;
+    lu5::Block x;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const double2 e = img[(16 + cc) * 32 + 16 + j];
+        x.re[cc] = mine ? e.x : (cc == j ? 1.0 : 0.0);  // (no step in this row of lanes: the identity)
+        x.im[cc] = mine ? e.y : 0.0;
+    }
+    LuArgs lu;
+    lu.lu_img = args.lu_img; lu.dinv = args.dinv; lu.perm = args.perm; lu.iperm = args.iperm;
+    lu.status = args.status; lu.nsteps = args.nsteps; lu.step0 = args.step0; lu.seg_len = args.seg_len;
+    lu.n = args.n; lu.dbg = 0; lu.fallbacks = nullptr;
+    lu5::lu_dpp_second(lu, m, x, mine);
+}
+
 }  // namespace pade3
 
 // structured M2 problem through the step table, Hermitian generators: the steps at order 3 or 5
@@ -252,11 +292,25 @@ bool pq3_supports(const FactorArgs& a) {
 void launch_pq3(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
 #ifdef QOCX_DIAG
     if (a.stamps != nullptr) {
-        hipLaunchKernelGGL(pade3::pade_pq3_kernel<true>, dim3(nsteps, batch), dim3(192), pade3::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((pade3::pade_pq3_kernel<true, false>), dim3(nsteps, batch), dim3(192), pade3::LDS_BYTES, st, a);
         return;
     }
 #endif
-    hipLaunchKernelGGL(pade3::pade_pq3_kernel<false>, dim3(nsteps, batch), dim3(192), pade3::LDS_BYTES, st, a);
+    if (pq3_parks(a, nsteps)) {
+        hipLaunchKernelGGL((pade3::pade_pq3_kernel<false, true>), dim3(nsteps, batch), dim3(192), pade3::LDS_BYTES, st, a);
+        if (a.four_steps == 1) launch_pq3_second(a, nsteps, batch, st);  // (2: the caller does, on a stream of its choice)
+        return;
+    }
+    hipLaunchKernelGGL((pade3::pade_pq3_kernel<false, false>), dim3(nsteps, batch), dim3(192), pade3::LDS_BYTES, st, a);
+}
+// FactorArgs::four_steps: the launch parks the Schur complements and leaves the second halves of the
+// factorisations to launch_pq3_second
+bool pq3_parks(const FactorArgs& a, int nsteps) {
+    return a.four_steps != 0 && a.seg_len == nsteps && a.stamps == nullptr && !(QOCX_DBG_BITS(a.dbg) & 4);
+}
+void launch_pq3_second(const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
+    const int total = nsteps * batch;
+    hipLaunchKernelGGL(pade3::lu5_second_kernel, dim3((total + 3) / 4), dim3(64), 0, st, a, total);
 }
 
 }  // namespace qocx
