@@ -66,7 +66,7 @@ def make_controls(first_seed, count):
 PMC_SUMMARY = "profiles/r05_pmc_hbm.json"
 PMC_SQ_SUMMARY = "profiles/r05_pmc_sq.json"  # SQ counters of the same command (tools/profile_round.sh)
 PMC_META = "profiles/r05_profile_meta.json"  # what the counter passes were taken from (kernel sources)
-K1A_KERNEL = "qocx::pade3::pade_pq3_kernel<false>"  # the roofline kernel of the headline workload
+K1A_KERNEL = "qocx::pade3::pade_pq3_kernel<false, false>"  # the roofline kernel of the headline workload
 # the kernel sources whose change makes the committed counters of K1A_KERNEL stale
 K1A_SOURCES = ("qoc_amd/csrc/qocx_pade3.hip", "qoc_amd/csrc/qocx_lu5.h", "qoc_amd/csrc/qocx_wave.h")
 
