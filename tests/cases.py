@@ -374,7 +374,7 @@ def lindblad_case(name, n, N, S, K, seeds, h_seed, Nc=None, T=None, complex_cont
     return c
 
 
-def lindblad_wellconditioned_case(name, n, N, Nc, T, sigma, drive, seeds=2):
+def lindblad_wellconditioned_case(name, n, N, Nc, T, sigma, drive, seeds=2, operators=2):
     """
     VERDICT r1: fixtures whose gradient is not tiny. An anharmonic oscillator with two quadrature
     drives, weak decay and dephasing, |0><0| -> |1><1| (a reachable target), few control knots:
@@ -397,6 +397,13 @@ def lindblad_wellconditioned_case(name, n, N, Nc, T, sigma, drive, seeds=2):
     c.initial_densities = init
     c.dissipators = np.array([0.02, 0.01])
     c.operators = np.stack([a / np.sqrt(n - 1), ad @ a / (n - 1)])
+    if operators == 3:    # three real operators: decay, dephasing, two-photon loss
+        c.dissipators = np.array([0.02, 0.01, 0.015])
+        c.operators = np.stack([a / np.sqrt(n - 1), ad @ a / (n - 1), a @ a / (n - 1)])
+    elif operators == 4:  # ... and a complex one
+        c.dissipators = np.array([0.02, 0.01, 0.015, 0.012])
+        c.operators = np.stack([a / np.sqrt(n - 1), ad @ a / (n - 1), a @ a / (n - 1),
+                                (a + 1j * ad @ a) / (n - 1)])
     c.grad_rtol = 1e-8
     return c
 
@@ -421,6 +428,12 @@ def lindblad_cases():
                                       drive=0.2886751345948129),
         lindblad_wellconditioned_case("lindblad_wc_n16", n=16, N=13, Nc=4, T=3.0, sigma=0.8,
                                       drive=0.5),
+        # three and four Lindblad operators (round 5: the chain form of the stage loop runs them on
+        # four waves with other job tables than two), the fourth one complex
+        lindblad_wellconditioned_case("lindblad_wc_l3", n=16, N=13, Nc=4, T=3.0, sigma=0.8,
+                                      drive=0.5, operators=3),
+        lindblad_wellconditioned_case("lindblad_wc_l4", n=12, N=11, Nc=4, T=2.5, sigma=0.8,
+                                      drive=0.5, operators=4),
     ]
 
 

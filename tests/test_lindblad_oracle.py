@@ -200,6 +200,8 @@ CONTROLLER_GAP = {
     "lindblad_timedep": 3.10e-6,
     "lindblad_timedep_data": 3.53e-4,
     "lindblad_wc_c4": 1.61e-6,
+    "lindblad_wc_l3": 1.153e-3,
+    "lindblad_wc_l4": 7.65e-5,
     "lindblad_wc_n16": 4.53e-4,
     "lindblad_wc_n4": 3.11e-5,
 }

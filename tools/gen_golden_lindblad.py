@@ -67,7 +67,8 @@ def richardson_fd(case, controls, index, h):
 # is large (the well-conditioned fixtures), and the measured number is printed and stored.
 FD_COUNT = {"lindblad_c4_full": 2, "lindblad_bench_c4": 2, "lindblad_wc_c4": 3}
 FD_STEP = {"lindblad_wc_n4": 4e-2, "lindblad_wc_n16": 4e-2, "lindblad_timedep_data": 4e-2,
-           "lindblad_bench_c4": 4e-2, "lindblad_opaque_wc": 1.5e-2, "lindblad_wc_c4": 4e-2}
+           "lindblad_bench_c4": 4e-2, "lindblad_opaque_wc": 1.5e-2, "lindblad_wc_c4": 4e-2,
+           "lindblad_wc_l3": 4e-2, "lindblad_wc_l4": 4e-2}
 
 
 def main(only=None):
