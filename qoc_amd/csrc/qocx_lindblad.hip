@@ -1979,6 +1979,35 @@ __global__ __launch_bounds__(64) void lindblad_combine_kernel(LindbladArgs a) {
             Mat y, kb, kbd, z, z2;
             I::dump_load(y, a.ystages + base + (size_t)i * I::MAT);
             I::dump_load(kb, a.kbstages + base + (size_t)i * I::MAT);
+            if (a.hermitian) {
+                // Hermitian Y_i, kbar_i, anti-Hermitian Gp_k (host-checked): Z = P - P^H with P = Y kbar, and
+                // tr(Z Gp_k) = 2 Re tr(P Gp_k) - ONE product, its left operand the conjugate of Y's own
+                // registers (the C layout of Y^T), nothing through LDS
+                double yr[4], yi[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    yr[kk] = y.re[0][0][kk];
+                    yi[kk] = -y.im[0][0][kk];
+                }
+                I::mat_zero(z);
+                I::Wave::gemm_r(z, yr, yi, kb);
+                const double ci = RK_C_DEV[i];
+                for (int k = 0; k < K; ++k) {
+                    Mat gt;
+                    I::dump_load(gt, a.gpt_cimg + (size_t)k * I::MAT);
+                    double pr = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr += z.re[0][0][r] * gt.re[0][0][r] - z.im[0][0][r] * gt.im[0][0][r];
+                    const double g = cs.x * (2.0 * wave_sum(pr));
+#pragma unroll
+                    for (int kk = 0; kk < QOCX_LINDBLAD_MAX_K; ++kk)
+                        if (kk == k) {
+                            ga[kk] += (1.0 - ci) * g;
+                            gb[kk] += ci * g;
+                        }
+                }
+                continue;
+            }
             wave_sync();
             cmat_to_lds<1>(kb, slot_zk.re, slot_zk.im);
             wave_sync();
