@@ -987,7 +987,8 @@ struct Wave {
     // touches LDS for the exchange of the partial sums only; otherwise through the wave's own planar
     // slot. Real Lindblad operators (LindbladArgs::ops_real): 16 MFMAs per chain instead of 24. Jobs by wave:
     //   nops = 2: A_L y | chain 1 | chain 2 | y A_R            (12 | 24 | 24 | 12 MFMAs)
-    //   nops = 3: A_L y + y A_R | chain 1 | chain 2 | chain 3  (24 each)
+    //   nops = 3: A_L y + y A_R | chain 1 | chain 2 | chain 3  (24 each; Hermitian: y A_R = (A_L y)^H, a
+    //             transposition through the wave's slot instead of the second product)
     //   nops = 4: A_L y + chain 1 | y A_R + chain 2 | chain 3 | chain 4  (36 | 36 | 24 | 24)
     // The Runge-Kutta bookkeeping is substep_q2's: every wave keeps a quarter of every h k_j.
     // ADJ: Gen^H, GenRight^H, L^H (y L). Returns with `result` whole in every wave, no barrier behind it.
@@ -1170,7 +1171,23 @@ struct Wave {
                 }
                 gemm_r(acc, gr_, gi_, arg);
             }
-            if constexpr (has_gr) {
+            if constexpr (JOBS == 3) {
+                if (herm) {
+                    // three operators, Hermitian problem: y A_R = (A_L y)^H - the mirror of the product this
+                    // wave has just formed, through its own planar slot, instead of twelve more MFMAs on the
+                    // wave that is the critical one here
+                    Mat ah;
+                    cmat_to_lds<LNB>(acc, mine.re, mine.im);
+                    wave_sync();
+                    load_adjoint(ah, mine);
+                    mat_axpy(acc, 1.0, ah);
+                    wave_sync();
+                } else {
+                    Mat gr = ra;
+                    mat_axpy(gr, -ci, rd);
+                    gemm_r(acc, yr, yi, gr);
+                }
+            } else if constexpr (has_gr) {
                 Mat gr = ra;
                 mat_axpy(gr, -ci, rd);
                 gemm_r(acc, yr, yi, gr);
