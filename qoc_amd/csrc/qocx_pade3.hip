@@ -102,8 +102,10 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
 
     // ---- generator: the wave's column block tj of a = dt (-i H), H = h0 + sum_k u_k g_k
     // (schroedingerdiscrete.py:485-486, mathmethods.py:90-93); C-image index ((ti * 2 + tj) * 4 + r) * 64 + lane
+    // (wave 2 owns tile (1,1): its column block is wave 1's - it takes it from the slot behind the first
+    // barrier instead of forming a third copy from the images in L2)
     d4 are[2], aim[2];
-    {
+    if (w < 2) {
         const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
         const double2* h0 = args.h0_cimg + tsel * MAT;
         const double2* g = args.g_cimg + tsel * args.K * MAT;
@@ -143,6 +145,16 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
     clk.lap(0);
     __syncthreads();  // 1
     clk.lap(2);
+    if (w == 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (16 * t + 4 * r + q) * PITCH + 16 * tj + c;
+                are[t][r] = sl[off];
+                aim[t][r] = sl[PLANE + off];
+            }
+    }
 
     const double* bt = pade_table(order);
     auto b_own = [&](int kk, double& bre, double& bim) {  // B = a, the wave's column block
