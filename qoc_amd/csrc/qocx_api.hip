@@ -1324,6 +1324,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             // per segment -, the evaluation 8.05 -> 8.05 (1) / 7.93 ms (2). Off: 1.3 % for a kernel and a
             // stream more and 2 GB more traffic per evaluation.)
             fa.four_steps = (int)ctx->knob("k1a_four", 0);
+            fa.gen_share = (int)ctx->knob("k1a_share", 2);
             if (fa.four_steps == 2 && ctx->lu_stream == nullptr) fa.four_steps = 1;
             // (the bound at the step midpoints, where it applies, speaks for the two-wave K1a only: the
             // four-wave kernels and the slot capacity keep the bound over the knots)
@@ -2618,7 +2619,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_four", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

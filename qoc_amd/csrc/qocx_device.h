@@ -54,6 +54,7 @@ struct FactorArgs {
     int lu_dpp = 0;            // fused K1b on the vector unit for provably diagonal pivots (qocx_lu5.h)
     int three_wave = 0;        // orders 3 / 5, Hermitian, step table: one tile per wave on three waves (qocx_pade3.hip)
     int four_steps = 0;     // three-wave K1a: the second halves of the factorisations four to a wave in a kernel of their own (knob "k1a_four"; 1: launch_pq launches it, 2: the caller)
+    int gen_share = 2;      // three-wave K1a: which tiles of the generator come from the LDS slot instead of the images (knob "k1a_share")
     // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
     // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
     // order and squaring count, taken from the bound dt (||H0||_1 + sum |u_k| ||G_k||_1): the kernel

@@ -102,10 +102,14 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
 
     // ---- generator: the wave's column block tj of a = dt (-i H), H = h0 + sum_k u_k g_k
     // (schroedingerdiscrete.py:485-486, mathmethods.py:90-93); C-image index ((ti * 2 + tj) * 4 + r) * 64 + lane
-    // (wave 2 owns tile (1,1): its column block is wave 1's - it takes it from the slot behind the first
-    // barrier instead of forming a third copy from the images in L2)
+    // Only three of the six tiles the waves hold are formed from the images in L2: wave 2 (tile (1,1)) has
+    // wave 1's column block and takes it from the slot behind the first barrier; tile (1,0) of wave 0's
+    // column block is the mirror of wave 1's tile (0,1) - a^H = -a, bit for bit with Hermitian images -,
+    // which wave 1 puts into the slot beside its own tiles.
     d4 are[2], aim[2];
-    if (w < 2) {
+    const int share = args.gen_share;  // 0: every wave its own column block, 1: wave 2 from the slot, 2: and wave 0's tile (1,0)
+    if (w < 2 || share == 0) {
+        const int tcount = (w == 0 && share == 2) ? 1 : 2;
         const size_t tsel = (args.nt == 1) ? 0 : (size_t)step;
         const double2* h0 = args.h0_cimg + tsel * MAT;
         const double2* g = args.g_cimg + tsel * args.K * MAT;
@@ -113,39 +117,55 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
         d4 hre[2], him[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
+            if (t < tcount) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double2 e = h0[((t * 2 + tj) * 4 + r) * 64 + lane];
-                hre[t][r] = e.x;
-                him[t][r] = e.y;
+                for (int r = 0; r < 4; ++r) {
+                    const double2 e = h0[((t * 2 + tj) * 4 + r) * 64 + lane];
+                    hre[t][r] = e.x;
+                    him[t][r] = e.y;
+                }
             }
         for (int k = 0; k < args.K; ++k) {
             const double uk = ctl[k];
             const double2* gk = g + (size_t)k * MAT;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
+                if (t < tcount) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 e = gk[((t * 2 + tj) * 4 + r) * 64 + lane];
-                    hre[t][r] += uk * e.x;
-                    him[t][r] += uk * e.y;
+                    for (int r = 0; r < 4; ++r) {
+                        const double2 e = gk[((t * 2 + tj) * 4 + r) * 64 + lane];
+                        hre[t][r] += uk * e.x;
+                        him[t][r] += uk * e.y;
+                    }
                 }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            are[t] = args.dt * him[t];
-            aim[t] = -args.dt * hre[t];
-        }
+        for (int t = 0; t < 2; ++t)
+            if (t < tcount) {
+                are[t] = args.dt * him[t];
+                aim[t] = -args.dt * hre[t];
+            }
     }
-    // the whole of `a` into the slot: wave 0 its column block 0, wave 1 column block 1
-    if (w < 2) {
-        stage_tile(sl, 0, tj, are[0], aim[0]);
-        stage_tile(sl, 1, tj, are[1], aim[1]);
+    // the whole of `a` into the slot: wave 0 tile (0,0), wave 1 column block 1 and the mirror of its tile (0,1)
+    if (w == 0) {
+        stage_tile(sl, 0, 0, are[0], aim[0]);
+        if (share != 2) stage_tile(sl, 1, 0, are[1], aim[1]);
+    }
+    if (w == 1) {
+        stage_tile(sl, 0, 1, are[0], aim[0]);
+        stage_tile(sl, 1, 1, are[1], aim[1]);
+        if (share == 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // element (16 + c, 4 r + q) = -conj(a[4 r + q][16 + c])
+            const int off = (16 + c) * PITCH + 4 * r + q;
+            sl[off] = -are[0][r];
+            sl[PLANE + off] = aim[0][r];
+        }
     }
     clk.lap(0);
     __syncthreads();  // 1
     clk.lap(2);
-    if (w == 2) {
+    if (w == 2 && share != 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -154,6 +174,14 @@ __global__ __launch_bounds__(192, 3) void pade_pq3_kernel(FactorArgs args) {
                 are[t][r] = sl[off];
                 aim[t][r] = sl[PLANE + off];
             }
+    }
+    if (w == 0 && share == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // tile (1, 0)
+            const int off = (16 + 4 * r + q) * PITCH + c;
+            are[1][r] = sl[off];
+            aim[1][r] = sl[PLANE + off];
+        }
     }
 
     const double* bt = pade_table(order);
