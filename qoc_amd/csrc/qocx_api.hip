@@ -1346,6 +1346,11 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         // every Pade denominator of the evaluation diagonally dominant by the margin of qocx_lu5.h
         // (eps_m(theta) <= 0.40 for every order m at the host's bound theta of the step norm)
         la.all_dominant = (pade_eps_max(ctx->norm_bound) <= 0.40 && ctx->knob("lu_dpp", 1) != 0) ? 1 : 0;
+        // n <= 8: two consecutive steps of a seed as the diagonal blocks of one 16 x 16 tile through K1a and
+        // K1b (pade_pq8_kernel, inv16_dpp_kernel<1, true>); the sweeps and K3 see the usual images
+        const bool pack8 = ctx->nb == 1 && ctx->n <= 8 && inverse_sweep && !dense && la.all_dominant && !explicit_gen &&
+                           nodes == 1 && !m4lin && ctx->knob("pack8", 1) != 0;
+        fa.pack8 = la.pack8 = pack8 ? 1 : 0;
         la.redo = nullptr;
         la.fallbacks = ctx->lu_fallbacks.p;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
@@ -1485,7 +1490,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             }
             if (!fused_lu) {
                 time_begin(ctx, 4, cs);
-                qocx::launch_lu(ctx->nb, la, (size_t)bc * len, fs);
+                qocx::launch_lu(ctx->nb, la, la.pack8 ? (size_t)bc * ((len + 1) / 2) : (size_t)bc * len, fs);
                 time_end(ctx, cs);
             }
             if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], fs));
@@ -2619,7 +2624,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

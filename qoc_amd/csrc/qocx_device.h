@@ -54,6 +54,7 @@ struct FactorArgs {
     int lu_dpp = 0;            // fused K1b on the vector unit for provably diagonal pivots (qocx_lu5.h)
     int three_wave = 0;        // orders 3 / 5, Hermitian, step table: one tile per wave on three waves (qocx_pade3.hip)
     int four_steps = 0;     // three-wave K1a: the second halves of the factorisations four to a wave in a kernel of their own (knob "k1a_four"; 1: launch_pq launches it, 2: the caller)
+    int pack8 = 0;          // n <= 8, one-wave K1a: two consecutive steps of a seed as the diagonal blocks of ONE 16 x 16 tile (pade_pq8_kernel)
     int gen_share = 2;      // three-wave K1a: which tiles of the generator come from the LDS slot instead of the images (knob "k1a_share")
     // Step table (round 4, launch_step_table): `controls` is [B][nsteps][K] = the interpolated
     // controls u_k(t_mid) of every step (interp unused), and s_arr already holds every step's Pade
@@ -104,6 +105,7 @@ struct LuArgs {
     int dbg = 0;                 // timing experiment (dbg_skip bit 4): loads and stores only
     int inverse = 0;             // lu_img receives P^-1 instead of the factors (n <= 32; qocx_lu.h inv_body)
     int all_dominant = 0;        // every matrix of the launch is diagonally dominant by the margin of qocx_lu5.h
+    int pack8 = 0;         // inv16: the image of every EVEN step of the launch holds two steps (FactorArgs::pack8); the inverses go out unpacked
                                  // (the host's bound of the step norm says so): n <= 16 inverses four to a wave
     // 33 <= n <= 64, round 4: [matrices] flags of the MFMA factorisation (qocx_lu4m.hip) - 1: its
     // diagonal-pivot attempt was abandoned, lu4_kernel factors the matrix; nullptr: lu4_kernel factors

@@ -47,7 +47,34 @@ struct PqOut {
     int* s_out;       // squarings (and the Pade order: step_entry, qocx_wave.h)
     int* status;      // bit 1: non-finite norm
     int pade_policy;  // FactorArgs::pade_policy
+    // pack8 (n <= 8): the tile holds TWO steps as its diagonal 8 x 8 blocks (pade_pq8_kernel). P goes out
+    // as the packed tile (K1b unpacks the inverse), Q as the two padded images the sweeps read.
+    int pack8 = 0;
+    double2* q_img2 = nullptr;  // Q image of the second step, nullptr: there is none
+    int* s_out2 = nullptr;
 };
+
+// pack8: block (0,0) of the tile in the LDS slot -> img0, block (1,1) -> img1 (column-major 16 x 16 images
+// of 8 x 8 problems, the pad block the identity). Lane l: column l % 16, rows 4 (l / 16) .. + 3 of the image.
+__device__ __forceinline__ void lds_to_images8(const double* lre, const double* lim, double2* img0, double2* img1) {
+    typedef Geo<1> G;
+    const int lane = lane_id(), col = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        double2* img = blk == 0 ? img0 : img1;
+        if (img == nullptr) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = r0 + rr;
+            double2 v = make_double2(row == col ? 1.0 : 0.0, 0.0);
+            if (row < 8 && col < 8) {
+                const int off = (8 * blk + row) * G::PITCH + 8 * blk + col;
+                v = make_double2(lre[off], lim[off]);
+            }
+            img[col * 16 + row] = v;
+        }
+    }
+}
 
 template <int NB>
 struct PqLds {
@@ -223,7 +250,10 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
     }
     const double scale = ldexp(1.0, -sq);
     if (sq > 0) cmat_scale<NB>(a, scale);
-    if (lane == 0) *out.s_out = step_entry(sq, order);
+    if (lane == 0) {
+        *out.s_out = step_entry(sq, order);
+        if (out.s_out2 != nullptr) *out.s_out2 = step_entry(sq, order);
+    }
 
     const int q = lane >> 4, c = lane & 15;
     CMat<NB> u, v;
@@ -428,7 +458,12 @@ __device__ __forceinline__ void pade_pq_body(Gen gen, const PqOut& out, char* sm
         }
     cmat_to_lds<NB>(t, lre, lim);
     wave_sync();
-    lds_to_image<NB>(lre, lim, out.q_img);
+    if constexpr (NB == 1) {
+        if (out.pack8) lds_to_images8(lre, lim, out.q_img, out.q_img2);
+        else lds_to_image<NB>(lre, lim, out.q_img);
+    } else {
+        lds_to_image<NB>(lre, lim, out.q_img);
+    }
     wave_sync();
 #pragma unroll
     for (int ti = 0; ti < NB; ++ti)
@@ -499,6 +534,75 @@ __global__ __launch_bounds__(64) void pade_pq_kernel(FactorArgs args) {
             }
     };
     pade_pq_body<NB, HERM>(gen, out, smem);
+}
+
+// n <= 8: TWO consecutive steps of a seed per wave, as the diagonal 8 x 8 blocks of one 16 x 16 tile
+// ("n = 8 packs several matrices per wavefront"). A block-diagonal generator stays block
+// diagonal through every product of the Pade evaluation, its 1-norm is the larger of the two, so both
+// steps take the order and the squaring count of the larger one (the smaller one is evaluated by a
+// higher-order approximant than it needs: the same matrix to rounding) and the body runs unchanged - half
+// the workgroups for the same steps. grid (ceil(seg_len / 2), seeds).
+template <bool HERM>
+__global__ __launch_bounds__(64) void pade_pq8_kernel(FactorArgs args) {
+    typedef Geo<1> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int local = 2 * (int)blockIdx.x, b = blockIdx.y;
+    const int step = args.step0 + local;
+    const bool second = local + 1 < args.seg_len;
+    const int lane = lane_id(), q = lane >> 4, c = lane & 15;
+    const size_t m = (size_t)b * args.nsteps + step;
+    PqOut out;
+    out.q_img = args.q_img + m * G::MAT;
+    out.p_img = args.lu_img + m * G::MAT;   // the packed tile, at the even step
+    out.s_out = args.s_arr + m;
+    out.status = args.status;
+    out.pade_policy = args.pade_policy;
+    out.pack8 = 1;
+    out.q_img2 = second ? args.q_img + (m + 1) * G::MAT : nullptr;
+    out.s_out2 = second ? args.s_arr + m + 1 : nullptr;
+    const double* ctl_b = args.controls + (size_t)b * args.nc * args.K;
+    const double dt = args.dt;
+    const int K = args.K;
+    auto gen = [&](CMat<1>& a) {
+        // register r of lane (q, c): tile element (4 r + q, c); inside block blk = c / 8 it is element
+        // (row % 8, c % 8) of the generator of step + blk, which the C-image holds in register (row % 8) / 4
+        // of lane ((row % 8) % 4, c % 8); outside the diagonal blocks zero
+        const int blk = c >> 3;
+        const int st = step + ((blk == 1 && second) ? 1 : 0);
+        const StepInterp si = args.interp[st];
+        const size_t tsel = (args.nt == 1) ? 0 : (size_t)st;
+        const double2* h0 = args.h0_cimg + tsel * G::MAT;
+        const double2* g = args.g_cimg + tsel * K * G::MAT;
+        double hre[4], him[4];
+        int src[4];
+        bool on[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + q;
+            on[r] = (row >> 3) == blk && (blk == 0 || second);
+            const int lr = row & 7;
+            src[r] = (lr >> 2) * 64 + (lr & 3) * 16 + (c & 7);
+            const double2 e = h0[src[r]];
+            hre[r] = e.x;
+            him[r] = e.y;
+        }
+        for (int k = 0; k < K; ++k) {
+            const double uk = control_at(ctl_b, si, K, k);
+            const double2* gk = g + (size_t)k * G::MAT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 e = gk[src[r]];
+                hre[r] += uk * e.x;
+                him[r] += uk * e.y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.re[0][0][r] = on[r] ? dt * him[r] : 0.0;
+            a.im[0][0][r] = on[r] ? -dt * hre[r] : 0.0;
+        }
+    };
+    pade_pq_body<1, HERM>(gen, out, smem);
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
@@ -1729,7 +1833,12 @@ bool pq_second_pending(int nb, const FactorArgs& a, int nsteps) {
     return nb == 2 && !one_wave_pq() && a.three_wave && pq3_supports(a) && a.four_steps == 2 && pq3_parks(a, nsteps);
 }
 void launch_pq(int nb, const FactorArgs& a, int nsteps, int batch, hipStream_t st) {
-    if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
+    if (nb == 1 && a.pack8 && a.seg_len == nsteps) {
+        if (a.hermitian)
+            hipLaunchKernelGGL((pade_pq8_kernel<true>), dim3((nsteps + 1) / 2, batch), dim3(64), PqLds<1>::BYTES, st, a);
+        else
+            hipLaunchKernelGGL((pade_pq8_kernel<false>), dim3((nsteps + 1) / 2, batch), dim3(64), PqLds<1>::BYTES, st, a);
+    } else if (nb == 1) launch_pq_t<1>(a, nsteps, batch, st);
     else if (nb == 4) launch_pq4(a, nsteps, batch, st);
     else if (one_wave_pq()) launch_pq_t<2>(a, nsteps, batch, st);
     else if (a.three_wave && pq3_supports(a)) {
@@ -1752,8 +1861,11 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
     else launch_pq2_explicit(a_in, n, a, count, st);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
-    if (a.inverse && nb == 1 && a.all_dominant)
-        hipLaunchKernelGGL(inv16::inv16_dpp_kernel<1>, dim3((unsigned)((count + 3) / 4)), dim3(64), 0, st, a, (unsigned)count);
+    if (a.inverse && nb == 1 && a.all_dominant && a.pack8) {
+        // (count: pairs of steps; FactorArgs::pack8)
+        hipLaunchKernelGGL((inv16::inv16_dpp_kernel<1, true>), dim3((unsigned)((count + 3) / 4)), dim3(64), 0, st, a, (unsigned)count);
+    } else if (a.inverse && nb == 1 && a.all_dominant)
+        hipLaunchKernelGGL((inv16::inv16_dpp_kernel<1, false>), dim3((unsigned)((count + 3) / 4)), dim3(64), 0, st, a, (unsigned)count);
     else if (a.inverse && nb == 1) hipLaunchKernelGGL(inv_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (a.inverse && nb == 2) hipLaunchKernelGGL(inv_kernel<2>, dim3((unsigned)count), dim3(64), 0, st, a);
     else if (nb == 1) hipLaunchKernelGGL(lu_kernel<1>, dim3((unsigned)count), dim3(64), 0, st, a);

@@ -350,13 +350,19 @@ __device__ __forceinline__ void pivots(Block& x, double& myrr, double& myri, int
 
 // work item w -> matrix (w / seg_len) * nsteps + step0 + w % seg_len; the image (column-major 16 x 16)
 // is inverted in place
-template <int NB>  // (a template, NB = 1 only: the header goes into several translation units)
+// PACK8 (LuArgs::pack8, n <= 8): work item w is a PAIR of steps - seed w / pairs, steps step0 + 2 (w %
+// pairs) and the next one, pairs = ceil(seg_len / 2) - whose denominators K1a left as the diagonal blocks
+// of the tile in the even step's image; the inverse of a block-diagonal matrix is block diagonal, and its
+// blocks go out as the two padded 16 x 16 images the sweeps read (pad block: the identity).
+template <int NB, bool PACK8>  // (a template, NB = 1 only: the header goes into several translation units)
 __global__ __launch_bounds__(64) void inv16_dpp_kernel(LuArgs args, unsigned count) {
     static_assert(NB == 1, "one MFMA tile");
     const int lane = lane_id(), d = lane >> 4, j = lane & 15;
     const unsigned w = min(4u * blockIdx.x + (unsigned)d, count - 1u);
     const bool live = 4u * blockIdx.x + (unsigned)d < count;
-    const size_t m = (size_t)(w / args.seg_len) * args.nsteps + args.step0 + w % args.seg_len;
+    const unsigned pairs = PACK8 ? (unsigned)(args.seg_len + 1) / 2u : 1u;
+    const size_t m = PACK8 ? (size_t)(w / pairs) * args.nsteps + args.step0 + 2 * (w % pairs)
+                           : (size_t)(w / args.seg_len) * args.nsteps + args.step0 + w % args.seg_len;
     double2* img = args.lu_img + m * 256;
     Block x;
 #pragma unroll
@@ -367,10 +373,32 @@ __global__ __launch_bounds__(64) void inv16_dpp_kernel(LuArgs args, unsigned cou
     }
     double myrr = 0.0, myri = 0.0;
     pivots(x, myrr, myri, j, std::make_integer_sequence<int, 16>{});
-    if (live) {
+    if (live && !PACK8) {
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             img[c * 16 + j] = make_double2(x.re[c] * myrr - x.im[c] * myri, x.re[c] * myri + x.im[c] * myrr);
+    }
+    if (live && PACK8) {
+        // lane j holds row j of the tile's inverse: row j % 8 of block j / 8, i.e. of step m + j / 8; it writes
+        // that row and the pad row 8 + j % 8 of the step's image
+        const int blk = j >> 3, lr = j & 7;
+        const bool second = 2 * (int)(w % pairs) + 1 < args.seg_len;
+        if (blk == 0 || second) {
+            double2* out = args.lu_img + (m + blk) * 256;
+            double2 row[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {  // (blk is lane-dependent: a select per column of the block)
+                const double xr = blk ? x.re[8 + cc] : x.re[cc], xi = blk ? x.im[8 + cc] : x.im[cc];
+                row[cc] = make_double2(xr * myrr - xi * myri, xr * myri + xi * myrr);
+            }
+            // (block 0 overwrites the packed tile it has just read - every lane of this row of 16 lanes has
+            // its row in registers - block 1 the image of the odd step)
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                out[cc * 16 + lr] = cc < 8 ? row[cc] : make_double2(0.0, 0.0);
+                out[cc * 16 + 8 + lr] = make_double2(cc == 8 + lr ? 1.0 : 0.0, 0.0);
+            }
+        }
     }
 }
 

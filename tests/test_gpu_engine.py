@@ -223,6 +223,44 @@ def test_chunked_equals_unchunked(engine):
     engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("n, N, non_herm", [(8, 41, False), (8, 40, False), (5, 24, False), (2, 9, False),
+                                            (7, 33, True)])
+def test_two_steps_to_a_tile_at_n_up_to_8(engine, n, N, non_herm):
+    """
+    Round 5 (knob "pack8", on): at n <= 8 K1a and K1b take two consecutive steps of a seed as the diagonal
+    blocks of ONE 16 x 16 tile (pade_pq8_kernel, inv16_dpp_kernel<1, true>). A
+    block-diagonal generator stays block diagonal through the Pade evaluation and through the inverse; the
+    pair shares the order and squaring count of its larger member. Against one step per tile: equal to
+    rounding (a step may be evaluated by a higher-order approximant than it needs), and bit for bit where
+    both steps of every pair choose the same order anyway; odd and even step counts, time segments whose
+    lengths are odd, control magnitudes that put neighbouring steps on different orders, a non-Hermitian
+    generator. Reference: qoc/standard/functions/expm.py:210-252.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_random("pack8_n%d" % n, n=n, N=N, seeds=3, h_seed=7700 + n, S=1, K=1, Nc=N,
+                                 dt=0.05, sigma=0.6)
+    case.h0 = case.h0 * 0.1  # (a small drift: the steps of the last control array alternate between orders 3 and 5)
+    if non_herm:
+        rng = np.random.default_rng(7800 + n)
+        case.h0 = case.h0 - 0.2j * np.diag(rng.uniform(0, 1, n))
+    gh.setup_engine(engine, case)
+    # (the last control array swings between tiny and large: neighbouring steps on different orders)
+    swing = case.controls[0] * np.where((np.arange(case.controls[0].shape[0]) // 2) % 2 == 0, 0.01, 2.5)[:, None]
+    u = np.concatenate([case.controls, swing[None]])
+    try:
+        for pipe in (1, 3, 0):
+            engine.set_pipeline(pipe)
+            engine.set_knob("pack8", 0)
+            ref = engine.evaluate(u, True)
+            engine.set_knob("pack8", 1)
+            out = engine.evaluate(u, True)
+            for a, b in zip(ref, out):
+                assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(a))), (pipe,)
+    finally:
+        engine.set_knob("pack8", 1)
+        engine.set_pipeline(0)
+
+
 @pytest.mark.parametrize("n, dt, scale, non_herm", [(32, 0.05, 1.0, False), (20, 0.4, 6.0, False),
                                                     (27, 0.3, 3.0, True), (8, 0.05, 1.0, False),
                                                     (13, 1.0, 6.0, True)])
