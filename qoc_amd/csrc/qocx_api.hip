@@ -1213,7 +1213,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ctx->last_chunk = bc;
         int nseg = ctx->pipe_user > 0 ? ctx->pipe_user
                                       : ((size_t)bc * nsteps >= 16384 && nsteps >= 64 ? 8 : 1);
-        if (ctx->pipe_user <= 0 && nseg == 1 && latency && unit && nsteps >= 64) nseg = 4;
+        // (one control set, two-sided: TWO segments - the forward sweep takes the first as soon as it is
+        // factored, the adjoint sweep the second, then they swap; every further segment is two more launch
+        // latencies on the chain: configs[1] 0.535 -> 0.505 ms, dim 32 x 1000 steps 1.54 -> 1.50)
+        if (ctx->pipe_user <= 0 && nseg == 1 && latency && unit && nsteps >= 64) nseg = 2;
         nseg = std::max(1, std::min(std::min(nseg, max_seg), nsteps));
         hipStream_t ss = (nseg == 1) ? cs : ctx->sweep_streams[0];
         // segment boundaries; the last two segments are shorter, because the forward sweep of the
@@ -1222,7 +1225,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         // targets from the LAST segment while the forward sweep propagates the states from the
         // FIRST one; the compute stream factors the segments from both ends towards the middle,
         // and K3 follows from the middle outwards once both sweeps have crossed a segment.
-        const bool bidir = unit && nseg >= 4 && ctx->knob("bidir", 1) && (int)ctx->sweep_streams.size() >= 2;
+        const bool bidir = unit && nseg >= (int)ctx->knob("bidir_min_segments", 2) && ctx->knob("bidir", 1) && (int)ctx->sweep_streams.size() >= 2;
         std::vector<int> lo(nseg + 1);
         {
             std::vector<double> wgt(nseg, 1.0);
@@ -2624,7 +2627,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 // the same numbers to rounding) and the diagnostic ones that exist in libqocx_diag.so only
 // (qocx_diag.h): timing experiments that return garbage and the stamped kernel builds.
 static const char* const kVariantKnobs[] = {
-    "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "unit_adjoint",
+    "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
     "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};

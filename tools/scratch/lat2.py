@@ -4,20 +4,26 @@ import numpy as np
 import bench
 from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 e = Engine(0)
-n, steps = 8, 500
-a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128); ad = a.conj().T
-h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
-g = [a + ad, 1j * (a - ad)]
-psi0 = np.eye(n, dtype=np.complex128)[:1]; target = np.eye(n, dtype=np.complex128)[1:2]
+n, steps = int(sys.argv[1]), int(sys.argv[2])
+if n == 8:
+    a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128); ad = a.conj().T
+    h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
+    g = [a + ad, 1j * (a - ad)]
+    psi0 = np.eye(n, dtype=np.complex128)[:1]; target = np.eye(n, dtype=np.complex128)[1:2]
+else:
+    bench.DIM = n
+    h0, g, psi0, target = bench.make_problem()
 e.set_schroedinger_problem(n, 1, bench.K_CTRL, steps + 1, steps + 1, bench.DT * steps, h0[None], np.stack(g)[None], psi0,
     costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
 u = 0.1 * np.random.default_rng(77).standard_normal((1, steps + 1, bench.K_CTRL))
 e.set_knob("latency", 1); e.set_knob("sweep_impl", 3)
-for pipe, outer in ((0, 3), (0, 1), (4, 1), (6, 1), (8, 1), (0, 3), (0, 1)):
-    e.set_pipeline(pipe); e.set_knob("k3_split_outer", outer)
-    for _ in range(5): e.evaluate(u, True)
+ref = None
+for pipe, mins in ((0, 4), (2, 2), (3, 2), (6, 2), (8, 2), (0, 4), (2, 2)):
+    e.set_pipeline(pipe); e.set_knob("bidir_min_segments", mins)
+    for _ in range(5): out = e.evaluate(u, True)
     e.synchronize()
     t0 = time.perf_counter()
-    for _ in range(300): e.evaluate(u, True)
+    for _ in range(300): out = e.evaluate(u, True)
     wall = (time.perf_counter() - t0) / 300
-    print(json.dumps(dict(pipeline=pipe, k3_split_outer=outer, ms=round(wall * 1e3, 4))), flush=True)
+    if ref is None: ref = out
+    print(json.dumps(dict(pipeline=pipe, bidir_min_segments=mins, ms=round(wall * 1e3, 4))), "identical", all(np.array_equal(a, b) for a, b in zip(ref, out)), flush=True)
