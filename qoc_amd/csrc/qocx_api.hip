@@ -1354,6 +1354,10 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         const bool pack8 = ctx->nb == 1 && ctx->n <= 8 && inverse_sweep && !dense && la.all_dominant && !explicit_gen &&
                            nodes == 1 && !m4lin && ctx->knob("pack8", 1) != 0;
         fa.pack8 = la.pack8 = pack8 ? 1 : 0;
+        // One control set at a time (latency mode), inverse-image sweep: K1b's sibling umul_kernel leaves the
+        // propagator itself in the Q image; the sweeps apply ONE matrix per sub-step, the adjoint sweep hands
+        // lambda' to K3, which forms x = P^-H lambda' from the P^-1 image (knob "sweep_umode").
+        const bool umode = latency && inverse_sweep && !dense && ctx->nb <= 2 && ctx->knob("sweep_umode", 1) != 0;
         la.redo = nullptr;
         la.fallbacks = ctx->lu_fallbacks.p;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
@@ -1373,6 +1377,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         sa.q_img = fa.q_img; sa.lu_img = fa.lu_img; sa.dinv = la.dinv;
         sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
         sa.psi0 = ctx->psi0.p;
+        sa.umode = umode ? 1 : 0;
         sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
         sa.n = ctx->knob("sweep_nine", 1) ? ctx->n : 0;
         sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
@@ -1494,6 +1499,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             if (!fused_lu) {
                 time_begin(ctx, 4, cs);
                 qocx::launch_lu(ctx->nb, la, la.pack8 ? (size_t)bc * ((len + 1) / 2) : (size_t)bc * len, fs);
+                // one control set: the propagator U = P^-1 Q in place of Q, one product per sweep sub-step
+                if (umode) qocx::launch_umul(ctx->nb, la, fa.q_img, (size_t)bc * len, fs);
                 time_end(ctx, cs);
             }
             if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], fs));
@@ -1546,6 +1553,8 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         ka.g_timg = m4lin ? ctx->ge_timg.p : ctx->g_timg.p;
         ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.S = S;
         ka.lds_pad = (int)ctx->knob("k3_lds_pad", 0);
+        ka.umode = umode ? 1 : 0;
+        ka.pinv_img = fa.lu_img;
         ka.direct = fa.direct;
         ka.n = ctx->n;
         ka.dt = ctx->dt; ka.s_arr = ctx->s_arr.p;
@@ -2630,7 +2639,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

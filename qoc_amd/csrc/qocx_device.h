@@ -138,6 +138,8 @@ struct SweepArgs {
     int onebuf = 0;       // one state: one operand set in LDS; 1: one seed per workgroup, 2: two
     int one_state = 0;    // one state, n <= 32: the dedicated kernel of qocx_sweep1.hip (knob "sweep_one")
     int ring2 = 0;        // sweep1, n > 16: two operand sets in LDS, every fetch a whole step ahead (70 KiB per seed)
+    int umode = 0;        // sweepi: q_img holds the propagator U = P^-1 Q (launch_umul): ONE product per sub-step;
+                          // the adjoint leaves lambda' in `xs` and K3 forms x = P^-H lambda' (KrylovArgs::umode)
     int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
     int dbg;              // sweep3 timing diagnostics (results are garbage): bit 0 no inversion,
                           // bit 1 no solves, bit 2 no LU fetch, bit 3 no Q fetch, bit 4 no Q touch
@@ -166,6 +168,8 @@ struct SweepArgs {
 };
 
 struct KrylovArgs {
+    int umode = 0;                       // `xs` holds lambda' (SweepArgs::umode): x = P^-H lambda' is formed here from pinv_img
+    const double2* pinv_img = nullptr;   // [B][nsteps] column-major P^-1 images (the LU buffer in inverse mode)
     int lds_pad = 0;  // extra dynamic LDS per workgroup (bytes): fewer K3 waves per CU beside the tail sweeps (knob "k3_lds_pad")
     const double* controls;
     const StepInterp* interp;
@@ -343,6 +347,8 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
 void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 bool pq3_supports(const FactorArgs& a);
 void launch_pq3(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
+// q_img := P^-1 Q of `count` steps (work item w -> seed w / seg_len, step step0 + w % seg_len), n <= 32
+void launch_umul(int nb, const LuArgs& a, double2* q_img, size_t count, hipStream_t st);
 bool pq3_parks(const FactorArgs& a, int nsteps);
 void launch_pq3_second(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 // true: launch_pq left the second halves of the factorisations to launch_pq3_second (FactorArgs::four_steps == 2)

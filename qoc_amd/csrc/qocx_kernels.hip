@@ -605,6 +605,53 @@ __global__ __launch_bounds__(64) void pade_pq8_kernel(FactorArgs args) {
     pade_pq_body<1, HERM>(gen, out, smem);
 }
 
+// U = P^-1 Q, in place of Q (round 5, one control set at a time: the sweep of such an evaluation is a chain
+// of matrix-vector products and nothing else, qocx_sweepi.hip - with the propagator itself in the image a
+// sub-step is ONE product instead of two). One wave per step; P^-1 is the left operand (LDS planes), Q the
+// right one (C layout), both read from their column-major images.
+template <int NB>
+__global__ __launch_bounds__(64) void umul_kernel(LuArgs args, double2* q_all, unsigned count) {
+    typedef Geo<NB> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lre = reinterpret_cast<double*>(smem);
+    double* lim = lre + G::PLANE;
+    double* lsum = lim + G::PLANE;
+    const unsigned w = blockIdx.x;
+    if (w >= count) return;
+    const size_t m = (size_t)(w / args.seg_len) * args.nsteps + args.step0 + w % args.seg_len;
+    const double2* pinv = args.lu_img + m * G::MAT;
+    double2* qimg = q_all + m * G::MAT;
+    const int q = lane_id() >> 4, c = lane_id() & 15;
+    CMat<NB> a, b;
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // element (16 ti + 4 r + q, 16 tj + c) of a column-major image
+                const int at = (16 * tj + c) * G::NP + 16 * ti + 4 * r + q;
+                const double2 e = pinv[at], f = qimg[at];
+                a.re[ti][tj][r] = e.x;
+                a.im[ti][tj][r] = e.y;
+                b.re[ti][tj][r] = f.x;
+                b.im[ti][tj][r] = f.y;
+            }
+    cmat_to_lds3<NB>(a, lre, lim, lsum);
+    wave_sync();
+    CAcc3<NB> acc;
+    acc3_zero<NB>(acc);
+    zgemm3_acc<NB, false>(acc, lre, lim, lsum, [&](int kk, int tj, double& bre, double& bim) {
+        bre = b.re[kk >> 2][tj][kk & 3];
+        bim = b.im[kk >> 2][tj][kk & 3];
+    });
+    CMat<NB> u;
+    acc3_finish<NB>(u, acc);
+    wave_sync();
+    cmat_to_lds<NB>(u, lre, lim);
+    wave_sync();
+    lds_to_image<NB>(lre, lim, qimg);
+}
+
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
 // the form a Magnus M4/M6 generator kernel would feed).
 template <int NB, bool HERM>
@@ -1446,7 +1493,25 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     for (int sub = 0; sub < nsub; ++sub)
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
-            const double2 x = xs_b[(((size_t)tx + sub) * S + s) * NP + i];
+            double2 x = xs_b[(((size_t)tx + sub) * S + s) * NP + i];
+            if (args.umode) {
+                // the adjoint sweep left lambda' (its cotangent BEFORE the step): x = P^-H lambda', from the
+                // column-major image of P^-1 - lane (h, i): elements (cc H + h, i) of column i
+                const double2* pin = args.pinv_img + m * G::MAT + (size_t)i * NP;
+                vv[i] = x;
+                wave_sync();
+                double sr = 0, si_ = 0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const double2 e = pin[cc * H + h];
+                    const double2 l = vv[cc * H + h];
+                    sr = fma(e.y, l.y, fma(e.x, l.x, sr));     // conj(e) * l
+                    si_ = fma(-e.y, l.x, fma(e.x, l.y, si_));
+                    column_fence<NB>(cc);
+                }
+                x = make_double2(sum_groups<NB>(sr), sum_groups<NB>(si_));
+                wave_sync();
+            }
             chains(are, aim, hre, him, x, states_b[(t * S + s) * NP + i],
                    states_b[((t + 1) * S + s) * NP + i], abr, abi);
         }
@@ -1859,6 +1924,13 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
     else if (nb == 4) launch_pq4_explicit(a_in, n, a, count, st);
     else if (one_wave_pq()) launch_pq_explicit_t<2>(a_in, n, a, count, st);
     else launch_pq2_explicit(a_in, n, a, count, st);
+}
+void launch_umul(int nb, const LuArgs& a, double2* q_img, size_t count, hipStream_t st) {
+    if (count == 0) return;
+    if (nb == 1)
+        hipLaunchKernelGGL(umul_kernel<1>, dim3((unsigned)count), dim3(64), PqLds<1>::BYTES, st, a, q_img, (unsigned)count);
+    else
+        hipLaunchKernelGGL(umul_kernel<2>, dim3((unsigned)count), dim3(64), PqLds<2>::BYTES, st, a, q_img, (unsigned)count);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     if (a.inverse && nb == 1 && a.all_dominant && a.pack8) {

@@ -115,6 +115,9 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
     // Both roles walk the same steps and leave at the same one when the sub-step capacity runs
     // out: the test depends on slot counts only, which every wave keeps.
     auto issue = [&](size_t m, int ring, bool adjoint) {
+        // (umode, two fetch waves: the second one's pieces are the P^-1 image, which nobody reads - it keeps
+        // walking the barriers)
+        if (C::LOADERS == 2 && args.umode && role == 2) return;
 #pragma unroll
         for (int jj = 0; jj < C::PER_LOADER; ++jj) {
             const int j = (role - 1) * C::PER_LOADER + jj, jl = j % C::PIECES;
@@ -213,10 +216,12 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
             for (int sub = 0; sub < nsub; ++sub) {
                 for (int s = 0; s < S; ++s) {
                     double zre, zim;
-                    matvec<NB, false>(qc, vecs + s * NP, lane, h, zre, zim);  // z = Q psi
-                    tmp[i] = make_double2(zre, zim);
-                    wave_sync();
-                    matvec<NB, false>(pc, tmp, lane, h, zre, zim);            // psi' = P^-1 z
+                    matvec<NB, false>(qc, vecs + s * NP, lane, h, zre, zim);  // z = Q psi (umode: psi' = U psi)
+                    if (!args.umode) {
+                        tmp[i] = make_double2(zre, zim);
+                        wave_sync();
+                        matvec<NB, false>(pc, tmp, lane, h, zre, zim);        // psi' = P^-1 z
+                    }
                     wave_sync();
                     const double2 p = make_double2(zre, zim);
                     vecs[s * NP + i] = p;
@@ -295,14 +300,20 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
         for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
             for (int s = 0; s < S; ++s) {
-                double xre, xim;
-                matvec<NB, true>(pc, lam + s * NP, lane, h, xre, xim);  // x = P^-H lambda'
-                const double2 x = make_double2(xre, xim);
-                tmp[i] = x;
-                if (g0) xs_b[((size_t)slot * S + s) * NP + i] = x;
-                wave_sync();
                 double yre, yim;
-                matvec<NB, true>(qc, tmp, lane, h, yre, yim);            // lambda = Q^H x
+                if (args.umode) {
+                    // lambda = U^H lambda'; K3 forms x = P^-H lambda' from what goes to `xs` here
+                    if (g0) xs_b[((size_t)slot * S + s) * NP + i] = lam[s * NP + i];
+                    matvec<NB, true>(qc, lam + s * NP, lane, h, yre, yim);
+                } else {
+                    double xre, xim;
+                    matvec<NB, true>(pc, lam + s * NP, lane, h, xre, xim);  // x = P^-H lambda'
+                    const double2 x = make_double2(xre, xim);
+                    tmp[i] = x;
+                    if (g0) xs_b[((size_t)slot * S + s) * NP + i] = x;
+                    wave_sync();
+                    matvec<NB, true>(qc, tmp, lane, h, yre, yim);            // lambda = Q^H x
+                }
                 wave_sync();
                 lam[s * NP + i] = make_double2(yre, yim);
                 wave_sync();

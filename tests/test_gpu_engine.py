@@ -223,6 +223,51 @@ def test_chunked_equals_unchunked(engine):
     engine.set_pipeline(0)
 
 
+@pytest.mark.parametrize("n, S, dt, scale, non_herm", [(8, 1, 0.05, 1.0, False), (16, 2, 0.4, 4.0, False),
+                                                       (32, 1, 0.05, 1.0, False), (27, 3, 0.3, 3.0, True),
+                                                       (5, 1, 1.0, 6.0, True)])
+def test_propagator_image_sweep_of_one_control_set(engine, n, S, dt, scale, non_herm):
+    """
+    Round 5 (knob "sweep_umode", on in latency mode): with one control set at a time the inverse-image sweep
+    (qocx_sweepi.hip) applies the propagator U = P^-1 Q itself - umul_kernel leaves it in the Q image - ONE
+    matrix-vector product per sub-step instead of two; the adjoint sweep hands lambda' to K3, which forms
+    x = P^-H lambda' from the P^-1 image. Against the two-product form: cost, gradient and final states
+    equal to rounding - unit adjoint and the forward -> cost -> adjoint order, step costs, several states,
+    squarings (dt * scale large), row exchanges (non-Hermitian generator), one and two MFMA tiles, one
+    launch and time segments. Reference: qoc/core/schroedingerdiscrete.py:393-436, expm.py:246-250.
+    """
+    from tests import gpu_helpers as gh
+    case = cases_mod.case_random("umode_n%d" % n, n=n, N=31, seeds=1, h_seed=7900 + n, S=S, K=2, Nc=11, dt=dt,
+                                 sigma=0.6)
+    case.h0 = case.h0 * scale
+    if non_herm:
+        rng = np.random.default_rng(7950 + n)
+        case.h0 = case.h0 - 0.3j * np.diag(rng.uniform(0, 1, n)) + 1.0 * np.roll(np.eye(n), 1, axis=0)
+    rng = np.random.default_rng(7960 + n)
+    forb = np.stack([cases_mod.column_states(cases_mod.random_unitary(rng, n)[:, :2]) for _ in range(S)])
+    variants = [(case.cost_specs, 1),
+                (case.cost_specs + [("ForbidStates", dict(forbidden_states=forb, system_eval_count=case.N,
+                                                          cost_eval_step=3, cost_multiplier=0.3))], 3)]
+    try:
+        engine.set_knob("latency", 1)
+        for specs, ces in variants:
+            case.cost_specs, case.cost_eval_step = specs, ces
+            gh.setup_engine(engine, case)
+            u = np.asarray(case.controls[:1])
+            for pipe in (0, 1, 3):
+                engine.set_pipeline(pipe)
+                engine.set_knob("sweep_umode", 0)
+                ref = engine.evaluate(u, True)
+                engine.set_knob("sweep_umode", 1)
+                out = engine.evaluate(u, True)
+                for a, b in zip(ref, out):
+                    assert np.max(np.abs(a - b)) <= 2e-11 * max(1.0, np.max(np.abs(a))), (ces, pipe)
+    finally:
+        engine.set_knob("latency", 0)
+        engine.set_knob("sweep_umode", 1)
+        engine.set_pipeline(0)
+
+
 @pytest.mark.parametrize("n, N, non_herm", [(8, 41, False), (8, 40, False), (5, 24, False), (2, 9, False),
                                             (7, 33, True)])
 def test_two_steps_to_a_tile_at_n_up_to_8(engine, n, N, non_herm):

@@ -1,0 +1,21 @@
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import bench
+from qoc_amd.engine import Engine, COST_TARGET_COHERENT
+e = Engine(0)
+n, steps = 8, 500
+a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128); ad = a.conj().T
+h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
+g = [a + ad, 1j * (a - ad)]
+psi0 = np.eye(n, dtype=np.complex128)[:1]; target = np.eye(n, dtype=np.complex128)[1:2]
+e.set_schroedinger_problem(n, 1, bench.K_CTRL, steps + 1, steps + 1, bench.DT * steps, h0[None], np.stack(g)[None], psi0,
+    costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+u = 0.1 * np.random.default_rng(77).standard_normal((1, steps + 1, bench.K_CTRL))
+e.set_knob("latency", 1); e.set_knob("sweep_impl", 3)
+for _ in range(5): e.evaluate(u, True)
+e.set_timing(True)
+for _ in range(3): e.evaluate(u, True)
+NAMES = {0: "K1a", 1: "sweep", 2: "K3", 3: "scatter", 4: "K1b", 5: "lindblad"}
+for w, a_, b_ in sorted(e.timeline(), key=lambda r: r[1]):
+    print("{:8s} {:7.3f} -> {:7.3f}  ({:.3f})".format(NAMES[int(w)], a_, b_, b_ - a_))
