@@ -1635,12 +1635,18 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
             // two factor streams: the second one starts behind everything the compute stream has
             // enqueued so far (the step table, the previous evaluation's tail)
             const bool two_k1a = fused_lu && ctx->lu_stream != nullptr && ctx->knob("k1a_streams", 1) >= 2;
+            // (one control set: 0.478 -> 0.456 ms at configs[1], 1.10 -> 1.05 ms at dim 32 x 1000 steps; the
+            // 256-seed evaluation, whose factor launches are what it waits for: 7.87 -> 8.00 ms)
+            const bool adj_first = ctx->knob("bidir_adj_first", (size_t)bc * nsteps < 16384 ? 1 : 0) != 0;
             if (two_k1a) {
                 HIP_TRY(hipEventRecord(ctx->ev_pq[nseg], cs));
                 HIP_TRY(hipStreamWaitEvent(ctx->lu_stream, ctx->ev_pq[nseg], 0));
             }
             for (int t = 0; t < nseg; ++t) {
-                const int i = (t % 2 == 0) ? t / 2 : nseg - 1 - t / 2;
+                // (the adjoint sweep is the slower of the two - it gathers its images transposed -: ITS side
+                // first, knob "bidir_adj_first")
+                const bool back = adj_first ? (t % 2 == 0) : (t % 2 == 1);
+                const int i = back ? nseg - 1 - t / 2 : t / 2;
                 QOCX_STEP(factor_segment(i, (two_k1a && (t % 2 == 1)) ? ctx->lu_stream : cs));
                 factored[i] = 1;
                 in_tail = (t == nseg - 1);
@@ -2636,7 +2642,7 @@ int qocx_eval_lindblad(qocx_ctx* ctx, int32_t batch, const double* controls, int
 // the same numbers to rounding) and the diagnostic ones that exist in libqocx_diag.so only
 // (qocx_diag.h): timing experiments that return garbage and the stamped kernel builds.
 static const char* const kVariantKnobs[] = {
-    "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "unit_adjoint",
+    "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "bidir_adj_first", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
     "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};

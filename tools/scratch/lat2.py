@@ -19,11 +19,11 @@ u = 0.1 * np.random.default_rng(77).standard_normal((1, steps + 1, bench.K_CTRL)
 e.set_knob("latency", 1); e.set_knob("sweep_impl", 3)
 ref = None
 for um in (0, 1, 0, 1):
-    e.set_knob("sweep_umode", um)
+    e.set_knob("bidir_adj_first", um)
     for _ in range(5): out = e.evaluate(u, True)
     e.synchronize()
     t0 = time.perf_counter()
     for _ in range(300): out = e.evaluate(u, True)
     wall = (time.perf_counter() - t0) / 300
     if ref is None: ref = out
-    print(json.dumps(dict(sweep_umode=um, ms=round(wall * 1e3, 4))), "max diff", [float(np.max(np.abs(a - b))) for a, b in zip(ref, out)], "scale", float(np.max(np.abs(ref[1]))), flush=True)
+    print(json.dumps(dict(bidir_adj_first=um, ms=round(wall * 1e3, 4))), "max diff", [float(np.max(np.abs(a - b))) for a, b in zip(ref, out)], "scale", float(np.max(np.abs(ref[1]))), flush=True)

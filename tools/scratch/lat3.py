@@ -4,11 +4,15 @@ import numpy as np
 import bench
 from qoc_amd.engine import Engine, COST_TARGET_COHERENT
 e = Engine(0)
-n, steps = 8, 500
-a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128); ad = a.conj().T
-h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
-g = [a + ad, 1j * (a - ad)]
-psi0 = np.eye(n, dtype=np.complex128)[:1]; target = np.eye(n, dtype=np.complex128)[1:2]
+n, steps = int(sys.argv[1]), int(sys.argv[2])
+if n == 8:
+    a = np.diag(np.sqrt(np.arange(1, n)), 1).astype(np.complex128); ad = a.conj().T
+    h0 = 2 * np.pi * 0.05 * ad @ a + 0.5 * 2 * np.pi * (-0.2) * ad @ ad @ a @ a
+    g = [a + ad, 1j * (a - ad)]
+    psi0 = np.eye(n, dtype=np.complex128)[:1]; target = np.eye(n, dtype=np.complex128)[1:2]
+else:
+    bench.DIM = n
+    h0, g, psi0, target = bench.make_problem()
 e.set_schroedinger_problem(n, 1, bench.K_CTRL, steps + 1, steps + 1, bench.DT * steps, h0[None], np.stack(g)[None], psi0,
     costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
 u = 0.1 * np.random.default_rng(77).standard_normal((1, steps + 1, bench.K_CTRL))
