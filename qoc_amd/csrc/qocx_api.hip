@@ -220,6 +220,7 @@ struct qocx_ctx {
     size_t pin_controls_cap = 0;
     DevBuf<double2> final_out, step_states;
     DevBuf<double2> q_img, lu_img, dinv, states, xs;
+    DevBuf<double2> qt_img;  // one control set (sweep_umode): the transposed propagator images
     DevBuf<int> perm, iperm, s_arr, offs, status;
     DevBuf<int> lu_fallbacks;  // [1] matrices that left the diagonal-pivot MFMA factorisation (qocx_lu_fallbacks)
     DevBuf<int> lu_redo;  // 33 <= n <= 64: matrices the MFMA factorisation hands to the general one (LuArgs::redo)
@@ -578,7 +579,7 @@ int qocx_destroy(qocx_ctx* ctx) {
     ctx->gen_rm.release(); ctx->genbar_rm.release(); ctx->stamps.release();
     DevBuf<double2>* b2[] = {&ctx->h0_cimg, &ctx->g_cimg, &ctx->h0_rimg, &ctx->g_rimg, &ctx->h0_timg,
                              &ctx->g_timg, &ctx->psi0, &ctx->cost_vectors, &ctx->final_out,
-                             &ctx->step_states, &ctx->q_img, &ctx->lu_img, &ctx->dinv,
+                             &ctx->step_states, &ctx->q_img, &ctx->qt_img, &ctx->lu_img, &ctx->dinv,
                              &ctx->states, &ctx->xs};
     for (auto* b : b2) b->release();
     DevBuf<double>* b1[] = {&ctx->weight, &ctx->controls, &ctx->cost_out, &ctx->grads, &ctx->gstep,
@@ -1358,6 +1359,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         // propagator itself in the Q image; the sweeps apply ONE matrix per sub-step, the adjoint sweep hands
         // lambda' to K3, which forms x = P^-H lambda' from the P^-1 image (knob "sweep_umode").
         const bool umode = latency && inverse_sweep && !dense && ctx->nb <= 2 && ctx->knob("sweep_umode", 1) != 0;
+        if (umode && ctx->qt_img.ensure((size_t)chunk * nsteps * mat)) return QOCX_ERR_HIP;
         la.redo = nullptr;
         la.fallbacks = ctx->lu_fallbacks.p;
         if (ctx->nb == 4 && ctx->knob("lu_mfma", 1) != 0) {  // qocx_lu4m.hip in front of lu4_kernel
@@ -1378,6 +1380,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         sa.perm = la.perm; sa.iperm = la.iperm; sa.s_arr = fa.s_arr;
         sa.psi0 = ctx->psi0.p;
         sa.umode = umode ? 1 : 0;
+        sa.qt_img = umode ? ctx->qt_img.p : nullptr;
         sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces; sa.want_grad = want_grad;
         sa.n = ctx->knob("sweep_nine", 1) ? ctx->n : 0;
         sa.has_step_costs = ctx->has_step_costs; sa.slot_cap = ctx->slot_cap;
@@ -1500,7 +1503,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
                 time_begin(ctx, 4, cs);
                 qocx::launch_lu(ctx->nb, la, la.pack8 ? (size_t)bc * ((len + 1) / 2) : (size_t)bc * len, fs);
                 // one control set: the propagator U = P^-1 Q in place of Q, one product per sweep sub-step
-                if (umode) qocx::launch_umul(ctx->nb, la, fa.q_img, (size_t)bc * len, fs);
+                if (umode) qocx::launch_umul(ctx->nb, la, fa.q_img, ctx->qt_img.p, (size_t)bc * len, fs);
                 time_end(ctx, cs);
             }
             if (nseg > 1) HIP_TRY(hipEventRecord(ctx->ev_factored[i], fs));

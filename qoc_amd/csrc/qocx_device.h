@@ -138,6 +138,7 @@ struct SweepArgs {
     int onebuf = 0;       // one state: one operand set in LDS; 1: one seed per workgroup, 2: two
     int one_state = 0;    // one state, n <= 32: the dedicated kernel of qocx_sweep1.hip (knob "sweep_one")
     int ring2 = 0;        // sweep1, n > 16: two operand sets in LDS, every fetch a whole step ahead (70 KiB per seed)
+    const double2* qt_img = nullptr;  // umode: U^T images (launch_umul) - the adjoint sweep copies them straight instead of gathering
     int umode = 0;        // sweepi: q_img holds the propagator U = P^-1 Q (launch_umul): ONE product per sub-step;
                           // the adjoint leaves lambda' in `xs` and K3 forms x = P^-H lambda' (KrylovArgs::umode)
     int loader;           // 1: a dedicated fetch wave per seed issues the LDS-DMA
@@ -348,7 +349,8 @@ void launch_pq2(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 bool pq3_supports(const FactorArgs& a);
 void launch_pq3(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 // q_img := P^-1 Q of `count` steps (work item w -> seed w / seg_len, step step0 + w % seg_len), n <= 32
-void launch_umul(int nb, const LuArgs& a, double2* q_img, size_t count, hipStream_t st);
+// (qt_img: where the transposed images go, for the adjoint sweep)
+void launch_umul(int nb, const LuArgs& a, double2* q_img, double2* qt_img, size_t count, hipStream_t st);
 bool pq3_parks(const FactorArgs& a, int nsteps);
 void launch_pq3_second(const FactorArgs& a, int nsteps, int batch, hipStream_t st);
 // true: launch_pq left the second halves of the factorisations to launch_pq3_second (FactorArgs::four_steps == 2)

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void pade_pq8_kernel(FactorArgs args) {
 // sub-step is ONE product instead of two). One wave per step; P^-1 is the left operand (LDS planes), Q the
 // right one (C layout), both read from their column-major images.
 template <int NB>
-__global__ __launch_bounds__(64) void umul_kernel(LuArgs args, double2* q_all, unsigned count) {
+__global__ __launch_bounds__(64) void umul_kernel(LuArgs args, double2* q_all, double2* qt_all, unsigned count) {
     typedef Geo<NB> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lre = reinterpret_cast<double*>(smem);
@@ -650,6 +650,15 @@ __global__ __launch_bounds__(64) void umul_kernel(LuArgs args, double2* q_all, u
     cmat_to_lds<NB>(u, lre, lim);
     wave_sync();
     lds_to_image<NB>(lre, lim, qimg);
+    {   // U^T as well (the adjoint sweep's image): element (i, k) of the image is U[k][i]
+        double2* timg = qt_all + m * G::MAT;
+        const int lane = lane_id(), i = lane % G::NP, h = lane / G::NP;
+#pragma unroll
+        for (int cc = 0; cc < G::CPL; ++cc) {
+            const int off = (cc * G::H + h) * G::PITCH + i;
+            timg[cc * 64 + lane] = make_double2(lre[off], lim[off]);
+        }
+    }
 }
 
 // Explicit-generator variant: a[count][n][n] row-major complex in HBM (debug entry point; also
@@ -1925,12 +1934,12 @@ void launch_pq_explicit(int nb, const double2* a_in, int n, const FactorArgs& a,
     else if (one_wave_pq()) launch_pq_explicit_t<2>(a_in, n, a, count, st);
     else launch_pq2_explicit(a_in, n, a, count, st);
 }
-void launch_umul(int nb, const LuArgs& a, double2* q_img, size_t count, hipStream_t st) {
+void launch_umul(int nb, const LuArgs& a, double2* q_img, double2* qt_img, size_t count, hipStream_t st) {
     if (count == 0) return;
     if (nb == 1)
-        hipLaunchKernelGGL(umul_kernel<1>, dim3((unsigned)count), dim3(64), PqLds<1>::BYTES, st, a, q_img, (unsigned)count);
+        hipLaunchKernelGGL(umul_kernel<1>, dim3((unsigned)count), dim3(64), PqLds<1>::BYTES, st, a, q_img, qt_img, (unsigned)count);
     else
-        hipLaunchKernelGGL(umul_kernel<2>, dim3((unsigned)count), dim3(64), PqLds<2>::BYTES, st, a, q_img, (unsigned)count);
+        hipLaunchKernelGGL(umul_kernel<2>, dim3((unsigned)count), dim3(64), PqLds<2>::BYTES, st, a, q_img, qt_img, (unsigned)count);
 }
 void launch_lu(int nb, const LuArgs& a, size_t count, hipStream_t st) {
     if (a.inverse && nb == 1 && a.all_dominant && a.pack8) {

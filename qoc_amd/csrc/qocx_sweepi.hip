@@ -121,12 +121,14 @@ __global__ __launch_bounds__(64 * (1 + Cfg<NB>::LOADERS)) void sweepi_kernel(Swe
 #pragma unroll
         for (int jj = 0; jj < C::PER_LOADER; ++jj) {
             const int j = (role - 1) * C::PER_LOADER + jj, jl = j % C::PIECES;
-            const double2* img = (j < C::PIECES ? args.q_img : args.lu_img) + m * MAT;
+            // (umode, adjoint: the stored U^T image, a straight copy like the forward one)
+            const bool stored_t = adjoint && args.umode && j < C::PIECES;
+            const double2* img = (stored_t ? args.qt_img : j < C::PIECES ? args.q_img : args.lu_img) + m * MAT;
             double2* dst = (j < C::PIECES ? qbuf : pibuf) + ring * MAT + jl * 64;
             // plain image: piece jl is its KiB jl; transposed (adjoint): LDS element (col H jl + l / NP,
             // row l % NP) is image element (row H jl + l / NP, col l % NP)
-            const size_t el = adjoint ? (size_t)(lane % NP) * NP + H * jl + lane / NP
-                                      : (size_t)jl * 64 + lane;
+            const size_t el = (adjoint && !stored_t) ? (size_t)(lane % NP) * NP + H * jl + lane / NP
+                                                     : (size_t)jl * 64 + lane;
             dma16(img + el, dst);
         }
     };
