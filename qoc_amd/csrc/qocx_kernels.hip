@@ -1325,7 +1325,9 @@ __device__ __forceinline__ void column_fence(int cc) {
     }
 }
 
-template <int NB, bool EXPLICIT, bool SKEW>
+// UMODE (KrylovArgs::umode, one control set at a time): a copy of its own, so that the kernels of the batched
+// evaluation keep their registers (168: three waves to a SIMD; tests/test_build_resources.py)
+template <int NB, bool EXPLICIT, bool SKEW, bool UMODE = false>
 __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* smem) {
     typedef Geo<NB> G;
     typedef KrylovLds<NB> L;
@@ -1503,7 +1505,7 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
         for (int s = 0; s < S; ++s) {
             const size_t t = (size_t)t0 + sub;
             double2 x = xs_b[(((size_t)tx + sub) * S + s) * NP + i];
-            if (args.umode) {
+            if constexpr (UMODE) {
                 // the adjoint sweep left lambda' (its cotangent BEFORE the step): x = P^-H lambda', from the
                 // column-major image of P^-1 - lane (h, i): elements (cc H + h, i) of column i
                 const double2* pin = args.pinv_img + m * G::MAT + (size_t)i * NP;
@@ -1558,17 +1560,17 @@ __device__ __forceinline__ void krylov_grad_body(const KrylovArgs& args, char* s
     }
 }
 
-template <int NB, bool EXPLICIT>
+template <int NB, bool EXPLICIT, bool UMODE = false>
 __global__ __launch_bounds__(64) void krylov_grad_kernel(KrylovArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    krylov_grad_body<NB, EXPLICIT, false>(args, smem);
+    krylov_grad_body<NB, EXPLICIT, false, UMODE>(args, smem);
 }
 
 // Hermitian-generator variant: half the generator registers, so two waves share a SIMD.
-template <int NB, bool EXPLICIT>
+template <int NB, bool EXPLICIT, bool UMODE = false>
 __global__ __launch_bounds__(64, NB < 4 ? 2 : 1) void krylov_grad_skew_kernel(KrylovArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    krylov_grad_body<NB, EXPLICIT, true>(args, smem);
+    krylov_grad_body<NB, EXPLICIT, true, UMODE>(args, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1885,6 +1887,17 @@ template <int NB>
 static void launch_krylov_t(const KrylovArgs& a, int nsteps, int batch, hipStream_t st) {
     // a.skew: Hermitian H. The Magnus generators of skew-Hermitian node generators are
     // skew-Hermitian too (up to rounding), so the explicit path may use the same variant.
+    if (a.umode) {  // one control set at a time: x = P^-H lambda' is formed in the kernel
+        if (a.m_rm != nullptr && a.skew)
+            hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, true, true>), dim3(nsteps, batch), dim3(64), KrylovLds<NB>::BYTES, st, a);
+        else if (a.m_rm != nullptr)
+            hipLaunchKernelGGL((krylov_grad_kernel<NB, true, true>), dim3(nsteps, batch), dim3(64), KrylovLds<NB>::BYTES, st, a);
+        else if (a.skew)
+            hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, false, true>), dim3(nsteps, batch), dim3(64), KrylovLds<NB>::BYTES, st, a);
+        else
+            hipLaunchKernelGGL((krylov_grad_kernel<NB, false, true>), dim3(nsteps, batch), dim3(64), KrylovLds<NB>::BYTES, st, a);
+        return;
+    }
     if (a.m_rm != nullptr && a.skew)
         hipLaunchKernelGGL((krylov_grad_skew_kernel<NB, true>), dim3(nsteps, batch), dim3(64),
                            KrylovLds<NB>::BYTES, st, a);

@@ -53,7 +53,7 @@ def test_headline_kernels_share_a_simd():
     sweep4 = find(kernels, "sweep_kernelILi2ELi4ELb0ELb0E")
     k1a = find(pade2, "pade_pq2_kernelILb1ELb0ELb1E")   # Hermitian, product build, step table (the headline's)
     k1a_norm = find(pade2, "pade_pq2_kernelILb1ELb0ELb0E")  # ... deciding order / squarings from the matrix norm
-    k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0E")
+    k3 = find(kernels, "krylov_grad_skew_kernelILi2ELb0ELb0E")  # (the third flag: the copy of latency mode, sweep_umode)
     lu = find(kernels, "lu_kernelILi2E")
     for entry in (sweep, sweep1, sweep4, k1a, k1a_norm, k3, lu):
         assert entry["VGPRs Spill"] == 0 and entry["ScratchSize"] == 0
