@@ -642,8 +642,11 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count;
-    if (n < 1 || n > 64)
-        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..64 for the wavefront engine");
+    if (n < 1 || n > 256)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..256 (1..64: the wavefront kernels; 65..256: the general "
+                                  "path of qocx_general.hip)");
+    if (n > 64 && p->magnus_policy != QOCX_MAGNUS_M2)
+        return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2 only");
     if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "state_count must be in 1..64");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
@@ -663,7 +666,9 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
 
     // matrices are padded to 16, 32 or 64: one, four or sixteen MFMA tiles (33 <= n <= 64 runs on
     // the four-wave K1a of qocx_pade4.hip and the NB = 4 forms of K1b / K2 / K3)
-    const int nb = (n <= 16) ? 1 : (n <= 32 ? 2 : 4), np = 16 * nb, mat = np * np, nt = p->nt;
+    // (n > 64: nb = ceil(n / 16) > 4 selects the general path; it reads the row-major padded matrices that
+    // h0_timg / g_timg hold - the column-major images of the transposes)
+    const int nb = (n <= 16) ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n + 15) / 16)), np = 16 * nb, mat = np * np, nt = p->nt;
     ctx->has_problem = false;
     ctx->n = n; ctx->nb = nb; ctx->np = np; ctx->S = S; ctx->K = K; ctx->nc = nc; ctx->N = N;
     ctx->nsteps = nsteps; ctx->ces = p->cost_eval_step; ctx->nt = nt; ctx->nodes = nodes;
@@ -883,7 +888,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (ctx->costs.upload(dcosts, ctx->stream)) return QOCX_ERR_HIP;
     if (ctx->cost_vectors.upload(pool, ctx->stream)) return QOCX_ERR_HIP;
     if (ctx->cost_counts.upload(counts, ctx->stream)) return QOCX_ERR_HIP;
-    if (qocx::sweep_lds_bytes(nb, S) > 160 * 1024)
+    if (nb <= 4 && qocx::sweep_lds_bytes(nb, S) > 160 * 1024)
         return fail(QOCX_ERR_ARG, "state_count too large for the sweep kernel's LDS");
     ctx->has_problem = true;
     ctx->have_results = false;
@@ -930,6 +935,118 @@ static double magnus_norm_bound(int nodes, double bound) {
         return b1 + 0.5 * b3 + (1.0 / 240) * 2 * x * y;
     }
     return bound;
+}
+
+// Evaluation for Hilbert sizes above 64 (qocx_general.hip): classic order, one stream - factor every step,
+// forward sweep, adjoint sweep, K3, scatter - per memory chunk of seeds.
+static int eval_general(qocx_ctx* ctx, int want_grad) {
+    const int B = ctx->B, np = ctx->np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
+    const size_t mat = (size_t)np * np;
+    const bool explicit_gen = ctx->explicit_mode;
+    if (ctx->nodes != 1) return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2 only");
+    const size_t per_seed = (size_t)nsteps * (mat * 32 + 4) + ctx->slot_cap * S * np * 32 +
+                            (size_t)(nsteps + 1) * 4 + (size_t)nsteps * std::max(K, 1) * 8;
+    const int max_blocks = 2 * ctx->cu_count;
+    int chunk = ctx->chunk_user;
+    if (chunk <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = ctx->q_img.count * 16 + ctx->lu_img.count * 16 + ctx->states.count * 16 +
+                            ctx->xs.count * 16 + ctx->magnus_scratch.count * 16;
+        const size_t fixed = (size_t)max_blocks * 7 * mat * 16;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.6);
+        chunk = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (budget > fixed ? budget - fixed : 0) / per_seed));
+    }
+    chunk = std::min(chunk, B);
+    const size_t cm = (size_t)chunk * nsteps;
+    const int blocks = (int)std::min<size_t>(cm, (size_t)max_blocks);
+    if (ctx->q_img.ensure(cm * mat) || ctx->lu_img.ensure(cm * mat) || ctx->s_arr.ensure(cm) ||
+        ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
+        ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
+        ctx->offs.ensure((size_t)chunk * (nsteps + 1)) || ctx->gstep.ensure(cm * std::max(K, 1)) ||
+        ctx->cost_out.ensure(B) || ctx->grads.ensure((size_t)B * ctx->nc * std::max(K, 1)) ||
+        ctx->final_out.ensure((size_t)B * S * np) || ctx->lam_buf.ensure((size_t)chunk * S * np) ||
+        ctx->magnus_scratch.ensure((size_t)blocks * 7 * mat))
+        return QOCX_ERR_HIP;
+    if (ctx->keep_step_states)
+        if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
+    hipStream_t cs = ctx->stream;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = std::min(chunk, B - b0);
+        ctx->last_chunk = bc;
+        qocx::GeneralArgs fa;
+        fa.np = np; fa.K = K; fa.nc = ctx->nc; fa.nsteps = nsteps; fa.nt = ctx->nt; fa.dt = ctx->dt;
+        fa.controls = ctx->controls.p ? ctx->controls.p + (size_t)b0 * ctx->nc * K : nullptr;
+        fa.interp = ctx->interp.p;
+        fa.h0_rm = ctx->h0_timg.p; fa.g_rm = ctx->g_timg.p;
+        fa.gen_rm = explicit_gen ? ctx->gen_rm.p + (size_t)b0 * nsteps * mat : nullptr;
+        fa.pade_policy = (int)ctx->knob("pade_order", 0);
+        fa.sq_max = std::min(30, ctx->sbound);
+        fa.q_img = ctx->q_img.p; fa.pinv_img = ctx->lu_img.p; fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
+        fa.scratch = ctx->magnus_scratch.p;
+        fa.total = (size_t)bc * nsteps;
+        const int fblocks = (int)std::min<size_t>(fa.total, (size_t)blocks);
+        time_begin(ctx, 0, cs);
+        qocx::launch_general_factor(fa, fblocks, cs);
+        time_end(ctx, cs);
+
+        qocx::GeneralSweepArgs sa;
+        sa.np = np; sa.S = S; sa.nsteps = nsteps; sa.cost_eval_step = ctx->ces;
+        sa.has_step_costs = ctx->has_step_costs; sa.phase = want_grad ? 3 : 1;
+        sa.q_img = fa.q_img; sa.pinv_img = fa.pinv_img; sa.s_arr = fa.s_arr; sa.psi0 = ctx->psi0.p;
+        sa.slot_cap = ctx->slot_cap; sa.states = ctx->states.p; sa.xs = ctx->xs.p; sa.offs = ctx->offs.p;
+        sa.lam_buf = ctx->lam_buf.p;
+        sa.cost_count = ctx->cost_count; sa.costs = ctx->costs.p; sa.cost_vectors = ctx->cost_vectors.p;
+        sa.cost_counts = ctx->cost_counts.p;
+        sa.inj_count = ctx->inj_count;
+        sa.inj_index = ctx->inj_count > 0 ? ctx->inj_index.p : nullptr;
+        sa.inj_bars = ctx->inj_count > 0 ? ctx->inj_bars.p + (size_t)b0 * ctx->inj_count * S * np : nullptr;
+        sa.cost_out = ctx->cost_out.p + b0;
+        sa.final_out = ctx->final_out.p + (size_t)b0 * S * np;
+        sa.step_states = ctx->keep_step_states ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
+        sa.status = ctx->status.p;
+        time_begin(ctx, 1, cs);
+        qocx::launch_general_sweep(sa, bc, cs);
+        time_end(ctx, cs);
+
+        if (want_grad) {
+            qocx::GeneralKrylovArgs ka;
+            ka.np = np; ka.S = S; ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.dt = ctx->dt;
+            ka.controls = fa.controls; ka.interp = fa.interp; ka.h0_rm = fa.h0_rm; ka.g_rm = fa.g_rm;
+            ka.gen_rm = fa.gen_rm;
+            ka.mbar_rm = explicit_gen ? ctx->genbar_rm.p + (size_t)b0 * nsteps * mat : nullptr;
+            ka.s_arr = fa.s_arr; ka.offs = ctx->offs.p; ka.states = ctx->states.p; ka.xs = ctx->xs.p;
+            ka.slot_cap = ctx->slot_cap; ka.gstep = ctx->gstep.p; ka.scratch = ctx->magnus_scratch.p;
+            ka.total = fa.total;
+            time_begin(ctx, 2, cs);
+            if (qocx::launch_general_krylov(ka, fblocks, cs)) return fail(QOCX_ERR_HIP, "K3 (general): LDS size refused");
+            time_end(ctx, cs);
+            if (!explicit_gen) {
+                qocx::ScatterArgs sc;
+                sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
+                sc.weight = ctx->weight.p;
+                sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
+                sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
+                sc.lam_scale = nullptr; sc.S = S;
+                time_begin(ctx, 3, cs);
+                qocx::launch_scatter(sc, cs);
+                time_end(ctx, cs);
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    int status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    time_collect(ctx);
+    if (status & 2) return fail(QOCX_ERR_ARG, "non-finite generator norm");
+    if (status & 1) return fail(QOCX_ERR_SINGULAR, "Singular matrix");
+    if (status & 4) return fail(QOCX_ERR_CAPACITY, "squaring sub-step capacity exceeded");
+    ctx->have_results = true;
+    ctx->have_grads = want_grad != 0;
+    ctx->have_step_states = ctx->keep_step_states != 0;
+    return 0;
 }
 
 extern "C" {
@@ -1127,6 +1244,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         if (ctx->genbar_rm.ensure((size_t)B * nsteps * mat)) return QOCX_ERR_HIP;
     if (ctx->inj_count > 0 && ctx->inj_batch != B)
         return fail(QOCX_ERR_STATE, "state cotangents were set for a different batch size");
+    if (ctx->nb > 4) return eval_general(ctx, want_grad);  // 65 <= n <= 256 (qocx_general.hip)
 
     // Unit adjoint (qocx_sweep_common.h): a property of the PROBLEM and of the context's knobs, never
     // of the batch size, chunking or segmentation - results stay bit-identical across those.

@@ -315,6 +315,71 @@ struct LindbladArgs {
     double2* lam_scale = nullptr;  // [B][S]: phase 1 out
 };
 
+// ---- Hilbert sizes above 64 (qocx_general.hip): row-major padded np x np matrices in HBM, np = 16 ceil(n / 16) ----
+struct GeneralArgs {  // K1a + K1b: one work item per (seed, step), `total` = seeds * nsteps
+    int np, K, nc, nsteps, nt;
+    double dt;
+    const double* controls;    // [B][nc][K]
+    const StepInterp* interp;  // [nsteps]
+    const double2* h0_rm;      // [nt] row-major
+    const double2* g_rm;       // [nt][K]
+    const double2* gen_rm;     // explicit mode: [B][nsteps] generators sampled by the host, else nullptr
+    int pade_policy, sq_max;
+    double2* q_img;            // out: Q, row-major
+    double2* pinv_img;         // out: P^-1, row-major
+    int* s_arr;
+    int* status;
+    double2* scratch;          // [blocks][7] matrices
+    size_t total;
+};
+struct GeneralSweepArgs {  // K2: one workgroup per seed
+    int np, S, nsteps, cost_eval_step, has_step_costs, phase;  // phase bit 0 forward, bit 1 adjoint
+    const double2* q_img;
+    const double2* pinv_img;
+    const int* s_arr;
+    const double2* psi0;       // [S][np]
+    size_t slot_cap;
+    double2* states;           // [B][slot_cap][S][np]
+    double2* xs;
+    int* offs;                 // [B][nsteps + 1]
+    double2* lam_buf;          // [B][S][np]
+    int cost_count;
+    const DevCost* costs;
+    const double2* cost_vectors;
+    const int* cost_counts;
+    const int* inj_index;
+    const double2* inj_bars;
+    int inj_count;
+    double* cost_out;
+    double2* final_out;
+    double2* step_states;
+    int* status;
+};
+struct GeneralKrylovArgs {  // K3: one work item per (seed, step)
+    int np, S, K, nc, nsteps, nt;
+    double dt;
+    const double* controls;
+    const StepInterp* interp;
+    const double2* h0_rm;
+    const double2* g_rm;
+    const double2* gen_rm;     // explicit mode (then mbar_rm receives the generator cotangents)
+    double2* mbar_rm;
+    const int* s_arr;
+    const int* offs;
+    const double2* states;
+    const double2* xs;
+    size_t slot_cap;
+    double* gstep;             // [B][nsteps][K]
+    double2* scratch;          // [blocks][3] matrices
+    size_t total;
+};
+int general_factor_lds();
+int general_sweep_lds(int np);
+int general_krylov_lds(int np);
+void launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st);
+void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st);
+int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st);
+
 // Multi-start driver on the device (qocx_optim.hip)
 struct OptimArgs {
     int kind;  // 0 SGD, 1 Adam

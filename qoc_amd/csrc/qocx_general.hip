@@ -1,0 +1,749 @@
+// qocx_general.hip - the Schroedinger path for Hilbert sizes ABOVE 64 (65 <= n <= 256, M2): the same
+// algorithm as the wavefront kernels - Pade numerator / denominator per step, the
+// sweep applies P^-1 Q per squaring sub-step, the Krylov-chain adjoint forms the generator cotangent -
+// with every matrix in HBM / L2 instead of registers and LDS, one workgroup of four waves per work item.
+// The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502, its report has rows to
+// n = 1024); this file turns the hard error above n = 64 into a working path. It is NOT tuned like the
+// n <= 64 kernels: row-major padded matrices, vector-unit complex GEMMs staged through LDS, an explicit
+// inverse by Gauss-Jordan with partial pivoting (so a sub-step is two matrix-vector products and no
+// serial triangular solve), classic order of the evaluation (factor, forward sweep, adjoint sweep, K3).
+//   reference: expm_pade qoc/standard/functions/expm.py:210-252 (orders by norm: the table :194-209),
+//   costs qoc/standard/costs/targetstateinfidelity.py:52-61, forbidstates.py:64-81
+#include "qocx_wave.h"
+
+namespace qocx {
+namespace general {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ void cfma(double2& acc, const double2 a, const double2 b) {  // acc += a b
+    acc.x = fma(a.x, b.x, fma(-a.y, b.y, acc.x));
+    acc.y = fma(a.x, b.y, fma(a.y, b.x, acc.y));
+}
+__device__ __forceinline__ void cfma_conj(double2& acc, const double2 a, const double2 b) {  // acc += conj(a) b
+    acc.x = fma(a.x, b.x, fma(a.y, b.y, acc.x));
+    acc.y = fma(a.x, b.y, fma(-a.y, b.x, acc.y));
+}
+__device__ __forceinline__ double2 cmul(const double2 a, const double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// sums over the workgroup (every thread calls; the result is uniform). red: 16 doubles of LDS
+__device__ __forceinline__ double2 block_sum2(double a, double b, double* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[2 * (threadIdx.x >> 6)] = a;
+        red[2 * (threadIdx.x >> 6) + 1] = b;
+    }
+    __syncthreads();
+    return make_double2((red[0] + red[2]) + (red[4] + red[6]), (red[1] + red[3]) + (red[5] + red[7]));
+}
+__device__ __forceinline__ double block_max(double a, double* red) {
+    a = wave_max(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// y[r] = sum_c op(M[r][c]) v[c]: a wave per row, lanes along the row (coalesced), one reduction per row.
+// v, y in LDS (y != v); ends with a barrier.
+template <bool CONJ>
+__device__ __forceinline__ void matvec_rows(const double2* __restrict__ M, const double2* v, double2* y, int np) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = w; r < np; r += 4) {
+        double2 acc = make_double2(0, 0);
+        const double2* row = M + (size_t)r * np;
+        for (int c = lane; c < np; c += 64) {
+            if (CONJ) cfma_conj(acc, row[c], v[c]);
+            else cfma(acc, row[c], v[c]);
+        }
+        const double sr = wave_sum(acc.x), si = wave_sum(acc.y);
+        if (lane == 0) y[r] = make_double2(sr, si);
+    }
+    __syncthreads();
+}
+
+// y[c] = sum_r op(M[r][c]) v[r]: a lane per column, rows split over the waves that are left; partial sums
+// through `part` ([4][np] in LDS). v, y in LDS (y != v); ends with a barrier.
+template <bool CONJ>
+__device__ __forceinline__ void matvec_cols(const double2* __restrict__ M, const double2* v, double2* y, double2* part,
+                                            int np) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunks = (np + 63) >> 6, groups = 4 / chunks;  // np <= 256
+    const int chunk = w % chunks, grp = w / chunks, c = chunk * 64 + lane;
+    if (grp < groups && c < np) {
+        double2 acc = make_double2(0, 0);
+        for (int r = grp; r < np; r += groups) {
+            if (CONJ) cfma_conj(acc, M[(size_t)r * np + c], v[r]);
+            else cfma(acc, M[(size_t)r * np + c], v[r]);
+        }
+        part[grp * np + c] = acc;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < np; cc += TPB) {
+        double2 s = part[cc];
+        for (int g = 1; g < groups; ++g) {
+            s.x += part[g * np + cc].x;
+            s.y += part[g * np + cc].y;
+        }
+        y[cc] = s;
+    }
+    __syncthreads();
+}
+
+// C = A B (row-major np x np in HBM / L2, np a multiple of 16): 64 x 64 output tiles, a thread holds the
+// 4 x 4 outputs (ty + 16 i, tx + 16 j), operands staged 16 columns at a time through LDS (34 KiB at smem).
+struct GemmLds {
+    double2 as[64][17];
+    double2 bs[16][64];
+};
+__device__ __forceinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
+                                     int np, char* smem) {
+    GemmLds& L = *reinterpret_cast<GemmLds*>(smem);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    for (int r0 = 0; r0 < np; r0 += 64)
+        for (int c0 = 0; c0 < np; c0 += 64) {
+            const int ni = min(4, (np - r0) >> 4), nj = min(4, (np - c0) >> 4);
+            double2 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = make_double2(0, 0);
+            for (int k0 = 0; k0 < np; k0 += 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = tid + TPB * q;
+                    const int rr = idx >> 4, kk = idx & 15;
+                    L.as[rr][kk] = (r0 + rr < np) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
+                    const int kb = idx >> 6, cc = idx & 63;
+                    L.bs[kb][cc] = (c0 + cc < np) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int kk = 0; kk < 16; ++kk) {
+                    double2 a[4], b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = L.as[ty + 16 * i][kk];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = L.bs[kk][tx + 16 * j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < ni)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < nj) cfma(acc[i][j], a[i], b[j]);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i < ni && j < nj) C[(size_t)(r0 + ty + 16 * i) * np + c0 + tx + 16 * j] = acc[i][j];
+        }
+    __syncthreads();
+}
+
+// M := M^-1 in place (row-major np x np in HBM / L2): Gauss-Jordan with partial pivoting (largest
+// |re| + |im| of the column, LAPACK's izamax measure; ties to the smaller row), the column interchanges undone
+// at the end. smem: row (np), col (np), piv (np ints), red. false (uniform): a zero / non-finite pivot.
+__device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* smem) {
+    double2* rowk = reinterpret_cast<double2*>(smem);
+    double2* colk = rowk + np;
+    int* piv = reinterpret_cast<int*>(colk + np);
+    double* red = reinterpret_cast<double*>(piv + np);
+    int* redi = reinterpret_cast<int*>(red + 8);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    bool ok = true;
+    for (int k = 0; k < np; ++k) {
+        double best = -1.0;
+        int bi = k;
+        for (int r = k + tid; r < np; r += TPB) {
+            const double2 e = M[(size_t)r * np + k];
+            const double v = fabs(e.x) + fabs(e.y);
+            if (v > best || !(v == v)) {
+                best = (v == v) ? v : 1e308;
+                bi = r;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[w] = best;
+            redi[w] = bi;
+        }
+        __syncthreads();
+        best = red[0];
+        int p = redi[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (red[q] > best || (red[q] == best && redi[q] < p)) {
+                best = red[q];
+                p = redi[q];
+            }
+        if (!(best > 0.0) || !(best < 1e300)) ok = false;  // singular or not finite: finish without dividing by it
+        if (tid == 0) piv[k] = p;
+        // rows k and p change places; the new row k (unscaled) goes to LDS
+        for (int c = tid; c < np; c += TPB) {
+            const double2 a = M[(size_t)p * np + c];
+            if (p != k) M[(size_t)p * np + c] = M[(size_t)k * np + c];
+            rowk[c] = a;
+        }
+        __syncthreads();
+        for (int r = tid; r < np; r += TPB) colk[r] = (r == k) ? rowk[k] : M[(size_t)r * np + k];
+        __syncthreads();
+        double2 inv = make_double2(1.0, 0.0);
+        {
+            const double2 d = rowk[k];
+            const double den = d.x * d.x + d.y * d.y;
+            if (ok && den > 0.0) inv = make_double2(d.x / den, -d.y / den);
+        }
+        __syncthreads();
+        for (int c = tid; c < np; c += TPB) rowk[c] = (c == k) ? inv : cmul(rowk[c], inv);
+        __syncthreads();
+        for (int e = tid; e < np * np; e += TPB) {
+            const int r = e / np, c = e - r * np;
+            double2 v;
+            if (r == k) {
+                v = rowk[c];
+            } else {
+                const double2 f = colk[r];
+                const double2 nf = make_double2(-f.x, -f.y);
+                if (c == k) {
+                    v = cmul(nf, rowk[k]);
+                } else {
+                    v = M[e];
+                    cfma(v, nf, rowk[c]);
+                }
+            }
+            M[e] = v;
+        }
+        __syncthreads();
+    }
+    for (int k = np - 1; k >= 0; --k) {
+        const int p = piv[k];
+        if (p != k) {
+            for (int r = tid; r < np; r += TPB) {
+                const double2 a = M[(size_t)r * np + k];
+                M[(size_t)r * np + k] = M[(size_t)r * np + p];
+                M[(size_t)r * np + p] = a;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+
+// ---- K1a + K1b ---------------------------------------------------------------------------------------
+// One work item = one propagator step of one seed: generator, 1-norm, order / squarings, the Pade
+// polynomials, Q to q_img, P^-1 to pinv_img, the step's entry of s_arr. Persistent workgroups (grid-stride)
+// with 7 scratch matrices each.
+__global__ __launch_bounds__(TPB) void factor_kernel(GeneralArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem + sizeof(GemmLds));
+    const int np = a.np, mat = np * np, tid = threadIdx.x;
+    double2* sc = a.scratch + (size_t)blockIdx.x * 7 * mat;
+    double2 *A = sc, *A2 = sc + mat, *A4 = sc + 2 * (size_t)mat, *A6 = sc + 3 * (size_t)mat, *X = sc + 4 * (size_t)mat,
+            *Y = sc + 5 * (size_t)mat, *Z = sc + 6 * (size_t)mat;
+    for (size_t wi = blockIdx.x; wi < a.total; wi += gridDim.x) {
+        const int b = (int)(wi / a.nsteps), step = (int)(wi % a.nsteps);
+        const size_t m = (size_t)b * a.nsteps + step;
+        // generator a = -i dt H(u(t_mid), t_mid) (schroedingerdiscrete.py:483-487, mathmethods.py:72), or
+        // the host's sample of it (explicit mode)
+        if (a.gen_rm != nullptr) {
+            const double2* g = a.gen_rm + m * mat;
+            for (int e = tid; e < mat; e += TPB) A[e] = g[e];
+        } else {
+            const size_t tsel = (a.nt == 1) ? 0 : (size_t)step;
+            const double2* h0 = a.h0_rm + tsel * mat;
+            const double2* gk = a.g_rm + tsel * a.K * mat;
+            const double* ctl_b = a.controls + (size_t)b * a.nc * a.K;
+            const StepInterp si = a.interp[step];
+            for (int e = tid; e < mat; e += TPB) {
+                double2 h = h0[e];
+                for (int k = 0; k < a.K; ++k) {
+                    const double uk = control_at(ctl_b, si, a.K, k);
+                    const double2 g = gk[(size_t)k * mat + e];
+                    h.x = fma(uk, g.x, h.x);
+                    h.y = fma(uk, g.y, h.y);
+                }
+                A[e] = make_double2(a.dt * h.y, -a.dt * h.x);
+            }
+        }
+        __syncthreads();
+        // 1-norm (expm.py:116), order and squarings (expm.py:238-241; order by norm: qocx_wave.h)
+        double colmax = 0.0;
+        for (int c = tid; c < np; c += TPB) {
+            double s = 0.0;
+            for (int r = 0; r < np; ++r) {
+                const double2 e = A[(size_t)r * np + c];
+                s += sqrt(e.x * e.x + e.y * e.y);
+            }
+            colmax = (s > colmax || !(s == s)) ? ((s == s) ? s : 1e308) : colmax;
+        }
+        const double norm1 = block_max(colmax, red);
+        int sq = 0, order = pade_order_for(norm1, a.pade_policy);
+        {
+            double th = QOCX_THETA13;
+            while (norm1 > th && sq < 30) {
+                th *= 2.0;
+                ++sq;
+            }
+            if (!(norm1 <= th)) {
+                if (tid == 0) atomicOr(a.status, 2);
+                sq = 0;
+                order = 13;
+            }
+            if (sq > a.sq_max) {  // (cannot happen: the host's bound is above every step's norm)
+                if (tid == 0) atomicOr(a.status, 4);
+                sq = a.sq_max;
+            }
+        }
+        if (sq > 0) {
+            const double scale = ldexp(1.0, -sq);
+            for (int e = tid; e < mat; e += TPB) {
+                double2 v = A[e];
+                v.x *= scale;
+                v.y *= scale;
+                A[e] = v;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) a.s_arr[m] = step_entry(sq, order);
+        const double* bt = pade_table(order);
+        double2* Q = a.q_img + m * mat;
+        double2* P = a.pinv_img + m * mat;
+        gemm(A, A, A2, np, smem);
+        if (order == 13) {
+            gemm(A2, A2, A4, np, smem);
+            gemm(A2, A4, A6, np, smem);
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 x2 = A2[e], x4 = A4[e], x6 = A6[e];
+                X[e] = make_double2(bt[13] * x6.x + bt[11] * x4.x + bt[9] * x2.x, bt[13] * x6.y + bt[11] * x4.y + bt[9] * x2.y);
+            }
+            __syncthreads();
+            gemm(A6, X, Y, np, smem);
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 x2 = A2[e], x4 = A4[e], x6 = A6[e];
+                double2 y = Y[e];
+                y.x += bt[7] * x6.x + bt[5] * x4.x + bt[3] * x2.x;
+                y.y += bt[7] * x6.y + bt[5] * x4.y + bt[3] * x2.y;
+                if (e / np == e % np) y.x += bt[1];
+                Y[e] = y;
+            }
+            __syncthreads();
+            gemm(A, Y, X, np, smem);  // X = U (the odd part)
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 x2 = A2[e], x4 = A4[e], x6 = A6[e];
+                Y[e] = make_double2(bt[12] * x6.x + bt[10] * x4.x + bt[8] * x2.x, bt[12] * x6.y + bt[10] * x4.y + bt[8] * x2.y);
+            }
+            __syncthreads();
+            gemm(A6, Y, Z, np, smem);
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 x2 = A2[e], x4 = A4[e], x6 = A6[e], u = X[e];
+                double2 v = Z[e];
+                v.x += bt[6] * x6.x + bt[4] * x4.x + bt[2] * x2.x;
+                v.y += bt[6] * x6.y + bt[4] * x4.y + bt[2] * x2.y;
+                if (e / np == e % np) v.x += bt[0];
+                Q[e] = make_double2(v.x + u.x, v.y + u.y);
+                P[e] = make_double2(v.x - u.x, v.y - u.y);
+            }
+        } else {
+            // orders 3, 5, 7, 9: u = a (sum b_{2j+1} a^{2j}), v = sum b_{2j} a^{2j}; A4, A6, A8 (in Z) as needed
+            if (order >= 5) gemm(A2, A2, A4, np, smem);
+            if (order >= 7) gemm(A2, A4, A6, np, smem);
+            if (order >= 9) gemm(A4, A4, Z, np, smem);
+            for (int e = tid; e < mat; e += TPB) {
+                double2 y = make_double2(0, 0);
+                const double2 x2 = A2[e];
+                y.x = bt[3] * x2.x;
+                y.y = bt[3] * x2.y;
+                if (order >= 5) { const double2 x4 = A4[e]; y.x += bt[5] * x4.x; y.y += bt[5] * x4.y; }
+                if (order >= 7) { const double2 x6 = A6[e]; y.x += bt[7] * x6.x; y.y += bt[7] * x6.y; }
+                if (order >= 9) { const double2 x8 = Z[e]; y.x += bt[9] * x8.x; y.y += bt[9] * x8.y; }
+                if (e / np == e % np) y.x += bt[1];
+                Y[e] = y;
+            }
+            __syncthreads();
+            gemm(A, Y, X, np, smem);
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 x2 = A2[e], u = X[e];
+                double2 v = make_double2(bt[2] * x2.x, bt[2] * x2.y);
+                if (order >= 5) { const double2 x4 = A4[e]; v.x += bt[4] * x4.x; v.y += bt[4] * x4.y; }
+                if (order >= 7) { const double2 x6 = A6[e]; v.x += bt[6] * x6.x; v.y += bt[6] * x6.y; }
+                if (order >= 9) { const double2 x8 = Z[e]; v.x += bt[8] * x8.x; v.y += bt[8] * x8.y; }
+                if (e / np == e % np) v.x += bt[0];
+                Q[e] = make_double2(v.x + u.x, v.y + u.y);
+                P[e] = make_double2(v.x - u.x, v.y - u.y);
+            }
+        }
+        __syncthreads();
+        if (!invert(P, np, smem))
+            if (tid == 0) atomicOr(a.status, 1);
+        __syncthreads();
+    }
+}
+
+// ---- K2 ------------------------------------------------------------------------------------------------
+// inner product <t|v> over the workgroup (uniform)
+__device__ __forceinline__ double2 inner_g(const double2* t, const double2* v, int np, double* red) {
+    double pr = 0, pi = 0;
+    for (int i = threadIdx.x; i < np; i += TPB) {
+        const double2 a = t[i], p = v[i];
+        pr += a.x * p.x + a.y * p.y;  // conj(t) v
+        pi += a.x * p.y - a.y * p.x;
+    }
+    return block_sum2(pr, pi, red);
+}
+
+// The selected costs on the S states at `vecs` ([S][np], HBM); lam != nullptr: += dC/dRe + i dC/dIm
+// (formulas and cotangents as eval_costs of qocx_sweep_common.h)
+__device__ __forceinline__ double eval_costs_g(const GeneralSweepArgs& args, bool step_pass, bool final_pass,
+                                               const double2* vecs, double2* lam, double* red) {
+    const int np = args.np, S = args.S;
+    double total = 0;
+    for (int ci = 0; ci < args.cost_count; ++ci) {
+        const DevCost c = args.costs[ci];
+        const bool on = c.step_cost ? step_pass : final_pass;
+        if (!on) continue;
+        const double2* pool = args.cost_vectors + (size_t)c.vec_offset * np;
+        if (c.kind == QOCX_DEV_COST_COHERENT) {
+            double tre = 0, tim = 0;
+            for (int s = 0; s < S; ++s) {
+                const double2 ip = inner_g(pool + (size_t)s * np, vecs + (size_t)s * np, np, red);
+                tre += ip.x;
+                tim += ip.y;
+            }
+            total += c.scale * (1.0 - (tre * tre + tim * tim) / ((double)S * S));
+            if (lam != nullptr) {
+                const double f = -2.0 * c.scale / ((double)S * S);
+                for (int s = 0; s < S; ++s)
+                    for (int i = threadIdx.x; i < np; i += TPB) {
+                        const double2 t = pool[(size_t)s * np + i];
+                        double2 l = lam[(size_t)s * np + i];
+                        l.x += f * (tre * t.x - tim * t.y);
+                        l.y += f * (tre * t.y + tim * t.x);
+                        lam[(size_t)s * np + i] = l;
+                    }
+            }
+        } else if (c.kind == QOCX_DEV_COST_INCOHERENT) {
+            double fid = 0;
+            const double f = -2.0 * c.scale / (double)S;
+            for (int s = 0; s < S; ++s) {
+                const double2 ip = inner_g(pool + (size_t)s * np, vecs + (size_t)s * np, np, red);
+                fid += ip.x * ip.x + ip.y * ip.y;
+                if (lam != nullptr)
+                    for (int i = threadIdx.x; i < np; i += TPB) {
+                        const double2 t = pool[(size_t)s * np + i];
+                        double2 l = lam[(size_t)s * np + i];
+                        l.x += f * (ip.x * t.x - ip.y * t.y);
+                        l.y += f * (ip.x * t.y + ip.y * t.x);
+                        lam[(size_t)s * np + i] = l;
+                    }
+            }
+            total += c.scale * (1.0 - fid / (double)S);
+        } else {  // QOCX_DEV_COST_FORBID
+            int base = 0;
+            double acc = 0;
+            for (int s = 0; s < S; ++s) {
+                const int fs = args.cost_counts[c.cnt_offset + s];
+                const double w = 1.0 / (double)fs;
+                for (int f = 0; f < fs; ++f) {
+                    const double2* t = pool + (size_t)(base + f) * np;
+                    const double2 ip = inner_g(t, vecs + (size_t)s * np, np, red);
+                    acc += w * (ip.x * ip.x + ip.y * ip.y);
+                    if (lam != nullptr) {
+                        const double g = 2.0 * c.scale * w;
+                        for (int i = threadIdx.x; i < np; i += TPB) {
+                            const double2 tv = t[i];
+                            double2 l = lam[(size_t)s * np + i];
+                            l.x += g * (ip.x * tv.x - ip.y * tv.y);
+                            l.y += g * (ip.x * tv.y + ip.y * tv.x);
+                            lam[(size_t)s * np + i] = l;
+                        }
+                    }
+                }
+                base += fs;
+            }
+            total += c.scale * acc;
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// One workgroup per seed: forward sweep (phase bit 0) over all steps, adjoint sweep (bit 1) back.
+// The loop of schroedingerdiscrete.py:393-436 with psi' = (P^-1 Q)^(2^s) psi per step (expm.py:246-250).
+__global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int np = args.np, S = args.S, nsteps = args.nsteps, tid = threadIdx.x, b = blockIdx.x;
+    const int mat = np * np;
+    double2* v0 = reinterpret_cast<double2*>(smem);
+    double2* v1 = v0 + np;
+    double2* v2 = v1 + np;
+    double2* part = v2 + np;  // [4][np]
+    double* red = reinterpret_cast<double*>(part + 4 * np);
+    const size_t cap = args.slot_cap;
+    double2* states_b = args.states + (size_t)b * cap * S * np;
+    double2* xs_b = args.xs + (size_t)b * cap * S * np;
+    int* offs_b = args.offs + (size_t)b * (nsteps + 1);
+    double2* lam = args.lam_buf + (size_t)b * S * np;
+
+    if (args.phase & 1) {
+        for (int e = tid; e < S * np; e += TPB) states_b[e] = args.psi0[e];
+        __syncthreads();
+        int slot = 0;
+        double cost = 0;
+        bool overflow = false;
+        for (int step = 0; step <= nsteps; ++step) {
+            const double2* cur = states_b + (size_t)slot * S * np;
+            if (step != 0 && step != nsteps && args.has_step_costs && (step % args.cost_eval_step) == 0)
+                cost += eval_costs_g(args, true, false, cur, nullptr, red);
+            if (args.step_states != nullptr)
+                for (int e = tid; e < S * np; e += TPB)
+                    args.step_states[((size_t)b * (nsteps + 1) + step) * S * np + e] = cur[e];
+            if (tid == 0) offs_b[step] = slot;
+            if (step == nsteps) break;
+            const size_t m = (size_t)b * nsteps + step;
+            const int nsub = 1 << step_squarings(args.s_arr[m]);
+            const double2* Q = args.q_img + m * mat;
+            const double2* Pi = args.pinv_img + m * mat;
+            for (int sub = 0; sub < nsub; ++sub) {
+                if ((size_t)slot + 1 >= cap) {
+                    overflow = true;
+                    break;
+                }
+                for (int s = 0; s < S; ++s) {
+                    for (int i = tid; i < np; i += TPB) v0[i] = states_b[((size_t)slot * S + s) * np + i];
+                    __syncthreads();
+                    matvec_rows<false>(Q, v0, v1, np);
+                    matvec_rows<false>(Pi, v1, v2, np);
+                    for (int i = tid; i < np; i += TPB) states_b[((size_t)(slot + 1) * S + s) * np + i] = v2[i];
+                    __syncthreads();
+                }
+                ++slot;
+            }
+            if (overflow) break;
+        }
+        if (overflow) {
+            if (tid == 0) atomicOr(args.status, 4);
+            return;
+        }
+        {
+            // step costs on the final states if the last step is a cost step, then the final costs
+            // (schroedingerdiscrete.py:412-416, :428-433)
+            const double2* fin = states_b + (size_t)slot * S * np;
+            if (args.has_step_costs && (nsteps % args.cost_eval_step) == 0)
+                cost += eval_costs_g(args, true, false, fin, nullptr, red);
+            cost += eval_costs_g(args, false, true, fin, nullptr, red);
+            for (int e = tid; e < S * np; e += TPB) args.final_out[(size_t)b * S * np + e] = fin[e];
+            if (tid == 0) args.cost_out[b] = cost;
+        }
+        __syncthreads();
+    }
+    if (!(args.phase & 2)) return;
+
+    auto inject = [&](int step) {
+        if (args.inj_index == nullptr) return;
+        const int row = args.inj_index[step];
+        if (row < 0) return;
+        for (int e = tid; e < S * np; e += TPB) {
+            const double2 x = args.inj_bars[((size_t)b * args.inj_count + row) * S * np + e];
+            double2 l = lam[e];
+            l.x += x.x;
+            l.y += x.y;
+            lam[e] = l;
+        }
+        __syncthreads();
+    };
+    int slot = offs_b[nsteps];
+    for (int e = tid; e < S * np; e += TPB) lam[e] = make_double2(0, 0);
+    __syncthreads();
+    (void)eval_costs_g(args, (nsteps % args.cost_eval_step) == 0, true, states_b + (size_t)slot * S * np, lam, red);
+    inject(nsteps);
+    for (int step = nsteps - 1; step >= 0; --step) {
+        const size_t m = (size_t)b * nsteps + step;
+        const int nsub = 1 << step_squarings(args.s_arr[m]);
+        const double2* Q = args.q_img + m * mat;
+        const double2* Pi = args.pinv_img + m * mat;
+        for (int sub = nsub - 1; sub >= 0; --sub) {
+            --slot;
+            for (int s = 0; s < S; ++s) {
+                for (int i = tid; i < np; i += TPB) v0[i] = lam[(size_t)s * np + i];
+                __syncthreads();
+                matvec_cols<true>(Pi, v0, v1, part, np);  // x = P^-H lambda'
+                matvec_cols<true>(Q, v1, v2, part, np);   // lambda = Q^H x
+                for (int i = tid; i < np; i += TPB) {
+                    xs_b[((size_t)slot * S + s) * np + i] = v1[i];
+                    lam[(size_t)s * np + i] = v2[i];
+                }
+                __syncthreads();
+            }
+        }
+        if (step != 0 && (step % args.cost_eval_step) == 0 && args.has_step_costs)
+            (void)eval_costs_g(args, true, false, states_b + (size_t)slot * S * np, lam, red);
+        if (step != 0) inject(step);
+    }
+}
+
+// ---- K3 ------------------------------------------------------------------------------------------------
+// Krylov-chain adjoint of the Pade step (qocx_kernels.hip, krylov_grad_body): per (sub-step, state)
+// tau_i = (a^H)^i x, rho_{M-1} = b_M sigma, rho_{i-1} = b_i w_i + a rho_i, abar += sum_i tau_i rho_i^H; then
+// g_k = Re <abar, -i dts G_k> (or Mbar = 2^-s abar in explicit mode). One work item = one step of one seed;
+// scratch per workgroup: a, a^T, abar.
+__global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int np = a.np, mat = np * np, tid = threadIdx.x, S = a.S, K = a.K;
+    double2* tau = reinterpret_cast<double2*>(smem);  // [13][np]
+    double2* rho = tau + 13 * np;                     // [13][np]
+    double2* sig = rho + 13 * np;
+    double2* del = sig + np;
+    double2* part = del + np;  // [4][np]
+    double* red = reinterpret_cast<double*>(part + 4 * np);
+    double2* A = a.scratch + (size_t)blockIdx.x * 3 * mat;
+    double2* AT = A + mat;
+    double2* AB = AT + mat;
+    for (size_t wi = blockIdx.x; wi < a.total; wi += gridDim.x) {
+        const int b = (int)(wi / a.nsteps), step = (int)(wi % a.nsteps);
+        const size_t m = (size_t)b * a.nsteps + step;
+        const int entry = a.s_arr[m];
+        const int sq = step_squarings(entry), M = step_order(entry), nsub = 1 << sq;
+        const double dts = a.dt * ldexp(1.0, -sq);
+        const double* bt = pade_table(M);
+        const size_t cap = a.slot_cap;
+        const double2* states_b = a.states + (size_t)b * cap * S * np;
+        const double2* xs_b = a.xs + (size_t)b * cap * S * np;
+        const int t0 = a.offs[(size_t)b * (a.nsteps + 1) + step];
+        if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) continue;  // the sweep overflowed (status bit 2)
+        const size_t tsel = (a.nt == 1) ? 0 : (size_t)step;
+        const double2* gk = a.g_rm ? a.g_rm + tsel * K * mat : nullptr;
+        // the scaled generator and its transpose
+        if (a.gen_rm != nullptr) {
+            const double2* g = a.gen_rm + m * mat;
+            const double scl = ldexp(1.0, -sq);
+            for (int e = tid; e < mat; e += TPB) {
+                const int r = e / np, c = e - r * np;
+                const double2 v = make_double2(scl * g[e].x, scl * g[e].y);
+                A[e] = v;
+                AT[(size_t)c * np + r] = v;
+            }
+        } else {
+            const double2* h0 = a.h0_rm + tsel * mat;
+            const double* ctl_b = a.controls + (size_t)b * a.nc * K;
+            const StepInterp si = a.interp[step];
+            for (int e = tid; e < mat; e += TPB) {
+                const int r = e / np, c = e - r * np;
+                double2 h = h0[e];
+                for (int k = 0; k < K; ++k) {
+                    const double uk = control_at(ctl_b, si, K, k);
+                    const double2 g = gk[(size_t)k * mat + e];
+                    h.x = fma(uk, g.x, h.x);
+                    h.y = fma(uk, g.y, h.y);
+                }
+                const double2 v = make_double2(dts * h.y, -dts * h.x);
+                A[e] = v;
+                AT[(size_t)c * np + r] = v;
+            }
+        }
+        __syncthreads();
+        bool first = true;
+        for (int sub = 0; sub < nsub; ++sub)
+            for (int s = 0; s < S; ++s) {
+                const size_t t = (size_t)t0 + sub;
+                for (int i = tid; i < np; i += TPB) {
+                    const double2 p0 = states_b[(t * S + s) * np + i], p1 = states_b[((t + 1) * S + s) * np + i];
+                    tau[i] = xs_b[(t * S + s) * np + i];
+                    sig[i] = make_double2(p0.x + p1.x, p0.y + p1.y);
+                    del[i] = make_double2(p0.x - p1.x, p0.y - p1.y);
+                }
+                __syncthreads();
+                // tau_j = a^H tau_{j-1}: (a^H v)_c = sum_r conj(a[r][c]) v_r
+                for (int jj = 1; jj < M; ++jj) matvec_cols<true>(A, tau + (jj - 1) * np, tau + jj * np, part, np);
+                for (int i = tid; i < np; i += TPB) rho[(M - 1) * np + i] = make_double2(bt[M] * sig[i].x, bt[M] * sig[i].y);
+                __syncthreads();
+                // rho_{i-1} = b_i w_i + a rho_i: (a v)_r = sum_c a^T[c][r] v_c
+                for (int ii = M - 1; ii >= 1; --ii) {
+                    matvec_cols<false>(AT, rho + ii * np, rho + (ii - 1) * np, part, np);
+                    const double2* wv = (ii & 1) ? sig : del;
+                    for (int i = tid; i < np; i += TPB) {
+                        double2 r = rho[(ii - 1) * np + i];
+                        r.x = fma(bt[ii], wv[i].x, r.x);
+                        r.y = fma(bt[ii], wv[i].y, r.y);
+                        rho[(ii - 1) * np + i] = r;
+                    }
+                    __syncthreads();
+                }
+                // abar[r][c] += sum_i tau_i[r] conj(rho_i[c])
+                for (int e = tid; e < mat; e += TPB) {
+                    const int r = e / np, c = e - r * np;
+                    double2 acc = first ? make_double2(0, 0) : AB[e];
+                    for (int ii = 0; ii < M; ++ii) {
+                        const double2 tv = tau[ii * np + r], rv = rho[ii * np + c];
+                        acc.x = fma(tv.y, rv.y, fma(tv.x, rv.x, acc.x));
+                        acc.y = fma(-tv.x, rv.y, fma(tv.y, rv.x, acc.y));
+                    }
+                    AB[e] = acc;
+                }
+                first = false;
+                __syncthreads();
+            }
+        if (a.gen_rm != nullptr) {  // Mbar = 2^-s abar: the host finishes the chain rule
+            double2* mb = a.mbar_rm + m * mat;
+            const double scl = ldexp(1.0, -sq);
+            for (int e = tid; e < mat; e += TPB) mb[e] = make_double2(scl * AB[e].x, scl * AB[e].y);
+        } else {
+            // g_k = Re sum conj(abar) E_k, E_k = -i dts G_k
+            for (int k = 0; k < K; ++k) {
+                double acc = 0;
+                for (int e = tid; e < mat; e += TPB) {
+                    const double2 g = gk[(size_t)k * mat + e], ab = AB[e];
+                    acc = fma(ab.y, -dts * g.x, fma(ab.x, dts * g.y, acc));
+                }
+                const double2 tot = block_sum2(acc, 0.0, red);
+                if (tid == 0) a.gstep[m * K + k] = tot.x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace general
+
+int general_factor_lds() { return (int)sizeof(general::GemmLds) + 256; }
+int general_sweep_lds(int np) { return 7 * np * 16 + 256; }
+int general_krylov_lds(int np) { return (13 + 13 + 2 + 4) * np * 16 + 256; }
+
+void launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(general::factor_kernel, dim3(blocks), dim3(general::TPB), general_factor_lds(), st, a);
+}
+
+void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(general::sweep_kernel, dim3(batch), dim3(general::TPB), general_sweep_lds(a.np), st, a);
+}
+
+int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st) {
+    const int bytes = general_krylov_lds(a.np);
+    static int attr_bytes = 0;
+    if (bytes > 48 * 1024 && bytes > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(general::krylov_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return 1;
+        attr_bytes = bytes;
+    }
+    hipLaunchKernelGGL(general::krylov_kernel, dim3(blocks), dim3(general::TPB), bytes, st, a);
+    return 0;
+}
+
+}  // namespace qocx

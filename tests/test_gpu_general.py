@@ -1,0 +1,184 @@
+"""
+GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 256,
+Magnus M2): through the C ABI against the oracle at the tolerances of the wavefront kernels (states and
+cost 1e-10, gradients 1e-8). The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import qoc_numpy as onp
+from tests import cases as cases_mod
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from qoc_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+GENERAL_EDGE_CASES = [
+    dict(n=65, N=6, Nc=4, K=2, S=1, dt=0.05, ces=1, sigma=0.5),    # 15 padded rows (np = 80)
+    dict(n=130, N=5, Nc=5, K=3, S=3, dt=0.02, ces=2, sigma=0.3),   # np = 144: three column chunks
+    dict(n=100, N=7, Nc=3, K=2, S=5, dt=0.2, ces=3, sigma=1.0),    # squarings, five states
+    dict(n=200, N=4, Nc=4, K=1, S=2, dt=0.1, ces=1, sigma=0.5),    # np = 208: four column chunks
+    dict(n=256, N=3, Nc=2, K=2, S=1, dt=0.03, ces=1, sigma=0.4),   # the largest size
+]
+
+
+@pytest.mark.parametrize("spec", GENERAL_EDGE_CASES, ids=lambda s: "n{n}_N{N}_Nc{Nc}_K{K}_S{S}".format(**s))
+def test_general_path_edge_shapes(engine, spec):
+    from tests.test_gpu_engine import test_edge_shapes_against_oracle as check
+    check(engine, spec)
+
+
+@pytest.mark.parametrize("pade_order, count, seed", [(0, 12, 65256), (13, 5, 1365)])
+def test_general_path_fuzz(engine, pade_order, count, seed):
+    """tests/fuzz_parity.py at 65 <= n <= 256: random grids, state counts, Hermitian or not, time dependent
+    or not, 0..4 squarings, every state-cost kind; order by norm and the reference's always-[13/13]."""
+    from tests import fuzz_parity
+    rng = np.random.default_rng(seed)
+    engine.set_knob("pade_order", pade_order)
+    checked = 0
+    try:
+        for index in range(count):
+            worst, tag = fuzz_parity.one(engine, rng, index, nmin=65, nmax=256, smax=3)
+            if worst is None:
+                continue
+            checked += 1
+            assert worst < 1.0, tag
+    finally:
+        engine.set_knob("pade_order", 0)
+    assert checked >= count - 2
+
+
+def test_general_path_chunks_and_batch_independence(engine):
+    """Memory chunks of seeds and the batch a seed sits in do not change its numbers (bit for bit)."""
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    n, N, K, S = 72, 9, 2, 2
+    rng = np.random.default_rng(7272)
+    h0 = cases_mod.gue(rng, n) * 1.5
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    init = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    engine.set_schroedinger_problem(n, S, K, N, N, 0.1 * (N - 1), h0[None], np.stack(g)[None], init,
+                                    costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ)])
+    controls = 0.5 * rng.standard_normal((5, N, K))
+    ref = engine.evaluate(controls, True)
+    try:
+        for chunk in (1, 2):
+            engine.set_chunk(chunk)
+            out = engine.evaluate(controls, True)
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), chunk
+    finally:
+        engine.set_chunk(0)
+    one = engine.evaluate(controls[3:4], True)
+    assert one[0][0] == ref[0][3] and np.array_equal(one[1][0], ref[1][3]) and np.array_equal(one[2][0], ref[2][3])
+    # forward only: same costs and states, no gradient work
+    cost, _, final = engine.evaluate(controls, False)
+    assert np.array_equal(cost, ref[0]) and np.array_equal(final, ref[2])
+
+
+def test_general_path_user_cost_and_opaque_hamiltonian():
+    """The two host routes above n = 64: state cotangents supplied by the host (a user Cost plugin, with
+    and without its states_bar hook) against the built-in ForbidStates, and a Hamiltonian that is not
+    linear in its controls (explicit generators + their cotangents, chain rule on the host) against
+    central differences of its own cost and the oracle's forward pass."""
+    from qoc_amd.core import device
+    from qoc_amd.standard import ForbidStates, TargetStateInfidelity
+    from tests.test_host_api import _UserOccupation
+    n, N, K, ces = 70, 21, 2, 5
+    rng = np.random.default_rng(70)
+    h0 = cases_mod.gue(rng, n)
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    g2 = cases_mod.gue(rng, n)
+    init = np.zeros((1, n, 1), dtype=np.complex128)
+    init[0, 0, 0] = 1
+    targ = np.zeros((1, n, 1), dtype=np.complex128)
+    targ[0, 2, 0] = 1
+    forb = np.zeros((1, 1, n, 1), dtype=np.complex128)
+    forb[0, 0, 1, 0] = 1
+    T = 0.15 * (N - 1)
+    count = (N - 1) // ces
+
+    def linear(u, t):
+        return h0 + u[0] * g[0] + u[1] * g[1]
+
+    args = dict(control_count=K, control_eval_count=N, cost_eval_step=ces)
+    batch = 0.4 * rng.standard_normal((3, N, K))
+    ev_ref = device.SchroedingerEvaluator(
+        T, linear, init, N, costs=[TargetStateInfidelity(targ),
+                                   ForbidStates(forb, N, cost_eval_step=ces, cost_multiplier=0.7)], **args)
+    e0, g0, f0, _ = ev_ref.evaluate_batch(batch)
+    ocosts = [onp.TargetStateInfidelity(targ),
+              onp.ForbidStates(forb, N, cost_eval_step=ces, cost_multiplier=0.7)]
+    problem = onp.SchroedingerProblem(T, linear, init, N, control_eval_count=N, costs=ocosts,
+                                      cost_eval_step=ces, control_count=K)
+    for b in range(batch.shape[0]):
+        err, gr, fin = onp.evaluate_with_grad(problem, batch[b])
+        assert abs(err - e0[b]) < 1e-10 and rel_err(f0[b], fin) < 1e-10
+        assert np.max(np.abs(gr - g0[b])) < 1e-8 * np.max(np.abs(gr))
+    for with_hook in (True, False):
+        ev_user = device.SchroedingerEvaluator(
+            T, linear, init, N, costs=[TargetStateInfidelity(targ),
+                                       _UserOccupation(count, with_hook, cost_multiplier=0.7)], **args)
+        e1, g1, f1, _ = ev_user.evaluate_batch(batch)
+        assert np.max(np.abs(e0 - e1)) < 1e-12 and rel_err(f1, f0) < 1e-12
+        assert rel_err(g1, g0) < (1e-11 if with_hook else 1e-7)
+
+    def nonlinear(u, t):
+        return h0 + u[0] * g[0] + u[1] * g[1] + (u[0] ** 2) * g2
+
+    ev = device.SchroedingerEvaluator(T, nonlinear, init, N, costs=[TargetStateInfidelity(targ)],
+                                      control_count=K, control_eval_count=N)
+    assert ev.opaque_hamiltonian is not None
+    errors, grads, finals, _ = ev.evaluate_batch(batch[:1], want_grad=True)
+    oproblem = onp.SchroedingerProblem(T, nonlinear, init, N, control_eval_count=N,
+                                       costs=[onp.TargetStateInfidelity(targ)], control_count=K)
+    oerr, ofin = onp.evaluate(oproblem, batch[0])[:2]
+    assert abs(errors[0] - oerr) < 1e-10 and rel_err(finals[0], ofin) < 1e-10
+    for (j, k) in ((0, 0), (7, 1), (N - 1, 0)):
+        h = 1e-5
+        up, dn = batch[:1].copy(), batch[:1].copy()
+        up[0, j, k] += h
+        dn[0, j, k] -= h
+        fd = (ev.evaluate_batch(up, want_grad=False)[0][0] - ev.evaluate_batch(dn, want_grad=False)[0][0]) / (2 * h)
+        assert abs(fd - grads[0][j, k]) < 1e-7 * max(1.0, np.max(np.abs(grads[0])))
+
+
+def test_general_path_entry_points():
+    """evolve / grape through the reference's entry points at n = 80: the error falls, bounds hold."""
+    import qoc_amd
+    from qoc_amd.standard import Adam, TargetStateInfidelity
+    n, N = 80, 11
+    rng = np.random.default_rng(80)
+    h0 = cases_mod.gue(rng, n)
+    g0 = cases_mod.gue(rng, n)
+    init = np.zeros((1, n, 1), dtype=np.complex128)
+    init[0, 0, 0] = 1
+    targ = np.zeros((1, n, 1), dtype=np.complex128)
+    targ[0, 1, 0] = 1
+
+    def hamiltonian(u, t):
+        return h0 + u[0] * g0
+
+    controls = 0.2 * rng.standard_normal((N, 1))
+    ev = qoc_amd.evolve_schroedinger_discrete(1.0, hamiltonian, init, N, controls=controls,
+                                             costs=[TargetStateInfidelity(targ)])
+    problem = onp.SchroedingerProblem(1.0, hamiltonian, init, N, control_eval_count=N,
+                                      costs=[onp.TargetStateInfidelity(targ)], control_count=1)
+    oerr, ofin = onp.evaluate(problem, controls)[:2]
+    assert abs(ev.error - oerr) < 1e-10 and rel_err(ev.final_states, ofin) < 1e-10
+    result = qoc_amd.grape_schroedinger_discrete(
+        1, N, [TargetStateInfidelity(targ)], 1.0, hamiltonian, init, N, initial_controls=controls.copy(),
+        iteration_count=6, log_iteration_step=0, optimizer=Adam(learning_rate=5e-2),
+        max_control_norms=np.array([2.0]))
+    assert result.best_error < ev.error and np.all(np.abs(result.best_controls) <= 2.0 + 1e-12)
