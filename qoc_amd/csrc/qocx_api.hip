@@ -645,8 +645,10 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (n < 1 || n > 256)
         return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..256 (1..64: the wavefront kernels; 65..256: the general "
                                   "path of qocx_general.hip)");
-    if (n > 64 && p->magnus_policy != QOCX_MAGNUS_M2)
-        return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2 only");
+    if (n > 64 && p->magnus_policy != QOCX_MAGNUS_M2 &&
+        !(p->magnus_policy == QOCX_MAGNUS_M4 && p->nt == 1 && K >= 1 && K <= QOCX_M4LIN_MAX_K))
+        return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2, or M4 with a time-independent "
+                                  "system and 1..8 controls (its commutator-free form)");
     if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "state_count must be in 1..64");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
@@ -943,9 +945,12 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
     const int B = ctx->B, np = ctx->np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
     const size_t mat = (size_t)np * np;
     const bool explicit_gen = ctx->explicit_mode;
-    if (ctx->nodes != 1) return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2 only");
+    // M4 with a time-independent system: linear in Ke effective controls with constant matrices (M4LinArgs)
+    const bool m4lin = ctx->m4lin_Ke > 0 && ctx->nodes == 2 && !explicit_gen;
+    if (ctx->nodes != 1 && !m4lin) return fail(QOCX_ERR_ARG, "hilbert_size above 64: magnus_policy not supported");
+    const int Kk = m4lin ? ctx->m4lin_Ke : K;
     const size_t per_seed = (size_t)nsteps * (mat * 32 + 4) + ctx->slot_cap * S * np * 32 +
-                            (size_t)(nsteps + 1) * 4 + (size_t)nsteps * std::max(K, 1) * 8;
+                            (size_t)(nsteps + 1) * 4 + (size_t)nsteps * std::max(Kk, 1) * 40;
     const int max_blocks = 2 * ctx->cu_count;
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
@@ -963,7 +968,8 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
     if (ctx->q_img.ensure(cm * mat) || ctx->lu_img.ensure(cm * mat) || ctx->s_arr.ensure(cm) ||
         ctx->states.ensure((size_t)chunk * ctx->slot_cap * S * np) ||
         ctx->xs.ensure(want_grad ? (size_t)chunk * ctx->slot_cap * S * np : 1) ||
-        ctx->offs.ensure((size_t)chunk * (nsteps + 1)) || ctx->gstep.ensure(cm * std::max(K, 1)) ||
+        ctx->offs.ensure((size_t)chunk * (nsteps + 1)) || ctx->gstep.ensure(cm * std::max(Kk, 1)) ||
+        (m4lin && (ctx->veff.ensure(cm * Kk) || ctx->gnode.ensure(want_grad ? cm * 2 * K : 1))) ||
         ctx->cost_out.ensure(B) || ctx->grads.ensure((size_t)B * ctx->nc * std::max(K, 1)) ||
         ctx->final_out.ensure((size_t)B * S * np) || ctx->lam_buf.ensure((size_t)chunk * S * np) ||
         ctx->magnus_scratch.ensure((size_t)blocks * 7 * mat))
@@ -986,9 +992,21 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
         fa.q_img = ctx->q_img.p; fa.pinv_img = ctx->lu_img.p; fa.s_arr = ctx->s_arr.p; fa.status = ctx->status.p;
         fa.scratch = ctx->magnus_scratch.p;
         fa.total = (size_t)bc * nsteps;
+        qocx::M4LinArgs m4;
+        if (m4lin) {
+            m4.controls = fa.controls; m4.interp = ctx->interp.p;
+            m4.K = K; m4.Ke = Kk; m4.nc = ctx->nc; m4.nsteps = nsteps; m4.S = S;
+            m4.f0dt = (std::sqrt(3.0) / 12) * ctx->dt;
+            m4.veff = ctx->veff.p; m4.gstep = ctx->gstep.p; m4.gnode = ctx->gnode.p;
+            m4.lam_scale = nullptr;
+            m4.total = fa.total;
+            qocx::launch_m4lin_controls(m4, cs);
+            fa.controls = ctx->veff.p; fa.interp = ctx->interp_id.p; fa.g_rm = ctx->ge_timg.p;
+            fa.K = Kk; fa.nc = nsteps;
+        }
         const int fblocks = (int)std::min<size_t>(fa.total, (size_t)blocks);
         time_begin(ctx, 0, cs);
-        qocx::launch_general_factor(fa, fblocks, cs);
+        if (qocx::launch_general_factor(fa, fblocks, cs)) return fail(QOCX_ERR_HIP, "K1a (general): LDS size refused");
         time_end(ctx, cs);
 
         qocx::GeneralSweepArgs sa;
@@ -1012,7 +1030,7 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
 
         if (want_grad) {
             qocx::GeneralKrylovArgs ka;
-            ka.np = np; ka.S = S; ka.K = K; ka.nc = ctx->nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.dt = ctx->dt;
+            ka.np = np; ka.S = S; ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.dt = ctx->dt;
             ka.controls = fa.controls; ka.interp = fa.interp; ka.h0_rm = fa.h0_rm; ka.g_rm = fa.g_rm;
             ka.gen_rm = fa.gen_rm;
             ka.mbar_rm = explicit_gen ? ctx->genbar_rm.p + (size_t)b0 * nsteps * mat : nullptr;
@@ -1027,9 +1045,13 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
                 sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;
                 sc.weight = ctx->weight.p;
                 sc.grads = ctx->grads.p + (size_t)b0 * ctx->nc * K;
-                sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps;
+                sc.B = bc; sc.nc = ctx->nc; sc.K = K; sc.nsteps = nsteps * ctx->nodes;
                 sc.lam_scale = nullptr; sc.S = S;
                 time_begin(ctx, 3, cs);
+                if (m4lin) {  // effective-control cotangents -> node cotangents
+                    qocx::launch_m4lin_chain(m4, cs);
+                    sc.gstep = ctx->gnode.p;
+                }
                 qocx::launch_scatter(sc, cs);
                 time_end(ctx, cs);
             }

@@ -373,10 +373,10 @@ struct GeneralKrylovArgs {  // K3: one work item per (seed, step)
     double2* scratch;          // [blocks][3] matrices
     size_t total;
 };
-int general_factor_lds();
+int general_factor_lds(int np);
 int general_sweep_lds(int np);
 int general_krylov_lds(int np);
-void launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st);
+int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st);
 void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st);
 int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st);
 

@@ -9,6 +9,8 @@
 // serial triangular solve), classic order of the evaluation (factor, forward sweep, adjoint sweep, K3).
 //   reference: expm_pade qoc/standard/functions/expm.py:210-252 (orders by norm: the table :194-209),
 //   costs qoc/standard/costs/targetstateinfidelity.py:52-61, forbidstates.py:64-81
+#include <algorithm>
+
 #include "qocx_wave.h"
 
 namespace qocx {
@@ -148,101 +150,152 @@ __device__ __forceinline__ void gemm(const double2* __restrict__ A, const double
 }
 
 // M := M^-1 in place (row-major np x np in HBM / L2): Gauss-Jordan with partial pivoting (largest
-// |re| + |im| of the column, LAPACK's izamax measure; ties to the smaller row), the column interchanges undone
-// at the end. smem: row (np), col (np), piv (np ints), red. false (uniform): a zero / non-finite pivot.
+// |re| + |im| of the column, LAPACK's izamax measure; ties to the smaller row), BLOCKED by KB pivots so that the
+// matrix crosses the memory system np / KB times instead of np times: the KB columns of a block are
+// eliminated in LDS (thread r owns row r), their row interchanges are applied to the other columns, and every
+// other column takes the block's KB elimination steps as ONE rank-KB update
+//   X <- Y + (G - E)(E^T Y),  Y = the interchanged X,  G = the eliminated panel,  E = the block's unit columns
+// (the steps T_j = I + w_j e_kj^T commute past the later interchanges with w_j interchanged along, which is
+// what swapping whole panel rows in LDS does). The column interchanges are undone at the end in one pass.
+// false (uniform): a zero / non-finite pivot.
+constexpr int KB = 16, GP = KB + 1;
+__host__ __device__ constexpr int invert_lds(int np) { return np * GP * 16 + KB * np * 16 + 8 * np + 128; }
 __device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* smem) {
-    double2* rowk = reinterpret_cast<double2*>(smem);
-    double2* colk = rowk + np;
-    int* piv = reinterpret_cast<int*>(colk + np);
-    double* red = reinterpret_cast<double*>(piv + np);
+    double2* G = reinterpret_cast<double2*>(smem);  // [np][GP]
+    double2* R = G + (size_t)np * GP;               // [KB][np]
+    int* piv = reinterpret_cast<int*>(R + (size_t)KB * np);
+    int* idx = piv + np;
+    double* red = reinterpret_cast<double*>(idx + np);
     int* redi = reinterpret_cast<int*>(red + 8);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    bool ok = true;
-    for (int k = 0; k < np; ++k) {
-        double best = -1.0;
-        int bi = k;
-        for (int r = k + tid; r < np; r += TPB) {
-            const double2 e = M[(size_t)r * np + k];
-            const double v = fabs(e.x) + fabs(e.y);
-            if (v > best || !(v == v)) {
+    bool ok = true, any_swap = false;
+    for (int k0 = 0; k0 < np; k0 += KB) {
+        for (int e = tid; e < np * KB; e += TPB) {
+            const int r = e / KB, j = e - r * KB;
+            G[r * GP + j] = M[(size_t)r * np + k0 + j];
+        }
+        __syncthreads();
+        const int r = tid;  // np <= TPB: a row of the panel per thread
+        for (int j = 0; j < KB; ++j) {
+            const int k = k0 + j;
+            double best = -1.0;
+            int bi = k;
+            if (r < np && r >= k) {
+                const double2 e = G[r * GP + j];
+                const double v = fabs(e.x) + fabs(e.y);
                 best = (v == v) ? v : 1e308;
                 bi = r;
             }
-        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off);
-            if (ob > best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ob > best || (ob == best && oi < bi)) {
+                    best = ob;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                red[w] = best;
+                redi[w] = bi;
+            }
+            __syncthreads();
+            best = red[0];
+            int p = redi[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (red[q] > best || (red[q] == best && redi[q] < p)) {
+                    best = red[q];
+                    p = redi[q];
+                }
+            if (!(best > 0.0) || !(best < 1e300)) ok = false;  // singular or not finite: finish without dividing by it
+            if (tid == 0) piv[k] = p;
+            if (p != k) {
+                any_swap = true;
+                if (tid < KB) {
+                    const double2 t = G[k * GP + tid];
+                    G[k * GP + tid] = G[p * GP + tid];
+                    G[p * GP + tid] = t;
+                }
+            }
+            __syncthreads();
+            double2 inv = make_double2(1.0, 0.0);
+            {
+                const double2 d = G[k * GP + j];
+                const double den = d.x * d.x + d.y * d.y;
+                if (ok && den > 0.0) inv = make_double2(d.x / den, -d.y / den);
+            }
+            double2 f = make_double2(0, 0);
+            if (r < np && r != k) f = G[r * GP + j];
+            __syncthreads();
+            if (tid < KB) G[k * GP + tid] = (tid == j) ? inv : cmul(G[k * GP + tid], inv);
+            __syncthreads();
+            if (r < np && r != k) {
+                const double2 nf = make_double2(-f.x, -f.y);
+#pragma unroll
+                for (int jj = 0; jj < KB; ++jj) {
+                    const double2 pk = G[k * GP + jj];
+                    if (jj == j) {
+                        G[r * GP + jj] = cmul(nf, pk);
+                    } else {
+                        double2 v = G[r * GP + jj];
+                        cfma(v, nf, pk);
+                        G[r * GP + jj] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // the block's row interchanges on the other columns, in their order
+        for (int j = 0; j < KB; ++j) {
+            const int k = k0 + j, p = piv[k];
+            if (p != k) {
+                for (int c = tid; c < np; c += TPB)
+                    if (c < k0 || c >= k0 + KB) {
+                        const double2 t = M[(size_t)k * np + c];
+                        M[(size_t)k * np + c] = M[(size_t)p * np + c];
+                        M[(size_t)p * np + c] = t;
+                    }
+                __syncthreads();
             }
         }
-        __syncthreads();
-        if (lane == 0) {
-            red[w] = best;
-            redi[w] = bi;
-        }
-        __syncthreads();
-        best = red[0];
-        int p = redi[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (red[q] > best || (red[q] == best && redi[q] < p)) {
-                best = red[q];
-                p = redi[q];
-            }
-        if (!(best > 0.0) || !(best < 1e300)) ok = false;  // singular or not finite: finish without dividing by it
-        if (tid == 0) piv[k] = p;
-        // rows k and p change places; the new row k (unscaled) goes to LDS
-        for (int c = tid; c < np; c += TPB) {
-            const double2 a = M[(size_t)p * np + c];
-            if (p != k) M[(size_t)p * np + c] = M[(size_t)k * np + c];
-            rowk[c] = a;
-        }
-        __syncthreads();
-        for (int r = tid; r < np; r += TPB) colk[r] = (r == k) ? rowk[k] : M[(size_t)r * np + k];
-        __syncthreads();
-        double2 inv = make_double2(1.0, 0.0);
-        {
-            const double2 d = rowk[k];
-            const double den = d.x * d.x + d.y * d.y;
-            if (ok && den > 0.0) inv = make_double2(d.x / den, -d.y / den);
-        }
-        __syncthreads();
-        for (int c = tid; c < np; c += TPB) rowk[c] = (c == k) ? inv : cmul(rowk[c], inv);
+        for (int e = tid; e < KB * np; e += TPB) R[e] = M[(size_t)k0 * np + e];  // rows k0 .. k0 + KB - 1
         __syncthreads();
         for (int e = tid; e < np * np; e += TPB) {
-            const int r = e / np, c = e - r * np;
+            const int rr = e / np, c = e - rr * np;
             double2 v;
-            if (r == k) {
-                v = rowk[c];
+            if (c >= k0 && c < k0 + KB) {
+                v = G[rr * GP + c - k0];
             } else {
-                const double2 f = colk[r];
-                const double2 nf = make_double2(-f.x, -f.y);
-                if (c == k) {
-                    v = cmul(nf, rowk[k]);
-                } else {
-                    v = M[e];
-                    cfma(v, nf, rowk[c]);
-                }
+                v = (rr >= k0 && rr < k0 + KB) ? make_double2(0, 0) : M[e];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) cfma(v, G[rr * GP + j], R[j * np + c]);
             }
             M[e] = v;
         }
         __syncthreads();
     }
-    for (int k = np - 1; k >= 0; --k) {
-        const int p = piv[k];
-        if (p != k) {
-            for (int r = tid; r < np; r += TPB) {
-                const double2 a = M[(size_t)r * np + k];
-                M[(size_t)r * np + k] = M[(size_t)r * np + p];
-                M[(size_t)r * np + p] = a;
+    if (any_swap) {
+        // column c of the inverse is the column that the interchanges, undone from the last to the first, leave there
+        if (tid == 0) {
+            for (int c = 0; c < np; ++c) idx[c] = c;
+            for (int k = np - 1; k >= 0; --k) {
+                const int p = piv[k], t = idx[k];
+                idx[k] = idx[p];
+                idx[p] = t;
+            }
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < np; r0 += KB) {
+            for (int e = tid; e < KB * np; e += TPB) R[e] = M[(size_t)r0 * np + e];
+            __syncthreads();
+            for (int e = tid; e < KB * np; e += TPB) {
+                const int j = e / np, c = e - j * np;
+                M[(size_t)r0 * np + e] = R[j * np + idx[c]];
             }
             __syncthreads();
         }
     }
-    __syncthreads();
     return ok;
 }
 
@@ -252,8 +305,8 @@ __device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* sm
 // with 7 scratch matrices each.
 __global__ __launch_bounds__(TPB) void factor_kernel(GeneralArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem + sizeof(GemmLds));
     const int np = a.np, mat = np * np, tid = threadIdx.x;
+    double* red = reinterpret_cast<double*>(smem + (sizeof(GemmLds) > (size_t)invert_lds(np) ? sizeof(GemmLds) : (size_t)invert_lds(np)));
     double2* sc = a.scratch + (size_t)blockIdx.x * 7 * mat;
     double2 *A = sc, *A2 = sc + mat, *A4 = sc + 2 * (size_t)mat, *A6 = sc + 3 * (size_t)mat, *X = sc + 4 * (size_t)mat,
             *Y = sc + 5 * (size_t)mat, *Z = sc + 6 * (size_t)mat;
@@ -721,12 +774,21 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
 
 }  // namespace general
 
-int general_factor_lds() { return (int)sizeof(general::GemmLds) + 256; }
+int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
 int general_sweep_lds(int np) { return 7 * np * 16 + 256; }
 int general_krylov_lds(int np) { return (13 + 13 + 2 + 4) * np * 16 + 256; }
 
-void launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(general::factor_kernel, dim3(blocks), dim3(general::TPB), general_factor_lds(), st, a);
+int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
+    const int bytes = general_factor_lds(a.np);
+    static int attr_bytes = 0;
+    if (bytes > 48 * 1024 && bytes > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(general::factor_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return 1;
+        attr_bytes = bytes;
+    }
+    hipLaunchKernelGGL(general::factor_kernel, dim3(blocks), dim3(general::TPB), bytes, st, a);
+    return 0;
 }
 
 void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st) {

@@ -112,6 +112,17 @@ def test_sixteen_tile_kernels_do_not_spill():
     assert herm16_5["Occupancy"] == 2 and herm16_5["ScratchSize"] == 0 and herm16_5["VGPRs Spill"] == 0
 
 
+def test_general_path_kernels_do_not_spill():
+    """65 <= n <= 256 (qocx_general.hip): workgroups of 256 threads on matrices in HBM / L2; the GEMM of the
+    factor kernel holds 4 x 4 complex outputs per thread - two workgroups per CU, no scratch anywhere."""
+    general = resources("qocx_general.hip")
+    factor = find(general, "factor_kernel")
+    assert factor["ScratchSize"] == 0 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
+    for frag in ("sweep_kernel", "krylov_kernel"):
+        entry = find(general, frag)
+        assert entry["ScratchSize"] == 0 and entry["VGPRs Spill"] == 0 and total_registers(entry) <= 128
+
+
 def test_release_library_has_no_diagnostic_switches():
     """the knobs that return garbage (timing experiments), the stamped kernel
     builds and the QOCX_* environment switches exist in libqocx_diag.so only (-DQOCX_DIAG,

@@ -519,7 +519,7 @@ def test_error_paths(engine):
         assert err.value.code == -1 and "hilbert_size" in err.value.message
         with pytest.raises(QocxError) as err:  # above 64 (qocx_general.hip): M2 only
             fresh.set_schroedinger_problem(65, 1, 0, 0, 5, 1.0, np.eye(65), None, np.eye(65)[:1],
-                                           magnus_policy="M4")
+                                           magnus_policy="M6")
         assert err.value.code == -1 and "M2" in err.value.message
         with pytest.raises(QocxError) as err:  # sixteen tiles: 14 states do not fit the sweep's LDS
             fresh.set_schroedinger_problem(40, 14, 0, 0, 5, 1.0, np.eye(40), None, np.eye(40)[:14])

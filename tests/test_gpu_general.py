@@ -182,3 +182,40 @@ def test_general_path_entry_points():
         iteration_count=6, log_iteration_step=0, optimizer=Adam(learning_rate=5e-2),
         max_control_norms=np.array([2.0]))
     assert result.best_error < ev.error and np.all(np.abs(result.best_controls) <= 2.0 + 1e-12)
+
+
+def test_general_path_pivots_off_the_diagonal(engine):
+    """A generator whose Pade denominator is NOT diagonally dominant (a scaled cyclic shift: the sub-diagonal of
+    P = v - u carries b_1 theta > b_0): the blocked Gauss-Jordan inversion interchanges rows in every block and
+    undoes the column interchanges at the end; checked that LAPACK pivots off the diagonal there too."""
+    import scipy.linalg
+    from qoc_amd.engine import COST_TARGET_INCOHERENT
+    from tests import device_model as dm
+    n, N, K, S = 66, 4, 1, 2
+    rng = np.random.default_rng(66)
+    dt = 0.25
+    shift = np.roll(np.eye(n), 1, axis=0)
+    h0 = 1j * (4.0 / dt) * shift + 0.3 * cases_mod.gue(rng, n)
+    g = [cases_mod.gue(rng, n)]
+    a = -1j * dt * h0
+    u, v = dm.pade_uv(a, 13)
+    piv = scipy.linalg.lu_factor(v - u)[1]
+    assert np.count_nonzero(piv != np.arange(n)) > n // 2
+    init = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    T = dt * (N - 1)
+    engine.set_schroedinger_problem(n, S, K, N, N, T, h0[None], np.stack(g)[None], init,
+                                    costs=[dict(kind=COST_TARGET_INCOHERENT, step_cost=0, scale=1.0, vectors=targ)])
+    controls = 0.1 * rng.standard_normal((2, N, K))
+    cost, grads, final = engine.evaluate(controls, want_grad=True)
+    problem = onp.SchroedingerProblem(
+        T, lambda uu, t: h0 + uu[0] * g[0], init[:, :, None], N, control_eval_count=N,
+        costs=[onp.TargetStateInfidelity(targ[:, :, None], neglect_relative_pahse=True)], control_count=K)
+    for b in range(2):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        # (this propagator is far from unitary: the states grow, so every gate is relative)
+        assert abs(err - cost[b]) < 1e-10 * max(1.0, abs(err))
+        assert rel_err(final[b][:, :, None], fin) < 1e-10
+        assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
