@@ -17,6 +17,7 @@ The line also carries, measured in the same run on rank 0:
                 inclusive; SURVEY.md 8d's "controls in, results out");
   secondary     BASELINE.json configs[3]: dim=16 Lindblad, 500 steps, 64 seeds - ms per
                 evaluation, steps/s and the roofline of the Lindblad kernel;
+  general_path  the path for Hilbert sizes above 64 (qocx_general.hip) at dim = 128, 16 seeds x 250 steps;
   cpu_baseline  the oracle on the host cores (all cores, and one core: the reference's execution
                 model).
 
@@ -293,6 +294,49 @@ def latency_secondary(engine, reps=200):
     return out
 
 
+def general_secondary(engine, n=128, seeds=16, steps=250):
+    """The path for Hilbert sizes above 64 (qoc_amd/csrc/qocx_general.hip): the headline's GUE problem at
+    dim = 128, forward + gradient, with the flops of its Pade products and inversion against the FP64 peak."""
+    global DIM
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    keep = DIM
+    DIM = n
+    try:
+        h0, g, psi0, target = make_problem()
+        controls = make_controls(0, seeds)[:, :steps + 1]
+    finally:
+        DIM = keep
+    engine.set_schroedinger_problem(
+        n, 1, K_CTRL, steps + 1, steps + 1, DT * steps, h0[None], np.stack(g)[None], psi0,
+        costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=target)])
+    engine.upload_controls(np.ascontiguousarray(controls))
+    engine.set_timing(True)
+    engine.eval_resident(True)
+    engine.synchronize()
+    engine.reset_timing()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        engine.eval_resident(True)
+    engine.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    orders = engine.pade_orders()
+    kernels = {k: v[1] / reps for k, v in engine.timing().items() if v[0]}
+    engine.set_timing(False)
+    products = {3: 2, 5: 3, 7: 4, 9: 5, 13: 6}
+    total = max(1, sum(orders.values()))
+    # complex n^3 products of the Pade chain + the n^3 of the explicit inverse, 8 flops per complex multiply-add
+    flops_per_step = 8.0 * n ** 3 * (sum(products[o] * c for o, c in orders.items()) / total + 1.0)
+    factor_ms = kernels.get("pade_pq", 0.0)
+    return dict(workload="dim={} Schroedinger (general path, qocx_general.hip), {} steps, {} seeds".format(n, steps, seeds),
+                ms_per_evaluation=wall * 1e3, value=seeds * steps / wall, unit="propagator-steps/s",
+                pade_orders={str(o): c for o, c in orders.items() if c},
+                kernel_ms_per_evaluation=kernels,
+                roofline=dict(bound="mfma", kernel="qocx::general::factor_kernel", flops_per_step=flops_per_step,
+                              achieved=flops_per_step * seeds * steps / (factor_ms * 1e-3) / 1e12 if factor_ms else None,
+                              peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s"))
+
+
 # the two-sided launches of configs[3] (chain form of the stage loop), as the profiles name them
 LB_KERNEL = "qocx::lindblad_kernel<1, false, true, true, false, true, true>"
 
@@ -487,10 +531,12 @@ def main():
                                     "the reference executes it (expm.py:230-233)")
     secondary = None
     latency = None
+    general = None
     if world == 1 and not args.no_secondary and not standin:
         engine.set_timing(True)
         secondary = lindblad_secondary(engine)
         latency = None if args.no_latency else latency_secondary(engine)
+        general = None if args.no_latency else general_secondary(engine)
     engine.set_timing(False)
 
     units_per_step = world * seeds * (N_EVAL - 1)
@@ -610,6 +656,7 @@ def main():
         "reference_order": reference_order,
         "secondary": secondary,
         "latency": latency,
+        "general_path": general,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not standin:

@@ -4,7 +4,7 @@
 // with every matrix in HBM / L2 instead of registers and LDS, one workgroup of four waves per work item.
 // The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502, its report has rows to
 // n = 1024); this file turns the hard error above n = 64 into a working path. It is NOT tuned like the
-// n <= 64 kernels: row-major padded matrices, vector-unit complex GEMMs staged through LDS, an explicit
+// n <= 64 kernels: row-major padded matrices, complex GEMMs on the matrix cores staged through LDS, an explicit
 // inverse by Gauss-Jordan with partial pivoting (so a sub-step is two matrix-vector products and no
 // serial triangular solve), classic order of the evaluation (factor, forward sweep, adjoint sweep, K3).
 //   reference: expm_pade qoc/standard/functions/expm.py:210-252 (orders by norm: the table :194-209),
@@ -96,55 +96,71 @@ __device__ __forceinline__ void matvec_cols(const double2* __restrict__ M, const
     __syncthreads();
 }
 
-// C = A B (row-major np x np in HBM / L2, np a multiple of 16): 64 x 64 output tiles, a thread holds the
-// 4 x 4 outputs (ty + 16 i, tx + 16 j), operands staged 16 columns at a time through LDS (34 KiB at smem).
+// C = A B (row-major np x np in HBM / L2, np a multiple of 16) on the matrix cores: 64 x 64 output tiles, a
+// wave owns a 32 x 32 quadrant (2 x 2 tiles of v_mfma_f64_16x16x4_f64, complex = 4 real products per tile and
+// k-step), operands staged 16 columns at a time through LDS (34 KiB at smem): lane (q, c) reads its A fragment
+// A[16 i + c][4 kk + q] and its B fragment B[4 kk + q][16 j + c] as one 16-byte complex number each.
 struct GemmLds {
     double2 as[64][17];
     double2 bs[16][64];
 };
-__device__ __forceinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
+__device__ __noinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
                                      int np, char* smem) {
     GemmLds& L = *reinterpret_cast<GemmLds*>(smem);
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     for (int r0 = 0; r0 < np; r0 += 64)
         for (int c0 = 0; c0 < np; c0 += 64) {
-            const int ni = min(4, (np - r0) >> 4), nj = min(4, (np - c0) >> 4);
-            double2 acc[4][4];
+            const bool vi[2] = {r0 + wr < np, r0 + wr + 16 < np}, vj[2] = {c0 + wc < np, c0 + wc + 16 < np};
+            d4 re[2][2], im[2][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = make_double2(0, 0);
+                for (int j = 0; j < 2; ++j) re[i][j] = im[i][j] = d4{0, 0, 0, 0};
             for (int k0 = 0; k0 < np; k0 += 16) {
+                // (measured: the next chunk prefetched into registers while this one's products run - no gain,
+                // the workgroup that shares the CU covers the wait)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int idx = tid + TPB * q;
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int idx = tid + TPB * qq;
                     const int rr = idx >> 4, kk = idx & 15;
                     L.as[rr][kk] = (r0 + rr < np) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
                     const int kb = idx >> 6, cc = idx & 63;
                     L.bs[kb][cc] = (c0 + cc < np) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
                 }
                 __syncthreads();
-#pragma unroll 4
-                for (int kk = 0; kk < 16; ++kk) {
-                    double2 a[4], b[4];
+                if (vi[0] && vj[0]) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = L.as[ty + 16 * i][kk];
+                    for (int kk = 0; kk < 4; ++kk) {
+                        double2 af[2], bf[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) b[j] = L.bs[kk][tx + 16 * j];
+                        for (int i = 0; i < 2; ++i) af[i] = L.as[wr + 16 * i + c][4 * kk + q];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < ni)
+                        for (int j = 0; j < 2; ++j) bf[j] = L.bs[4 * kk + q][wc + 16 * j + c];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (j < nj) cfma(acc[i][j], a[i], b[j]);
+                        for (int i = 0; i < 2; ++i)
+                            if (vi[i])
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    if (vj[j]) {
+                                        re[i][j] = mfma_f64(af[i].x, bf[j].x, re[i][j]);
+                                        re[i][j] = mfma_f64(-af[i].y, bf[j].y, re[i][j]);
+                                        im[i][j] = mfma_f64(af[i].x, bf[j].y, im[i][j]);
+                                        im[i][j] = mfma_f64(af[i].y, bf[j].x, im[i][j]);
+                                    }
+                    }
                 }
                 __syncthreads();
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i < ni && j < nj) C[(size_t)(r0 + ty + 16 * i) * np + c0 + tx + 16 * j] = acc[i][j];
+                for (int j = 0; j < 2; ++j)
+                    if (vi[i] && vj[j])
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            C[(size_t)(r0 + wr + 16 * i + 4 * r + q) * np + c0 + wc + 16 * j + c] =
+                                make_double2(re[i][j][r], im[i][j][r]);
         }
     __syncthreads();
 }
@@ -160,7 +176,7 @@ __device__ __forceinline__ void gemm(const double2* __restrict__ A, const double
 // false (uniform): a zero / non-finite pivot.
 constexpr int KB = 16, GP = KB + 1;
 __host__ __device__ constexpr int invert_lds(int np) { return np * GP * 16 + KB * np * 16 + 8 * np + 128; }
-__device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* smem) {
+__device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem) {
     double2* G = reinterpret_cast<double2*>(smem);  // [np][GP]
     double2* R = G + (size_t)np * GP;               // [KB][np]
     int* piv = reinterpret_cast<int*>(R + (size_t)KB * np);
@@ -261,17 +277,39 @@ __device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* sm
         }
         for (int e = tid; e < KB * np; e += TPB) R[e] = M[(size_t)k0 * np + e];  // rows k0 .. k0 + KB - 1
         __syncthreads();
-        for (int e = tid; e < np * np; e += TPB) {
-            const int rr = e / np, c = e - rr * np;
-            double2 v;
-            if (c >= k0 && c < k0 + KB) {
-                v = G[rr * GP + c - k0];
-            } else {
-                v = (rr >= k0 && rr < k0 + KB) ? make_double2(0, 0) : M[e];
+        {
+            // the rank-16 update on the matrix cores, a 16 x 16 tile of the matrix per wave and turn: the tile
+            // (or zero, in the block's own rows) is the accumulator, G[16 ti .., 0..15] the A operand, R the B one
+            const int q = lane >> 4, c = lane & 15, nt = np >> 4, pt = k0 >> 4;
+            for (int t = w; t < nt * nt; t += 4) {
+                const int ti = t / nt, tj = t - ti * nt;
+                if (tj == pt) continue;
+                const size_t base = (size_t)(16 * ti + q) * np + 16 * tj + c;  // element (16 ti + 4 r + q, 16 tj + c)
+                d4 re = d4{0, 0, 0, 0}, im = d4{0, 0, 0, 0};
+                if (ti != pt) {
 #pragma unroll
-                for (int j = 0; j < KB; ++j) cfma(v, G[rr * GP + j], R[j * np + c]);
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const double2 e = M[base + (size_t)4 * rr * np];
+                        re[rr] = e.x;
+                        im[rr] = e.y;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double2 a = G[(16 * ti + c) * GP + 4 * kk + q];
+                    const double2 b = R[(4 * kk + q) * np + 16 * tj + c];
+                    re = mfma_f64(a.x, b.x, re);
+                    re = mfma_f64(-a.y, b.y, re);
+                    im = mfma_f64(a.x, b.y, im);
+                    im = mfma_f64(a.y, b.x, im);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) M[base + (size_t)4 * rr * np] = make_double2(re[rr], im[rr]);
             }
-            M[e] = v;
+            for (int e = tid; e < np * KB; e += TPB) {  // the block's own columns: the eliminated panel
+                const int rr = e / KB, j = e - rr * KB;
+                M[(size_t)rr * np + k0 + j] = G[rr * GP + j];
+            }
         }
         __syncthreads();
     }
@@ -303,7 +341,7 @@ __device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* sm
 // One work item = one propagator step of one seed: generator, 1-norm, order / squarings, the Pade
 // polynomials, Q to q_img, P^-1 to pinv_img, the step's entry of s_arr. Persistent workgroups (grid-stride)
 // with 7 scratch matrices each.
-__global__ __launch_bounds__(TPB) void factor_kernel(GeneralArgs a) {
+__global__ __launch_bounds__(TPB, 2) void factor_kernel(GeneralArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int np = a.np, mat = np * np, tid = threadIdx.x;
     double* red = reinterpret_cast<double*>(smem + (sizeof(GemmLds) > (size_t)invert_lds(np) ? sizeof(GemmLds) : (size_t)invert_lds(np)));

@@ -113,11 +113,11 @@ def test_sixteen_tile_kernels_do_not_spill():
 
 
 def test_general_path_kernels_do_not_spill():
-    """65 <= n <= 256 (qocx_general.hip): workgroups of 256 threads on matrices in HBM / L2; the GEMM of the
-    factor kernel holds 4 x 4 complex outputs per thread - two workgroups per CU, no scratch anywhere."""
+    """65 <= n <= 256 (qocx_general.hip): workgroups of 256 threads on matrices in HBM / L2; the factor kernel
+    (MFMA GEMM and the blocked inversion as calls: a frame of saved registers, no spills) fits twice on a CU."""
     general = resources("qocx_general.hip")
     factor = find(general, "factor_kernel")
-    assert factor["ScratchSize"] == 0 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
+    assert factor["ScratchSize"] <= 128 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
     for frag in ("sweep_kernel", "krylov_kernel"):
         entry = find(general, frag)
         assert entry["ScratchSize"] == 0 and entry["VGPRs Spill"] == 0 and total_registers(entry) <= 128
