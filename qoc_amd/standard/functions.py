@@ -43,11 +43,12 @@ _EXPM_ENGINE = []
 
 def expm(a):
     """
-    Matrix exponential of one square complex matrix (n <= 64, the engine's size limit) by the
+    Matrix exponential of one square complex matrix (n <= 256, the engine's size limit) by the
     engine's Pade scaling-and-squaring path - the same kernels the propagation uses: exp(a) is the
     one-step propagator of H = i a over dt = 1 applied to the identity columns (the engine takes the
     Pade order from the norm, [13/13] with squarings for large ones; qoc/standard/functions/expm.py:210-252).
-    Above n = 32 the engine propagates at most 13 states at a time, so the columns go in blocks.
+    For 33 <= n <= 64 the engine propagates at most 13 states at a time, above that (its general path)
+    at most 64, so the columns go in blocks.
     There is no CPU implementation in this package; without the HIP library / a GPU the call raises.
     """
     from qoc_amd.core import device
@@ -55,12 +56,12 @@ def expm(a):
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError("expm expects one square matrix, got shape {}".format(a.shape))
     n = a.shape[0]
-    if n > 64:
-        raise NotImplementedError("expm on the MI355X engine handles n <= 64 (got {})".format(n))
+    if n > 256:
+        raise NotImplementedError("expm on the MI355X engine handles n <= 256 (got {})".format(n))
     if not _EXPM_ENGINE:
         _EXPM_ENGINE.append(device.make_backend())
     engine = _EXPM_ENGINE[0]
-    block = n if n <= 32 else 13
+    block = n if n <= 32 else (13 if n <= 64 else 64)
     out = np.empty((n, n), dtype=np.complex128)
     eye = np.eye(n, dtype=np.complex128)
     for c0 in range(0, n, block):

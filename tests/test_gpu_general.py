@@ -219,3 +219,15 @@ def test_general_path_pivots_off_the_diagonal(engine):
         assert abs(err - cost[b]) < 1e-10 * max(1.0, abs(err))
         assert rel_err(final[b][:, :, None], fin) < 1e-10
         assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
+
+
+def test_expm_above_64():
+    """qoc_amd.standard.expm (the reference's qoc.standard.functions.expm) on the general path: n = 100, a
+    non-normal matrix with a norm that needs squarings, against SciPy."""
+    import scipy.linalg
+    from qoc_amd.standard import functions
+    rng = np.random.default_rng(100)
+    a = 0.8 * (rng.standard_normal((100, 100)) + 1j * rng.standard_normal((100, 100))) / 10
+    out = functions.expm(a)
+    ref = scipy.linalg.expm(a)
+    assert rel_err(out, ref) < 1e-12
