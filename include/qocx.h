@@ -120,7 +120,7 @@ typedef struct qocx_lindblad_problem {
     int32_t control_eval_count;   /* Nc                                                            */
     int32_t system_eval_count;    /* N >= 2                                                        */
     int32_t cost_eval_step;
-    int32_t operator_count;       /* L >= 0 Lindblad operators                                     */
+    int32_t operator_count;       /* L Lindblad operators, 0..8 (17 <= n <= 32: as many as fit the LDS, 5) */
     double evolution_time;
     const double* h0;             /* [n][n] complex                                                */
     const double* g;              /* [K][n][n] complex                                             */

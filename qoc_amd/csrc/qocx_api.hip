@@ -2148,7 +2148,9 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
         return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..32 for the Lindblad engine");
     if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "density_count must be in 1..64");
     if (K < 0 || K > QOCX_LINDBLAD_MAX_K) return fail(QOCX_ERR_ARG, "control_count must be in 0..8");
-    if (L < 0 || L > 4) return fail(QOCX_ERR_ARG, "operator_count must be in 0..4");
+    // (1..4 operators: the several-wave / tile-per-wave stage loops; 5..8: the one-wave kernels, whose stage
+    // loop walks any number of operators)
+    if (L < 0 || L > 8) return fail(QOCX_ERR_ARG, "operator_count must be in 0..8");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
     if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");
     if (p->cost_eval_step < 1) return fail(QOCX_ERR_ARG, "cost_eval_step must be >= 1");
@@ -2166,7 +2168,7 @@ int qocx_set_lindblad_problem(qocx_ctx* ctx, const qocx_lindblad_problem* p) {
     // form of L = 1 although they multiply by that zero: 17.2 -> 11.5 ms on configs[3]'s sizes)
     ctx->lb.pad_op = (L == 1 && n <= 16 && p->op_stages == nullptr && ctx->knob("lindblad_pad_operator", 1) != 0) ? 1 : 0;
     const int Lmw = ctx->lb.pad_op ? 2 : L;
-    ctx->lb.multi_wave = (!ctx->lb.global_scratch && L > 0 &&
+    ctx->lb.multi_wave = (!ctx->lb.global_scratch && L > 0 && L <= 4 &&
                           qocx::lindblad_lds_size(n, S, Lmw, 2, K) <= 160 * 1024 &&
                           !qocx::diag_getenv("QOCX_LINDBLAD_SINGLE_WAVE")) ? 1 : 0;
     ctx->lb.cache_gen = (ctx->lb.multi_wave && p->fixed_subdivision <= 0 &&

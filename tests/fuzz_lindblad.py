@@ -3,7 +3,7 @@ fuzz_lindblad.py - TEST TOOLING (parity checker; lives under tests/ because it d
 against the NumPy model of the device algorithm (tests/lindblad_model.py), which the CPU suite
 holds against the reference fixtures.
 
-    python -m tests.fuzz_lindblad [count] [seed]
+    python -m tests.fuzz_lindblad [count] [seed] [lmin lmax]
 """
 import os
 import sys
@@ -13,16 +13,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import qoc_lindblad_numpy as ol  # noqa: E402
-from qoc_amd.engine import Engine, COST_FORBID_DENSITY, COST_TARGET_DENSITY  # noqa: E402
+from qoc_amd.engine import Engine, QocxError, COST_FORBID_DENSITY, COST_TARGET_DENSITY  # noqa: E402
 from tests import lindblad_model as lm  # noqa: E402
 from tests.cases import gue, random_density  # noqa: E402
 
 
-def one(engine, rng, index):
+def one(engine, rng, index, lmin=0, lmax=3):
     n = int(rng.integers(1, 33)) if rng.random() < 0.5 else int(rng.integers(1, 17))
     S = int(rng.integers(1, 4))
     K = int(rng.integers(0, 4))
-    L = int(rng.integers(0, 4))
+    L = int(rng.integers(lmin, lmax + 1))
     N = int(rng.integers(2, 6))
     Nc = int(rng.integers(2, 9)) if K else 0
     ces = int(rng.integers(1, 3))
@@ -43,8 +43,14 @@ def one(engine, rng, index):
                           vectors=forb, counts=[2] * S))
         costs.append(ol.ForbidDensities(forb.reshape(S, 2, n, n), N, cost_eval_step=ces,
                                         cost_multiplier=1.5))
-    engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs,
-                                cost_eval_step=ces)
+    tag = "n={} S={} K={} L={} N={} Nc={} ces={} B={}".format(n, S, K, L, N, Nc, ces, batch)
+    try:
+        engine.set_lindblad_problem(n, S, K, Nc, N, T, h0, g, gam, ops, rho0, costs=descs,
+                                    cost_eval_step=ces)
+    except QocxError as exc:
+        if L > 4 and "LDS" in exc.message:  # 17 <= n <= 32: the operator images of more than five do not fit
+            return 0.0, tag + " (rejected: operators beyond the LDS, not compared)"
+        raise
     controls = (float(10 ** rng.uniform(-1, 0.3)) * rng.standard_normal((batch, Nc, K))
                 if K else None)
     cost, grads, final = engine.evaluate_lindblad(controls if K else batch, want_grad=K > 0)
@@ -111,12 +117,17 @@ def one_two_sided(engine, rng, index):
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    lmin = int(sys.argv[3]) if len(sys.argv) > 3 else None  # [lmin lmax]: operator counts of one()
+    lmax = int(sys.argv[4]) if len(sys.argv) > 4 else lmin
     rng = np.random.default_rng(seed)
     engine = Engine(0)
     bad, skipped, overall = 0, 0, 0.0
     for index in range(count):
         # (every other case from the two-sided shapes)
-        worst, tag = (one_two_sided if index % 2 else one)(engine, rng, index)
+        if lmin is not None:
+            worst, tag = one(engine, rng, index, lmin, lmax)
+        else:
+            worst, tag = (one_two_sided if index % 2 else one)(engine, rng, index)
         overall = max(overall, worst)
         skipped += tag.endswith("not compared)")
         if worst > 1.0:

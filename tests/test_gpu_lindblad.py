@@ -457,6 +457,25 @@ def test_lindblad_random_shapes_fuzz(engine):
         assert worst < 1.0, tag
 
 
+def test_lindblad_five_to_eight_operators(engine):
+    """More than four Lindblad operators (three qubits with T1 and T_phi each are six): the one-wave kernels,
+    whose stage loop walks any number of operators - n <= 16: up to eight; 17 <= n <= 32: as many as the LDS
+    holds (five), more are rejected by name. tests/fuzz_lindblad.py against the device model."""
+    from qoc_amd.engine import QocxError
+    from tests import fuzz_lindblad
+    rng = np.random.default_rng(5008)
+    compared = 0
+    for index in range(30):
+        worst, tag = fuzz_lindblad.one(engine, rng, index, lmin=5, lmax=8)
+        assert worst < 1.0, tag
+        compared += not tag.endswith("not compared)")
+    assert compared >= 15
+    with pytest.raises(QocxError) as err:
+        engine.set_lindblad_problem(4, 1, 0, 0, 3, 1.0, np.eye(4), [], np.full(9, 0.1),
+                                    np.stack([np.eye(4)] * 9), np.eye(4)[None] / 4, costs=[])
+    assert "operator_count" in err.value.message
+
+
 @pytest.mark.parametrize("name", ["lindblad_n4", "lindblad_c4_short"])
 def test_lindblad_launch_variants_agree(engine, name):
     """

@@ -193,3 +193,50 @@ def test_opaque_hamiltonian_on_the_lindblad_grape_path_on_gpu():
     """See tests/test_lindblad_host_api.py::check_opaque_lindblad_grape."""
     from tests.test_lindblad_host_api import check_opaque_lindblad_grape
     check_opaque_lindblad_grape()
+
+
+def test_three_qubits_with_six_lindblad_operators_on_gpu():
+    """Three qubits (n = 8) with T1 and T_phi on each - six Lindblad operators, beyond the four of the several-wave
+    stage loops: evolve against the oracle's restatement of the reference's adaptive integrator
+    (lindbladdiscrete.py:357-441) at the forward gates, and GRAPE runs on it."""
+    from oracle import qoc_lindblad_numpy as ol
+    from qoc_amd.standard import TargetDensityInfidelity
+    sm = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    sz = np.diag([1.0, -1.0]).astype(np.complex128)
+    sx = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+    eye = np.eye(2, dtype=np.complex128)
+
+    def on(op, q):
+        mats = [eye, eye, eye]
+        mats[q] = op
+        return np.kron(np.kron(mats[0], mats[1]), mats[2])
+
+    h0 = sum(0.3 * (q + 1) * on(sz, q) for q in range(3)) + 0.2 * (on(sx, 0) @ on(sx, 1) + on(sx, 1) @ on(sx, 2))
+    drives = [on(sx, q) for q in range(3)]
+    ops = np.stack([on(sm, q) for q in range(3)] + [on(sz, q) for q in range(3)])
+    gammas = np.array([0.05, 0.04, 0.06, 0.02, 0.03, 0.01])
+
+    def hamiltonian(u, t):
+        return h0 + sum(u[k] * drives[k] for k in range(3))
+
+    def lindblad_data(t):
+        return gammas, ops
+
+    n, N, T = 8, 11, 2.0
+    rho0 = np.zeros((1, n, n), dtype=np.complex128)
+    rho0[0, 0, 0] = 1
+    targ = np.zeros((1, n, n), dtype=np.complex128)
+    targ[0, 7, 7] = 1
+    controls = 0.5 * np.random.default_rng(6).standard_normal((N, 3))
+    result = qoc_amd.evolve_lindblad_discrete(T, rho0, N, controls=controls, costs=[TargetDensityInfidelity(targ)],
+                                              hamiltonian=hamiltonian, lindblad_data=lindblad_data)
+    problem = ol.LindbladProblem(T, rho0, N, hamiltonian=hamiltonian, lindblad_data=lindblad_data,
+                                 control_eval_count=N, costs=[ol.TargetDensityInfidelity(targ)], control_count=3)
+    err, fin = ol.evaluate(problem, controls)
+    assert abs(result.error - err) < 1e-9
+    assert np.max(np.abs(result.final_densities - fin)) < 1e-8
+    grape = qoc_amd.grape_lindblad_discrete(
+        3, N, [TargetDensityInfidelity(targ)], T, rho0, N, hamiltonian=hamiltonian, lindblad_data=lindblad_data,
+        initial_controls=controls.copy(), iteration_count=5, log_iteration_step=0, optimizer=Adam(learning_rate=5e-2),
+        max_control_norms=np.full(3, 3.0))
+    assert grape.best_error < result.error
