@@ -229,6 +229,7 @@ struct qocx_ctx {
     int nodes = 1;
     int cu_count = 256;
     int hermitian = 0;  // every h0[t], g[t][k] equals its conjugate transpose bit for bit
+    bool general_path = false;  // the evaluation runs on qocx_general.hip (n > 64, or S beyond the sweep's LDS)
     DevBuf<double2> m_rm, mbar_rm, magnus_scratch, lam_buf;
     // M4 with time-independent H0 / G_k as a linear problem in Ke effective controls (M4LinArgs)
     int m4lin_Ke = 0;  // 0: not available for this problem
@@ -890,8 +891,14 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (ctx->costs.upload(dcosts, ctx->stream)) return QOCX_ERR_HIP;
     if (ctx->cost_vectors.upload(pool, ctx->stream)) return QOCX_ERR_HIP;
     if (ctx->cost_counts.upload(counts, ctx->stream)) return QOCX_ERR_HIP;
-    if (nb <= 4 && qocx::sweep_lds_bytes(nb, S) > 160 * 1024)
-        return fail(QOCX_ERR_ARG, "state_count too large for the sweep kernel's LDS");
+    // More states than the wavefront sweep's LDS holds (33 <= n <= 64: more than 13 - a full propagator there
+    // has n): the general path, whose sweep keeps its vectors in HBM, takes the problem where it can
+    ctx->general_path = nb > 4;
+    if (nb <= 4 && qocx::sweep_lds_bytes(nb, S) > 160 * 1024) {
+        if (!(nodes == 1 || (nodes == 2 && ctx->m4lin_Ke > 0)))
+            return fail(QOCX_ERR_ARG, "state_count too large for the sweep kernel's LDS (M6 / time-dependent M4)");
+        ctx->general_path = true;
+    }
     ctx->has_problem = true;
     ctx->have_results = false;
     ctx->B = 0;
@@ -1266,7 +1273,7 @@ int qocx_eval_resident(qocx_ctx* ctx, int32_t want_grad) {
         if (ctx->genbar_rm.ensure((size_t)B * nsteps * mat)) return QOCX_ERR_HIP;
     if (ctx->inj_count > 0 && ctx->inj_batch != B)
         return fail(QOCX_ERR_STATE, "state cotangents were set for a different batch size");
-    if (ctx->nb > 4) return eval_general(ctx, want_grad);  // 65 <= n <= 256 (qocx_general.hip)
+    if (ctx->general_path) return eval_general(ctx, want_grad);  // 65 <= n <= 256, or more states than the sweep's LDS (qocx_general.hip)
 
     // Unit adjoint (qocx_sweep_common.h): a property of the PROBLEM and of the context's knobs, never
     // of the batch size, chunking or segmentation - results stay bit-identical across those.

@@ -231,3 +231,33 @@ def test_expm_above_64():
     out = functions.expm(a)
     ref = scipy.linalg.expm(a)
     assert rel_err(out, ref) < 1e-12
+
+
+def test_full_propagator_between_33_and_64(engine):
+    """33 <= n <= 64 with more states than the wavefront sweep's LDS holds (13): a full propagator (S = n = 40)
+    runs on the general path (its sweep keeps the vectors in HBM) - against the oracle, and against the wavefront
+    kernels on the first 13 columns."""
+    from qoc_amd.engine import COST_TARGET_COHERENT
+    n, N, K = 40, 6, 2
+    rng = np.random.default_rng(4040)
+    h0 = cases_mod.gue(rng, n) * 1.5
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    init = np.eye(n, dtype=np.complex128)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    targ = q.T.copy()
+    T = 0.1 * (N - 1)
+    controls = 0.5 * rng.standard_normal((2, N, K))
+    engine.set_schroedinger_problem(n, n, K, N, N, T, h0[None], np.stack(g)[None], init,
+                                    costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ)])
+    cost, grads, final = engine.evaluate(controls, want_grad=True)
+    problem = onp.SchroedingerProblem(T, lambda u, t: h0 + u[0] * g[0] + u[1] * g[1], init[:, :, None], N,
+                                      control_eval_count=N, costs=[onp.TargetStateInfidelity(targ[:, :, None])],
+                                      control_count=K)
+    for b in range(2):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        assert abs(err - cost[b]) < 1e-10 and rel_err(final[b][:, :, None], fin) < 1e-10
+        assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
+    engine.set_schroedinger_problem(n, 13, K, N, N, T, h0[None], np.stack(g)[None], init[:13],
+                                    costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ[:13])])
+    _, _, final13 = engine.evaluate(controls, want_grad=False)
+    assert rel_err(final13, final[:, :13]) < 1e-12
