@@ -85,6 +85,20 @@ def test_general_path_chunks_and_batch_independence(engine):
     # forward only: same costs and states, no gradient work
     cost, _, final = engine.evaluate(controls, False)
     assert np.array_equal(cost, ref[0]) and np.array_equal(final, ref[2])
+    # the states at every system step (save_intermediate_states of the entry points) against the oracle's
+    engine.set_keep_step_states(True)
+    try:
+        engine.evaluate(controls[:2], False)
+        steps = engine.download_step_states()
+    finally:
+        engine.set_keep_step_states(False)
+    problem = onp.SchroedingerProblem(0.1 * (N - 1), lambda u, t: h0 + u[0] * g[0] + u[1] * g[1], init[:, :, None],
+                                      N, control_eval_count=N, costs=[onp.TargetStateInfidelity(targ[:, :, None])],
+                                      control_count=K)
+    for b in range(2):
+        inter = []
+        onp.evaluate(problem, controls[b], intermediate=inter)
+        assert rel_err(steps[b][:, :, :, None], np.stack(inter)) < 1e-10
 
 
 def test_general_path_user_cost_and_opaque_hamiltonian():
