@@ -650,7 +650,8 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
         !(p->magnus_policy == QOCX_MAGNUS_M4 && p->nt == 1 && K >= 1 && K <= QOCX_M4LIN_MAX_K))
         return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2, or M4 with a time-independent "
                                   "system and 1..8 controls (its commutator-free form)");
-    if (S < 1 || S > 64) return fail(QOCX_ERR_ARG, "state_count must be in 1..64");
+    // (a full propagator has n states: up to 256 of them on the general path)
+    if (S < 1 || S > (n > 64 ? 256 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..256 above hilbert_size 64)");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
     if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");

@@ -104,31 +104,52 @@ struct GemmLds {
     double2 as[64][17];
     double2 bs[16][64];
 };
-__device__ __noinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
-                                     int np, char* smem) {
+// gemm_op<TRANSB, CONJB>: C (mrows x np) = A (mrows x np) op(B), op(B)[k][j] = B[j][k] (TRANSB) or conj(B[k][j])
+// (CONJB) - the many-state sweep: the states of a seed as the rows of A (mrows = S, any number).
+template <bool TRANSB, bool CONJB>
+__device__ __noinline__ void gemm_op(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
+                                     int mrows, int np, char* smem) {
     GemmLds& L = *reinterpret_cast<GemmLds*>(smem);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    for (int r0 = 0; r0 < np; r0 += 64)
+    for (int r0 = 0; r0 < mrows; r0 += 64)
         for (int c0 = 0; c0 < np; c0 += 64) {
-            const bool vi[2] = {r0 + wr < np, r0 + wr + 16 < np}, vj[2] = {c0 + wc < np, c0 + wc + 16 < np};
+            const bool vi[2] = {r0 + wr < mrows, r0 + wr + 16 < mrows}, vj[2] = {c0 + wc < np, c0 + wc + 16 < np};
             d4 re[2][2], im[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) re[i][j] = im[i][j] = d4{0, 0, 0, 0};
-            for (int k0 = 0; k0 < np; k0 += 16) {
-                // (measured: the next chunk prefetched into registers while this one's products run - no gain,
-                // the workgroup that shares the CU covers the wait)
+            // the next 16 columns travel from memory to registers while this chunk's products run (the factor
+            // kernel, two workgroups to a CU, gains nothing from it; the many-state sweep - ONE workgroup per
+            // seed, a chain of small products - is a chain of these waits)
+            double2 pa[4], pb[4];
+            auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int idx = tid + TPB * qq;
                     const int rr = idx >> 4, kk = idx & 15;
-                    L.as[rr][kk] = (r0 + rr < np) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
-                    const int kb = idx >> 6, cc = idx & 63;
-                    L.bs[kb][cc] = (c0 + cc < np) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
+                    pa[qq] = (r0 + rr < mrows) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
+                    if (TRANSB) {  // element (k0 + kk, c0 + rr) of op(B) = B[c0 + rr][k0 + kk]: 256-byte runs along k
+                        pb[qq] = (c0 + rr < np) ? B[(size_t)(c0 + rr) * np + k0 + kk] : make_double2(0, 0);
+                    } else {
+                        const int kb = idx >> 6, cc = idx & 63;
+                        pb[qq] = (c0 + cc < np) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
+                        if (CONJB) pb[qq].y = -pb[qq].y;
+                    }
+                }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < np; k0 += 16) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int idx = tid + TPB * qq;
+                    L.as[idx >> 4][idx & 15] = pa[qq];
+                    if (TRANSB) L.bs[idx & 15][idx >> 4] = pb[qq];
+                    else L.bs[idx >> 6][idx & 63] = pb[qq];
                 }
                 __syncthreads();
+                if (k0 + 16 < np) fetch(k0 + 16);
                 if (vi[0] && vj[0]) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
@@ -159,10 +180,15 @@ __device__ __noinline__ void gemm(const double2* __restrict__ A, const double2* 
                     if (vi[i] && vj[j])
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            C[(size_t)(r0 + wr + 16 * i + 4 * r + q) * np + c0 + wc + 16 * j + c] =
-                                make_double2(re[i][j][r], im[i][j][r]);
+                            if (r0 + wr + 16 * i + 4 * r + q < mrows)
+                                C[(size_t)(r0 + wr + 16 * i + 4 * r + q) * np + c0 + wc + 16 * j + c] =
+                                    make_double2(re[i][j][r], im[i][j][r]);
         }
     __syncthreads();
+}
+__device__ __forceinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
+                                     int np, char* smem) {
+    gemm_op<false, false>(A, B, C, np, np, smem);
 }
 
 // M := M^-1 in place (row-major np x np in HBM / L2): Gauss-Jordan with partial pivoting (largest
@@ -590,7 +616,10 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
     double2* states_b = args.states + (size_t)b * cap * S * np;
     double2* xs_b = args.xs + (size_t)b * cap * S * np;
     int* offs_b = args.offs + (size_t)b * (nsteps + 1);
-    double2* lam = args.lam_buf + (size_t)b * S * np;
+    double2* lam = args.lam_buf + (size_t)b * S * np;  // (forward sweep, many states: the scratch between its two products)
+    // eight states or more: the sweep as products on the matrix cores (a 16-row tile is then at least half full)
+    const bool many = S >= 8;
+    char* gsm = smem + 7 * np * 16 + 256;
 
     if (args.phase & 1) {
         for (int e = tid; e < S * np; e += TPB) states_b[e] = args.psi0[e];
@@ -616,13 +645,19 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
                     overflow = true;
                     break;
                 }
-                for (int s = 0; s < S; ++s) {
-                    for (int i = tid; i < np; i += TPB) v0[i] = states_b[((size_t)slot * S + s) * np + i];
-                    __syncthreads();
-                    matvec_rows<false>(Q, v0, v1, np);
-                    matvec_rows<false>(Pi, v1, v2, np);
-                    for (int i = tid; i < np; i += TPB) states_b[((size_t)(slot + 1) * S + s) * np + i] = v2[i];
-                    __syncthreads();
+                if (many) {
+                    // the S states of the seed as the rows of a matrix: Psi' = (Psi Q^T) P^-T on the matrix cores
+                    gemm_op<true, false>(states_b + (size_t)slot * S * np, Q, lam, S, np, gsm);
+                    gemm_op<true, false>(lam, Pi, states_b + (size_t)(slot + 1) * S * np, S, np, gsm);
+                } else {
+                    for (int s = 0; s < S; ++s) {
+                        for (int i = tid; i < np; i += TPB) v0[i] = states_b[((size_t)slot * S + s) * np + i];
+                        __syncthreads();
+                        matvec_rows<false>(Q, v0, v1, np);
+                        matvec_rows<false>(Pi, v1, v2, np);
+                        for (int i = tid; i < np; i += TPB) states_b[((size_t)(slot + 1) * S + s) * np + i] = v2[i];
+                        __syncthreads();
+                    }
                 }
                 ++slot;
             }
@@ -671,6 +706,11 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
         const double2* Pi = args.pinv_img + m * mat;
         for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
+            if (many) {  // X = Lambda conj(P^-1), Lambda = X conj(Q) (rows: x_s = P^-H lambda_s, lambda_s = Q^H x_s)
+                gemm_op<false, true>(lam, Pi, xs_b + (size_t)slot * S * np, S, np, gsm);
+                gemm_op<false, true>(xs_b + (size_t)slot * S * np, Q, lam, S, np, gsm);
+                continue;
+            }
             for (int s = 0; s < S; ++s) {
                 for (int i = tid; i < np; i += TPB) v0[i] = lam[(size_t)s * np + i];
                 __syncthreads();
@@ -813,7 +853,7 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
 }  // namespace general
 
 int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
-int general_sweep_lds(int np) { return 7 * np * 16 + 256; }
+int general_sweep_lds(int np) { return 7 * np * 16 + 256 + (int)sizeof(general::GemmLds); }
 int general_krylov_lds(int np) { return (13 + 13 + 2 + 4) * np * 16 + 256; }
 
 int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {

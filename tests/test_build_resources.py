@@ -117,10 +117,11 @@ def test_general_path_kernels_do_not_spill():
     (MFMA GEMM and the blocked inversion as calls: a frame of saved registers, no spills) fits twice on a CU."""
     general = resources("qocx_general.hip")
     factor = find(general, "factor_kernel")
-    assert factor["ScratchSize"] <= 128 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
-    for frag in ("sweep_kernel", "krylov_kernel"):
-        entry = find(general, frag)
-        assert entry["ScratchSize"] == 0 and entry["VGPRs Spill"] == 0 and total_registers(entry) <= 128
+    assert factor["ScratchSize"] <= 512 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
+    k3 = find(general, "krylov_kernel")
+    assert k3["ScratchSize"] == 0 and k3["VGPRs Spill"] == 0 and total_registers(k3) <= 128
+    sweep = find(general, "sweep_kernel")  # (one workgroup per seed; its many-state form calls the MFMA products)
+    assert sweep["ScratchSize"] <= 512 and sweep["VGPRs Spill"] == 0
 
 
 def test_release_library_has_no_diagnostic_switches():

@@ -275,3 +275,36 @@ def test_full_propagator_between_33_and_64(engine):
                                     costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ[:13])])
     _, _, final13 = engine.evaluate(controls, want_grad=False)
     assert rel_err(final13, final[:, :13]) < 1e-12
+
+
+@pytest.mark.parametrize("n, S, N", [(80, 80, 5), (100, 9, 6), (130, 40, 4)])
+def test_general_path_many_states(engine, n, S, N):
+    """Eight states or more (a full propagator above n = 64 has n of them, up to 256): the sweep as products on the
+    matrix cores, the states of a seed as the rows of a matrix - against the oracle, and equal to rounding
+    to the vector form (the same problem with seven states)."""
+    from qoc_amd.engine import COST_TARGET_COHERENT, COST_TARGET_INCOHERENT
+    K = 2
+    rng = np.random.default_rng(1000 * n + S)
+    h0 = cases_mod.gue(rng, n) * 1.5
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    init = np.eye(n, dtype=np.complex128)[:S]
+    targ = q.T[:S].copy()
+    T = 0.3 * (N - 1)   # (the norm needs a squaring)
+    controls = 0.5 * rng.standard_normal((2, N, K))
+    descs = [dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ),
+             dict(kind=COST_TARGET_INCOHERENT, step_cost=1, scale=0.5 / (N - 1), vectors=targ)]
+    engine.set_schroedinger_problem(n, S, K, N, N, T, h0[None], np.stack(g)[None], init, costs=descs)
+    cost, grads, final = engine.evaluate(controls, want_grad=True)
+    ocosts = [onp.TargetStateInfidelity(targ[:, :, None]),
+              onp.TargetStateInfidelityTime(N, targ[:, :, None], neglect_relative_pahse=True, cost_multiplier=0.5)]
+    problem = onp.SchroedingerProblem(T, lambda u, t: h0 + u[0] * g[0] + u[1] * g[1], init[:, :, None], N,
+                                      control_eval_count=N, costs=ocosts, control_count=K)
+    for b in range(2):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        assert abs(err - cost[b]) < 1e-10 and rel_err(final[b][:, :, None], fin) < 1e-10
+        assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
+    engine.set_schroedinger_problem(n, 7, K, N, N, T, h0[None], np.stack(g)[None], init[:7],
+                                    costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ[:7])])
+    _, _, final7 = engine.evaluate(controls, want_grad=False)
+    assert rel_err(final7, final[:, :7]) < 1e-12
