@@ -949,6 +949,7 @@ static double magnus_norm_bound(int nodes, double bound) {
 
 // Evaluation for Hilbert sizes above 64 (qocx_general.hip): classic order, one stream - factor every step,
 // forward sweep, adjoint sweep, K3, scatter - per memory chunk of seeds.
+namespace qocx { size_t general_krylov_scratch(int np, int S); }
 static int eval_general(qocx_ctx* ctx, int want_grad) {
     const int B = ctx->B, np = ctx->np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
     const size_t mat = (size_t)np * np;
@@ -982,6 +983,10 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
         ctx->final_out.ensure((size_t)B * S * np) || ctx->lam_buf.ensure((size_t)chunk * S * np) ||
         ctx->magnus_scratch.ensure((size_t)blocks * 7 * mat))
         return QOCX_ERR_HIP;
+    // K3 of many states keeps the chains of every state in scratch: as many workgroups as 8 GB hold
+    const size_t k3_elems = qocx::general_krylov_scratch(np, S);
+    const int k3_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks, ((size_t)8 << 30) / (k3_elems * 16)));
+    if (want_grad && ctx->magnus_scratch.ensure((size_t)k3_blocks * k3_elems)) return QOCX_ERR_HIP;
     if (ctx->keep_step_states)
         if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
@@ -1032,8 +1037,25 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
         sa.final_out = ctx->final_out.p + (size_t)b0 * S * np;
         sa.step_states = ctx->keep_step_states ? ctx->step_states.p + (size_t)b0 * (nsteps + 1) * S * np : nullptr;
         sa.status = ctx->status.p;
+        // Many states, final costs only, few seeds (a full propagator of one control set): the states of a seed
+        // in groups of rows on several workgroups (qocx_general.hip, split mode) - knob "general_split" 0: off
+        int groups = 1;
+        if (S >= 16 && !ctx->has_step_costs && ctx->inj_count == 0 && !ctx->keep_step_states &&
+            ctx->knob("general_split", 1) != 0)
+            groups = std::min((S + 7) / 8, std::max(1, 2 * ctx->cu_count / bc));
         time_begin(ctx, 1, cs);
-        qocx::launch_general_sweep(sa, bc, cs);
+        if (groups >= 2) {
+            sa.phase = 1 | 8 | (groups << 8);
+            qocx::launch_general_sweep(sa, bc, cs);
+            sa.phase = 4 | 8 | (want_grad ? 16 : 0);
+            qocx::launch_general_sweep(sa, bc, cs);
+            if (want_grad) {
+                sa.phase = 2 | 8 | (groups << 8);
+                qocx::launch_general_sweep(sa, bc, cs);
+            }
+        } else {
+            qocx::launch_general_sweep(sa, bc, cs);
+        }
         time_end(ctx, cs);
 
         if (want_grad) {
@@ -1046,7 +1068,8 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
             ka.slot_cap = ctx->slot_cap; ka.gstep = ctx->gstep.p; ka.scratch = ctx->magnus_scratch.p;
             ka.total = fa.total;
             time_begin(ctx, 2, cs);
-            if (qocx::launch_general_krylov(ka, fblocks, cs)) return fail(QOCX_ERR_HIP, "K3 (general): LDS size refused");
+            if (qocx::launch_general_krylov(ka, std::min(fblocks, k3_blocks), cs))
+                return fail(QOCX_ERR_HIP, "K3 (general): LDS size refused");
             time_end(ctx, cs);
             if (!explicit_gen) {
                 qocx::ScatterArgs sc;
@@ -2798,7 +2821,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "bidir_adj_first", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "general_split", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -106,9 +106,11 @@ struct GemmLds {
 };
 // gemm_op<TRANSB, CONJB>: C (mrows x np) = A (mrows x np) op(B), op(B)[k][j] = B[j][k] (TRANSB) or conj(B[k][j])
 // (CONJB) - the many-state sweep: the states of a seed as the rows of A (mrows = S, any number).
-template <bool TRANSB, bool CONJB>
+// TRANSA (K3 of many states): C (np x np) = A^T conj'd per CONJB ... = sum over the kdim rows k of A[k][r] op(B)[k][c]
+// (A, B: kdim x np; any kdim); ACC: added to what C holds.
+template <bool TRANSA, bool TRANSB, bool CONJB, bool ACC>
 __device__ __noinline__ void gemm_op(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
-                                     int mrows, int np, char* smem) {
+                                     int mrows, int np, int kdim, char* smem) {
     GemmLds& L = *reinterpret_cast<GemmLds*>(smem);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
@@ -129,27 +131,33 @@ __device__ __noinline__ void gemm_op(const double2* __restrict__ A, const double
                 for (int qq = 0; qq < 4; ++qq) {
                     const int idx = tid + TPB * qq;
                     const int rr = idx >> 4, kk = idx & 15;
-                    pa[qq] = (r0 + rr < mrows) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
+                    if (TRANSA) {  // element (r0 + ra, k0 + ka) of A^T = A[k0 + ka][r0 + ra]: runs along the row index
+                        const int ka = idx >> 6, ra = idx & 63;
+                        pa[qq] = (r0 + ra < mrows && k0 + ka < kdim) ? A[(size_t)(k0 + ka) * np + r0 + ra] : make_double2(0, 0);
+                    } else {
+                        pa[qq] = (r0 + rr < mrows) ? A[(size_t)(r0 + rr) * np + k0 + kk] : make_double2(0, 0);
+                    }
                     if (TRANSB) {  // element (k0 + kk, c0 + rr) of op(B) = B[c0 + rr][k0 + kk]: 256-byte runs along k
                         pb[qq] = (c0 + rr < np) ? B[(size_t)(c0 + rr) * np + k0 + kk] : make_double2(0, 0);
                     } else {
                         const int kb = idx >> 6, cc = idx & 63;
-                        pb[qq] = (c0 + cc < np) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
+                        pb[qq] = (c0 + cc < np && k0 + kb < kdim) ? B[(size_t)(k0 + kb) * np + c0 + cc] : make_double2(0, 0);
                         if (CONJB) pb[qq].y = -pb[qq].y;
                     }
                 }
             };
             fetch(0);
-            for (int k0 = 0; k0 < np; k0 += 16) {
+            for (int k0 = 0; k0 < kdim; k0 += 16) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int idx = tid + TPB * qq;
-                    L.as[idx >> 4][idx & 15] = pa[qq];
+                    if (TRANSA) L.as[idx & 63][idx >> 6] = pa[qq];
+                    else L.as[idx >> 4][idx & 15] = pa[qq];
                     if (TRANSB) L.bs[idx & 15][idx >> 4] = pb[qq];
                     else L.bs[idx >> 6][idx & 63] = pb[qq];
                 }
                 __syncthreads();
-                if (k0 + 16 < np) fetch(k0 + 16);
+                if (k0 + 16 < kdim) fetch(k0 + 16);
                 if (vi[0] && vj[0]) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
@@ -180,15 +188,21 @@ __device__ __noinline__ void gemm_op(const double2* __restrict__ A, const double
                     if (vi[i] && vj[j])
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (r0 + wr + 16 * i + 4 * r + q < mrows)
-                                C[(size_t)(r0 + wr + 16 * i + 4 * r + q) * np + c0 + wc + 16 * j + c] =
-                                    make_double2(re[i][j][r], im[i][j][r]);
+                            if (r0 + wr + 16 * i + 4 * r + q < mrows) {
+                                double2* dst = C + (size_t)(r0 + wr + 16 * i + 4 * r + q) * np + c0 + wc + 16 * j + c;
+                                double2 v = make_double2(re[i][j][r], im[i][j][r]);
+                                if (ACC) {
+                                    v.x += dst->x;
+                                    v.y += dst->y;
+                                }
+                                *dst = v;
+                            }
         }
     __syncthreads();
 }
 __device__ __forceinline__ void gemm(const double2* __restrict__ A, const double2* __restrict__ B, double2* __restrict__ C,
                                      int np, char* smem) {
-    gemm_op<false, false>(A, B, C, np, np, smem);
+    gemm_op<false, false, false, false>(A, B, C, np, np, np, smem);
 }
 
 // M := M^-1 in place (row-major np x np in HBM / L2): Gauss-Jordan with partial pivoting (largest
@@ -620,21 +634,30 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
     // eight states or more: the sweep as products on the matrix cores (a 16-row tile is then at least half full)
     const bool many = S >= 8;
     char* gsm = smem + 7 * np * 16 + 256;
+    // Split mode (phase bit 3; many states, final costs only): the states of a seed do not meet between the
+    // costs, so gridDim.y workgroups take a group of rows each - a full propagator of ONE control set is
+    // otherwise a chain of small products on one CU. The costs and the seed of lambda are a launch of their own
+    // (phase bit 2, one workgroup per seed) between the forward launch and the adjoint one.
+    const bool split = (args.phase & 8) != 0;
+    const int per = split ? (S + (int)gridDim.y - 1) / (int)gridDim.y : S;
+    const int s0 = split ? (int)blockIdx.y * per : 0, cnt = min(per, S - s0);
+    if (cnt <= 0) return;
+    const size_t roff = (size_t)s0 * np;  // the group's first row inside a slot
 
     if (args.phase & 1) {
-        for (int e = tid; e < S * np; e += TPB) states_b[e] = args.psi0[e];
+        for (int e = tid; e < cnt * np; e += TPB) states_b[roff + e] = args.psi0[roff + e];
         __syncthreads();
         int slot = 0;
         double cost = 0;
         bool overflow = false;
         for (int step = 0; step <= nsteps; ++step) {
             const double2* cur = states_b + (size_t)slot * S * np;
-            if (step != 0 && step != nsteps && args.has_step_costs && (step % args.cost_eval_step) == 0)
+            if (!split && step != 0 && step != nsteps && args.has_step_costs && (step % args.cost_eval_step) == 0)
                 cost += eval_costs_g(args, true, false, cur, nullptr, red);
             if (args.step_states != nullptr)
-                for (int e = tid; e < S * np; e += TPB)
-                    args.step_states[((size_t)b * (nsteps + 1) + step) * S * np + e] = cur[e];
-            if (tid == 0) offs_b[step] = slot;
+                for (int e = tid; e < cnt * np; e += TPB)
+                    args.step_states[((size_t)b * (nsteps + 1) + step) * S * np + roff + e] = cur[roff + e];
+            if (tid == 0 && s0 == 0) offs_b[step] = slot;
             if (step == nsteps) break;
             const size_t m = (size_t)b * nsteps + step;
             const int nsub = 1 << step_squarings(args.s_arr[m]);
@@ -647,8 +670,8 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
                 }
                 if (many) {
                     // the S states of the seed as the rows of a matrix: Psi' = (Psi Q^T) P^-T on the matrix cores
-                    gemm_op<true, false>(states_b + (size_t)slot * S * np, Q, lam, S, np, gsm);
-                    gemm_op<true, false>(lam, Pi, states_b + (size_t)(slot + 1) * S * np, S, np, gsm);
+                    gemm_op<false, true, false, false>(states_b + (size_t)slot * S * np + roff, Q, lam + roff, cnt, np, np, gsm);
+                    gemm_op<false, true, false, false>(lam + roff, Pi, states_b + (size_t)(slot + 1) * S * np + roff, cnt, np, np, gsm);
                 } else {
                     for (int s = 0; s < S; ++s) {
                         for (int i = tid; i < np; i += TPB) v0[i] = states_b[((size_t)slot * S + s) * np + i];
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
             if (tid == 0) atomicOr(args.status, 4);
             return;
         }
-        {
+        if (!split) {
             // step costs on the final states if the last step is a cost step, then the final costs
             // (schroedingerdiscrete.py:412-416, :428-433)
             const double2* fin = states_b + (size_t)slot * S * np;
@@ -678,6 +701,18 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
             if (tid == 0) args.cost_out[b] = cost;
         }
         __syncthreads();
+    }
+    if (args.phase & 4) {  // split mode, between the launches: final costs, final states, the seed of lambda
+        const double2* fin = states_b + (size_t)offs_b[nsteps] * S * np;
+        const double cost = eval_costs_g(args, false, true, fin, nullptr, red);
+        for (int e = tid; e < S * np; e += TPB) args.final_out[(size_t)b * S * np + e] = fin[e];
+        if (tid == 0) args.cost_out[b] = cost;
+        if (args.phase & 16) {
+            for (int e = tid; e < S * np; e += TPB) lam[e] = make_double2(0, 0);
+            __syncthreads();
+            (void)eval_costs_g(args, false, true, fin, lam, red);
+        }
+        return;
     }
     if (!(args.phase & 2)) return;
 
@@ -695,10 +730,12 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
         __syncthreads();
     };
     int slot = offs_b[nsteps];
-    for (int e = tid; e < S * np; e += TPB) lam[e] = make_double2(0, 0);
-    __syncthreads();
-    (void)eval_costs_g(args, (nsteps % args.cost_eval_step) == 0, true, states_b + (size_t)slot * S * np, lam, red);
-    inject(nsteps);
+    if (!split) {
+        for (int e = tid; e < S * np; e += TPB) lam[e] = make_double2(0, 0);
+        __syncthreads();
+        (void)eval_costs_g(args, (nsteps % args.cost_eval_step) == 0, true, states_b + (size_t)slot * S * np, lam, red);
+        inject(nsteps);
+    }
     for (int step = nsteps - 1; step >= 0; --step) {
         const size_t m = (size_t)b * nsteps + step;
         const int nsub = 1 << step_squarings(args.s_arr[m]);
@@ -707,8 +744,8 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
         for (int sub = nsub - 1; sub >= 0; --sub) {
             --slot;
             if (many) {  // X = Lambda conj(P^-1), Lambda = X conj(Q) (rows: x_s = P^-H lambda_s, lambda_s = Q^H x_s)
-                gemm_op<false, true>(lam, Pi, xs_b + (size_t)slot * S * np, S, np, gsm);
-                gemm_op<false, true>(xs_b + (size_t)slot * S * np, Q, lam, S, np, gsm);
+                gemm_op<false, false, true, false>(lam + roff, Pi, xs_b + (size_t)slot * S * np + roff, cnt, np, np, gsm);
+                gemm_op<false, false, true, false>(xs_b + (size_t)slot * S * np + roff, Q, lam + roff, cnt, np, np, gsm);
                 continue;
             }
             for (int s = 0; s < S; ++s) {
@@ -723,10 +760,16 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
                 __syncthreads();
             }
         }
+        if (split) continue;  // (no step costs, no host cotangents in split mode)
         if (step != 0 && (step % args.cost_eval_step) == 0 && args.has_step_costs)
             (void)eval_costs_g(args, true, false, states_b + (size_t)slot * S * np, lam, red);
         if (step != 0) inject(step);
     }
+}
+
+// scratch of one K3 workgroup (complex elements): a, a^T, abar, and for eight states or more the chains of all states
+__host__ __device__ constexpr size_t krylov_scratch_elems(int np, int S) {
+    return (size_t)3 * np * np + (S >= 8 ? (size_t)28 * S * np : 0);
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------------
@@ -734,8 +777,8 @@ __global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
 // tau_i = (a^H)^i x, rho_{M-1} = b_M sigma, rho_{i-1} = b_i w_i + a rho_i, abar += sum_i tau_i rho_i^H; then
 // g_k = Re <abar, -i dts G_k> (or Mbar = 2^-s abar in explicit mode). One work item = one step of one seed;
 // scratch per workgroup: a, a^T, abar.
-__global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool MANY>
+__device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* smem) {
     const int np = a.np, mat = np * np, tid = threadIdx.x, S = a.S, K = a.K;
     double2* tau = reinterpret_cast<double2*>(smem);  // [13][np]
     double2* rho = tau + 13 * np;                     // [13][np]
@@ -743,9 +786,18 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
     double2* del = sig + np;
     double2* part = del + np;  // [4][np]
     double* red = reinterpret_cast<double*>(part + 4 * np);
-    double2* A = a.scratch + (size_t)blockIdx.x * 3 * mat;
+    // eight states or more: the chains of all states at once, as products on the matrix cores - the tau_j, rho_i of
+    // every state in scratch ([13][S][np] each, + sigma, delta), abar += T^T conj(R) over the 13 S rows
+    // (a kernel of its own, krylov_many_kernel: the products' registers would cost the vector form its occupancy)
+    constexpr bool many = MANY;
+    const size_t sn = (size_t)S * np;
+    double2* A = a.scratch + (size_t)blockIdx.x * krylov_scratch_elems(np, S);
     double2* AT = A + mat;
     double2* AB = AT + mat;
+    double2* TT = AB + mat;       // [13][S][np]
+    double2* RR = TT + 13 * sn;   // [13][S][np]
+    double2* SG = RR + 13 * sn;   // [S][np] sigma, then [S][np] delta
+    double2* DL = SG + sn;
     for (size_t wi = blockIdx.x; wi < a.total; wi += gridDim.x) {
         const int b = (int)(wi / a.nsteps), step = (int)(wi % a.nsteps);
         const size_t m = (size_t)b * a.nsteps + step;
@@ -790,7 +842,42 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
         }
         __syncthreads();
         bool first = true;
-        for (int sub = 0; sub < nsub; ++sub)
+        if constexpr (MANY) {
+            for (int sub = 0; sub < nsub; ++sub) {
+                const size_t t = (size_t)t0 + sub;
+                const double2* p0 = states_b + t * sn;
+                const double2* p1 = states_b + (t + 1) * sn;
+                const double2* xx = xs_b + t * sn;
+                for (size_t e = tid; e < sn; e += TPB) {
+                    const double2 u = p0[e], v = p1[e];
+                    TT[e] = xx[e];
+                    SG[e] = make_double2(u.x + v.x, u.y + v.y);
+                    DL[e] = make_double2(u.x - v.x, u.y - v.y);
+                    RR[(size_t)(M - 1) * sn + e] = make_double2(bt[M] * (u.x + v.x), bt[M] * (u.y + v.y));
+                }
+                __syncthreads();
+                // T_j = T_{j-1} conj(a) (rows: tau_j = a^H tau_{j-1}); R_{i-1} = b_i W_i + R_i a^T (rows: a rho_i)
+                for (int jj = 1; jj < M; ++jj)
+                    gemm_op<false, false, true, false>(TT + (size_t)(jj - 1) * sn, A, TT + (size_t)jj * sn, S, np, np, smem);
+                for (int ii = M - 1; ii >= 1; --ii) {
+                    gemm_op<false, true, false, false>(RR + (size_t)ii * sn, A, RR + (size_t)(ii - 1) * sn, S, np, np, smem);
+                    const double2* wv = (ii & 1) ? SG : DL;
+                    double2* out = RR + (size_t)(ii - 1) * sn;
+                    for (size_t e = tid; e < sn; e += TPB) {
+                        double2 r = out[e];
+                        r.x = fma(bt[ii], wv[e].x, r.x);
+                        r.y = fma(bt[ii], wv[e].y, r.y);
+                        out[e] = r;
+                    }
+                    __syncthreads();
+                }
+                // abar[r][c] (+)= sum over (i, s) of tau_i[s][r] conj(rho_i[s][c])
+                if (first) gemm_op<true, false, true, false>(TT, RR, AB, np, np, M * S, smem);
+                else gemm_op<true, false, true, true>(TT, RR, AB, np, np, M * S, smem);
+                first = false;
+            }
+        }
+        for (int sub = 0; sub < (many ? 0 : nsub); ++sub)
             for (int s = 0; s < S; ++s) {
                 const size_t t = (size_t)t0 + sub;
                 for (int i = tid; i < np; i += TPB) {
@@ -849,12 +936,21 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    krylov_body<false>(a, smem);
+}
+__global__ __launch_bounds__(TPB) void krylov_many_kernel(GeneralKrylovArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    krylov_body<true>(a, smem);
+}
 
 }  // namespace general
 
 int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
 int general_sweep_lds(int np) { return 7 * np * 16 + 256 + (int)sizeof(general::GemmLds); }
-int general_krylov_lds(int np) { return (13 + 13 + 2 + 4) * np * 16 + 256; }
+int general_krylov_lds(int np) { return std::max((13 + 13 + 2 + 4) * np * 16, (int)sizeof(general::GemmLds)) + 256; }
+size_t general_krylov_scratch(int np, int S) { return general::krylov_scratch_elems(np, S); }
 
 int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
     const int bytes = general_factor_lds(a.np);
@@ -869,8 +965,12 @@ int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
     return 0;
 }
 
+// a.phase: bit 0 forward, bit 1 adjoint; split mode (bit 3; bits 8.. = workgroups per seed): bit 2 the cost launch
+// (bit 4: it also seeds lambda)
 void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(general::sweep_kernel, dim3(batch), dim3(general::TPB), general_sweep_lds(a.np), st, a);
+    const int groups = (a.phase & 8) ? std::max(1, a.phase >> 8) : 1;
+    hipLaunchKernelGGL(general::sweep_kernel, dim3(batch, (a.phase & 4) ? 1 : groups), dim3(general::TPB),
+                       general_sweep_lds(a.np), st, a);
 }
 
 int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st) {
@@ -878,11 +978,14 @@ int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st
     static int attr_bytes = 0;
     if (bytes > 48 * 1024 && bytes > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(general::krylov_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(general::krylov_many_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
             return 1;
         attr_bytes = bytes;
     }
-    hipLaunchKernelGGL(general::krylov_kernel, dim3(blocks), dim3(general::TPB), bytes, st, a);
+    if (a.S >= 8) hipLaunchKernelGGL(general::krylov_many_kernel, dim3(blocks), dim3(general::TPB), bytes, st, a);
+    else hipLaunchKernelGGL(general::krylov_kernel, dim3(blocks), dim3(general::TPB), bytes, st, a);
     return 0;
 }
 

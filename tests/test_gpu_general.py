@@ -304,6 +304,22 @@ def test_general_path_many_states(engine, n, S, N):
         err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
         assert abs(err - cost[b]) < 1e-10 and rel_err(final[b][:, :, None], fin) < 1e-10
         assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
+    # final costs only: the states of a seed in groups of rows on several workgroups (split mode) - the same
+    # products on the same rows, so the same numbers as one workgroup per seed (knob general_split 0)
+    engine.set_schroedinger_problem(n, S, K, N, N, T, h0[None], np.stack(g)[None], init, costs=descs[:1])
+    split = engine.evaluate(controls, want_grad=True)
+    engine.set_knob("general_split", 0)
+    try:
+        whole = engine.evaluate(controls, want_grad=True)
+    finally:
+        engine.set_knob("general_split", 1)
+    for a, b in zip(split, whole):
+        assert np.array_equal(a, b)
+    problem.costs = ocosts[:1]
+    problem.step_costs = []
+    err, gr, fin = onp.evaluate_with_grad(problem, controls[0])
+    assert abs(err - split[0][0]) < 1e-10 and rel_err(split[2][0][:, :, None], fin) < 1e-10
+    assert np.max(np.abs(gr - split[1][0])) < 1e-8 * np.max(np.abs(gr))
     engine.set_schroedinger_problem(n, 7, K, N, N, T, h0[None], np.stack(g)[None], init[:7],
                                     costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ[:7])])
     _, _, final7 = engine.evaluate(controls, want_grad=False)
