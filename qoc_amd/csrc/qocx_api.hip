@@ -646,10 +646,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     if (n < 1 || n > 256)
         return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..256 (1..64: the wavefront kernels; 65..256: the general "
                                   "path of qocx_general.hip)");
-    if (n > 64 && p->magnus_policy != QOCX_MAGNUS_M2 &&
-        !(p->magnus_policy == QOCX_MAGNUS_M4 && p->nt == 1 && K >= 1 && K <= QOCX_M4LIN_MAX_K))
-        return fail(QOCX_ERR_ARG, "hilbert_size above 64 runs under magnus_policy M2, or M4 with a time-independent "
-                                  "system and 1..8 controls (its commutator-free form)");
+
     // (a full propagator has n states: up to 256 of them on the general path)
     if (S < 1 || S > (n > 64 ? 256 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..256 above hilbert_size 64)");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
@@ -895,11 +892,7 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     // More states than the wavefront sweep's LDS holds (33 <= n <= 64: more than 13 - a full propagator there
     // has n): the general path, whose sweep keeps its vectors in HBM, takes the problem where it can
     ctx->general_path = nb > 4;
-    if (nb <= 4 && qocx::sweep_lds_bytes(nb, S) > 160 * 1024) {
-        if (!(nodes == 1 || (nodes == 2 && ctx->m4lin_Ke > 0)))
-            return fail(QOCX_ERR_ARG, "state_count too large for the sweep kernel's LDS (M6 / time-dependent M4)");
-        ctx->general_path = true;
-    }
+    if (nb <= 4 && qocx::sweep_lds_bytes(nb, S) > 160 * 1024) ctx->general_path = true;
     ctx->has_problem = true;
     ctx->have_results = false;
     ctx->B = 0;
@@ -949,14 +942,19 @@ static double magnus_norm_bound(int nodes, double bound) {
 
 // Evaluation for Hilbert sizes above 64 (qocx_general.hip): classic order, one stream - factor every step,
 // forward sweep, adjoint sweep, K3, scatter - per memory chunk of seeds.
-namespace qocx { size_t general_krylov_scratch(int np, int S); }
+namespace qocx {
+size_t general_krylov_scratch(int np, int S);
+void launch_general_magnus(const MagnusArgs& a, bool vjp, int blocks, hipStream_t st);
+}
 static int eval_general(qocx_ctx* ctx, int want_grad) {
     const int B = ctx->B, np = ctx->np, S = ctx->S, K = ctx->K, nsteps = ctx->nsteps;
     const size_t mat = (size_t)np * np;
     const bool explicit_gen = ctx->explicit_mode;
     // M4 with a time-independent system: linear in Ke effective controls with constant matrices (M4LinArgs)
     const bool m4lin = ctx->m4lin_Ke > 0 && ctx->nodes == 2 && !explicit_gen;
-    if (ctx->nodes != 1 && !m4lin) return fail(QOCX_ERR_ARG, "hilbert_size above 64: magnus_policy not supported");
+    // M6, and M4 on a time-dependent system: generators and reverse rules by qocx_general.hip's magnus_kernel
+    const bool magnus = ctx->nodes > 1 && !m4lin && !explicit_gen;
+    const int nodes = magnus ? ctx->nodes : 1;
     const int Kk = m4lin ? ctx->m4lin_Ke : K;
     const size_t per_seed = (size_t)nsteps * (mat * 32 + 4) + ctx->slot_cap * S * np * 32 +
                             (size_t)(nsteps + 1) * 4 + (size_t)nsteps * std::max(Kk, 1) * 40;
@@ -987,6 +985,10 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
     const size_t k3_elems = qocx::general_krylov_scratch(np, S);
     const int k3_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks, ((size_t)8 << 30) / (k3_elems * 16)));
     if (want_grad && ctx->magnus_scratch.ensure((size_t)k3_blocks * k3_elems)) return QOCX_ERR_HIP;
+    const int mg_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks, ((size_t)8 << 30) / (24 * mat * 16)));
+    if (magnus && (ctx->magnus_scratch.ensure((size_t)mg_blocks * 24 * mat) || ctx->m_rm.ensure(cm * mat) ||
+                   ctx->mbar_rm.ensure(want_grad ? cm * mat : 1) || ctx->gstep.ensure(cm * nodes * std::max(K, 1))))
+        return QOCX_ERR_HIP;
     if (ctx->keep_step_states)
         if (ctx->step_states.ensure((size_t)B * (nsteps + 1) * S * np)) return QOCX_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(int), ctx->stream));
@@ -1018,6 +1020,19 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
             fa.K = Kk; fa.nc = nsteps;
         }
         const int fblocks = (int)std::min<size_t>(fa.total, (size_t)blocks);
+        qocx::MagnusArgs ma;
+        if (magnus) {
+            ma.controls = fa.controls; ma.interp = ctx->interp.p;
+            ma.h0_cimg = ctx->h0_timg.p; ma.g_cimg = ctx->g_timg.p;  // (row-major padded matrices here)
+            ma.K = K; ma.nc = ctx->nc; ma.nsteps = nsteps; ma.nt = ctx->nt; ma.nodes = nodes;
+            ma.step0 = 0; ma.seg_len = nsteps; ma.skew = 0; ma.dt = ctx->dt;
+            ma.m_rm = ctx->m_rm.p; ma.mbar_rm = nullptr; ma.gstep = nullptr;
+            ma.scratch = ctx->magnus_scratch.p; ma.total = fa.total; ma.n = np;
+            time_begin(ctx, 0, cs);
+            qocx::launch_general_magnus(ma, false, std::min(fblocks, mg_blocks), cs);
+            time_end(ctx, cs);
+            fa.gen_rm = ctx->m_rm.p;  // the factor kernel and K3 take the step generators as they are
+        }
         time_begin(ctx, 0, cs);
         if (qocx::launch_general_factor(fa, fblocks, cs)) return fail(QOCX_ERR_HIP, "K1a (general): LDS size refused");
         time_end(ctx, cs);
@@ -1063,7 +1078,7 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
             ka.np = np; ka.S = S; ka.K = fa.K; ka.nc = fa.nc; ka.nsteps = nsteps; ka.nt = ctx->nt; ka.dt = ctx->dt;
             ka.controls = fa.controls; ka.interp = fa.interp; ka.h0_rm = fa.h0_rm; ka.g_rm = fa.g_rm;
             ka.gen_rm = fa.gen_rm;
-            ka.mbar_rm = explicit_gen ? ctx->genbar_rm.p + (size_t)b0 * nsteps * mat : nullptr;
+            ka.mbar_rm = explicit_gen ? ctx->genbar_rm.p + (size_t)b0 * nsteps * mat : (magnus ? ctx->mbar_rm.p : nullptr);
             ka.s_arr = fa.s_arr; ka.offs = ctx->offs.p; ka.states = ctx->states.p; ka.xs = ctx->xs.p;
             ka.slot_cap = ctx->slot_cap; ka.gstep = ctx->gstep.p; ka.scratch = ctx->magnus_scratch.p;
             ka.total = fa.total;
@@ -1071,6 +1086,12 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
             if (qocx::launch_general_krylov(ka, std::min(fblocks, k3_blocks), cs))
                 return fail(QOCX_ERR_HIP, "K3 (general): LDS size refused");
             time_end(ctx, cs);
+            if (magnus) {
+                ma.m_rm = nullptr; ma.mbar_rm = ctx->mbar_rm.p; ma.gstep = ctx->gstep.p;
+                time_begin(ctx, 2, cs);
+                qocx::launch_general_magnus(ma, true, std::min(fblocks, mg_blocks), cs);
+                time_end(ctx, cs);
+            }
             if (!explicit_gen) {
                 qocx::ScatterArgs sc;
                 sc.gstep = ka.gstep; sc.row_ptr = ctx->row_ptr.p; sc.col_step = ctx->col_step.p;

@@ -617,7 +617,8 @@ __device__ __forceinline__ double eval_costs_g(const GeneralSweepArgs& args, boo
 
 // One workgroup per seed: forward sweep (phase bit 0) over all steps, adjoint sweep (bit 1) back.
 // The loop of schroedingerdiscrete.py:393-436 with psi' = (P^-1 Q)^(2^s) psi per step (expm.py:246-250).
-__global__ __launch_bounds__(TPB) void sweep_kernel(GeneralSweepArgs args) {
+// (two waves per SIMD for every caller of the product functions: their registers are allocated once, for the loosest caller)
+__global__ __launch_bounds__(TPB, 2) void sweep_kernel(GeneralSweepArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int np = args.np, S = args.S, nsteps = args.nsteps, tid = threadIdx.x, b = blockIdx.x;
     const int mat = np * np;
@@ -940,12 +941,213 @@ __global__ __launch_bounds__(TPB) void krylov_kernel(GeneralKrylovArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     krylov_body<false>(a, smem);
 }
-__global__ __launch_bounds__(TPB) void krylov_many_kernel(GeneralKrylovArgs a) {
+__global__ __launch_bounds__(TPB, 2) void krylov_many_kernel(GeneralKrylovArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     krylov_body<true>(a, smem);
 }
 
+// ---- Magnus M4 / M6 generators and their reverse rules (mathmethods.py:96-164) ---------------------------------
+// One work item = one step of one seed; every matrix in scratch (24 per workgroup), commutators as two products
+// on the matrix cores. MagnusArgs as the wavefront kernels take it, with h0_cimg / g_cimg pointing at the
+// row-major padded matrices and n = the padded size. VJP: the node generators, b_i, x, w, y are recomputed, the
+// cotangent of M (K3's Mbar) goes back through the commutators (Z = [X, Y]: Xbar = Zbar Y^H - Y^H Zbar,
+// Ybar = X^H Zbar - Zbar X^H) and is contracted with -i G_k at every node.
+template <bool VJP>
+__global__ __launch_bounds__(TPB, 2) void magnus_kernel(MagnusArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int np = a.n, mat = np * np, tid = threadIdx.x, K = a.K, nodes = a.nodes;
+    double* red = reinterpret_cast<double*>(smem + sizeof(GemmLds));
+    double2* sc = a.scratch + (size_t)blockIdx.x * 24 * mat;
+    auto mx = [&](int i) { return sc + (size_t)i * mat; };
+    const double F0 = sqrt(15.0) / 3, F1 = 10.0 / 3, F2 = 0.5, F3 = 1.0 / 240, F4 = 1.0 / 60;
+    const double M4F0 = sqrt(3.0) / 12;
+    const double dt = a.dt;
+    // OUT = [X, Y] (T: a temporary)
+    auto comm = [&](const double2* X, const double2* Y, double2* OUT, double2* T) {
+        gemm(X, Y, OUT, np, smem);
+        gemm(Y, X, T, np, smem);
+        for (int e = tid; e < mat; e += TPB) {
+            double2 v = OUT[e];
+            v.x -= T[e].x;
+            v.y -= T[e].y;
+            OUT[e] = v;
+        }
+        __syncthreads();
+    };
+    auto herm = [&](double2* dst, const double2* src) {
+        for (int e = tid; e < mat; e += TPB) {
+            const int r = e / np, c = e - r * np;
+            const double2 v = src[(size_t)c * np + r];
+            dst[e] = make_double2(v.x, -v.y);
+        }
+        __syncthreads();
+    };
+    // Z = [X, Y], Zbar given: XB = Zbar Y^H - Y^H Zbar, YB = X^H Zbar - Zbar X^H (T, TH: temporaries)
+    auto comm_vjp = [&](const double2* X, const double2* Y, const double2* ZB, double2* XB, double2* YB, double2* T,
+                        double2* TH) {
+        herm(TH, Y);
+        gemm(ZB, TH, XB, np, smem);
+        gemm(TH, ZB, T, np, smem);
+        for (int e = tid; e < mat; e += TPB) {
+            double2 v = XB[e];
+            v.x -= T[e].x;
+            v.y -= T[e].y;
+            XB[e] = v;
+        }
+        __syncthreads();
+        herm(TH, X);
+        gemm(TH, ZB, YB, np, smem);
+        gemm(ZB, TH, T, np, smem);
+        for (int e = tid; e < mat; e += TPB) {
+            double2 v = YB[e];
+            v.x -= T[e].x;
+            v.y -= T[e].y;
+            YB[e] = v;
+        }
+        __syncthreads();
+    };
+    for (size_t wi = blockIdx.x; wi < a.total; wi += gridDim.x) {
+        const int b = (int)(wi / a.nsteps), step = (int)(wi % a.nsteps);
+        const size_t m = (size_t)b * a.nsteps + step;
+        const double* ctl_b = a.controls + (size_t)b * a.nc * K;
+        // node generators a_q = -i H(u(t_q), t_q) into matrices 0 .. nodes - 1
+        for (int q = 0; q < nodes; ++q) {
+            const size_t tsel = (a.nt == 1) ? 0 : (size_t)step * nodes + q;
+            const double2* h0 = a.h0_cimg + tsel * mat;
+            const double2* gk = a.g_cimg + tsel * K * mat;
+            const StepInterp si = a.interp[(size_t)step * nodes + q];
+            double2* A = mx(q);
+            for (int e = tid; e < mat; e += TPB) {
+                double2 h = h0[e];
+                for (int k = 0; k < K; ++k) {
+                    const double uk = control_at(ctl_b, si, K, k);
+                    const double2 g = gk[(size_t)k * mat + e];
+                    h.x = fma(uk, g.x, h.x);
+                    h.y = fma(uk, g.y, h.y);
+                }
+                A[e] = make_double2(h.y, -h.x);
+            }
+        }
+        __syncthreads();
+        if (nodes == 2) {
+            double2 *a1 = mx(0), *a2 = mx(1), *c = mx(2), *t = mx(3);
+            if (!VJP) {
+                comm(a2, a1, c, t);
+                double2* out = a.m_rm + m * mat;
+                for (int e = tid; e < mat; e += TPB)
+                    out[e] = make_double2((dt / 2) * (a1[e].x + a2[e].x) + M4F0 * dt * dt * c[e].x,
+                                          (dt / 2) * (a1[e].y + a2[e].y) + M4F0 * dt * dt * c[e].y);
+            } else {
+                const double2* mb = a.mbar_rm + m * mat;
+                double2 *zb = mx(4), *a2b = mx(5), *a1b = mx(6), *th = mx(7);
+                for (int e = tid; e < mat; e += TPB) zb[e] = make_double2(M4F0 * dt * dt * mb[e].x, M4F0 * dt * dt * mb[e].y);
+                __syncthreads();
+                comm_vjp(a2, a1, zb, a2b, a1b, t, th);
+                for (int q = 0; q < 2; ++q) {
+                    const double2* ab = q == 0 ? a1b : a2b;
+                    const size_t tsel = (a.nt == 1) ? 0 : (size_t)step * 2 + q;
+                    const double2* gk = a.g_cimg + tsel * K * mat;
+                    for (int k = 0; k < K; ++k) {
+                        double acc = 0;
+                        for (int e = tid; e < mat; e += TPB) {
+                            const double2 g = gk[(size_t)k * mat + e];
+                            const double bx = (dt / 2) * mb[e].x + ab[e].x, by = (dt / 2) * mb[e].y + ab[e].y;
+                            acc = fma(bx, g.y, fma(-by, g.x, acc));
+                        }
+                        const double2 tot = block_sum2(acc, 0.0, red);
+                        if (tid == 0) a.gstep[(m * 2 + q) * K + k] = tot.x;
+                    }
+                }
+            }
+        } else {  // M6
+            double2 *a1 = mx(0), *a2 = mx(1), *a3 = mx(2), *b1 = mx(3), *b2 = mx(4), *b3 = mx(5), *c12 = mx(6), *x = mx(7),
+                    *w = mx(8), *y = mx(9), *t = mx(10), *th = mx(11);
+            for (int e = tid; e < mat; e += TPB) {
+                const double2 u1 = a1[e], u2 = a2[e], u3 = a3[e];
+                b1[e] = make_double2(dt * u2.x, dt * u2.y);
+                b2[e] = make_double2(F0 * dt * (u3.x - u1.x), F0 * dt * (u3.y - u1.y));
+                b3[e] = make_double2(F1 * dt * (u3.x - 2 * u2.x + u1.x), F1 * dt * (u3.y - 2 * u2.y + u1.y));
+            }
+            __syncthreads();
+            comm(b1, b2, c12, t);
+            for (int e = tid; e < mat; e += TPB) {
+                x[e] = make_double2(-20 * b1[e].x - b3[e].x + c12[e].x, -20 * b1[e].y - b3[e].y + c12[e].y);
+                w[e] = make_double2(2 * b3[e].x + c12[e].x, 2 * b3[e].y + c12[e].y);
+            }
+            __syncthreads();
+            comm(b1, w, y, t);  // y := [b1, w] for now
+            for (int e = tid; e < mat; e += TPB) y[e] = make_double2(b2[e].x - F4 * y[e].x, b2[e].y - F4 * y[e].y);
+            __syncthreads();
+            if (!VJP) {
+                double2* cxy = mx(12);
+                comm(x, y, cxy, t);
+                double2* out = a.m_rm + m * mat;
+                for (int e = tid; e < mat; e += TPB)
+                    out[e] = make_double2(b1[e].x + F2 * b3[e].x + F3 * cxy[e].x, b1[e].y + F2 * b3[e].y + F3 * cxy[e].y);
+            } else {
+                const double2* mb = a.mbar_rm + m * mat;
+                double2 *zb = mx(12), *xb = mx(13), *yb = mx(14), *wb = mx(15), *d1 = mx(16), *d2 = mx(17), *b1b = mx(18),
+                        *b2b = mx(19), *b3b = mx(20), *c12b = mx(21);
+                for (int e = tid; e < mat; e += TPB) zb[e] = make_double2(F3 * mb[e].x, F3 * mb[e].y);
+                __syncthreads();
+                comm_vjp(x, y, zb, xb, yb, t, th);
+                for (int e = tid; e < mat; e += TPB) {
+                    b1b[e] = make_double2(mb[e].x - 20 * xb[e].x, mb[e].y - 20 * xb[e].y);
+                    b3b[e] = make_double2(F2 * mb[e].x - xb[e].x, F2 * mb[e].y - xb[e].y);
+                    c12b[e] = xb[e];
+                    b2b[e] = yb[e];
+                    zb[e] = make_double2(-F4 * yb[e].x, -F4 * yb[e].y);
+                }
+                __syncthreads();
+                comm_vjp(b1, w, zb, d1, wb, t, th);
+                for (int e = tid; e < mat; e += TPB) {
+                    b1b[e] = make_double2(b1b[e].x + d1[e].x, b1b[e].y + d1[e].y);
+                    b3b[e] = make_double2(b3b[e].x + 2 * wb[e].x, b3b[e].y + 2 * wb[e].y);
+                    c12b[e] = make_double2(c12b[e].x + wb[e].x, c12b[e].y + wb[e].y);
+                }
+                __syncthreads();
+                comm_vjp(b1, b2, c12b, d1, d2, t, th);
+                // a1bar = -F0 dt b2bar + F1 dt b3bar, a2bar = dt b1bar - 2 F1 dt b3bar, a3bar = F0 dt b2bar + F1 dt b3bar
+                for (int q = 0; q < 3; ++q) {
+                    const size_t tsel = (a.nt == 1) ? 0 : (size_t)step * 3 + q;
+                    const double2* gk = a.g_cimg + tsel * K * mat;
+                    for (int k = 0; k < K; ++k) {
+                        double acc = 0;
+                        for (int e = tid; e < mat; e += TPB) {
+                            const double2 g = gk[(size_t)k * mat + e];
+                            const double p1x = b1b[e].x + d1[e].x, p1y = b1b[e].y + d1[e].y;
+                            const double p2x = b2b[e].x + d2[e].x, p2y = b2b[e].y + d2[e].y;
+                            const double p3x = b3b[e].x, p3y = b3b[e].y;
+                            double bx, by;
+                            if (q == 0) {
+                                bx = -F0 * dt * p2x + F1 * dt * p3x;
+                                by = -F0 * dt * p2y + F1 * dt * p3y;
+                            } else if (q == 1) {
+                                bx = dt * p1x - 2 * F1 * dt * p3x;
+                                by = dt * p1y - 2 * F1 * dt * p3y;
+                            } else {
+                                bx = F0 * dt * p2x + F1 * dt * p3x;
+                                by = F0 * dt * p2y + F1 * dt * p3y;
+                            }
+                            acc = fma(bx, g.y, fma(-by, g.x, acc));
+                        }
+                        const double2 tot = block_sum2(acc, 0.0, red);
+                        if (tid == 0) a.gstep[(m * 3 + q) * K + k] = tot.x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace general
+
+void launch_general_magnus(const MagnusArgs& a, bool vjp, int blocks, hipStream_t st) {
+    const int bytes = (int)sizeof(general::GemmLds) + 256;
+    if (vjp) hipLaunchKernelGGL(general::magnus_kernel<true>, dim3(blocks), dim3(general::TPB), bytes, st, a);
+    else hipLaunchKernelGGL(general::magnus_kernel<false>, dim3(blocks), dim3(general::TPB), bytes, st, a);
+}
 
 int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
 int general_sweep_lds(int np) { return 7 * np * 16 + 256 + (int)sizeof(general::GemmLds); }

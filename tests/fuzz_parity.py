@@ -32,8 +32,6 @@ def one(engine, rng, index, nmin=1, nmax=32, smin=1, smax=4, results=None):
     policy = ("M2", "M2", "M4", "M6")[int(rng.integers(0, 4))]
     hermitian = rng.random() < 0.7
     time_dep = rng.random() < 0.3
-    if n > 64 and (policy == "M6" or time_dep):  # the general path above n = 64 (qocx_general.hip): M2, or M4
-        policy = "M2"                             # on a time-independent system (its commutator-free form)
     dt = float(10 ** rng.uniform(-2, 0.3))
     scale = float(10 ** rng.uniform(-0.5, 0.8))
     h0 = gue(rng, n) * scale

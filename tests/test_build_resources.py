@@ -120,9 +120,14 @@ def test_general_path_kernels_do_not_spill():
     assert factor["ScratchSize"] <= 512 and factor["VGPRs Spill"] == 0 and total_registers(factor) <= 256
     k3 = find(general, "13krylov_kernel")  # (the many-state form with its product calls is a kernel of its own)
     assert k3["ScratchSize"] == 0 and k3["VGPRs Spill"] == 0 and total_registers(k3) <= 128
-    assert find(general, "krylov_many_kernel")["VGPRs Spill"] == 0
-    sweep = find(general, "sweep_kernel")  # (one workgroup per seed; its many-state form calls the MFMA products)
-    assert sweep["ScratchSize"] <= 512 and sweep["VGPRs Spill"] == 0
+    assert find(general, "krylov_many_kernel")["VGPRs Spill"] <= 16
+    # (every caller of the product functions is held to two waves per SIMD - the functions' registers are allocated
+    # once, for the loosest caller, and the factor kernel needs its two workgroups per CU; a dozen spills at most)
+    sweep = find(general, "sweep_kernel")
+    assert sweep["ScratchSize"] <= 512 and sweep["VGPRs Spill"] <= 16 and total_registers(sweep) <= 256
+    for frag in ("magnus_kernelILb0E", "magnus_kernelILb1E"):
+        entry = find(general, frag)
+        assert entry["VGPRs Spill"] == 0 and total_registers(entry) <= 256
 
 
 def test_release_library_has_no_diagnostic_switches():

@@ -517,13 +517,8 @@ def test_error_paths(engine):
         with pytest.raises(QocxError) as err:  # unsupported size
             fresh.set_schroedinger_problem(257, 1, 0, 0, 5, 1.0, np.eye(257), None, np.eye(257)[:1])
         assert err.value.code == -1 and "hilbert_size" in err.value.message
-        with pytest.raises(QocxError) as err:  # above 64 (qocx_general.hip): M2 only
-            fresh.set_schroedinger_problem(65, 1, 0, 0, 5, 1.0, np.eye(65), None, np.eye(65)[:1],
-                                           magnus_policy="M6")
-        assert err.value.code == -1 and "M2" in err.value.message
-        with pytest.raises(QocxError) as err:  # sixteen tiles: 14 states do not fit the sweep's LDS (M2 goes to
-            fresh.set_schroedinger_problem(40, 14, 0, 0, 5, 1.0, np.eye(40), None, np.eye(40)[:14],  # the general path)
-                                           magnus_policy="M6")
+        with pytest.raises(QocxError) as err:  # more than 64 states below hilbert_size 65
+            fresh.set_schroedinger_problem(40, 65, 0, 0, 5, 1.0, np.eye(40), None, np.ones((65, 40)))
         assert "state_count" in err.value.message
         with pytest.raises(QocxError):  # nt neither 1 nor (N-1) * nodes
             fresh.set_schroedinger_problem(4, 1, 0, 0, 5, 1.0, np.stack([np.eye(4)] * 3), None,

@@ -1,6 +1,6 @@
 """
 GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 256,
-Magnus M2): through the C ABI against the oracle at the tolerances of the wavefront kernels (states and
+every Magnus policy): through the C ABI against the oracle at the tolerances of the wavefront kernels (states and
 cost 1e-10, gradients 1e-8). The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502).
 """
 
@@ -324,3 +324,46 @@ def test_general_path_many_states(engine, n, S, N):
                                     costs=[dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ[:7])])
     _, _, final7 = engine.evaluate(controls, want_grad=False)
     assert rel_err(final7, final[:, :7]) < 1e-12
+
+
+@pytest.mark.parametrize("policy, n, K, time_dep", [("M6", 70, 2, True), ("M4", 80, 2, True), ("M4", 66, 9, False),
+                                                    ("M6", 40, 1, False)])
+def test_general_path_magnus_policies(engine, policy, n, K, time_dep):
+    """M4 / M6 on the general path (magnus_kernel: node generators, commutators as products on the matrix cores,
+    the reverse rules of mathmethods.py:96-164): time-dependent systems, M4 with more controls than its linear form
+    takes (8), and - n = 40 with 20 states - a size the wavefront kernels hand over because of the state count.
+    Against the oracle at the 1e-10 / 1e-8 gates."""
+    from qoc_amd.engine import COST_TARGET_COHERENT, COST_TARGET_INCOHERENT
+    from tests.fuzz_parity import NODES
+    N, S = 6, (20 if n == 40 else 2)
+    rng = np.random.default_rng(n + K)
+    h0 = cases_mod.gue(rng, n) * 1.2
+    g = [cases_mod.gue(rng, n) for _ in range(K)]
+    dt = 0.15
+    T = dt * (N - 1)
+
+    def base(t):
+        return h0 * (1 + 0.3 * np.cos(2.0 * t)) if time_dep else h0
+
+    init = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    targ = rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))
+    targ /= np.linalg.norm(targ, axis=1, keepdims=True)
+    if time_dep:
+        times = [j * dt + c * dt for j in range(N - 1) for c in NODES[policy]]
+        h0s, gs = np.stack([base(t) for t in times]), np.stack([np.stack(g) for _ in times])
+    else:
+        h0s, gs = h0[None], np.stack(g)[None]
+    descs = [dict(kind=COST_TARGET_COHERENT, step_cost=0, scale=1.0, vectors=targ),
+             dict(kind=COST_TARGET_INCOHERENT, step_cost=1, scale=0.5 / (N - 1), vectors=targ)]
+    engine.set_schroedinger_problem(n, S, K, N, N, T, h0s, gs, init, costs=descs, magnus_policy=policy)
+    controls = 0.6 * rng.standard_normal((2, N, K))
+    cost, grads, final = engine.evaluate(controls, want_grad=True)
+    ocosts = [onp.TargetStateInfidelity(targ[:, :, None]),
+              onp.TargetStateInfidelityTime(N, targ[:, :, None], neglect_relative_pahse=True, cost_multiplier=0.5)]
+    problem = onp.SchroedingerProblem(T, lambda u, t: base(t) + sum(u[k] * g[k] for k in range(K)), init[:, :, None],
+                                      N, control_eval_count=N, costs=ocosts, magnus_policy=policy, control_count=K)
+    for b in range(2):
+        err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
+        assert abs(err - cost[b]) < 1e-10 and rel_err(final[b][:, :, None], fin) < 1e-10
+        assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
