@@ -643,12 +643,12 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count;
-    if (n < 1 || n > 256)
-        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..256 (1..64: the wavefront kernels; 65..256: the general "
+    if (n < 1 || n > 512)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..512 (1..64: the wavefront kernels; 65..512: the general "
                                   "path of qocx_general.hip)");
 
     // (a full propagator has n states: up to 256 of them on the general path)
-    if (S < 1 || S > (n > 64 ? 256 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..256 above hilbert_size 64)");
+    if (S < 1 || S > (n > 64 ? 512 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..512 above hilbert_size 64)");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
     if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");

@@ -74,15 +74,19 @@ template <bool CONJ>
 __device__ __forceinline__ void matvec_cols(const double2* __restrict__ M, const double2* v, double2* y, double2* part,
                                             int np) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunks = (np + 63) >> 6, groups = 4 / chunks;  // np <= 256
-    const int chunk = w % chunks, grp = w / chunks, c = chunk * 64 + lane;
-    if (grp < groups && c < np) {
-        double2 acc = make_double2(0, 0);
-        for (int r = grp; r < np; r += groups) {
-            if (CONJ) cfma_conj(acc, M[(size_t)r * np + c], v[r]);
-            else cfma(acc, M[(size_t)r * np + c], v[r]);
+    const int chunks = (np + 63) >> 6, groups = chunks >= 4 ? 1 : 4 / chunks;
+    // (more than four chunks of 64 columns: a wave takes several, every row itself)
+    for (int ch = (chunks >= 4 ? w : w % chunks); ch < chunks; ch += (chunks >= 4 ? 4 : chunks)) {
+        const int grp = chunks >= 4 ? 0 : w / chunks, c = ch * 64 + lane;
+        if (grp < groups && c < np) {
+            double2 acc = make_double2(0, 0);
+            for (int r = grp; r < np; r += groups) {
+                if (CONJ) cfma_conj(acc, M[(size_t)r * np + c], v[r]);
+                else cfma(acc, M[(size_t)r * np + c], v[r]);
+            }
+            part[grp * np + c] = acc;
         }
-        part[grp * np + c] = acc;
+        if (chunks < 4) break;
     }
     __syncthreads();
     for (int cc = threadIdx.x; cc < np; cc += TPB) {
@@ -215,11 +219,15 @@ __device__ __forceinline__ void gemm(const double2* __restrict__ A, const double
 // what swapping whole panel rows in LDS does). The column interchanges are undone at the end in one pass.
 // false (uniform): a zero / non-finite pivot.
 constexpr int KB = 16, GP = KB + 1;
-__host__ __device__ constexpr int invert_lds(int np) { return np * GP * 16 + KB * np * 16 + 8 * np + 128; }
-__device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem) {
+// (np > 256 - up to 512 -: the block's pivot rows R wait in global scratch `rg` instead of LDS, a thread owns two
+// rows of the panel)
+__host__ __device__ constexpr int invert_lds(int np) {
+    return np * GP * 16 + (np <= 256 ? KB * np * 16 : 0) + 8 * np + 128;
+}
+__device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem, double2* __restrict__ rg) {
     double2* G = reinterpret_cast<double2*>(smem);  // [np][GP]
-    double2* R = G + (size_t)np * GP;               // [KB][np]
-    int* piv = reinterpret_cast<int*>(R + (size_t)KB * np);
+    double2* R = np <= 256 ? G + (size_t)np * GP : rg;  // [KB][np]
+    int* piv = reinterpret_cast<int*>(G + (size_t)np * GP + (np <= 256 ? (size_t)KB * np : 0));
     int* idx = piv + np;
     double* red = reinterpret_cast<double*>(idx + np);
     int* redi = reinterpret_cast<int*>(red + 8);
@@ -231,16 +239,23 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem)
             G[r * GP + j] = M[(size_t)r * np + k0 + j];
         }
         __syncthreads();
-        const int r = tid;  // np <= TPB: a row of the panel per thread
+        // rows tid and tid + TPB of the panel (np <= 2 TPB)
         for (int j = 0; j < KB; ++j) {
             const int k = k0 + j;
             double best = -1.0;
             int bi = k;
-            if (r < np && r >= k) {
-                const double2 e = G[r * GP + j];
-                const double v = fabs(e.x) + fabs(e.y);
-                best = (v == v) ? v : 1e308;
-                bi = r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = tid + h * TPB;
+                if (r < np && r >= k) {
+                    const double2 e = G[r * GP + j];
+                    double v = fabs(e.x) + fabs(e.y);
+                    v = (v == v) ? v : 1e308;
+                    if (v > best) {
+                        best = v;
+                        bi = r;
+                    }
+                }
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
@@ -281,22 +296,30 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem)
                 const double den = d.x * d.x + d.y * d.y;
                 if (ok && den > 0.0) inv = make_double2(d.x / den, -d.y / den);
             }
-            double2 f = make_double2(0, 0);
-            if (r < np && r != k) f = G[r * GP + j];
+            double2 f[2] = {make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = tid + h * TPB;
+                if (r < np && r != k) f[h] = G[r * GP + j];
+            }
             __syncthreads();
             if (tid < KB) G[k * GP + tid] = (tid == j) ? inv : cmul(G[k * GP + tid], inv);
             __syncthreads();
-            if (r < np && r != k) {
-                const double2 nf = make_double2(-f.x, -f.y);
 #pragma unroll
-                for (int jj = 0; jj < KB; ++jj) {
-                    const double2 pk = G[k * GP + jj];
-                    if (jj == j) {
-                        G[r * GP + jj] = cmul(nf, pk);
-                    } else {
-                        double2 v = G[r * GP + jj];
-                        cfma(v, nf, pk);
-                        G[r * GP + jj] = v;
+            for (int h = 0; h < 2; ++h) {
+                const int r = tid + h * TPB;
+                if (r < np && r != k) {
+                    const double2 nf = make_double2(-f[h].x, -f[h].y);
+#pragma unroll
+                    for (int jj = 0; jj < KB; ++jj) {
+                        const double2 pk = G[k * GP + jj];
+                        if (jj == j) {
+                            G[r * GP + jj] = cmul(nf, pk);
+                        } else {
+                            double2 v = G[r * GP + jj];
+                            cfma(v, nf, pk);
+                            G[r * GP + jj] = v;
+                        }
                     }
                 }
             }
@@ -521,7 +544,7 @@ __global__ __launch_bounds__(TPB, 2) void factor_kernel(GeneralArgs a) {
             }
         }
         __syncthreads();
-        if (!invert(P, np, smem))
+        if (!invert(P, np, smem, Z))  // (Z: free by now - the pivot rows of a block wait there above np = 256)
             if (tid == 0) atomicOr(a.status, 1);
         __syncthreads();
     }
@@ -770,7 +793,7 @@ __global__ __launch_bounds__(TPB, 2) void sweep_kernel(GeneralSweepArgs args) {
 
 // scratch of one K3 workgroup (complex elements): a, a^T, abar, and for eight states or more the chains of all states
 __host__ __device__ constexpr size_t krylov_scratch_elems(int np, int S) {
-    return (size_t)3 * np * np + (S >= 8 ? (size_t)28 * S * np : 0);
+    return (size_t)3 * np * np + (S >= 8 ? (size_t)28 * S * np : 0) + (np > 256 ? (size_t)26 * np : 0);
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------------
@@ -781,9 +804,14 @@ __host__ __device__ constexpr size_t krylov_scratch_elems(int np, int S) {
 template <bool MANY>
 __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* smem) {
     const int np = a.np, mat = np * np, tid = threadIdx.x, S = a.S, K = a.K;
-    double2* tau = reinterpret_cast<double2*>(smem);  // [13][np]
-    double2* rho = tau + 13 * np;                     // [13][np]
-    double2* sig = rho + 13 * np;
+    // (np > 256: the 26 chain vectors wait in global scratch, behind abar; LDS holds sigma, delta and the partial sums)
+    const bool big = np > 256;
+    double2* lds0 = reinterpret_cast<double2*>(smem);
+    double2* gvec = a.scratch + (size_t)blockIdx.x * krylov_scratch_elems(np, S) + (size_t)3 * np * np +
+                    (S >= 8 ? (size_t)28 * S * np : 0);
+    double2* tau = big ? gvec : lds0;                  // [13][np]
+    double2* rho = tau + 13 * np;                      // [13][np]
+    double2* sig = big ? lds0 : rho + 13 * np;
     double2* del = sig + np;
     double2* part = del + np;  // [4][np]
     double* red = reinterpret_cast<double*>(part + 4 * np);
@@ -1151,7 +1179,9 @@ void launch_general_magnus(const MagnusArgs& a, bool vjp, int blocks, hipStream_
 
 int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
 int general_sweep_lds(int np) { return 7 * np * 16 + 256 + (int)sizeof(general::GemmLds); }
-int general_krylov_lds(int np) { return std::max((13 + 13 + 2 + 4) * np * 16, (int)sizeof(general::GemmLds)) + 256; }
+int general_krylov_lds(int np) {
+    return std::max((np > 256 ? 2 + 4 : 13 + 13 + 2 + 4) * np * 16, (int)sizeof(general::GemmLds)) + 256;
+}
 size_t general_krylov_scratch(int np, int S) { return general::krylov_scratch_elems(np, S); }
 
 int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {

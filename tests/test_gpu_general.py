@@ -1,5 +1,5 @@
 """
-GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 256,
+GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 512,
 every Magnus policy): through the C ABI against the oracle at the tolerances of the wavefront kernels (states and
 cost 1e-10, gradients 1e-8). The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502).
 """
@@ -27,7 +27,9 @@ GENERAL_EDGE_CASES = [
     dict(n=130, N=5, Nc=5, K=3, S=3, dt=0.02, ces=2, sigma=0.3),   # np = 144: three column chunks
     dict(n=100, N=7, Nc=3, K=2, S=5, dt=0.2, ces=3, sigma=1.0),    # squarings, five states
     dict(n=200, N=4, Nc=4, K=1, S=2, dt=0.1, ces=1, sigma=0.5),    # np = 208: four column chunks
-    dict(n=256, N=3, Nc=2, K=2, S=1, dt=0.03, ces=1, sigma=0.4),   # the largest size
+    dict(n=256, N=3, Nc=2, K=2, S=1, dt=0.03, ces=1, sigma=0.4),   # the largest size with the pivot rows in LDS
+    dict(n=300, N=3, Nc=3, K=1, S=2, dt=0.05, ces=1, sigma=0.5),   # np = 304: two panel rows per thread, chain vectors in HBM
+    dict(n=512, N=3, Nc=2, K=1, S=1, dt=0.02, ces=1, sigma=0.3),   # the largest size
 ]
 
 
@@ -198,15 +200,16 @@ def test_general_path_entry_points():
     assert result.best_error < ev.error and np.all(np.abs(result.best_controls) <= 2.0 + 1e-12)
 
 
-def test_general_path_pivots_off_the_diagonal(engine):
+@pytest.mark.parametrize("n", [66, 300])
+def test_general_path_pivots_off_the_diagonal(engine, n):
     """A generator whose Pade denominator is NOT diagonally dominant (a scaled cyclic shift: the sub-diagonal of
     P = v - u carries b_1 theta > b_0): the blocked Gauss-Jordan inversion interchanges rows in every block and
     undoes the column interchanges at the end; checked that LAPACK pivots off the diagonal there too."""
     import scipy.linalg
     from qoc_amd.engine import COST_TARGET_INCOHERENT
     from tests import device_model as dm
-    n, N, K, S = 66, 4, 1, 2
-    rng = np.random.default_rng(66)
+    N, K, S = 4, 1, 2   # (n = 300: two panel rows per thread, the pivot rows of a block in global scratch)
+    rng = np.random.default_rng(n)
     dt = 0.25
     shift = np.roll(np.eye(n), 1, axis=0)
     h0 = 1j * (4.0 / dt) * shift + 0.3 * cases_mod.gue(rng, n)
