@@ -86,7 +86,7 @@ typedef struct qocx_cost_desc {
 typedef struct qocx_schroedinger_problem {
     int32_t struct_size;         /* sizeof(qocx_schroedinger_problem) of the CALLER's header: a
                                     stale binding is rejected (QOCX_ERR_ARG) instead of over-read  */
-    int32_t hilbert_size;        /* n, 1..512 (65..512: the general path, qocx_general.hip)                */
+    int32_t hilbert_size;        /* n, 1..1024 (65..1024: the general path, qocx_general.hip)              */
     int32_t state_count;         /* S >= 1                                                          */
     int32_t control_count;       /* K real controls, >= 0                                           */
     int32_t control_eval_count;  /* Nc (>= 2 when K > 0)                                            */

@@ -643,12 +643,12 @@ int qocx_set_schroedinger_problem(qocx_ctx* ctx, const qocx_schroedinger_problem
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = p->hilbert_size, S = p->state_count, K = p->control_count;
     const int N = p->system_eval_count, nc = p->control_eval_count;
-    if (n < 1 || n > 512)
-        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..512 (1..64: the wavefront kernels; 65..512: the general "
+    if (n < 1 || n > 1024)
+        return fail(QOCX_ERR_ARG, "hilbert_size must be in 1..1024 (1..64: the wavefront kernels; 65..1024: the general "
                                   "path of qocx_general.hip)");
 
     // (a full propagator has n states: up to 256 of them on the general path)
-    if (S < 1 || S > (n > 64 ? 512 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..512 above hilbert_size 64)");
+    if (S < 1 || S > (n > 64 ? 1024 : 64)) return fail(QOCX_ERR_ARG, "state_count must be in 1..64 (1..1024 above hilbert_size 64)");
     if (K < 0 || K > 64) return fail(QOCX_ERR_ARG, "control_count must be in 0..64");
     if (N < 2) return fail(QOCX_ERR_ARG, "system_eval_count must be >= 2");
     if (K > 0 && nc < 2) return fail(QOCX_ERR_ARG, "control_eval_count must be >= 2");
@@ -958,7 +958,8 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
     const int Kk = m4lin ? ctx->m4lin_Ke : K;
     const size_t per_seed = (size_t)nsteps * (mat * 32 + 4) + ctx->slot_cap * S * np * 32 +
                             (size_t)(nsteps + 1) * 4 + (size_t)nsteps * std::max(Kk, 1) * 40;
-    const int max_blocks = 2 * ctx->cu_count;
+    // (persistent workgroups with 7 scratch matrices each: as many as 16 GB hold, two per CU at most)
+    const int max_blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)2 * ctx->cu_count, ((size_t)16 << 30) / (7 * mat * 16)));
     int chunk = ctx->chunk_user;
     if (chunk <= 0) {
         size_t free_b = 0, total_b = 0;

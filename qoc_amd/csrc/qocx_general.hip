@@ -218,13 +218,15 @@ __device__ __forceinline__ void gemm(const double2* __restrict__ A, const double
 // (the steps T_j = I + w_j e_kj^T commute past the later interchanges with w_j interchanged along, which is
 // what swapping whole panel rows in LDS does). The column interchanges are undone at the end in one pass.
 // false (uniform): a zero / non-finite pivot.
-constexpr int KB = 16, GP = KB + 1;
-// (np > 256 - up to 512 -: the block's pivot rows R wait in global scratch `rg` instead of LDS, a thread owns two
-// rows of the panel)
+// (np > 256: the block's pivot rows R wait in global scratch `rg` instead of LDS, a thread owns several rows of the
+// panel; np > 512 - up to 1024 -: blocks of 8 pivots, so that the panel still fits the LDS)
+__host__ __device__ constexpr int invert_kb(int np) { return np > 512 ? 8 : 16; }
 __host__ __device__ constexpr int invert_lds(int np) {
-    return np * GP * 16 + (np <= 256 ? KB * np * 16 : 0) + 8 * np + 128;
+    return np * (invert_kb(np) + 1) * 16 + (np <= 256 ? invert_kb(np) * np * 16 : 0) + 8 * np + 128;
 }
-__device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem, double2* __restrict__ rg) {
+template <int KB>
+__device__ __noinline__ bool invert_kb_body(double2* __restrict__ M, int np, char* smem, double2* __restrict__ rg) {
+    constexpr int GP = KB + 1, ROWS = KB == 16 ? 2 : 4;  // rows of the panel per thread
     double2* G = reinterpret_cast<double2*>(smem);  // [np][GP]
     double2* R = np <= 256 ? G + (size_t)np * GP : rg;  // [KB][np]
     int* piv = reinterpret_cast<int*>(G + (size_t)np * GP + (np <= 256 ? (size_t)KB * np : 0));
@@ -239,13 +241,13 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem,
             G[r * GP + j] = M[(size_t)r * np + k0 + j];
         }
         __syncthreads();
-        // rows tid and tid + TPB of the panel (np <= 2 TPB)
+        // rows tid, tid + TPB, ... of the panel (np <= ROWS TPB)
         for (int j = 0; j < KB; ++j) {
             const int k = k0 + j;
             double best = -1.0;
             int bi = k;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < ROWS; ++h) {
                 const int r = tid + h * TPB;
                 if (r < np && r >= k) {
                     const double2 e = G[r * GP + j];
@@ -296,17 +298,17 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem,
                 const double den = d.x * d.x + d.y * d.y;
                 if (ok && den > 0.0) inv = make_double2(d.x / den, -d.y / den);
             }
-            double2 f[2] = {make_double2(0, 0), make_double2(0, 0)};
+            double2 f[ROWS];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < ROWS; ++h) {
                 const int r = tid + h * TPB;
-                if (r < np && r != k) f[h] = G[r * GP + j];
+                f[h] = (r < np && r != k) ? G[r * GP + j] : make_double2(0, 0);
             }
             __syncthreads();
             if (tid < KB) G[k * GP + tid] = (tid == j) ? inv : cmul(G[k * GP + tid], inv);
             __syncthreads();
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < ROWS; ++h) {
                 const int r = tid + h * TPB;
                 if (r < np && r != k) {
                     const double2 nf = make_double2(-f[h].x, -f[h].y);
@@ -341,24 +343,27 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem,
         for (int e = tid; e < KB * np; e += TPB) R[e] = M[(size_t)k0 * np + e];  // rows k0 .. k0 + KB - 1
         __syncthreads();
         {
-            // the rank-16 update on the matrix cores, a 16 x 16 tile of the matrix per wave and turn: the tile
-            // (or zero, in the block's own rows) is the accumulator, G[16 ti .., 0..15] the A operand, R the B one
-            const int q = lane >> 4, c = lane & 15, nt = np >> 4, pt = k0 >> 4;
+            // the rank-KB update on the matrix cores, a 16 x 16 tile of the matrix per wave and turn: the tile (zero
+            // in the block's own rows, untouched in its own columns) is the accumulator, G[16 ti .., 0..KB-1] the A
+            // operand, R the B one
+            const int q = lane >> 4, c = lane & 15, nt = np >> 4;
             for (int t = w; t < nt * nt; t += 4) {
                 const int ti = t / nt, tj = t - ti * nt;
-                if (tj == pt) continue;
+                if (KB == 16 && 16 * tj == k0) continue;
                 const size_t base = (size_t)(16 * ti + q) * np + 16 * tj + c;  // element (16 ti + 4 r + q, 16 tj + c)
+                const bool own_col = 16 * tj + c >= k0 && 16 * tj + c < k0 + KB;
                 d4 re = d4{0, 0, 0, 0}, im = d4{0, 0, 0, 0};
-                if (ti != pt) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = 16 * ti + 4 * rr + q;
+                    if (!(row >= k0 && row < k0 + KB)) {
                         const double2 e = M[base + (size_t)4 * rr * np];
                         re[rr] = e.x;
                         im[rr] = e.y;
                     }
                 }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < KB / 4; ++kk) {
                     const double2 a = G[(16 * ti + c) * GP + 4 * kk + q];
                     const double2 b = R[(4 * kk + q) * np + 16 * tj + c];
                     re = mfma_f64(a.x, b.x, re);
@@ -366,9 +371,11 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem,
                     im = mfma_f64(a.x, b.y, im);
                     im = mfma_f64(a.y, b.x, im);
                 }
+                if (!own_col)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) M[base + (size_t)4 * rr * np] = make_double2(re[rr], im[rr]);
+                    for (int rr = 0; rr < 4; ++rr) M[base + (size_t)4 * rr * np] = make_double2(re[rr], im[rr]);
             }
+            __syncthreads();  // (KB = 8: a tile column holds the block's own columns beside four others - all tiles first)
             for (int e = tid; e < np * KB; e += TPB) {  // the block's own columns: the eliminated panel
                 const int rr = e / KB, j = e - rr * KB;
                 M[(size_t)rr * np + k0 + j] = G[rr * GP + j];
@@ -398,6 +405,10 @@ __device__ __noinline__ bool invert(double2* __restrict__ M, int np, char* smem,
         }
     }
     return ok;
+}
+
+__device__ __forceinline__ bool invert(double2* __restrict__ M, int np, char* smem, double2* __restrict__ rg) {
+    return np > 512 ? invert_kb_body<8>(M, np, smem, rg) : invert_kb_body<16>(M, np, smem, rg);
 }
 
 // ---- K1a + K1b ---------------------------------------------------------------------------------------
@@ -1201,8 +1212,14 @@ int launch_general_factor(const GeneralArgs& a, int blocks, hipStream_t st) {
 // (bit 4: it also seeds lambda)
 void launch_general_sweep(const GeneralSweepArgs& a, int batch, hipStream_t st) {
     const int groups = (a.phase & 8) ? std::max(1, a.phase >> 8) : 1;
-    hipLaunchKernelGGL(general::sweep_kernel, dim3(batch, (a.phase & 4) ? 1 : groups), dim3(general::TPB),
-                       general_sweep_lds(a.np), st, a);
+    const int bytes = general_sweep_lds(a.np);
+    static int attr_bytes = 0;
+    if (bytes > 48 * 1024 && bytes > attr_bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(general::sweep_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_bytes = bytes;
+    }
+    hipLaunchKernelGGL(general::sweep_kernel, dim3(batch, (a.phase & 4) ? 1 : groups), dim3(general::TPB), bytes, st, a);
 }
 
 int launch_general_krylov(const GeneralKrylovArgs& a, int blocks, hipStream_t st) {

@@ -43,7 +43,7 @@ _EXPM_ENGINE = []
 
 def expm(a):
     """
-    Matrix exponential of one square complex matrix (n <= 512, the engine's size limit) by the
+    Matrix exponential of one square complex matrix (n <= 1024, the engine's size limit) by the
     engine's Pade scaling-and-squaring path - the same kernels the propagation uses: exp(a) is the
     one-step propagator of H = i a over dt = 1 applied to the identity columns (the engine takes the
     Pade order from the norm, [13/13] with squarings for large ones; qoc/standard/functions/expm.py:210-252).
@@ -56,8 +56,8 @@ def expm(a):
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError("expm expects one square matrix, got shape {}".format(a.shape))
     n = a.shape[0]
-    if n > 512:
-        raise NotImplementedError("expm on the MI355X engine handles n <= 512 (got {})".format(n))
+    if n > 1024:
+        raise NotImplementedError("expm on the MI355X engine handles n <= 1024 (got {})".format(n))
     if not _EXPM_ENGINE:
         _EXPM_ENGINE.append(device.make_backend())
     engine = _EXPM_ENGINE[0]

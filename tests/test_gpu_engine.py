@@ -515,7 +515,7 @@ def test_error_paths(engine):
             fresh.eval_resident(True)
         assert err.value.code == -3
         with pytest.raises(QocxError) as err:  # unsupported size
-            fresh.set_schroedinger_problem(513, 1, 0, 0, 5, 1.0, np.eye(513), None, np.eye(513)[:1])
+            fresh.set_schroedinger_problem(1025, 1, 0, 0, 5, 1.0, np.eye(1025), None, np.eye(1025)[:1])
         assert err.value.code == -1 and "hilbert_size" in err.value.message
         with pytest.raises(QocxError) as err:  # more than 64 states below hilbert_size 65
             fresh.set_schroedinger_problem(40, 65, 0, 0, 5, 1.0, np.eye(40), None, np.ones((65, 40)))

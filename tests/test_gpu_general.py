@@ -1,5 +1,5 @@
 """
-GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 512,
+GPU parity tests (-m gpu) of the path for Hilbert sizes ABOVE 64 (qoc_amd/csrc/qocx_general.hip, 65 <= n <= 1024,
 every Magnus policy): through the C ABI against the oracle at the tolerances of the wavefront kernels (states and
 cost 1e-10, gradients 1e-8). The reference is unbounded in n (qoc/core/schroedingerdiscrete.py:356-502).
 """
@@ -29,7 +29,9 @@ GENERAL_EDGE_CASES = [
     dict(n=200, N=4, Nc=4, K=1, S=2, dt=0.1, ces=1, sigma=0.5),    # np = 208: four column chunks
     dict(n=256, N=3, Nc=2, K=2, S=1, dt=0.03, ces=1, sigma=0.4),   # the largest size with the pivot rows in LDS
     dict(n=300, N=3, Nc=3, K=1, S=2, dt=0.05, ces=1, sigma=0.5),   # np = 304: two panel rows per thread, chain vectors in HBM
-    dict(n=512, N=3, Nc=2, K=1, S=1, dt=0.02, ces=1, sigma=0.3),   # the largest size
+    dict(n=512, N=3, Nc=2, K=1, S=1, dt=0.02, ces=1, sigma=0.3),   # the largest size with blocks of 16 pivots
+    dict(n=600, N=3, Nc=2, K=1, S=1, dt=0.02, ces=1, sigma=0.3),   # np = 608: blocks of 8 pivots, three panel rows per thread
+    dict(n=1024, N=2, Nc=2, K=1, S=1, dt=0.01, ces=1, sigma=0.3),  # the largest size (the last row of the reference's report)
 ]
 
 
@@ -200,7 +202,7 @@ def test_general_path_entry_points():
     assert result.best_error < ev.error and np.all(np.abs(result.best_controls) <= 2.0 + 1e-12)
 
 
-@pytest.mark.parametrize("n", [66, 300])
+@pytest.mark.parametrize("n", [66, 300, 530])
 def test_general_path_pivots_off_the_diagonal(engine, n):
     """A generator whose Pade denominator is NOT diagonally dominant (a scaled cyclic shift: the sub-diagonal of
     P = v - u carries b_1 theta > b_0): the blocked Gauss-Jordan inversion interchanges rows in every block and
@@ -208,7 +210,7 @@ def test_general_path_pivots_off_the_diagonal(engine, n):
     import scipy.linalg
     from qoc_amd.engine import COST_TARGET_INCOHERENT
     from tests import device_model as dm
-    N, K, S = 4, 1, 2   # (n = 300: two panel rows per thread, the pivot rows of a block in global scratch)
+    N, K, S = 4, 1, 2   # (n = 300: two panel rows per thread, the pivot rows of a block in global scratch; n = 530: blocks of 8 pivots)
     rng = np.random.default_rng(n)
     dt = 0.25
     shift = np.roll(np.eye(n), 1, axis=0)
