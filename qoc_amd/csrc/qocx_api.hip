@@ -1083,6 +1083,9 @@ static int eval_general(qocx_ctx* ctx, int want_grad) {
             ka.s_arr = fa.s_arr; ka.offs = ctx->offs.p; ka.states = ctx->states.p; ka.xs = ctx->xs.p;
             ka.slot_cap = ctx->slot_cap; ka.gstep = ctx->gstep.p; ka.scratch = ctx->magnus_scratch.p;
             ka.total = fa.total;
+            // (Magnus generators are skew only to rounding: the general chains there)
+            ka.skew = (magnus ? 0 : (explicit_gen ? ctx->explicit_hermitian : ctx->hermitian)) &&
+                      ctx->knob("general_skew", 1) != 0;
             time_begin(ctx, 2, cs);
             if (qocx::launch_general_krylov(ka, std::min(fblocks, k3_blocks), cs))
                 return fail(QOCX_ERR_HIP, "K3 (general): LDS size refused");
@@ -2843,7 +2846,7 @@ static const char* const kVariantKnobs[] = {
     "sweep_loader", "sweep_impl", "sweep3_phases", "magnus_general", "bidir", "bidir_min_segments", "bidir_adj_first", "unit_adjoint",
     "sweep_onebuf", "sweep_one", "latency", "fuse_lu", "lindblad_two_sided", "lindblad_side_limit", "k3_split", "k3_split_outer",
     "m4_linear", "pade_order", "lu_inverse", "sweep_dense", "krylov_dense", "magnus_4w",
-    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "general_split", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
+    "sweep_inverse", "sweep_inverse_small", "lu_mfma", "lu_dpp", "k1a_three", "pack8", "sweep_umode", "general_split", "general_skew", "k1a_four", "k1a_share", "k1a_streams", "sweep_tail_ring", "k3_lds_pad", "step_table", "sweep_nine", "lindblad_q2", "lindblad_chain", "lindblad_real_ops", "k1a_herm4", "lu_stream", "lindblad_4t", "lindblad_hermitian", "lindblad_pad_operator"};
 static const char* const kDiagKnobs[] = {"dbg_skip", "sweep3_dbg", "sweep3_stamps", "lindblad_stamps",
                                          "k1a_stamps", "k1a_dbg", "peak_mode"};
 

@@ -372,6 +372,7 @@ struct GeneralKrylovArgs {  // K3: one work item per (seed, step)
     double* gstep;             // [B][nsteps][K]
     double2* scratch;          // [blocks][3] matrices
     size_t total;
+    int skew = 0;              // the generator is skew-Hermitian bit for bit (Hermitian H): both chains run on a^H, one pass each
 };
 int general_factor_lds(int np);
 int general_sweep_lds(int np);

@@ -100,6 +100,47 @@ __device__ __forceinline__ void matvec_cols(const double2* __restrict__ M, const
     __syncthreads();
 }
 
+// Two of them on one pass over M: y1[c] = sum_r op(M[r][c]) v1[r], y2 likewise from v2 (part: [2][groups][np]).
+template <bool CONJ>
+__device__ __forceinline__ void matvec_cols2(const double2* __restrict__ M, const double2* v1, double2* y1, const double2* v2,
+                                             double2* y2, double2* part, int np) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunks = (np + 63) >> 6, groups = chunks >= 4 ? 1 : 4 / chunks;
+    double2* part2 = part + groups * np;
+    for (int ch = (chunks >= 4 ? w : w % chunks); ch < chunks; ch += (chunks >= 4 ? 4 : chunks)) {
+        const int grp = chunks >= 4 ? 0 : w / chunks, c = ch * 64 + lane;
+        if (grp < groups && c < np) {
+            double2 acc1 = make_double2(0, 0), acc2 = make_double2(0, 0);
+            for (int r = grp; r < np; r += groups) {
+                const double2 e = M[(size_t)r * np + c];
+                if (CONJ) {
+                    cfma_conj(acc1, e, v1[r]);
+                    cfma_conj(acc2, e, v2[r]);
+                } else {
+                    cfma(acc1, e, v1[r]);
+                    cfma(acc2, e, v2[r]);
+                }
+            }
+            part[grp * np + c] = acc1;
+            part2[grp * np + c] = acc2;
+        }
+        if (chunks < 4) break;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < np; cc += TPB) {
+        double2 s1 = part[cc], s2 = part2[cc];
+        for (int g = 1; g < groups; ++g) {
+            s1.x += part[g * np + cc].x;
+            s1.y += part[g * np + cc].y;
+            s2.x += part2[g * np + cc].x;
+            s2.y += part2[g * np + cc].y;
+        }
+        y1[cc] = s1;
+        y2[cc] = s2;
+    }
+    __syncthreads();
+}
+
 // C = A B (row-major np x np in HBM / L2, np a multiple of 16) on the matrix cores: 64 x 64 output tiles, a
 // wave owns a 32 x 32 quadrant (2 x 2 tiles of v_mfma_f64_16x16x4_f64, complex = 4 real products per tile and
 // k-step), operands staged 16 columns at a time through LDS (34 KiB at smem): lane (q, c) reads its A fragment
@@ -824,8 +865,8 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
     double2* rho = tau + 13 * np;                      // [13][np]
     double2* sig = big ? lds0 : rho + 13 * np;
     double2* del = sig + np;
-    double2* part = del + np;  // [4][np]
-    double* red = reinterpret_cast<double*>(part + 4 * np);
+    double2* part = del + np;  // [2][4][np]; above np = 256 (one group of rows): [2][np]... kept at [4][np]
+    double* red = reinterpret_cast<double*>(part + (big ? 4 : 8) * np);
     // eight states or more: the chains of all states at once, as products on the matrix cores - the tau_j, rho_i of
     // every state in scratch ([13][S][np] each, + sigma, delta), abar += T^T conj(R) over the 13 S rows
     // (a kernel of its own, krylov_many_kernel: the products' registers would cost the vector form its occupancy)
@@ -852,6 +893,9 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
         if (t0 < 0 || (size_t)t0 + (size_t)nsub >= cap) continue;  // the sweep overflowed (status bit 2)
         const size_t tsel = (a.nt == 1) ? 0 : (size_t)step;
         const double2* gk = a.g_rm ? a.g_rm + tsel * K * mat : nullptr;
+        // a skew-Hermitian generator (Hermitian H, host-checked bit for bit), one state at a time: a rho = -a^H rho, so
+        // both chains are products with a^H - ONE pass over the matrix per pair of chain steps, no transpose
+        const bool skew1 = !MANY && a.skew != 0;
         // the scaled generator and its transpose
         if (a.gen_rm != nullptr) {
             const double2* g = a.gen_rm + m * mat;
@@ -860,7 +904,7 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
                 const int r = e / np, c = e - r * np;
                 const double2 v = make_double2(scl * g[e].x, scl * g[e].y);
                 A[e] = v;
-                AT[(size_t)c * np + r] = v;
+                if (!skew1) AT[(size_t)c * np + r] = v;
             }
         } else {
             const double2* h0 = a.h0_rm + tsel * mat;
@@ -877,7 +921,7 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
                 }
                 const double2 v = make_double2(dts * h.y, -dts * h.x);
                 A[e] = v;
-                AT[(size_t)c * np + r] = v;
+                if (!skew1) AT[(size_t)c * np + r] = v;
             }
         }
         __syncthreads();
@@ -927,12 +971,27 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
                     del[i] = make_double2(p0.x - p1.x, p0.y - p1.y);
                 }
                 __syncthreads();
+                if (skew1) {
+                    for (int i = tid; i < np; i += TPB) rho[(M - 1) * np + i] = make_double2(bt[M] * sig[i].x, bt[M] * sig[i].y);
+                    __syncthreads();
+                    for (int jj = 1; jj < M; ++jj) {
+                        const int ii = M - jj;  // tau_jj = a^H tau_{jj-1};  rho_{ii-1} = b_ii w_ii - a^H rho_ii
+                        matvec_cols2<true>(A, tau + (jj - 1) * np, tau + jj * np, rho + ii * np, rho + (ii - 1) * np, part, np);
+                        const double2* wv = (ii & 1) ? sig : del;
+                        for (int i = tid; i < np; i += TPB) {
+                            const double2 r = rho[(ii - 1) * np + i];
+                            rho[(ii - 1) * np + i] = make_double2(fma(bt[ii], wv[i].x, -r.x), fma(bt[ii], wv[i].y, -r.y));
+                        }
+                        __syncthreads();
+                    }
+                }
                 // tau_j = a^H tau_{j-1}: (a^H v)_c = sum_r conj(a[r][c]) v_r
-                for (int jj = 1; jj < M; ++jj) matvec_cols<true>(A, tau + (jj - 1) * np, tau + jj * np, part, np);
-                for (int i = tid; i < np; i += TPB) rho[(M - 1) * np + i] = make_double2(bt[M] * sig[i].x, bt[M] * sig[i].y);
+                for (int jj = 1; jj < (skew1 ? 0 : M); ++jj) matvec_cols<true>(A, tau + (jj - 1) * np, tau + jj * np, part, np);
+                if (!skew1)
+                    for (int i = tid; i < np; i += TPB) rho[(M - 1) * np + i] = make_double2(bt[M] * sig[i].x, bt[M] * sig[i].y);
                 __syncthreads();
                 // rho_{i-1} = b_i w_i + a rho_i: (a v)_r = sum_c a^T[c][r] v_c
-                for (int ii = M - 1; ii >= 1; --ii) {
+                for (int ii = (skew1 ? 0 : M - 1); ii >= 1; --ii) {
                     matvec_cols<false>(AT, rho + ii * np, rho + (ii - 1) * np, part, np);
                     const double2* wv = (ii & 1) ? sig : del;
                     for (int i = tid; i < np; i += TPB) {
@@ -1191,7 +1250,7 @@ void launch_general_magnus(const MagnusArgs& a, bool vjp, int blocks, hipStream_
 int general_factor_lds(int np) { return std::max((int)sizeof(general::GemmLds), general::invert_lds(np)) + 256; }
 int general_sweep_lds(int np) { return 7 * np * 16 + 256 + (int)sizeof(general::GemmLds); }
 int general_krylov_lds(int np) {
-    return std::max((np > 256 ? 2 + 4 : 13 + 13 + 2 + 4) * np * 16, (int)sizeof(general::GemmLds)) + 256;
+    return std::max((np > 256 ? 2 + 4 : 13 + 13 + 2 + 8) * np * 16, (int)sizeof(general::GemmLds)) + 256;
 }
 size_t general_krylov_scratch(int np, int S) { return general::krylov_scratch_elems(np, S); }
 

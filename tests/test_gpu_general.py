@@ -84,6 +84,13 @@ def test_general_path_chunks_and_batch_independence(engine):
                 assert np.array_equal(a, b), chunk
     finally:
         engine.set_chunk(0)
+    # Hermitian H: K3 runs both chains on a^H, one pass over the generator per pair of chain steps (knob general_skew)
+    engine.set_knob("general_skew", 0)
+    try:
+        plain = engine.evaluate(controls, True)
+    finally:
+        engine.set_knob("general_skew", 1)
+    assert np.array_equal(plain[0], ref[0]) and rel_err(plain[1], ref[1]) < 1e-12
     one = engine.evaluate(controls[3:4], True)
     assert one[0][0] == ref[0][3] and np.array_equal(one[1][0], ref[1][3]) and np.array_equal(one[2][0], ref[2][3])
     # forward only: same costs and states, no gradient work
