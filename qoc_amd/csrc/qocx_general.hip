@@ -55,15 +55,29 @@ __device__ __forceinline__ double block_max(double a, double* red) {
 template <bool CONJ>
 __device__ __forceinline__ void matvec_rows(const double2* __restrict__ M, const double2* v, double2* y, int np) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = w; r < np; r += 4) {
-        double2 acc = make_double2(0, 0);
-        const double2* row = M + (size_t)r * np;
+    // four rows of the wave at a time: their loads are in flight together (one row per turn was a trip to memory per
+    // row - 31 us per 128 x 128 product), their reductions interleave
+    for (int r0 = w; r0 < np; r0 += 16) {
+        double2 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = make_double2(0, 0);
         for (int c = lane; c < np; c += 64) {
-            if (CONJ) cfma_conj(acc, row[c], v[c]);
-            else cfma(acc, row[c], v[c]);
+            const double2 vc = v[c];
+            double2 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                e[i] = (r0 + 4 * i < np) ? M[(size_t)(r0 + 4 * i) * np + c] : make_double2(0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (CONJ) cfma_conj(acc[i], e[i], vc);
+                else cfma(acc[i], e[i], vc);
+            }
         }
-        const double sr = wave_sum(acc.x), si = wave_sum(acc.y);
-        if (lane == 0) y[r] = make_double2(sr, si);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double sr = wave_sum(acc[i].x), si = wave_sum(acc[i].y);
+            if (lane == 0 && r0 + 4 * i < np) y[r0 + 4 * i] = make_double2(sr, si);
+        }
     }
     __syncthreads();
 }
@@ -80,6 +94,7 @@ __device__ __forceinline__ void matvec_cols(const double2* __restrict__ M, const
         const int grp = chunks >= 4 ? 0 : w / chunks, c = ch * 64 + lane;
         if (grp < groups && c < np) {
             double2 acc = make_double2(0, 0);
+#pragma unroll 8
             for (int r = grp; r < np; r += groups) {
                 if (CONJ) cfma_conj(acc, M[(size_t)r * np + c], v[r]);
                 else cfma(acc, M[(size_t)r * np + c], v[r]);
@@ -111,6 +126,7 @@ __device__ __forceinline__ void matvec_cols2(const double2* __restrict__ M, cons
         const int grp = chunks >= 4 ? 0 : w / chunks, c = ch * 64 + lane;
         if (grp < groups && c < np) {
             double2 acc1 = make_double2(0, 0), acc2 = make_double2(0, 0);
+#pragma unroll 8
             for (int r = grp; r < np; r += groups) {
                 const double2 e = M[(size_t)r * np + c];
                 if (CONJ) {
@@ -394,13 +410,24 @@ __device__ __noinline__ bool invert_kb_body(double2* __restrict__ M, int np, cha
                 const size_t base = (size_t)(16 * ti + q) * np + 16 * tj + c;  // element (16 ti + 4 r + q, 16 tj + c)
                 const bool own_col = 16 * tj + c >= k0 && 16 * tj + c < k0 + KB;
                 d4 re = d4{0, 0, 0, 0}, im = d4{0, 0, 0, 0};
+                if constexpr (KB == 16) {  // (a block is a whole tile row / tile column: decided per tile)
+                    if (16 * ti != k0) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = 16 * ti + 4 * rr + q;
-                    if (!(row >= k0 && row < k0 + KB)) {
-                        const double2 e = M[base + (size_t)4 * rr * np];
-                        re[rr] = e.x;
-                        im[rr] = e.y;
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const double2 e = M[base + (size_t)4 * rr * np];
+                            re[rr] = e.x;
+                            im[rr] = e.y;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int row = 16 * ti + 4 * rr + q;
+                        if (!(row >= k0 && row < k0 + KB)) {
+                            const double2 e = M[base + (size_t)4 * rr * np];
+                            re[rr] = e.x;
+                            im[rr] = e.y;
+                        }
                     }
                 }
 #pragma unroll
@@ -412,11 +439,11 @@ __device__ __noinline__ bool invert_kb_body(double2* __restrict__ M, int np, cha
                     im = mfma_f64(a.x, b.y, im);
                     im = mfma_f64(a.y, b.x, im);
                 }
-                if (!own_col)
+                if (KB == 16 || !own_col)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) M[base + (size_t)4 * rr * np] = make_double2(re[rr], im[rr]);
             }
-            __syncthreads();  // (KB = 8: a tile column holds the block's own columns beside four others - all tiles first)
+            if (KB != 16) __syncthreads();  // (KB = 8: a tile column holds the block's own columns beside eight others - all tiles first)
             for (int e = tid; e < np * KB; e += TPB) {  // the block's own columns: the eliminated panel
                 const int rr = e / KB, j = e - rr * KB;
                 M[(size_t)rr * np + k0 + j] = G[rr * GP + j];
