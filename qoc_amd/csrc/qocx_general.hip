@@ -897,7 +897,6 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
     // eight states or more: the chains of all states at once, as products on the matrix cores - the tau_j, rho_i of
     // every state in scratch ([13][S][np] each, + sigma, delta), abar += T^T conj(R) over the 13 S rows
     // (a kernel of its own, krylov_many_kernel: the products' registers would cost the vector form its occupancy)
-    constexpr bool many = MANY;
     const size_t sn = (size_t)S * np;
     double2* A = a.scratch + (size_t)blockIdx.x * krylov_scratch_elems(np, S);
     double2* AT = A + mat;
@@ -988,7 +987,7 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
                 first = false;
             }
         }
-        for (int sub = 0; sub < (many ? 0 : nsub); ++sub)
+        for (int sub = 0; !MANY && sub < nsub; ++sub)  // (up to seven states: state by state, vectors in LDS)
             for (int s = 0; s < S; ++s) {
                 const size_t t = (size_t)t0 + sub;
                 for (int i = tid; i < np; i += TPB) {
@@ -1011,23 +1010,23 @@ __device__ __forceinline__ void krylov_body(const GeneralKrylovArgs& a, char* sm
                         }
                         __syncthreads();
                     }
-                }
-                // tau_j = a^H tau_{j-1}: (a^H v)_c = sum_r conj(a[r][c]) v_r
-                for (int jj = 1; jj < (skew1 ? 0 : M); ++jj) matvec_cols<true>(A, tau + (jj - 1) * np, tau + jj * np, part, np);
-                if (!skew1)
+                } else {
+                    // tau_j = a^H tau_{j-1}: (a^H v)_c = sum_r conj(a[r][c]) v_r
+                    for (int jj = 1; jj < M; ++jj) matvec_cols<true>(A, tau + (jj - 1) * np, tau + jj * np, part, np);
                     for (int i = tid; i < np; i += TPB) rho[(M - 1) * np + i] = make_double2(bt[M] * sig[i].x, bt[M] * sig[i].y);
-                __syncthreads();
-                // rho_{i-1} = b_i w_i + a rho_i: (a v)_r = sum_c a^T[c][r] v_c
-                for (int ii = (skew1 ? 0 : M - 1); ii >= 1; --ii) {
-                    matvec_cols<false>(AT, rho + ii * np, rho + (ii - 1) * np, part, np);
-                    const double2* wv = (ii & 1) ? sig : del;
-                    for (int i = tid; i < np; i += TPB) {
-                        double2 r = rho[(ii - 1) * np + i];
-                        r.x = fma(bt[ii], wv[i].x, r.x);
-                        r.y = fma(bt[ii], wv[i].y, r.y);
-                        rho[(ii - 1) * np + i] = r;
-                    }
                     __syncthreads();
+                    // rho_{i-1} = b_i w_i + a rho_i: (a v)_r = sum_c a^T[c][r] v_c
+                    for (int ii = M - 1; ii >= 1; --ii) {
+                        matvec_cols<false>(AT, rho + ii * np, rho + (ii - 1) * np, part, np);
+                        const double2* wv = (ii & 1) ? sig : del;
+                        for (int i = tid; i < np; i += TPB) {
+                            double2 r = rho[(ii - 1) * np + i];
+                            r.x = fma(bt[ii], wv[i].x, r.x);
+                            r.y = fma(bt[ii], wv[i].y, r.y);
+                            rho[(ii - 1) * np + i] = r;
+                        }
+                        __syncthreads();
+                    }
                 }
                 // abar[r][c] += sum_i tau_i[r] conj(rho_i[c])
                 for (int e = tid; e < mat; e += TPB) {
