@@ -379,3 +379,16 @@ def test_general_path_magnus_policies(engine, policy, n, K, time_dep):
         err, gr, fin = onp.evaluate_with_grad(problem, controls[b])
         assert abs(err - cost[b]) < 1e-10 and rel_err(final[b][:, :, None], fin) < 1e-10
         assert np.max(np.abs(gr - grads[b])) < 1e-8 * np.max(np.abs(gr))
+
+
+def test_example_full_propagator_of_two_transmons():
+    """examples/two_transmon_cz_full_propagator.py (n = 100, 100 states): GRAPE lowers the error."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "two_transmon_cz_full_propagator.py")
+    spec = importlib.util.spec_from_file_location("example_cz", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    result = module.main(iteration_count=4)
+    assert result.best_iteration > 0 and np.isfinite(result.best_error) and result.best_error < 1.0
